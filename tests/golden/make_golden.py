@@ -1,0 +1,191 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.npz from the REAL reference (build container only).
+
+Run:  python tests/golden/make_golden.py        (needs /root/reference; CPU only)
+
+The reference's model classes are AST-extracted from its training scripts (the scripts
+themselves cannot be imported: they construct datasets and require CUDA at import time,
+code/ade20k/ade_semantic.py:81-98,351-357) and executed with torch on CPU.  Only data
+(inputs, weights, outputs, gradients) is written -- no reference source text.
+
+Fixtures:
+  convblock_*.npz, down_*.npz, up_*.npz, attn_*.npz : small per-module cases with every
+      tensor stored (fwd output, input grad, all parameter grads, new BN running stats).
+  unet1_*.npz, unet3_*.npz : whole-model 128x128 cases.  Weights/inputs/masks come from
+      the numpy default_rng recipe in oracle/maskunet_oracle.py (make_params/make_keeps/
+      make_inputs) so they are regenerated, not stored; stored are strided output slices,
+      the loss, per-parameter gradient norms and a few small full gradients.
+"""
+import ast
+import os
+import sys
+
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+from oracle import maskunet_oracle as O  # noqa: E402
+
+REF = "/root/reference/code"
+OUT = os.path.dirname(os.path.abspath(__file__))
+KEEP = {"Mask2FormerAttention", "ConvBlock", "DownSample", "UpSample", "UNet"}
+
+
+def load_reference(path):
+    tree = ast.parse(open(path).read())
+    body = [n for n in tree.body if isinstance(n, (ast.ClassDef, ast.FunctionDef)) and n.name in KEEP]
+    ns = {"torch": torch, "nn": nn, "F": F}
+    exec(compile(ast.Module(body=body, type_ignores=[]), path, "exec"), ns)
+    return ns
+
+
+def inject_mask(attn, keep):
+    add = torch.where(keep > 0, torch.zeros(()), torch.full((), -float("inf")))
+    attn.mask = add.unsqueeze(1).expand(-1, keep.shape[1], -1)
+
+
+def fill_module(mod, rng):
+    """Overwrite every parameter/buffer with the oracle's recipe, in state_dict order."""
+    sd = mod.state_dict()
+    new = {}
+    for k, v in sd.items():
+        leaf = k.split(".")[-1]
+        if leaf == "num_batches_tracked":
+            new[k] = torch.zeros((), dtype=torch.int64)
+            continue
+        if leaf == "running_mean":
+            kind = "rmean"
+        elif leaf == "running_var":
+            kind = "rvar"
+        elif v.dim() == 1 and leaf == "weight":
+            kind = "gamma"
+        elif v.dim() == 1 and leaf == "bias":
+            # Linear/conv bias vs norm bias: norm layers have a same-shaped 1-D weight
+            wkey = k[: -len("bias")] + "weight"
+            kind = "beta" if sd[wkey].dim() == 1 else "b%d" % int(np.prod(sd[wkey].shape[1:]))
+        else:
+            kind = "w"
+        new[k] = O.make_tensor(rng, tuple(v.shape), kind)
+    mod.load_state_dict(new)
+    return new
+
+
+def np_dict(d, prefix):
+    return {prefix + k: v.detach().cpu().numpy() for k, v in d.items()}
+
+
+def run_module_case(name, mod, inputs, training, keep=None, weights_seed=0):
+    rng = np.random.default_rng(weights_seed)
+    params = fill_module(mod, rng)
+    mod.train(training)
+    if keep is not None:
+        inject_mask(mod, keep)
+    ins = [t.clone().requires_grad_(True) for t in inputs]
+    out = mod(*ins)
+    # fixed pseudo-random cotangent so that grads are non-trivial
+    g = torch.from_numpy(np.random.default_rng(weights_seed + 1).standard_normal(out.shape).astype(np.float32))
+    out.backward(g)
+    rec = {}
+    rec.update(np_dict(params, "param/"))
+    for i, t in enumerate(inputs):
+        rec[f"in/{i}"] = t.numpy()
+        rec[f"gin/{i}"] = ins[i].grad.numpy()
+    rec["out"] = out.detach().numpy()
+    rec["gout"] = g.numpy()
+    if keep is not None:
+        rec["keep"] = keep.numpy()
+    for k, v in mod.named_parameters():
+        if v.grad is not None:
+            rec["gparam/" + k] = v.grad.numpy()
+    rec.update(np_dict({k: v for k, v in mod.state_dict().items() if "running" in k}, "newstat/"))
+    rec["training"] = np.array(int(training))
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **rec)
+    print("wrote", name, "out", tuple(out.shape), "absmax", float(out.abs().max()))
+
+
+def module_cases(ns):
+    r = np.random.default_rng(7)
+
+    def rnd(*s):
+        return torch.from_numpy(r.standard_normal(s).astype(np.float32))
+
+    for tr in (True, False):
+        tag = "train" if tr else "eval"
+        run_module_case(f"convblock_8_16_{tag}", ns["ConvBlock"](8, 16), [rnd(2, 8, 12, 12)], tr, weights_seed=11)
+        run_module_case(f"convblock_res_8_{tag}", ns["ConvBlock"](8, 8, residual=True), [rnd(2, 8, 12, 12)], tr, weights_seed=12)
+        run_module_case(f"convblock_mid_16_8_{tag}", ns["ConvBlock"](16, 8, 4), [rnd(2, 16, 6, 10)], tr, weights_seed=13)
+        run_module_case(f"down_16_32_{tag}", ns["DownSample"](16, 32), [rnd(2, 16, 16, 16)], tr, weights_seed=14)
+        run_module_case(f"up_32_16_{tag}", ns["UpSample"](32, 16), [rnd(2, 16, 8, 8), rnd(2, 16, 16, 16)], tr, weights_seed=15)
+    k1 = torch.from_numpy(r.integers(0, 2, size=(2, 64)).astype(np.uint8))
+    run_module_case("attn_32_8x8", ns["Mask2FormerAttention"](32, 32), [rnd(2, 32, 8, 8)], True, keep=k1, weights_seed=16)
+    k2 = torch.from_numpy(r.integers(0, 2, size=(2, 256)).astype(np.uint8))
+    run_module_case("attn_64_16x16", ns["Mask2FormerAttention"](64, 64), [rnd(2, 64, 16, 16)], True, keep=k2, weights_seed=17)
+    k3 = torch.from_numpy(r.integers(0, 2, size=(1, 24 * 8)).astype(np.uint8))
+    run_module_case("attn_128_24x8", ns["Mask2FormerAttention"](128, 128), [rnd(1, 128, 24, 8)], True, keep=k3, weights_seed=18)
+
+
+def unet_case(name, UNet, c_out, B, training, three_head, seed):
+    torch.manual_seed(0)
+    model = UNet(3, c_out, 16) if three_head else UNet(3, c_out)
+    shapes = O.unet_state_shapes(3, c_out, three_head)
+    # the oracle's key/shape table must equal the reference state_dict exactly
+    sd = model.state_dict()
+    assert [k for k, _, _ in shapes] == list(sd.keys()), "state_dict key order mismatch"
+    for k, shp, _ in shapes:
+        assert tuple(sd[k].shape) == tuple(shp), (k, sd[k].shape, shp)
+    params = O.make_params(shapes, seed)
+    model.load_state_dict(params)
+    model.train(training)
+    model.dropout.p = 0.0                      # batch-stat BN, dropout off
+    keeps = O.make_keeps(seed + 1, B)
+    for i in range(6):
+        inject_mask(getattr(model, f"self_attention{i + 1}"), keeps[i])
+    x, labels = O.make_inputs(seed + 2, B, c_out, ignore_frac=0.1 if three_head else 0.0)
+    out = model(x)
+    sem = out[0] if three_head else out
+    loss = F.cross_entropy(sem, labels, ignore_index=255 if three_head else -100)
+    if three_head:
+        # exercise all three outputs in the backward (the reference's own loss ignores the
+        # boundary map, city_instance.py:373-376; a parity test wants its gradients too)
+        loss = loss + 0.5 * out[2].square().mean() + 0.25 * out[1].square().mean()
+    rec = {"loss": np.array(loss.item(), dtype=np.float64), "training": np.array(int(training)),
+           "B": np.array(B), "c_out": np.array(c_out), "seed": np.array(seed)}
+    if training:
+        loss.backward()
+        for k, v in model.named_parameters():
+            rec["gnorm/" + k] = np.array(0.0 if v.grad is None else float(v.grad.double().norm()))
+            rec["ghas/" + k] = np.array(int(v.grad is not None))
+            if v.grad is not None and v.grad.numel() <= 1024:
+                rec["g/" + k] = v.grad.numpy()
+        rec["g_slice/norm.weight"] = model.norm.weight.grad[:, ::16, ::16].numpy()
+        rec["g_slice/initial_conv.conv_block.0.weight"] = model.initial_conv.conv_block[0].weight.grad.numpy()
+        for k, v in model.state_dict().items():
+            if "running" in k and v.numel() <= 256:
+                rec["newstat/" + k] = v.numpy()
+    outs = out if three_head else (out,)
+    for i, o in enumerate(outs):
+        rec[f"out{i}_slice"] = o.detach()[:, :, ::16, ::16].numpy()
+        rec[f"out{i}_sum"] = np.array(float(o.detach().double().sum()))
+        rec[f"out{i}_abssum"] = np.array(float(o.detach().double().abs().sum()))
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **rec)
+    print("wrote", name, "loss", loss.item())
+
+
+def main():
+    torch.set_num_threads(8)
+    ns1 = load_reference(os.path.join(REF, "ade20k/ade_semantic.py"))
+    ns3 = load_reference(os.path.join(REF, "cityscapes/city_instance.py"))
+    module_cases(ns1)
+    unet_case("unet1_c150_b2_train", ns1["UNet"], 150, 2, True, False, 100)
+    unet_case("unet1_c150_b2_eval", ns1["UNet"], 150, 2, False, False, 100)
+    # B=2, not 1: torch 2.10 CPU returns wrong BatchNorm grads at B=1 when grad_out arrives with
+    # channels-last strides (the permuted attention grad); the reference autograd then disagrees with
+    # its own finite differences.  Verified with FD; see DESIGN.md "oracle pinning".
+    unet_case("unet3_c19_b2_train", ns3["UNet"], 19, 2, True, True, 200)
+
+
+if __name__ == "__main__":
+    main()

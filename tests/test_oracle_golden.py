@@ -1,0 +1,151 @@
+"""CPU: pin the oracle (oracle/maskunet_oracle.py) against golden vectors generated from the
+real reference by tests/golden/make_golden.py.  fp32 oracle vs fp32 reference: tolerance 2e-5
+absolute on O(1) values (the fp32-vs-fp64 noise floor of the path is 7e-6..1.9e-5)."""
+import glob
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import maskunet_oracle as O
+
+TOL = 2e-5
+
+
+def _load(golden_dir, name):
+    z = np.load(os.path.join(golden_dir, name + ".npz"))
+    return {k: z[k] for k in z.files}
+
+
+def _params(rec, prefix_to, requires_grad=True):
+    p = {}
+    for k, v in rec.items():
+        if k.startswith("param/"):
+            t = torch.from_numpy(v.copy())
+            if requires_grad and t.dtype.is_floating_point and "running" not in k:
+                t.requires_grad_(True)
+            p[prefix_to + "." + k[len("param/"):]] = t
+    return p
+
+
+def _check(a, b, tol=TOL, what=""):
+    a = a.detach().numpy() if isinstance(a, torch.Tensor) else a
+    scale = max(1.0, float(np.abs(b).max()))
+    err = float(np.abs(a - b).max())
+    assert err <= tol * scale, f"{what}: max abs err {err:.3e} (scale {scale:.2f})"
+
+
+MODULE_CASES = sorted(os.path.basename(p)[:-4] for p in glob.glob(
+    os.path.join(os.path.dirname(__file__), "golden", "*.npz")) if not os.path.basename(p).startswith("unet"))
+
+
+def test_have_module_cases():
+    assert len(MODULE_CASES) >= 13
+
+
+@pytest.mark.parametrize("name", MODULE_CASES)
+def test_module_case(golden_dir, name):
+    rec = _load(golden_dir, name)
+    training = bool(rec["training"])
+    p = _params(rec, "m")
+    ins = [torch.from_numpy(rec[f"in/{i}"].copy()).requires_grad_(True) for i in range(2) if f"in/{i}" in rec]
+    ns = {}
+    if name.startswith("convblock"):
+        out = O.conv_block(ins[0], p, "m", "res" in name, training, ns)
+    elif name.startswith("down"):
+        out = O.downsample(ins[0], p, "m", training, ns)
+    elif name.startswith("up"):
+        out = O.upsample(ins[0], ins[1], p, "m", training, ns)
+    elif name.startswith("attn"):
+        out = O.mask_attention(ins[0], p, "m", torch.from_numpy(rec["keep"]))
+    else:
+        raise AssertionError(name)
+    _check(out, rec["out"], what="out")
+    out.backward(torch.from_numpy(rec["gout"]))
+    for i, t in enumerate(ins):
+        _check(t.grad, rec[f"gin/{i}"], what=f"gin{i}")
+    for k, v in rec.items():
+        if k.startswith("gparam/"):
+            _check(p["m." + k[len("gparam/"):]].grad, v, tol=5e-5, what=k)
+        if k.startswith("newstat/") and training and not name.startswith("attn"):
+            _check(ns["m." + k[len("newstat/"):]], v, what=k)
+
+
+def test_attention_blockwise_equals_materialised(golden_dir):
+    rec = _load(golden_dir, "attn_64_16x16")
+    p = _params(rec, "m", requires_grad=False)
+    x = torch.from_numpy(rec["in/0"])
+    keep = torch.from_numpy(rec["keep"])
+    a = O.mask_attention(x, p, "m", keep)
+    b = O.mask_attention(x, p, "m", keep, q_block=48)
+    _check(b, a.numpy(), tol=1e-6)
+
+
+def test_attention_channel_mismatch_raises(golden_dir):
+    rec = _load(golden_dir, "attn_32_8x8")
+    p = _params(rec, "m", requires_grad=False)
+    with pytest.raises(ValueError, match="Input channel size does not match"):
+        O.mask_attention(torch.zeros(1, 16, 8, 8), p, "m", torch.ones(1, 64, dtype=torch.uint8))
+
+
+def test_upsample_matches_torch():
+    x = torch.randn(2, 3, 5, 7)
+    ref = torch.nn.functional.interpolate(x, scale_factor=2, mode="bilinear", align_corners=True)
+    _check(O.upsample_bilinear2x(x), ref.numpy(), tol=1e-6)
+
+
+def _unet_case(golden_dir, name, three_head):
+    rec = _load(golden_dir, name)
+    B, c_out, seed = int(rec["B"]), int(rec["c_out"]), int(rec["seed"])
+    training = bool(rec["training"])
+    shapes = O.unet_state_shapes(3, c_out, three_head)
+    p = O.make_params(shapes, seed)
+    for k, v in p.items():
+        if v.dtype.is_floating_point and "running" not in k:
+            v.requires_grad_(training)
+    keeps = O.make_keeps(seed + 1, B)
+    x, labels = O.make_inputs(seed + 2, B, c_out, ignore_frac=0.1 if three_head else 0.0)
+    ns = {}
+    out = O.unet_forward(p, x, keeps, training=training, new_stats=ns, three_head=three_head)
+    outs = out if three_head else (out,)
+    for i, o in enumerate(outs):
+        _check(o[:, :, ::16, ::16], rec[f"out{i}_slice"], tol=5e-5, what=f"out{i}")
+        assert abs(float(o.detach().double().sum()) - float(rec[f"out{i}_sum"])) <= 2e-5 * float(rec[f"out{i}_abssum"]) + 1e-3
+    loss = O.pixel_cross_entropy(outs[0], labels, 255 if three_head else -100)
+    if three_head:
+        loss = loss + 0.5 * out[2].square().mean() + 0.25 * out[1].square().mean()
+    assert abs(loss.item() - float(rec["loss"])) <= 2e-5 * max(1.0, abs(float(rec["loss"])))
+    if not training:
+        return
+    loss.backward()
+    # gamma/beta of a BN that feeds straight into another BN (ade_semantic.py:218-219) have an
+    # analytically ~zero gradient: pure rounding noise, so compare with an absolute floor.
+    floor = 1e-6 * max(float(v) for k, v in rec.items() if k.startswith("gnorm/"))
+    for k, v in rec.items():
+        if k.startswith("gnorm/"):
+            key = k[len("gnorm/"):]
+            has = bool(rec["ghas/" + key])
+            g = p[key].grad
+            assert (g is not None) == has, key
+            if has:
+                assert abs(float(g.double().norm()) - float(v)) <= 2e-4 * float(v) + floor, key
+        elif k.startswith("g/"):
+            err = float(np.abs(p[k[2:]].grad.numpy() - v).max())
+            assert err <= 1e-4 * float(np.abs(v).max()) + floor, (k, err)
+        elif k.startswith("newstat/"):
+            _check(ns[k[len("newstat/"):]], v, what=k)
+    _check(p["norm.weight"].grad[:, ::16, ::16], rec["g_slice/norm.weight"], tol=1e-4)
+    _check(p["initial_conv.conv_block.0.weight"].grad, rec["g_slice/initial_conv.conv_block.0.weight"], tol=1e-4)
+
+
+def test_unet1_eval(golden_dir):
+    _unet_case(golden_dir, "unet1_c150_b2_eval", False)
+
+
+def test_unet1_train(golden_dir):
+    _unet_case(golden_dir, "unet1_c150_b2_train", False)
+
+
+def test_unet3_train(golden_dir):
+    _unet_case(golden_dir, "unet3_c19_b2_train", True)
