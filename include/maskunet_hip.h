@@ -1,0 +1,132 @@
+/* maskunet_hip.h -- C ABI of libmaskunet_hip.so (gfx950 / MI355X).
+ *
+ * This is the drop-in boundary for the MaskAttn-UNet forward/backward hot path.  The reference
+ * (Belis0811/MaskUnet) has no FFI of its own: its hot path is a chain of torch aten ops invoked from
+ * nn.Module.forward (code/ade20k/ade_semantic.py:152-314) and their autograd backward (:400).  Each
+ * entry point below replaces one such op group; the reference line it stands for is cited.  The
+ * Python binding that a maintainer would add is the ctypes table in maskunet_amd/_lib.py (shown in
+ * INTEGRATION.md).
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer unless the name ends in _host; the caller owns all memory
+ *     (outputs and workspaces included), nothing is allocated or freed inside, no host sync;
+ *   - `stream` is a hipStream_t passed as void*; all work is enqueued on it (capturable);
+ *   - activations are NHWC rows: a tensor [B,H,W,C] is M = B*H*W rows of C elements with row
+ *     stride `ld` (elements); internal channel counts are multiples of 32 (callers zero-pad);
+ *   - dtype: MU_F32 (0) = fp32 storage + exact-fp32 MFMA, MU_F16 (1) = fp16 storage + fp32 accumulate;
+ *     per-channel parameters, statistics and all parameter gradients are always fp32;
+ *   - return value: 0 on success, <0 on error (MU_ERR_*); no exceptions cross the boundary.
+ */
+#ifndef MASKUNET_HIP_H
+#define MASKUNET_HIP_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MU_OK 0
+#define MU_ERR_ARG (-1)       /* null pointer / non-positive size / unknown enum            */
+#define MU_ERR_SHAPE (-2)     /* shape not supported by the kernels (alignment, channel set) */
+#define MU_ERR_LAUNCH (-3)    /* HIP launch failure                                           */
+#define MU_ERR_WORKSPACE (-4) /* workspace smaller than mu_*_workspace_bytes()                */
+
+#define MU_F32 0
+#define MU_F16 1
+
+#define MU_ACT_NONE 0
+#define MU_ACT_GELU 1 /* exact erf GELU, ade_semantic.py:201,208 */
+#define MU_ACT_RELU 2 /* ade_semantic.py:286                      */
+
+/* library / build identification ("gfx950"); host pointer to a static string */
+const char* mu_version_host(void);
+
+/* ---- layout -------------------------------------------------------------------------------- */
+/* dst[b][c][r] = (dst_dtype) src[b][r][c], b < batch, r < R, c < C.  Replaces x.view(B,C,HW).permute
+ * (ade_semantic.py:168), the `.view(B,C,H,W)` re-interpretation of [B,N,C] (:190) and the
+ * NCHW<->NHWC conversions at the module boundary. */
+int mu_transpose(const void* src, int src_dtype, long src_ld, void* dst, int dst_dtype, long dst_ld, int batch, int R, int C,
+                 void* stream);
+/* elementwise dtype conversion of n elements */
+int mu_cast(const void* src, int src_dtype, void* dst, int dst_dtype, long n, void* stream);
+/* OIHW fp32 parameter -> tap-major compute layout [taps][rows_pad][cols_pad].
+ * mode 0: forward weights (rows=O, cols=I); mode 1: data-gradient weights (taps flipped, rows=I, cols=O). */
+int mu_prep_weight(const float* w_oihw, void* dst, int dtype, int O, int I, int taps, int rows_pad, int cols_pad, int mode,
+                   void* stream);
+
+/* ---- convolution / linear (MFMA implicit GEMM) --------------------------------------------- */
+/* y[p][co] = bias[co] + sum_{tap,ci} x[p+shift(tap)][ci] * w[tap][co][ci]; taps = 9 (3x3, pad 1) or 1.
+ * Replaces nn.Conv2d in ConvBlock (ade_semantic.py:199,202), the 1x1 heads (:284, city_instance.py:243-249)
+ * and nn.Linear query/key/value (:170-172, as one [3C,C] weight).  Called with mode-1 weights it is the
+ * data-gradient of the same layer. */
+int mu_conv_fwd(const void* x, const void* w, const float* bias, void* y, int B, int H, int W, int Cin, int Cout, int taps, long x_ld,
+                long y_ld, int dtype, void* stream);
+/* dw_oihw[o][i][tap] = sum_p dy[p][o] * x[p+shift(tap)][i] for o < cout_valid, i < cin_valid (fp32, OIHW). */
+long mu_conv_wgrad_workspace_bytes(int B, int H, int W, int Cin, int Cout, int taps);
+int mu_conv_wgrad(const void* x, const void* dy, float* dw_oihw, int B, int H, int W, int Cin, int Cout, int taps, int cin_valid,
+                  int cout_valid, long x_ld, long dy_ld, void* workspace, long ws_bytes, int dtype, void* stream);
+/* out[c] = sum_r x[r][c]  (bias gradients) */
+long mu_colsum_workspace_bytes(int C);
+int mu_colsum(const void* x, long M, int C, long ld, float* out, void* workspace, long ws_bytes, int dtype, void* stream);
+
+/* ---- BatchNorm2d (+activation, +residual) --------------------------------------------------- */
+/* nn.BatchNorm2d training statistics (ade_semantic.py:200,204,219,240,285): biased batch variance ->
+ * mean/rstd; running stats updated with the unbiased variance and `momentum` for c < c_valid
+ * (running_* may be NULL). */
+long mu_bn_workspace_bytes(int C);
+int mu_bn_train_stats(const void* x, long M, int C, long ld, float* mean, float* rstd, float* running_mean, float* running_var,
+                      int c_valid, float momentum, float eps, void* workspace, long ws_bytes, int dtype, void* stream);
+/* eval mode: mean/rstd from the running statistics */
+int mu_bn_eval_stats(const float* running_mean, const float* running_var, float eps, float* mean, float* rstd, int C, int c_valid,
+                     void* stream);
+/* y = act( res + (x-mean)*rstd*gamma + beta ); res may be NULL.  ConvBlock's BN+GELU (:200-201), BN (+x, GELU)
+ * (:204,208) and final_layer's BN+ReLU (:285-286). */
+int mu_bn_act_fwd(const void* x, const void* res, void* y, long M, int C, long ld, const float* mean, const float* rstd,
+                  const float* gamma, const float* beta, int act, int dtype, void* stream);
+/* backward of mu_bn_act_fwd: dx (wrt x), dres (wrt res, iff res given), dgamma, dbeta.  training=1 uses the
+ * batch-statistics formula, 0 treats mean/rstd as constants. */
+int mu_bn_act_bwd(const void* x, const void* res, const void* grad_out, void* dx, void* dres, long M, int C, long ld,
+                  const float* mean, const float* rstd, const float* gamma, const float* beta, int act, int training, float* dgamma,
+                  float* dbeta, void* workspace, long ws_bytes, int dtype, void* stream);
+
+/* ---- per-sample LayerNorm with full-shape affine: nn.LayerNorm([64,128,128]) (:281,311) ------ */
+long mu_ln_sample_workspace_bytes(int B);
+int mu_ln_sample_fwd(const void* x, const float* w, const float* b, void* y, float* mean, float* rstd, int B, long L, float eps,
+                     void* workspace, long ws_bytes, int dtype, void* stream);
+int mu_ln_sample_bwd(const void* x, const void* dy, const float* w, const float* mean, const float* rstd, void* dx, float* dw,
+                     float* db, int B, long L, void* workspace, long ws_bytes, int dtype, void* stream);
+
+/* ---- pooling / resampling -------------------------------------------------------------------- */
+/* nn.MaxPool2d(2) (:216); backward recomputes the arg-max (first maximum in scan order) */
+int mu_maxpool2_fwd(const void* x, void* y, int B, int H, int W, int C, int dtype, void* stream);
+int mu_maxpool2_bwd(const void* x, const void* dy, void* dx, int B, int H, int W, int C, int dtype, void* stream);
+/* y = cat([skip, bilinear_x2(x, align_corners=True)], channel)  (:235,250-253); x [B,h,w,Cx], skip [B,2h,2w,Cs] */
+int mu_upcat_fwd(const void* x, const void* skip, void* y, int B, int h, int w, int Cx, int Cs, int dtype, void* stream);
+int mu_upcat_bwd(const void* dy, void* dx, void* dskip, int B, int h, int w, int Cx, int Cs, int dtype, void* stream);
+/* nn.Dropout (:273,304,307): y = x*keep/(1-p); keep from `mask` (uint8, may be NULL) or the (seed,index) generator.
+ * The backward is the same call on the gradient with the same seed/mask. mask_out (may be NULL) receives keep. */
+int mu_dropout(const void* x, void* y, long n, float p, unsigned long long seed, const unsigned char* mask, unsigned char* mask_out,
+               int dtype, void* stream);
+
+/* out = a + b over n elements (joins the residual and projection gradients of the attention block, :187) */
+int mu_add(const void* a, const void* b, void* out, long n, int dtype, void* stream);
+
+/* ---- masked attention (flash-style) ---------------------------------------------------------- */
+/* Mask2FormerAttention core (ade_semantic.py:174-188) on projected qkv [B,N,3C]:
+ *   out = LayerNorm_C( softmax_keys( q k^T / sqrt(C) + keymask ) v + x ), token-major [B,N,C].
+ * The {0,-inf} key mask is given as the compacted list of kept keys: kidx[b][0..kcnt[b]) (int32, row
+ * stride nkmax).  Also returns what the backward needs: oattn (PV/l, pre-residual), lse2 (log2-domain
+ * log-sum-exp of the scaled scores), LayerNorm mean/rstd per token.  C in {32,64,128,256}. */
+int mu_attn_fwd(const void* qkv, const void* x, const int* kidx, const int* kcnt, const float* gamma, const float* beta, void* out,
+                void* oattn, float* lse2, float* ln_mean, float* ln_rstd, int B, int N, int C, int nkmax, float eps, int dtype,
+                void* stream);
+/* backward: grad_out [B,N,C] (wrt `out`) -> dY (grad wrt the pre-LayerNorm sum, i.e. the residual branch),
+ * dqkv [B,N,3C] (masked keys get exact zeros), dgamma, dbeta.  delta [B,N] is scratch output. */
+long mu_attn_bwd_workspace_bytes(int C);
+int mu_attn_bwd(const void* qkv, const void* x, const void* oattn, const void* grad_out, const int* kidx, const int* kcnt,
+                const float* lse2, const float* ln_mean, const float* ln_rstd, const float* gamma, void* dY, float* delta, void* dqkv,
+                float* dgamma, float* dbeta, int B, int N, int C, int nkmax, void* workspace, long ws_bytes, int dtype, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MASKUNET_HIP_H */

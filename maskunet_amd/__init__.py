@@ -1,0 +1,13 @@
+"""maskunet_amd -- MI355X-native (gfx950) MaskAttn-UNet forward/backward path.
+
+Drop-in for the model classes of Belis0811/MaskUnet (code/ade20k/ade_semantic.py:152-314,
+code/cityscapes/city_instance.py:216-276): same names, signatures and state_dict keys, running on
+hand-written HIP kernels through the C ABI in include/maskunet_hip.h.
+"""
+from .modules import (ConvBlock, DoubleConv, Down, DownSample, InstanceUNet, Mask2FormerAttention, MaskAttention, OutConv,
+                      UNet, Up, UpSample, set_default_compute_dtype)
+from .dp import DataParallel, shard_batch
+
+__all__ = ["ConvBlock", "DownSample", "UpSample", "Mask2FormerAttention", "UNet", "InstanceUNet", "DoubleConv", "Down", "Up",
+           "MaskAttention", "OutConv", "set_default_compute_dtype", "DataParallel", "shard_batch"]
+__version__ = "0.1.0"

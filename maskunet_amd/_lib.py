@@ -1,0 +1,114 @@
+"""ctypes binding of libmaskunet_hip.so (C ABI declared in include/maskunet_hip.h).
+
+There is deliberately NO fallback: if the shared library is missing or a call fails, the product
+path raises.  Build it with ``python -c "import __graft_entry__ as g; g.build()"`` or
+``make -C maskunet_amd/csrc``.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from ctypes import c_char_p, c_float, c_int, c_long, c_ulonglong, c_void_p
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmaskunet_hip.so")
+
+MU_F32, MU_F16 = 0, 1
+ACT_NONE, ACT_GELU, ACT_RELU = 0, 1, 2
+_ERR = {-1: "MU_ERR_ARG", -2: "MU_ERR_SHAPE", -3: "MU_ERR_LAUNCH", -4: "MU_ERR_WORKSPACE"}
+
+# name -> (restype, argtypes); must list EVERY symbol of include/maskunet_hip.h (tests/test_abi.py checks)
+P, I, L, F = c_void_p, c_int, c_long, c_float
+SIGNATURES = {
+    "mu_version_host": (c_char_p, []),
+    "mu_transpose": (I, [P, I, L, P, I, L, I, I, I, P]),
+    "mu_cast": (I, [P, I, P, I, L, P]),
+    "mu_prep_weight": (I, [P, P, I, I, I, I, I, I, I, P]),
+    "mu_conv_fwd": (I, [P, P, P, P, I, I, I, I, I, I, L, L, I, P]),
+    "mu_conv_wgrad_workspace_bytes": (L, [I, I, I, I, I, I]),
+    "mu_conv_wgrad": (I, [P, P, P, I, I, I, I, I, I, I, I, L, L, P, L, I, P]),
+    "mu_colsum_workspace_bytes": (L, [I]),
+    "mu_colsum": (I, [P, L, I, L, P, P, L, I, P]),
+    "mu_bn_workspace_bytes": (L, [I]),
+    "mu_bn_train_stats": (I, [P, L, I, L, P, P, P, P, I, F, F, P, L, I, P]),
+    "mu_bn_eval_stats": (I, [P, P, F, P, P, I, I, P]),
+    "mu_bn_act_fwd": (I, [P, P, P, L, I, L, P, P, P, P, I, I, P]),
+    "mu_bn_act_bwd": (I, [P, P, P, P, P, L, I, L, P, P, P, P, I, I, P, P, P, L, I, P]),
+    "mu_ln_sample_workspace_bytes": (L, [I]),
+    "mu_ln_sample_fwd": (I, [P, P, P, P, P, P, I, L, F, P, L, I, P]),
+    "mu_ln_sample_bwd": (I, [P, P, P, P, P, P, P, P, I, L, P, L, I, P]),
+    "mu_maxpool2_fwd": (I, [P, P, I, I, I, I, I, P]),
+    "mu_maxpool2_bwd": (I, [P, P, P, I, I, I, I, I, P]),
+    "mu_upcat_fwd": (I, [P, P, P, I, I, I, I, I, I, P]),
+    "mu_upcat_bwd": (I, [P, P, P, I, I, I, I, I, I, P]),
+    "mu_dropout": (I, [P, P, L, F, c_ulonglong, P, P, I, P]),
+    "mu_add": (I, [P, P, P, L, I, P]),
+    "mu_attn_fwd": (I, [P, P, P, P, P, P, P, P, P, P, P, I, I, I, I, F, I, P]),
+    "mu_attn_bwd_workspace_bytes": (L, [I]),
+    "mu_attn_bwd": (I, [P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, I, I, I, I, P, L, I, P]),
+}
+
+_lib = None
+
+
+def load() -> ctypes.CDLL:
+    """Load the shared library (once).  Raises if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"maskunet_amd: HIP library not found at {LIB_PATH}. It must be built (hipcc --offload-arch=gfx950): "
+            "run `make -C maskunet_amd/csrc` or `python -c 'import __graft_entry__ as g; g.build()'`. "
+            "There is no CPU fallback.")
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)          # AttributeError if a declared symbol is not exported
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def dt(t_or_dtype) -> int:
+    d = t_or_dtype.dtype if isinstance(t_or_dtype, torch.Tensor) else t_or_dtype
+    if d == torch.float32:
+        return MU_F32
+    if d == torch.float16:
+        return MU_F16
+    raise TypeError(f"maskunet_amd supports float32 and float16 compute, got {d}")
+
+
+def ptr(t):
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise RuntimeError("maskunet_amd: tensors must live on the GPU (the HIP path has no CPU fallback)")
+    return t.data_ptr()
+
+
+def stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def call(name: str, *args):
+    """Invoke an int-returning entry point and raise on a non-zero status."""
+    rc = getattr(load(), name)(*args)
+    if rc != 0:
+        raise RuntimeError(f"maskunet_amd: {name} failed with {_ERR.get(rc, rc)}")
+
+
+_workspaces = {}
+
+
+def workspace(nbytes: int, device) -> torch.Tensor:
+    """Grow-only scratch buffer per device.  Kernels that use it are stream-ordered, and every
+    consumer finishes with it before the next launch on the same stream touches it."""
+    key = (device.type, device.index)
+    ws = _workspaces.get(key)
+    if ws is None or ws.numel() < nbytes:
+        ws = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)
+        _workspaces[key] = ws
+    return ws

@@ -1,0 +1,635 @@
+// Masked single-head attention, flash-style (no N x N tensor), forward and backward.
+// Reference op replaced: Mask2FormerAttention.forward (ade_semantic.py:163-190):
+//   scores = QK^T/sqrt(C) + {0,-inf} key mask; softmax over keys; PV + x; LayerNorm([C]).
+// The additive key mask drops whole keys for every query, so the kernels iterate only over
+// the KEPT keys (compacted index list kidx[b][0..kcnt[b])): exp(-inf) = 0 exactly, hence
+// softmax over the kept keys is the reference's softmax; ~half the FLOPs disappear.
+//
+// Layouts: qkv [B,N,3C] (q | k | v per token), x/out/oattn/dY [B,N,C], all T (fp16 or fp32);
+// lse2/delta/ln_mean/ln_rstd fp32 [B,N].  lse2 is in log2 units of the scaled scores.
+//
+// MFMA: 16x16 tiles.  "row products" contract over C with both operands read as 16-byte row
+// pieces; "accumulator-operand products" feed a 16x16 accumulator tile (rows on registers,
+// columns on lanes) straight back as the B operand of the next MFMA, the other operand coming
+// from a transposing LDS read (fp16: ds_read_b64_tr_b16) or plain column reads (fp32).
+#include "common.h"
+#include "../../include/maskunet_hip.h"
+
+typedef __fp16 fp16x4v __attribute__((__vector_size__(4 * sizeof(__fp16))));
+#define LDS_TR16(ptr) __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) fp16x4v*)(ptr))
+
+template <typename T> struct AT;
+template <> struct AT<h16> {
+    static constexpr int VN = 8, KR = 32;
+    using Frag = h16x8;
+    struct AccA { h16x8 v; };
+    static __device__ __forceinline__ void mma_row(const Frag& a, const Frag& b, f32x4& c) {
+        c = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
+    }
+    // A operand [m = tile column col0+r16][k-slot j <-> tile row 4g+j, 16+4g+j]
+    static __device__ __forceinline__ AccA ld_acc_a(const h16* tile, int stride, int col0, int g, int r16) {
+        const int q = r16 >> 2, pc = r16 & 3;
+        auto lo = LDS_TR16(tile + (4 * g + q) * stride + col0 + 4 * pc);
+        auto hi = LDS_TR16(tile + (16 + 4 * g + q) * stride + col0 + 4 * pc);
+        AccA a;
+        a.v = (h16x8){(h16)lo[0], (h16)lo[1], (h16)lo[2], (h16)lo[3], (h16)hi[0], (h16)hi[1], (h16)hi[2], (h16)hi[3]};
+        return a;
+    }
+    static __device__ __forceinline__ void mma_acc(const AccA& a, const f32x4& p0, const f32x4& p1, f32x4& c) {
+        h16x8 b = {(h16)p0[0], (h16)p0[1], (h16)p0[2], (h16)p0[3], (h16)p1[0], (h16)p1[1], (h16)p1[2], (h16)p1[3]};
+        c = __builtin_amdgcn_mfma_f32_16x16x32_f16(a.v, b, c, 0, 0, 0);
+    }
+};
+template <> struct AT<float> {
+    static constexpr int VN = 4, KR = 16;
+    using Frag = f32x4;
+    struct AccA { float v[8]; };
+    static __device__ __forceinline__ void mma_row(const Frag& a, const Frag& b, f32x4& c) {
+#pragma unroll
+        for (int s = 0; s < 4; ++s) c = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s], b[s], c, 0, 0, 0);
+    }
+    static __device__ __forceinline__ AccA ld_acc_a(const float* tile, int stride, int col0, int g, int r16) {
+        AccA a;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            a.v[r] = tile[(4 * g + r) * stride + col0 + r16];
+            a.v[4 + r] = tile[(16 + 4 * g + r) * stride + col0 + r16];
+        }
+        return a;
+    }
+    static __device__ __forceinline__ void mma_acc(const AccA& a, const f32x4& p0, const f32x4& p1, f32x4& c) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) c = __builtin_amdgcn_mfma_f32_16x16x4f32(a.v[r], p0[r], c, 0, 0, 0);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) c = __builtin_amdgcn_mfma_f32_16x16x4f32(a.v[4 + r], p1[r], c, 0, 0, 0);
+    }
+};
+
+template <typename T> __device__ __forceinline__ typename AT<T>::Frag ld16(const T* p) {
+    return *reinterpret_cast<const typename AT<T>::Frag*>(p);
+}
+template <typename T> __device__ __forceinline__ typename AT<T>::Frag zero_frag() {
+    typename AT<T>::Frag f;
+#pragma unroll
+    for (int i = 0; i < AT<T>::VN; ++i) f[i] = (T)0;
+    return f;
+}
+__device__ __forceinline__ float grp_max(float v) { v = fmaxf(v, __shfl_xor(v, 16)); return fmaxf(v, __shfl_xor(v, 32)); }
+__device__ __forceinline__ float grp_sum(float v) { v += __shfl_xor(v, 16); return v + __shfl_xor(v, 32); }
+
+template <typename T> __device__ __forceinline__ void store4(T* p, const float v[4]);
+template <> __device__ __forceinline__ void store4<h16>(h16* p, const float v[4]) {
+    h16x4 o = {(h16)v[0], (h16)v[1], (h16)v[2], (h16)v[3]};
+    *reinterpret_cast<h16x4*>(p) = o;
+}
+template <> __device__ __forceinline__ void store4<float>(float* p, const float v[4]) {
+    *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
+}
+template <typename T> __device__ __forceinline__ void load4(const T* p, float v[4]);
+template <> __device__ __forceinline__ void load4<h16>(const h16* p, float v[4]) {
+    h16x4 o = *reinterpret_cast<const h16x4*>(p);
+    v[0] = (float)o[0]; v[1] = (float)o[1]; v[2] = (float)o[2]; v[3] = (float)o[3];
+}
+template <> __device__ __forceinline__ void load4<float>(const float* p, float v[4]) {
+    float4 o = *reinterpret_cast<const float4*>(p);
+    v[0] = o.x; v[1] = o.y; v[2] = o.z; v[3] = o.w;
+}
+
+#define ATT_KT 32      // keys (or queries) staged per LDS tile
+template <typename T, int D> struct TileGeom {
+    static constexpr int PAD = 16 / sizeof(T);    // one 16-byte chunk of padding per row
+    static constexpr int S = D + PAD;
+};
+
+// stage ATT_KT gathered rows of two row-major sources into LDS (zero rows past `nvalid`)
+template <typename T, int D>
+__device__ __forceinline__ void stage_rows(T* dstA, T* dstB, const T* srcA, const T* srcB, long ldA, long ldB, const int* idx,
+                                           int j0, int nvalid, int tid) {
+    constexpr int VN = AT<T>::VN, CPR = D / VN, S = TileGeom<T, D>::S;
+    for (int i = tid; i < ATT_KT * CPR; i += 256) {
+        const int row = i / CPR, c = (i % CPR) * VN;
+        const int j = j0 + row;
+        typename AT<T>::Frag a = zero_frag<T>(), b = zero_frag<T>();
+        if (j < nvalid) {
+            const long r = idx ? idx[j] : j;
+            a = ld16<T>(srcA + r * ldA + c);
+            b = ld16<T>(srcB + r * ldB + c);
+        }
+        *reinterpret_cast<typename AT<T>::Frag*>(dstA + row * S + c) = a;
+        *reinterpret_cast<typename AT<T>::Frag*>(dstB + row * S + c) = b;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// forward: block = 128 queries of one image (4 waves x 32 queries), loop over kept-key tiles.
+// epilogue fuses 1/l, the residual add and LayerNorm([C]) and stores token-major.
+// ------------------------------------------------------------------------------------------
+template <typename T, int D>
+__global__ __launch_bounds__(256) void attn_fwd_kernel(const T* __restrict__ qkv, const T* __restrict__ x, const int* __restrict__ kidx,
+                                                       const int* __restrict__ kcnt, const float* __restrict__ gamma,
+                                                       const float* __restrict__ beta, T* __restrict__ out, T* __restrict__ oattn,
+                                                       float* __restrict__ lse2, float* __restrict__ ln_mean, float* __restrict__ ln_rstd,
+                                                       int N, int nkmax, float scale_log2, float eps) {
+    using A = AT<T>;
+    using Frag = typename A::Frag;
+    constexpr int VN = A::VN, KR = A::KR, NKS = D / KR, NDT = D / 16, S = TileGeom<T, D>::S;
+    __shared__ __attribute__((aligned(16))) T Ks[ATT_KT * S];
+    __shared__ __attribute__((aligned(16))) T Vs[ATT_KT * S];
+
+    const int b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r16 = lane & 15, g = lane >> 4;
+    const int q0 = blockIdx.x * 128 + wave * 32;
+    const T* qkv_b = qkv + (long)b * N * 3 * D;
+    const int Nk = kcnt[b];
+    const int* kidx_b = kidx + (long)b * nkmax;
+
+    Frag qf[2][NKS];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        int qrow = q0 + t * 16 + r16;
+        if (qrow > N - 1) qrow = N - 1;
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks) qf[t][ks] = ld16<T>(qkv_b + (long)qrow * 3 * D + ks * KR + g * VN);
+    }
+    f32x4 o[NDT][2];
+#pragma unroll
+    for (int dt = 0; dt < NDT; ++dt)
+#pragma unroll
+        for (int t = 0; t < 2; ++t) o[dt][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    float m[2] = {-INFINITY, -INFINITY}, l[2] = {0.f, 0.f};
+
+    for (int j0 = 0; j0 < Nk; j0 += ATT_KT) {
+        __syncthreads();
+        stage_rows<T, D>(Ks, Vs, qkv_b + D, qkv_b + 2 * D, 3 * D, 3 * D, kidx_b, j0, Nk, tid);
+        __syncthreads();
+        f32x4 s[2][2];
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+            for (int t = 0; t < 2; ++t) s[kt][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks)
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt) {
+                Frag a = ld16<T>(Ks + (kt * 16 + r16) * S + ks * KR + g * VN);
+#pragma unroll
+                for (int t = 0; t < 2; ++t) A::mma_row(a, qf[t][ks], s[kt][t]);
+            }
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            float mx = -INFINITY;
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const bool ok = j0 + kt * 16 + 4 * g + r < Nk;
+                    const float v = ok ? s[kt][t][r] * scale_log2 : -INFINITY;
+                    s[kt][t][r] = v;
+                    mx = fmaxf(mx, v);
+                }
+            mx = grp_max(mx);
+            const float m_new = fmaxf(m[t], mx);
+            const float alpha = exp2f(m[t] - m_new);
+            m[t] = m_new;
+            float psum = 0.f;
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float p = exp2f(s[kt][t][r] - m_new);
+                    s[kt][t][r] = p;
+                    psum += p;
+                }
+            l[t] = l[t] * alpha + psum;
+#pragma unroll
+            for (int dt = 0; dt < NDT; ++dt) o[dt][t] *= alpha;
+        }
+#pragma unroll
+        for (int dt = 0; dt < NDT; ++dt) {
+            typename A::AccA va = A::ld_acc_a(Vs, S, dt * 16, g, r16);
+#pragma unroll
+            for (int t = 0; t < 2; ++t) A::mma_acc(va, s[0][t], s[1][t], o[dt][t]);
+        }
+    }
+
+    // epilogue: lane holds channels dt*16 + 4g + r of query (t, r16)
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        const float ltot = grp_sum(l[t]);
+        const float inv = 1.0f / ltot;
+        const int qrow = q0 + t * 16 + r16;
+        const bool valid = qrow < N;
+        const long tok = (long)b * N + (valid ? qrow : 0);
+        float y[NDT][4];
+        float sum = 0.f;
+#pragma unroll
+        for (int dt = 0; dt < NDT; ++dt) {
+            float xr[4] = {0.f, 0.f, 0.f, 0.f};
+            if (valid) load4<T>(x + tok * D + dt * 16 + 4 * g, xr);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                o[dt][t][r] *= inv;
+                y[dt][r] = o[dt][t][r] + xr[r];
+                sum += y[dt][r];
+            }
+        }
+        const float mean = grp_sum(sum) * (1.0f / D);
+        float sq = 0.f;
+#pragma unroll
+        for (int dt = 0; dt < NDT; ++dt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { const float d = y[dt][r] - mean; sq += d * d; }
+        const float rstd = rsqrtf(grp_sum(sq) * (1.0f / D) + eps);
+        if (valid) {
+#pragma unroll
+            for (int dt = 0; dt < NDT; ++dt) {
+                const int c = dt * 16 + 4 * g;
+                float ov[4], av[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    ov[r] = (y[dt][r] - mean) * rstd * gamma[c + r] + beta[c + r];
+                    av[r] = o[dt][t][r];
+                }
+                store4<T>(out + tok * D + c, ov);
+                store4<T>(oattn + tok * D + c, av);
+            }
+            if (g == 0) {
+                lse2[tok] = m[t] + log2f(ltot);
+                ln_mean[tok] = mean;
+                ln_rstd[tok] = rstd;
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// backward prepass: LayerNorm backward per token + delta = rowsum(dY * O) + dgamma/dbeta partials
+//   y = O + x; xhat = (y-mean)*rstd; dY = rstd*(g*gamma - mean_c(g*gamma) - xhat*mean_c(g*gamma*xhat))
+// one row is handled by C/VN adjacent lanes.
+// ------------------------------------------------------------------------------------------
+template <typename T, int D>
+__global__ __launch_bounds__(256) void attn_ln_bwd_kernel(const T* __restrict__ gout, const T* __restrict__ oattn, const T* __restrict__ x,
+                                                          const float* __restrict__ ln_mean, const float* __restrict__ ln_rstd,
+                                                          const float* __restrict__ gamma, T* __restrict__ dY, float* __restrict__ delta,
+                                                          double* __restrict__ part, long rows) {
+    constexpr int VN = AT<T>::VN, LPR = D / VN, RPI = 256 / LPR;     // lanes per row, rows per block-iteration
+    const int tid = threadIdx.x;
+    const int lc = tid % LPR, lr = tid / LPR;
+    const int c = lc * VN;
+    float ga[VN], dga[VN], dbe[VN];
+#pragma unroll
+    for (int i = 0; i < VN; ++i) { ga[i] = gamma[c + i]; dga[i] = 0.f; dbe[i] = 0.f; }
+    const long rows_per_blk = (rows + gridDim.x - 1) / gridDim.x;
+    const long r0 = (long)blockIdx.x * rows_per_blk, r1 = r0 + rows_per_blk < rows ? r0 + rows_per_blk : rows;
+    for (long rb = r0; rb < r1; rb += RPI) {
+        const long r = rb + lr;
+        const bool ok = r < r1;
+        const long rr = ok ? r : r0;
+        Vec16<T> gv, ov, xv, dv;
+        gv.load(gout + rr * D + c); ov.load(oattn + rr * D + c); xv.load(x + rr * D + c);
+        const float mu = ln_mean[rr], rs = ln_rstd[rr];
+        float xh[VN], gg[VN], a = 0.f, bsum = 0.f;
+#pragma unroll
+        for (int i = 0; i < VN; ++i) {
+            xh[i] = (ov.get(i) + xv.get(i) - mu) * rs;
+            gg[i] = gv.get(i) * ga[i];
+            a += gg[i];
+            bsum += gg[i] * xh[i];
+        }
+#pragma unroll
+        for (int o = 1; o < LPR; o <<= 1) { a += __shfl_xor(a, o); bsum += __shfl_xor(bsum, o); }
+        a *= (1.0f / D); bsum *= (1.0f / D);
+        float dl = 0.f;
+#pragma unroll
+        for (int i = 0; i < VN; ++i) {
+            const float d = rs * (gg[i] - a - xh[i] * bsum);
+            dv.set(i, d);
+            dl += dv.get(i) * ov.get(i);
+            if (ok) { dga[i] += gv.get(i) * xh[i]; dbe[i] += gv.get(i); }
+        }
+#pragma unroll
+        for (int o = 1; o < LPR; o <<= 1) dl += __shfl_xor(dl, o);
+        if (ok) {
+            dv.store(dY + r * D + c);
+            if (lc == 0) delta[r] = dl;
+        }
+    }
+    // column partials: reduce the RPI row-lanes of this block through LDS
+    __shared__ float sh[256 * 2 * 8];
+#pragma unroll
+    for (int i = 0; i < VN; ++i) { sh[(tid * VN + i) * 2] = dga[i]; sh[(tid * VN + i) * 2 + 1] = dbe[i]; }
+    __syncthreads();
+    for (int cc = tid; cc < D; cc += 256) {
+        double sa = 0.0, sb = 0.0;
+        const int lcc = cc / VN, ii = cc % VN;
+        for (int k = 0; k < RPI; ++k) {
+            const int t = k * LPR + lcc;
+            sa += (double)sh[(t * VN + ii) * 2];
+            sb += (double)sh[(t * VN + ii) * 2 + 1];
+        }
+        part[((long)blockIdx.x * D + cc) * 2] = sa;
+        part[((long)blockIdx.x * D + cc) * 2 + 1] = sb;
+    }
+}
+
+__global__ void attn_ln_bwd_final_kernel(const double* __restrict__ part, int nblk, int D, float* __restrict__ dgamma, float* __restrict__ dbeta) {
+    int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= D) return;
+    double a = 0.0, b = 0.0;
+    for (int k = 0; k < nblk; ++k) { a += part[((long)k * D + c) * 2]; b += part[((long)k * D + c) * 2 + 1]; }
+    dgamma[c] = (float)a;
+    dbeta[c] = (float)b;
+}
+
+// ------------------------------------------------------------------------------------------
+// backward dQ: same sweep as the forward.  S^T = K Q^T, dP^T = V dO^T, dS^T = P^T o (dP^T - delta) * scale,
+// dQ^T += K^T dS^T.
+// ------------------------------------------------------------------------------------------
+template <typename T, int D>
+__global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const T* __restrict__ qkv, const T* __restrict__ dY, const int* __restrict__ kidx,
+                                                          const int* __restrict__ kcnt, const float* __restrict__ lse2,
+                                                          const float* __restrict__ delta, T* __restrict__ dqkv, int N, int nkmax,
+                                                          float scale, float scale_log2) {
+    using A = AT<T>;
+    using Frag = typename A::Frag;
+    constexpr int VN = A::VN, KR = A::KR, NKS = D / KR, NDT = D / 16, S = TileGeom<T, D>::S;
+    __shared__ __attribute__((aligned(16))) T Ks[ATT_KT * S];
+    __shared__ __attribute__((aligned(16))) T Vs[ATT_KT * S];
+
+    const int b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r16 = lane & 15, g = lane >> 4;
+    const int q0 = blockIdx.x * 128 + wave * 32;
+    const T* qkv_b = qkv + (long)b * N * 3 * D;
+    const int Nk = kcnt[b];
+    const int* kidx_b = kidx + (long)b * nkmax;
+
+    Frag qf[2][NKS], dof[2][NKS];
+    float lse_q[2], del_q[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        int qrow = q0 + t * 16 + r16;
+        if (qrow > N - 1) qrow = N - 1;
+        const long tok = (long)b * N + qrow;
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks) {
+            qf[t][ks] = ld16<T>(qkv_b + (long)qrow * 3 * D + ks * KR + g * VN);
+            dof[t][ks] = ld16<T>(dY + tok * D + ks * KR + g * VN);
+        }
+        lse_q[t] = lse2[tok];
+        del_q[t] = delta[tok];
+    }
+    f32x4 dq[NDT][2];
+#pragma unroll
+    for (int dt = 0; dt < NDT; ++dt)
+#pragma unroll
+        for (int t = 0; t < 2; ++t) dq[dt][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    for (int j0 = 0; j0 < Nk; j0 += ATT_KT) {
+        __syncthreads();
+        stage_rows<T, D>(Ks, Vs, qkv_b + D, qkv_b + 2 * D, 3 * D, 3 * D, kidx_b, j0, Nk, tid);
+        __syncthreads();
+        f32x4 s[2][2], dp[2][2];
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+            for (int t = 0; t < 2; ++t) { s[kt][t] = (f32x4){0.f, 0.f, 0.f, 0.f}; dp[kt][t] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks)
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt) {
+                Frag ka = ld16<T>(Ks + (kt * 16 + r16) * S + ks * KR + g * VN);
+                Frag va = ld16<T>(Vs + (kt * 16 + r16) * S + ks * KR + g * VN);
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    A::mma_row(ka, qf[t][ks], s[kt][t]);
+                    A::mma_row(va, dof[t][ks], dp[kt][t]);
+                }
+            }
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const bool ok = j0 + kt * 16 + 4 * g + r < Nk;
+                    const float p = ok ? exp2f(s[kt][t][r] * scale_log2 - lse_q[t]) : 0.f;
+                    s[kt][t][r] = p * (dp[kt][t][r] - del_q[t]) * scale;
+                }
+#pragma unroll
+        for (int dt = 0; dt < NDT; ++dt) {
+            typename A::AccA ka = A::ld_acc_a(Ks, S, dt * 16, g, r16);
+#pragma unroll
+            for (int t = 0; t < 2; ++t) A::mma_acc(ka, s[0][t], s[1][t], dq[dt][t]);
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        const int qrow = q0 + t * 16 + r16;
+        if (qrow >= N) continue;
+        T* dst = dqkv + ((long)b * N + qrow) * 3 * D;
+#pragma unroll
+        for (int dt = 0; dt < NDT; ++dt) {
+            float v[4] = {dq[dt][t][0], dq[dt][t][1], dq[dt][t][2], dq[dt][t][3]};
+            store4<T>(dst + dt * 16 + 4 * g, v);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// backward dK/dV: a wave owns NKT*16 kept keys (K,V fragments in registers, dK^T/dV^T accumulators),
+// the block sweeps all queries in LDS tiles of 32.
+//   S = Q K^T, dP = dO V^T (rows = queries), P = exp2(S*c - lse2), dS = P o (dP - delta) * scale,
+//   dV^T += dO^T P, dK^T += Q^T dS.
+// ------------------------------------------------------------------------------------------
+template <typename T, int D, int NKT>
+__global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const T* __restrict__ qkv, const T* __restrict__ dY, const int* __restrict__ kidx,
+                                                           const int* __restrict__ kcnt, const float* __restrict__ lse2,
+                                                           const float* __restrict__ delta, T* __restrict__ dqkv, int N, int nkmax,
+                                                           float scale, float scale_log2) {
+    using A = AT<T>;
+    using Frag = typename A::Frag;
+    constexpr int VN = A::VN, KR = A::KR, NKS = D / KR, NDT = D / 16, S = TileGeom<T, D>::S;
+    __shared__ __attribute__((aligned(16))) T Qs[ATT_KT * S];
+    __shared__ __attribute__((aligned(16))) T Os[ATT_KT * S];
+    __shared__ float lse_s[ATT_KT], del_s[ATT_KT];
+
+    const int b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r16 = lane & 15, g = lane >> 4;
+    const int Nk = kcnt[b];
+    const int kb0 = blockIdx.x * (4 * NKT * 16);
+    if (kb0 >= Nk) return;                       // uniform per block
+    const int* kidx_b = kidx + (long)b * nkmax;
+    const T* qkv_b = qkv + (long)b * N * 3 * D;
+
+    Frag kf[NKT][NKS], vf[NKT][NKS];
+    int keyrow[NKT];
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt) {
+        const int j = kb0 + (wave * NKT + kt) * 16 + r16;
+        keyrow[kt] = j < Nk ? kidx_b[j] : -1;
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks) {
+            if (keyrow[kt] >= 0) {
+                kf[kt][ks] = ld16<T>(qkv_b + (long)keyrow[kt] * 3 * D + D + ks * KR + g * VN);
+                vf[kt][ks] = ld16<T>(qkv_b + (long)keyrow[kt] * 3 * D + 2 * D + ks * KR + g * VN);
+            } else {
+                kf[kt][ks] = zero_frag<T>();
+                vf[kt][ks] = zero_frag<T>();
+            }
+        }
+    }
+    f32x4 dk[NDT][NKT], dv[NDT][NKT];
+#pragma unroll
+    for (int dt = 0; dt < NDT; ++dt)
+#pragma unroll
+        for (int kt = 0; kt < NKT; ++kt) { dk[dt][kt] = (f32x4){0.f, 0.f, 0.f, 0.f}; dv[dt][kt] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+
+    for (int q0 = 0; q0 < N; q0 += ATT_KT) {
+        __syncthreads();
+        stage_rows<T, D>(Qs, Os, qkv_b, dY + (long)b * N * D, 3 * D, D, nullptr, q0, N, tid);
+        if (tid < ATT_KT) {
+            const int q = q0 + tid;
+            lse_s[tid] = q < N ? lse2[(long)b * N + q] : INFINITY;     // exp2(-inf) = 0 for padded queries
+            del_s[tid] = q < N ? delta[(long)b * N + q] : 0.f;
+        }
+        __syncthreads();
+        f32x4 s[2][NKT], dp[2][NKT];
+#pragma unroll
+        for (int qt = 0; qt < 2; ++qt)
+#pragma unroll
+            for (int kt = 0; kt < NKT; ++kt) { s[qt][kt] = (f32x4){0.f, 0.f, 0.f, 0.f}; dp[qt][kt] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks)
+#pragma unroll
+            for (int qt = 0; qt < 2; ++qt) {
+                Frag qa = ld16<T>(Qs + (qt * 16 + r16) * S + ks * KR + g * VN);
+                Frag oa = ld16<T>(Os + (qt * 16 + r16) * S + ks * KR + g * VN);
+#pragma unroll
+                for (int kt = 0; kt < NKT; ++kt) {
+                    A::mma_row(qa, kf[kt][ks], s[qt][kt]);
+                    A::mma_row(oa, vf[kt][ks], dp[qt][kt]);
+                }
+            }
+        // rows = queries qt*16 + 4g + r, column = this lane's key
+#pragma unroll
+        for (int qt = 0; qt < 2; ++qt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float ls = lse_s[qt * 16 + 4 * g + r], de = del_s[qt * 16 + 4 * g + r];
+#pragma unroll
+                for (int kt = 0; kt < NKT; ++kt) {
+                    const float p = exp2f(s[qt][kt][r] * scale_log2 - ls);
+                    s[qt][kt][r] = p;
+                    dp[qt][kt][r] = p * (dp[qt][kt][r] - de) * scale;
+                }
+            }
+#pragma unroll
+        for (int dt = 0; dt < NDT; ++dt) {
+            typename A::AccA oa = A::ld_acc_a(Os, S, dt * 16, g, r16);
+            typename A::AccA qa = A::ld_acc_a(Qs, S, dt * 16, g, r16);
+#pragma unroll
+            for (int kt = 0; kt < NKT; ++kt) {
+                A::mma_acc(oa, s[0][kt], s[1][kt], dv[dt][kt]);
+                A::mma_acc(qa, dp[0][kt], dp[1][kt], dk[dt][kt]);
+            }
+        }
+    }
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt) {
+        if (keyrow[kt] < 0) continue;
+        T* dst = dqkv + ((long)b * N + keyrow[kt]) * 3 * D;
+#pragma unroll
+        for (int dt = 0; dt < NDT; ++dt) {
+            float kv[4] = {dk[dt][kt][0], dk[dt][kt][1], dk[dt][kt][2], dk[dt][kt][3]};
+            float vv[4] = {dv[dt][kt][0], dv[dt][kt][1], dv[dt][kt][2], dv[dt][kt][3]};
+            store4<T>(dst + D + dt * 16 + 4 * g, kv);
+            store4<T>(dst + 2 * D + dt * 16 + 4 * g, vv);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// host entry points
+// ------------------------------------------------------------------------------------------
+template <typename T>
+static int attn_fwd_t(const T* qkv, const T* x, const int* kidx, const int* kcnt, const float* gamma, const float* beta, T* out,
+                      T* oattn, float* lse2, float* mean, float* rstd, int B, int N, int C, int nkmax, float eps, hipStream_t st) {
+    dim3 grid(mu_cdiv(N, 128), B);
+    const float sl2 = (float)(1.4426950408889634 / sqrt((double)C));
+#define LAUNCH_FWD(DD) attn_fwd_kernel<T, DD><<<grid, 256, 0, st>>>(qkv, x, kidx, kcnt, gamma, beta, out, oattn, lse2, mean, rstd, N, nkmax, sl2, eps)
+    switch (C) {
+        case 32: LAUNCH_FWD(32); break;
+        case 64: LAUNCH_FWD(64); break;
+        case 128: LAUNCH_FWD(128); break;
+        case 256: LAUNCH_FWD(256); break;
+        default: return MU_ERR_SHAPE;
+    }
+#undef LAUNCH_FWD
+    return MU_OK;
+}
+
+extern "C" int mu_attn_fwd(const void* qkv, const void* x, const int* kidx, const int* kcnt, const float* gamma, const float* beta,
+                           void* out, void* oattn, float* lse2, float* ln_mean, float* ln_rstd, int B, int N, int C, int nkmax,
+                           float eps, int dtype, void* stream) {
+    if (!qkv || !x || !kidx || !kcnt || !gamma || !beta || !out || !oattn || !lse2 || !ln_mean || !ln_rstd) return MU_ERR_ARG;
+    if (B <= 0 || N <= 0 || nkmax <= 0) return MU_ERR_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    int rc;
+    if (dtype == MU_F16) rc = attn_fwd_t<h16>((const h16*)qkv, (const h16*)x, kidx, kcnt, gamma, beta, (h16*)out, (h16*)oattn, lse2, ln_mean, ln_rstd, B, N, C, nkmax, eps, st);
+    else if (dtype == MU_F32) rc = attn_fwd_t<float>((const float*)qkv, (const float*)x, kidx, kcnt, gamma, beta, (float*)out, (float*)oattn, lse2, ln_mean, ln_rstd, B, N, C, nkmax, eps, st);
+    else return MU_ERR_ARG;
+    if (rc) return rc;
+    MU_CHECK_LAUNCH();
+    return MU_OK;
+}
+
+#define ATT_LN_MAXBLK 1024
+extern "C" long mu_attn_bwd_workspace_bytes(int C) { return (long)ATT_LN_MAXBLK * C * 2 * sizeof(double); }
+
+template <typename T>
+static int attn_bwd_t(const T* qkv, const T* x, const T* oattn, const T* gout, const int* kidx, const int* kcnt, const float* lse2,
+                      const float* mean, const float* rstd, const float* gamma, T* dY, float* delta, T* dqkv, float* dgamma,
+                      float* dbeta, int B, int N, int C, int nkmax, void* ws, hipStream_t st) {
+    const long rows = (long)B * N;
+    int nblk = (int)(rows / 64 < 1 ? 1 : (rows / 64 > ATT_LN_MAXBLK ? ATT_LN_MAXBLK : rows / 64));
+    const float scale = (float)(1.0 / sqrt((double)C));
+    const float sl2 = (float)(1.4426950408889634 / sqrt((double)C));
+    dim3 gq(mu_cdiv(N, 128), B);
+    if (hipMemsetAsync(dqkv, 0, (size_t)rows * 3 * C * sizeof(T), st) != hipSuccess) return MU_ERR_LAUNCH;
+#define LAUNCH_BWD(DD, NKT)                                                                                                     \
+    attn_ln_bwd_kernel<T, DD><<<nblk, 256, 0, st>>>(gout, oattn, x, mean, rstd, gamma, dY, delta, (double*)ws, rows);           \
+    attn_ln_bwd_final_kernel<<<mu_cdiv(DD, 64), 64, 0, st>>>((const double*)ws, nblk, DD, dgamma, dbeta);                       \
+    attn_bwd_dq_kernel<T, DD><<<gq, 256, 0, st>>>(qkv, dY, kidx, kcnt, lse2, delta, dqkv, N, nkmax, scale, sl2);                \
+    attn_bwd_dkv_kernel<T, DD, NKT><<<dim3(mu_cdiv(nkmax, 64 * NKT), B), 256, 0, st>>>(qkv, dY, kidx, kcnt, lse2, delta, dqkv, N, \
+                                                                                      nkmax, scale, sl2)
+    switch (C) {
+        case 32: LAUNCH_BWD(32, 2); break;
+        case 64: LAUNCH_BWD(64, 2); break;
+        case 128: LAUNCH_BWD(128, 2); break;
+        case 256: LAUNCH_BWD(256, 1); break;
+        default: return MU_ERR_SHAPE;
+    }
+#undef LAUNCH_BWD
+    return MU_OK;
+}
+
+extern "C" int mu_attn_bwd(const void* qkv, const void* x, const void* oattn, const void* grad_out, const int* kidx, const int* kcnt,
+                           const float* lse2, const float* ln_mean, const float* ln_rstd, const float* gamma, void* dY, float* delta,
+                           void* dqkv, float* dgamma, float* dbeta, int B, int N, int C, int nkmax, void* workspace, long ws_bytes,
+                           int dtype, void* stream) {
+    if (!qkv || !x || !oattn || !grad_out || !kidx || !kcnt || !lse2 || !ln_mean || !ln_rstd || !gamma || !dY || !delta || !dqkv ||
+        !dgamma || !dbeta || !workspace)
+        return MU_ERR_ARG;
+    if (B <= 0 || N <= 0 || nkmax <= 0) return MU_ERR_ARG;
+    if (ws_bytes < mu_attn_bwd_workspace_bytes(C)) return MU_ERR_WORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    int rc;
+    if (dtype == MU_F16)
+        rc = attn_bwd_t<h16>((const h16*)qkv, (const h16*)x, (const h16*)oattn, (const h16*)grad_out, kidx, kcnt, lse2, ln_mean, ln_rstd, gamma, (h16*)dY, delta, (h16*)dqkv, dgamma, dbeta, B, N, C, nkmax, workspace, st);
+    else if (dtype == MU_F32)
+        rc = attn_bwd_t<float>((const float*)qkv, (const float*)x, (const float*)oattn, (const float*)grad_out, kidx, kcnt, lse2, ln_mean, ln_rstd, gamma, (float*)dY, delta, (float*)dqkv, dgamma, dbeta, B, N, C, nkmax, workspace, st);
+    else return MU_ERR_ARG;
+    if (rc) return rc;
+    MU_CHECK_LAUNCH();
+    return MU_OK;
+}

@@ -1,0 +1,72 @@
+// Shared device helpers for the MaskAttn-UNet HIP kernels (gfx950 / CDNA4 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <hip/hip_fp16.h>
+#include <stdint.h>
+
+#include "../../include/maskunet_hip.h"
+
+#define MU_CHECK_LAUNCH()                                   \
+    do {                                                    \
+        hipError_t e__ = hipGetLastError();                 \
+        if (e__ != hipSuccess) return MU_ERR_LAUNCH;        \
+    } while (0)
+
+typedef _Float16 h16;
+typedef h16 h16x8 __attribute__((ext_vector_type(8)));
+typedef h16 h16x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+static inline int mu_cdiv(long a, long b) { return (int)((a + b - 1) / b); }
+
+// 16-byte vector of T: 8 halves or 4 floats.
+template <typename T> struct Vec16;
+template <> struct Vec16<float> {
+    static constexpr int N = 4;
+    float4 v;
+    __device__ __forceinline__ void load(const float* p) { v = *reinterpret_cast<const float4*>(p); }
+    __device__ __forceinline__ void store(float* p) const { *reinterpret_cast<float4*>(p) = v; }
+    __device__ __forceinline__ float get(int i) const { return reinterpret_cast<const float*>(&v)[i]; }
+    __device__ __forceinline__ void set(int i, float f) { reinterpret_cast<float*>(&v)[i] = f; }
+    __device__ __forceinline__ void zero() { v = make_float4(0.f, 0.f, 0.f, 0.f); }
+};
+template <> struct Vec16<h16> {
+    static constexpr int N = 8;
+    h16x8 v;
+    __device__ __forceinline__ void load(const h16* p) { v = *reinterpret_cast<const h16x8*>(p); }
+    __device__ __forceinline__ void store(h16* p) const { *reinterpret_cast<h16x8*>(p) = v; }
+    __device__ __forceinline__ float get(int i) const { return (float)v[i]; }
+    __device__ __forceinline__ void set(int i, float f) { v[i] = (h16)f; }
+    __device__ __forceinline__ void zero() { v = (h16x8)(h16)0; }
+};
+
+__device__ __forceinline__ float mu_gelu(float x) {
+    return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));
+}
+__device__ __forceinline__ float mu_gelu_grad(float x) {
+    // d/dx [0.5 x (1 + erf(x/sqrt2))] = 0.5 (1 + erf(x/sqrt2)) + x * exp(-x^2/2) / sqrt(2 pi)
+    return 0.5f * (1.0f + erff(x * 0.70710678118654752440f)) + x * 0.39894228040143267794f * __expf(-0.5f * x * x);
+}
+__device__ __forceinline__ float mu_act(float x, int act) {
+    return act == MU_ACT_GELU ? mu_gelu(x) : (act == MU_ACT_RELU ? fmaxf(x, 0.f) : x);
+}
+__device__ __forceinline__ float mu_act_grad(float x, int act) {
+    return act == MU_ACT_GELU ? mu_gelu_grad(x) : (act == MU_ACT_RELU ? (x > 0.f ? 1.f : 0.f) : 1.f);
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+__device__ __forceinline__ double wave_sum_d(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+    return v;
+}

@@ -1,0 +1,442 @@
+// MFMA implicit-GEMM kernels for the 3x3 / 1x1 convolutions and the Linear layers (NHWC).
+// Reference ops replaced: nn.Conv2d(k=3,pad=1,bias=False) in ConvBlock (ade_semantic.py:199,202),
+// nn.Conv2d 1x1 heads (:284; city_instance.py:243-249), nn.Linear q/k/v (:157-159,170-172) and
+// their autograd backward (data-grad = same kernel on flipped/transposed weights; weight-grad =
+// pixel-reduction "TN" kernel below).
+//
+// MFMA shapes: fp16 storage -> v_mfma_f32_16x16x32_f16, fp32 storage -> v_mfma_f32_16x16x4_f32
+// (exact fp32 FMA chain).  Both consume the same LDS image: rows of 64 bytes along K.
+#include "common.h"
+#include "../../include/maskunet_hip.h"
+
+template <typename T> struct Mma;
+template <> struct Mma<h16> {
+    static constexpr int VN = 8;    // elements per 16-byte fragment
+    using Frag = h16x8;
+    static __device__ __forceinline__ void mma(const Frag& a, const Frag& b, f32x4& c) {
+        c = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
+    }
+};
+template <> struct Mma<float> {
+    static constexpr int VN = 4;
+    using Frag = f32x4;
+    // lane group g holds k = 4g..4g+3; step s multiplies k = 4g+s of A with the same k of B
+    static __device__ __forceinline__ void mma(const Frag& a, const Frag& b, f32x4& c) {
+        c = __builtin_amdgcn_mfma_f32_16x16x4f32(a[0], b[0], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x4f32(a[1], b[1], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x4f32(a[2], b[2], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x4f32(a[3], b[3], c, 0, 0, 0);
+    }
+};
+
+// LDS image of a [rows][64 B] tile: 16-byte chunk c of row r lives at chunk c ^ f[(r>>2)&3],
+// f = {0,2,3,1}; makes the ds_read_b128 fragment reads (row = lane&15, chunk = lane>>4)
+// conflict-free within each of the instruction's four 16-lane service groups.
+__device__ __forceinline__ int swz64(int row, int chunk) { return chunk ^ ((0x78 >> (2 * ((row >> 2) & 3))) & 3); }
+
+// XCD-aware block id: blocks b and b+8 share an XCD (private L2); hand each XCD a contiguous
+// range of logical tiles so that tiles sharing an activation panel hit the same L2.
+__device__ __forceinline__ int xcd_remap(int bid, int nblk) {
+    const int q = nblk >> 3, r = nblk & 7, x = bid & 7;
+    return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (bid >> 3);
+}
+
+// ------------------------------------------------------------------------------------------
+// y[p][co] = bias[co] + sum_{tap,ci} x[p + shift(tap)][ci] * w[tap][co][ci]
+// block tile: (WR*TM*16) output channels x (WC*TN*16) pixels, 4 waves, D[co][pixel].
+// ------------------------------------------------------------------------------------------
+template <typename T, int TM, int TN, int WR, int TAPS>
+__global__ __launch_bounds__(256) void conv_nt_kernel(const T* __restrict__ x, const T* __restrict__ w, const float* __restrict__ bias,
+                                                      T* __restrict__ y, int B, int H, int W, int Cin, int Cout, long x_ld, long y_ld) {
+    using M_ = Mma<T>;
+    using Frag = typename M_::Frag;
+    constexpr int VN = M_::VN, KC = 4 * VN;
+    constexpr int WC = 4 / WR;
+    constexpr int BCO = WR * TM * 16, BPX = WC * TN * 16;
+    constexpr int NA = (BCO * 4 + 255) / 256, NB = (BPX * 4) / 256;
+    static_assert(BPX * 4 % 256 == 0, "pixel tile must be a multiple of 64");
+
+    __shared__ __attribute__((aligned(16))) char lds[2 * (BCO + BPX) * 64];
+    char* As = lds;
+    char* Bs = lds + 2 * BCO * 64;
+
+    const long Mtot = (long)B * H * W;
+    const int npb = (int)((Mtot + BPX - 1) / BPX), ncb = (Cout + BCO - 1) / BCO;
+    const int L = xcd_remap(blockIdx.x, npb * ncb);
+    const int cb = L % ncb, pb = L / ncb;
+    const int co0 = cb * BCO;
+    const long px0 = (long)pb * BPX;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wr = wave / WC, wc = wave % WC;
+    const int r16 = lane & 15, g = lane >> 4;
+    const int ch = tid & 3;                      // this thread's 16-byte chunk along K
+    const int ldrow = tid >> 2;                  // 0..63
+
+    // pixel bookkeeping for the rows this thread stages
+    long prow[NB]; int ph[NB], pw[NB]; bool pok[NB];
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+        long p = px0 + ldrow + i * 64;
+        pok[i] = p < Mtot;
+        long pp = pok[i] ? p : 0;
+        pw[i] = (int)(pp % W);
+        ph[i] = (int)((pp / W) % H);
+        prow[i] = pp;
+    }
+
+    const int kchunks = Cin / KC;
+    const int nsteps = TAPS * kchunks;
+    uint4 ra[NA], rb[NB];
+
+    auto gload = [&](int s) {
+        const int tap = s / kchunks, ci0 = (s % kchunks) * KC;
+        const int dh = TAPS == 9 ? tap / 3 - 1 : 0, dw = TAPS == 9 ? tap % 3 - 1 : 0;
+#pragma unroll
+        for (int i = 0; i < NA; ++i) {
+            const int row = ldrow + i * 64, co = co0 + row;
+            if (row < BCO && co < Cout)
+                ra[i] = *reinterpret_cast<const uint4*>(w + ((long)tap * Cout + co) * Cin + ci0 + ch * VN);
+            else
+                ra[i] = make_uint4(0, 0, 0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < NB; ++i) {
+            const int hh = ph[i] + dh, ww = pw[i] + dw;
+            if (pok[i] && hh >= 0 && hh < H && ww >= 0 && ww < W)
+                rb[i] = *reinterpret_cast<const uint4*>(x + (prow[i] + dh * W + dw) * x_ld + ci0 + ch * VN);
+            else
+                rb[i] = make_uint4(0, 0, 0, 0);
+        }
+    };
+    auto lstore = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < NA; ++i) {
+            const int row = ldrow + i * 64;
+            if (row < BCO) *reinterpret_cast<uint4*>(As + buf * BCO * 64 + row * 64 + swz64(row, ch) * 16) = ra[i];
+        }
+#pragma unroll
+        for (int i = 0; i < NB; ++i) {
+            const int row = ldrow + i * 64;
+            *reinterpret_cast<uint4*>(Bs + buf * BPX * 64 + row * 64 + swz64(row, ch) * 16) = rb[i];
+        }
+    };
+
+    f32x4 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    gload(0);
+    lstore(0);
+    __syncthreads();
+    for (int s = 0; s < nsteps; ++s) {
+        const int buf = s & 1;
+        if (s + 1 < nsteps) gload(s + 1);
+        Frag a[TM], b[TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const int row = (wr * TM + i) * 16 + r16;
+            a[i] = *reinterpret_cast<const Frag*>(As + buf * BCO * 64 + row * 64 + swz64(row, g) * 16);
+        }
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int row = (wc * TN + j) * 16 + r16;
+            b[j] = *reinterpret_cast<const Frag*>(Bs + buf * BPX * 64 + row * 64 + swz64(row, g) * 16);
+        }
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) M_::mma(a[i], b[j], acc[i][j]);
+        if (s + 1 < nsteps) lstore(buf ^ 1);
+        __syncthreads();
+    }
+
+    // epilogue: lane holds 4 consecutive output channels of one pixel per (i,j) tile
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const long p = px0 + (wc * TN + j) * 16 + r16;
+        if (p >= Mtot) continue;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const int co = co0 + (wr * TM + i) * 16 + 4 * g;
+            if (co >= Cout) continue;
+            float v[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = acc[i][j][r] + (bias ? bias[co + r] : 0.f);
+            if constexpr (sizeof(T) == 2) {
+                h16x4 o = {(h16)v[0], (h16)v[1], (h16)v[2], (h16)v[3]};
+                *reinterpret_cast<h16x4*>(y + p * y_ld + co) = o;
+            } else {
+                *reinterpret_cast<float4*>(y + p * y_ld + co) = make_float4(v[0], v[1], v[2], v[3]);
+            }
+        }
+    }
+}
+
+template <typename T, int TAPS>
+static int conv_fwd_launch(const T* x, const T* w, const float* bias, T* y, int B, int H, int W, int Cin, int Cout, long x_ld,
+                           long y_ld, hipStream_t st) {
+    const long M = (long)B * H * W;
+    const int npb = (int)((M + 127) / 128);
+    if (Cout % 128 == 0) {
+        conv_nt_kernel<T, 4, 4, 2, TAPS><<<npb * (Cout / 128), 256, 0, st>>>(x, w, bias, y, B, H, W, Cin, Cout, x_ld, y_ld);
+    } else if (Cout % 64 == 0) {
+        conv_nt_kernel<T, 4, 2, 1, TAPS><<<npb * (Cout / 64), 256, 0, st>>>(x, w, bias, y, B, H, W, Cin, Cout, x_ld, y_ld);
+    } else {
+        conv_nt_kernel<T, 2, 2, 1, TAPS><<<npb * (Cout / 32), 256, 0, st>>>(x, w, bias, y, B, H, W, Cin, Cout, x_ld, y_ld);
+    }
+    return MU_OK;
+}
+
+extern "C" int mu_conv_fwd(const void* x, const void* w, const float* bias, void* y, int B, int H, int W, int Cin, int Cout, int taps,
+                           long x_ld, long y_ld, int dtype, void* stream) {
+    if (!x || !w || !y || B <= 0 || H <= 0 || W <= 0) return MU_ERR_ARG;
+    if (Cin <= 0 || Cout <= 0 || Cin % 32 || Cout % 32 || x_ld < Cin || y_ld < Cout || x_ld % 8 || y_ld % 8) return MU_ERR_SHAPE;
+    if (taps != 1 && taps != 9) return MU_ERR_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == MU_F16) {
+        if (taps == 9) conv_fwd_launch<h16, 9>((const h16*)x, (const h16*)w, bias, (h16*)y, B, H, W, Cin, Cout, x_ld, y_ld, st);
+        else conv_fwd_launch<h16, 1>((const h16*)x, (const h16*)w, bias, (h16*)y, B, H, W, Cin, Cout, x_ld, y_ld, st);
+    } else if (dtype == MU_F32) {
+        if (taps == 9) conv_fwd_launch<float, 9>((const float*)x, (const float*)w, bias, (float*)y, B, H, W, Cin, Cout, x_ld, y_ld, st);
+        else conv_fwd_launch<float, 1>((const float*)x, (const float*)w, bias, (float*)y, B, H, W, Cin, Cout, x_ld, y_ld, st);
+    } else return MU_ERR_ARG;
+    MU_CHECK_LAUNCH();
+    return MU_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// weight gradient: dW[tap][co][ci] = sum_p dy[p][co] * x[p + shift(tap)][ci]
+// "TN" GEMM: both operands have the reduction index (pixel) as their row index in memory, so
+// fragments are fetched with transposing LDS reads (fp16: ds_read_b64_tr_b16; fp32: b32 columns).
+// Split over pixel ranges; fp32 partial slabs + deterministic reduce (no float atomics).
+// ------------------------------------------------------------------------------------------
+template <typename T> struct WgTile;
+template <> struct WgTile<h16> { static constexpr int PAD = 0; static constexpr int KP = 32; };
+// fp32: row pad (elements) puts the g=0/1 pixel rows of a ds_read_b32 on different banks
+template <> struct WgTile<float> { static constexpr int PAD = 16; static constexpr int KP = 16; };
+
+typedef __fp16 fp16x4v __attribute__((__vector_size__(4 * sizeof(__fp16))));
+
+template <typename T, int TM, int TN, int WR, int TAPS>
+__global__ __launch_bounds__(256) void conv_wgrad_kernel(const T* __restrict__ x, const T* __restrict__ dy, float* __restrict__ part,
+                                                         int B, int H, int W, int Cin, int Cout, long x_ld, long dy_ld, int nsplit,
+                                                         long pix_per_split) {
+    constexpr int VN = Mma<T>::VN;
+    constexpr int WC = 4 / WR;
+    constexpr int BCO = WR * TM * 16, BCI = WC * TN * 16;
+    constexpr int KP = WgTile<T>::KP;                        // pixels per LDS stage
+    constexpr int SA = BCO + WgTile<T>::PAD, SB = BCI + WgTile<T>::PAD;   // LDS row strides (elements)
+    constexpr int CA = BCO / VN, CB = BCI / VN;              // 16-byte chunks per row
+    constexpr int NA = (KP * CA + 255) / 256, NB = (KP * CB + 255) / 256;
+
+    __shared__ __attribute__((aligned(16))) T lds[2 * KP * (SA + SB)];
+    T* As = lds;
+    T* Bs = lds + 2 * KP * SA;
+
+    const long Mtot = (long)B * H * W;
+    const int nco = (Cout + BCO - 1) / BCO, nci = (Cin + BCI - 1) / BCI;
+    int bid = blockIdx.x;
+    const int split = bid % nsplit; bid /= nsplit;
+    const int cib = bid % nci; bid /= nci;
+    const int cob = bid % nco; bid /= nco;
+    const int tap = bid;
+    const int dh = TAPS == 9 ? tap / 3 - 1 : 0, dw = TAPS == 9 ? tap % 3 - 1 : 0;
+    const int co0 = cob * BCO, ci0 = cib * BCI;
+    const long p_begin = (long)split * pix_per_split;
+    const long p_end = p_begin + pix_per_split < Mtot ? p_begin + pix_per_split : Mtot;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wr = wave / WC, wc = wave % WC;
+    const int r16 = lane & 15, g = lane >> 4;
+
+    uint4 ra[NA], rb[NB];
+    auto gload = [&](long pbase) {
+#pragma unroll
+        for (int i = 0; i < NA; ++i) {
+            const int idx = tid + i * 256, row = idx / CA, c = (idx % CA) * VN;
+            const long p = pbase + row;
+            if (idx < KP * CA && p < p_end && co0 + c < Cout) ra[i] = *reinterpret_cast<const uint4*>(dy + p * dy_ld + co0 + c);
+            else ra[i] = make_uint4(0, 0, 0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < NB; ++i) {
+            const int idx = tid + i * 256, row = idx / CB, c = (idx % CB) * VN;
+            const long p = pbase + row;
+            bool ok = idx < KP * CB && p < p_end && ci0 + c < Cin;
+            if (ok && TAPS == 9) {
+                const int ww = (int)(p % W) + dw, hh = (int)((p / W) % H) + dh;
+                ok = hh >= 0 && hh < H && ww >= 0 && ww < W;
+            }
+            if (ok) rb[i] = *reinterpret_cast<const uint4*>(x + (p + dh * W + dw) * x_ld + ci0 + c);
+            else rb[i] = make_uint4(0, 0, 0, 0);
+        }
+    };
+    auto lstore = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < NA; ++i) {
+            const int idx = tid + i * 256, row = idx / CA, c = (idx % CA) * VN;
+            if (idx < KP * CA) *reinterpret_cast<uint4*>(As + (buf * KP + row) * SA + c) = ra[i];
+        }
+#pragma unroll
+        for (int i = 0; i < NB; ++i) {
+            const int idx = tid + i * 256, row = idx / CB, c = (idx % CB) * VN;
+            if (idx < KP * CB) *reinterpret_cast<uint4*>(Bs + (buf * KP + row) * SB + c) = rb[i];
+        }
+    };
+
+    f32x4 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    const int nsteps = (int)((p_end - p_begin + KP - 1) / KP);
+    if (nsteps > 0) {
+        gload(p_begin);
+        lstore(0);
+    }
+    __syncthreads();
+    for (int s = 0; s < nsteps; ++s) {
+        const int buf = s & 1;
+        if (s + 1 < nsteps) gload(p_begin + (long)(s + 1) * KP);
+        const T* At = As + buf * KP * SA;
+        const T* Bt = Bs + buf * KP * SB;
+        if constexpr (sizeof(T) == 2) {
+            // lane (16-lane group g, index li): q = li>>2 selects the pixel row of a 4x16 block,
+            // pc = li&3 its 4-column piece; the transposed read returns, for column li, the 4 rows.
+            const int q = r16 >> 2, pc = r16 & 3;
+            h16x8 a[TM], b[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                const int col = (wr * TM + i) * 16 + 4 * pc;
+                auto lo = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) fp16x4v*)(At + (8 * g + q) * SA + col));
+                auto hi = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) fp16x4v*)(At + (8 * g + 4 + q) * SA + col));
+                a[i] = (h16x8){(h16)lo[0], (h16)lo[1], (h16)lo[2], (h16)lo[3], (h16)hi[0], (h16)hi[1], (h16)hi[2], (h16)hi[3]};
+            }
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int col = (wc * TN + j) * 16 + 4 * pc;
+                auto lo = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) fp16x4v*)(Bt + (8 * g + q) * SB + col));
+                auto hi = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) fp16x4v*)(Bt + (8 * g + 4 + q) * SB + col));
+                b[j] = (h16x8){(h16)lo[0], (h16)lo[1], (h16)lo[2], (h16)lo[3], (h16)hi[0], (h16)hi[1], (h16)hi[2], (h16)hi[3]};
+            }
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[i], b[j], acc[i][j], 0, 0, 0);
+        } else {
+#pragma unroll
+            for (int ks = 0; ks < KP / 4; ++ks) {
+                float a[TM], b[TN];
+#pragma unroll
+                for (int i = 0; i < TM; ++i) a[i] = At[(4 * ks + g) * SA + (wr * TM + i) * 16 + r16];
+#pragma unroll
+                for (int j = 0; j < TN; ++j) b[j] = Bt[(4 * ks + g) * SB + (wc * TN + j) * 16 + r16];
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], b[j], acc[i][j], 0, 0, 0);
+            }
+        }
+        if (s + 1 < nsteps) lstore(buf ^ 1);
+        __syncthreads();
+    }
+
+    // partial slab [split][tap][Cout][Cin]; lane holds rows co = 4g+r, column ci = r16
+    float* out = part + ((long)split * TAPS + tap) * Cout * Cin;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int ci = ci0 + (wc * TN + j) * 16 + r16;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int co = co0 + (wr * TM + i) * 16 + 4 * g + r;
+                if (co < Cout && ci < Cin) out[(long)co * Cin + ci] = acc[i][j][r];
+            }
+        }
+}
+
+// dst_oihw[o][i][t] = sum_split part[split][t][o][i]   (valid region only)
+__global__ void wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ dst, int nsplit, int taps, int Cout, int Cin,
+                                    int O, int I) {
+    const long n = (long)O * I * taps;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < n; idx += (long)gridDim.x * blockDim.x) {
+        // iterate in slab order (t, o, i) for coalesced reads
+        const int i = idx % I;
+        const int o = (idx / I) % O;
+        const int t = idx / ((long)I * O);
+        float s = 0.f;
+        for (int k = 0; k < nsplit; ++k) s += part[(((long)k * taps + t) * Cout + o) * Cin + i];
+        dst[((long)o * I + i) * taps + t] = s;
+    }
+}
+
+static inline void wgrad_plan(long M, int Cin, int Cout, int taps, int bco, int bci, int* nsplit, long* pps) {
+    long tiles = (long)taps * ((Cout + bco - 1) / bco) * ((Cin + bci - 1) / bci);
+    long want = 2048 / tiles;
+    if (want < 1) want = 1;
+    long max_split = (M + 255) / 256;           // at least 256 pixels per split
+    if (want > max_split) want = max_split;
+    if (want > 256) want = 256;
+    long p = (M + want - 1) / want;
+    p = (p + 31) / 32 * 32;                    // multiple of both stage depths (32 / 16)
+    *pps = p;
+    *nsplit = (int)((M + p - 1) / p);
+}
+
+static inline void wgrad_tile(int Cin, int Cout, int* bco, int* bci) {
+    *bco = (Cout % 128 == 0) ? 128 : (Cout % 64 == 0 ? 64 : 32);
+    *bci = (Cin % 128 == 0) ? 128 : (Cin % 64 == 0 ? 64 : 32);
+    // supported tile pairs: 128x128, 64x64, 32x32 (+ mixed via the smaller square)
+    int m = *bco < *bci ? *bco : *bci;
+    *bco = m; *bci = m;
+}
+
+extern "C" long mu_conv_wgrad_workspace_bytes(int B, int H, int W, int Cin, int Cout, int taps) {
+    int bco, bci, nsplit; long pps;
+    wgrad_tile(Cin, Cout, &bco, &bci);
+    wgrad_plan((long)B * H * W, Cin, Cout, taps, bco, bci, &nsplit, &pps);
+    return (long)nsplit * taps * Cout * Cin * sizeof(float);
+}
+
+template <typename T, int TAPS>
+static int wgrad_launch(const T* x, const T* dy, float* part, int B, int H, int W, int Cin, int Cout, long x_ld, long dy_ld, int bt,
+                        int nsplit, long pps, hipStream_t st) {
+    const int nt = ((Cout + bt - 1) / bt) * ((Cin + bt - 1) / bt);
+    const int grid = TAPS * nt * nsplit;
+    if (bt == 128) conv_wgrad_kernel<T, 4, 4, 2, TAPS><<<grid, 256, 0, st>>>(x, dy, part, B, H, W, Cin, Cout, x_ld, dy_ld, nsplit, pps);
+    else if (bt == 64) conv_wgrad_kernel<T, 2, 2, 2, TAPS><<<grid, 256, 0, st>>>(x, dy, part, B, H, W, Cin, Cout, x_ld, dy_ld, nsplit, pps);
+    else conv_wgrad_kernel<T, 1, 1, 2, TAPS><<<grid, 256, 0, st>>>(x, dy, part, B, H, W, Cin, Cout, x_ld, dy_ld, nsplit, pps);
+    return MU_OK;
+}
+
+extern "C" int mu_conv_wgrad(const void* x, const void* dy, float* dw_oihw, int B, int H, int W, int Cin, int Cout, int taps,
+                             int cin_valid, int cout_valid, long x_ld, long dy_ld, void* workspace, long ws_bytes, int dtype,
+                             void* stream) {
+    if (!x || !dy || !dw_oihw || !workspace || B <= 0 || H <= 0 || W <= 0) return MU_ERR_ARG;
+    if (Cin % 32 || Cout % 32 || x_ld < Cin || dy_ld < Cout || x_ld % 8 || dy_ld % 8) return MU_ERR_SHAPE;
+    if (cin_valid <= 0 || cin_valid > Cin || cout_valid <= 0 || cout_valid > Cout) return MU_ERR_ARG;
+    if (taps != 1 && taps != 9) return MU_ERR_ARG;
+    int bco, bci, nsplit; long pps;
+    wgrad_tile(Cin, Cout, &bco, &bci);
+    wgrad_plan((long)B * H * W, Cin, Cout, taps, bco, bci, &nsplit, &pps);
+    if (ws_bytes < (long)nsplit * taps * Cout * Cin * (long)sizeof(float)) return MU_ERR_WORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    float* part = (float*)workspace;
+    if (dtype == MU_F16) {
+        if (taps == 9) wgrad_launch<h16, 9>((const h16*)x, (const h16*)dy, part, B, H, W, Cin, Cout, x_ld, dy_ld, bco, nsplit, pps, st);
+        else wgrad_launch<h16, 1>((const h16*)x, (const h16*)dy, part, B, H, W, Cin, Cout, x_ld, dy_ld, bco, nsplit, pps, st);
+    } else if (dtype == MU_F32) {
+        if (taps == 9) wgrad_launch<float, 9>((const float*)x, (const float*)dy, part, B, H, W, Cin, Cout, x_ld, dy_ld, bco, nsplit, pps, st);
+        else wgrad_launch<float, 1>((const float*)x, (const float*)dy, part, B, H, W, Cin, Cout, x_ld, dy_ld, bco, nsplit, pps, st);
+    } else return MU_ERR_ARG;
+    const long n = (long)cout_valid * cin_valid * taps;
+    const int grid = (int)((n + 255) / 256 > 2048 ? 2048 : (n + 255) / 256);
+    wgrad_reduce_kernel<<<grid, 256, 0, st>>>(part, dw_oihw, nsplit, taps, Cout, Cin, cout_valid, cin_valid);
+    MU_CHECK_LAUNCH();
+    return MU_OK;
+}

@@ -1,0 +1,453 @@
+// Bandwidth-bound layout / pooling / resampling kernels (NHWC, 16-byte vector accesses).
+// Reference ops replaced: x.view().permute (ade_semantic.py:168), the .view scramble (:190),
+// nn.MaxPool2d(2) (:216), nn.Upsample(bilinear, align_corners=True) + torch.cat (:235,250-253),
+// nn.Dropout(0.3) (:273,304,307), and the OIHW<->tap-major weight re-layouts of this build.
+#include "common.h"
+#include "../../include/maskunet_hip.h"
+
+// ------------------------------------------------------------------------------------------
+// batched 2-D transpose with dtype conversion:  dst[b][c][r] = src[b][r][c]
+// ------------------------------------------------------------------------------------------
+template <typename TS, typename TD>
+__global__ __launch_bounds__(256) void transpose_kernel(const TS* __restrict__ src, long src_ld, TD* __restrict__ dst,
+                                                        long dst_ld, int R, int C) {
+    __shared__ float tile[64][65];
+    const int b = blockIdx.z;
+    const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
+    const TS* s = src + (long)b * R * src_ld;
+    TD* d = dst + (long)b * C * dst_ld;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+#pragma unroll 4
+    for (int i = ty; i < 64; i += 4) {
+        int r = r0 + i, c = c0 + tx;
+        tile[i][tx] = (r < R && c < C) ? (float)s[(long)r * src_ld + c] : 0.f;
+    }
+    __syncthreads();
+#pragma unroll 4
+    for (int i = ty; i < 64; i += 4) {
+        int c = c0 + i, r = r0 + tx;
+        if (c < C && r < R) d[(long)c * dst_ld + r] = (TD)tile[tx][i];
+    }
+}
+
+extern "C" int mu_transpose(const void* src, int src_dtype, long src_ld, void* dst, int dst_dtype, long dst_ld,
+                            int batch, int R, int C, void* stream) {
+    if (!src || !dst || batch <= 0 || R <= 0 || C <= 0 || src_ld < C || dst_ld < R) return MU_ERR_ARG;
+    dim3 grid(mu_cdiv(C, 64), mu_cdiv(R, 64), batch), block(256);
+    hipStream_t st = (hipStream_t)stream;
+    if (src_dtype == MU_F32 && dst_dtype == MU_F32)
+        transpose_kernel<float, float><<<grid, block, 0, st>>>((const float*)src, src_ld, (float*)dst, dst_ld, R, C);
+    else if (src_dtype == MU_F32 && dst_dtype == MU_F16)
+        transpose_kernel<float, h16><<<grid, block, 0, st>>>((const float*)src, src_ld, (h16*)dst, dst_ld, R, C);
+    else if (src_dtype == MU_F16 && dst_dtype == MU_F32)
+        transpose_kernel<h16, float><<<grid, block, 0, st>>>((const h16*)src, src_ld, (float*)dst, dst_ld, R, C);
+    else if (src_dtype == MU_F16 && dst_dtype == MU_F16)
+        transpose_kernel<h16, h16><<<grid, block, 0, st>>>((const h16*)src, src_ld, (h16*)dst, dst_ld, R, C);
+    else
+        return MU_ERR_ARG;
+    MU_CHECK_LAUNCH();
+    return MU_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// weight re-layout: OIHW fp32 -> [tap][rows_pad][cols_pad] T
+//   mode 0 (forward):   dst[t][o][i]      = w[o][i][t]
+//   mode 1 (data-grad): dst[T-1-t][i][o]  = w[o][i][t]   (taps flipped, in/out swapped)
+// rows/cols beyond the valid extent are zero.
+// ------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void prep_weight_kernel(const float* __restrict__ w, T* __restrict__ dst, int O, int I, int taps,
+                                   int rows_pad, int cols_pad, int mode) {
+    long n = (long)taps * rows_pad * cols_pad;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < n; idx += (long)gridDim.x * blockDim.x) {
+        int c = idx % cols_pad;
+        int r = (idx / cols_pad) % rows_pad;
+        int t = idx / ((long)cols_pad * rows_pad);
+        float v = 0.f;
+        if (mode == 0) {
+            if (r < O && c < I) v = w[((long)r * I + c) * taps + t];
+        } else {
+            if (r < I && c < O) v = w[((long)c * I + r) * taps + (taps - 1 - t)];
+        }
+        dst[idx] = (T)v;
+    }
+}
+
+extern "C" int mu_prep_weight(const float* w_oihw, void* dst, int dtype, int O, int I, int taps, int rows_pad,
+                              int cols_pad, int mode, void* stream) {
+    if (!w_oihw || !dst || O <= 0 || I <= 0 || (taps != 1 && taps != 9)) return MU_ERR_ARG;
+    if (mode == 0 ? (rows_pad < O || cols_pad < I) : (rows_pad < I || cols_pad < O)) return MU_ERR_ARG;
+    long n = (long)taps * rows_pad * cols_pad;
+    int grid = (int)((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048);
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == MU_F32)
+        prep_weight_kernel<float><<<grid, 256, 0, st>>>(w_oihw, (float*)dst, O, I, taps, rows_pad, cols_pad, mode);
+    else if (dtype == MU_F16)
+        prep_weight_kernel<h16><<<grid, 256, 0, st>>>(w_oihw, (h16*)dst, O, I, taps, rows_pad, cols_pad, mode);
+    else
+        return MU_ERR_ARG;
+    MU_CHECK_LAUNCH();
+    return MU_OK;
+}
+
+// generic elementwise cast (fp32 parameter vectors -> compute dtype)
+template <typename TS, typename TD>
+__global__ void cast_kernel(const TS* __restrict__ s, TD* __restrict__ d, long n) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) d[i] = (TD)(float)s[i];
+}
+extern "C" int mu_cast(const void* src, int src_dtype, void* dst, int dst_dtype, long n, void* stream) {
+    if (!src || !dst || n <= 0) return MU_ERR_ARG;
+    int grid = (int)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
+    hipStream_t st = (hipStream_t)stream;
+    if (src_dtype == MU_F32 && dst_dtype == MU_F16) cast_kernel<float, h16><<<grid, 256, 0, st>>>((const float*)src, (h16*)dst, n);
+    else if (src_dtype == MU_F16 && dst_dtype == MU_F32) cast_kernel<h16, float><<<grid, 256, 0, st>>>((const h16*)src, (float*)dst, n);
+    else if (src_dtype == MU_F32 && dst_dtype == MU_F32) cast_kernel<float, float><<<grid, 256, 0, st>>>((const float*)src, (float*)dst, n);
+    else if (src_dtype == MU_F16 && dst_dtype == MU_F16) cast_kernel<h16, h16><<<grid, 256, 0, st>>>((const h16*)src, (h16*)dst, n);
+    else return MU_ERR_ARG;
+    MU_CHECK_LAUNCH();
+    return MU_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// MaxPool2d(2), NHWC.  Backward recomputes the arg-max from x (first maximum in (kh,kw) scan
+// order, the aten tie rule) so no index tensor is stored; windows are disjoint -> no atomics.
+// ------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void maxpool_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, int B, int H, int W, int C) {
+    constexpr int N = Vec16<T>::N;
+    const int cv = C / N, Ho = H / 2, Wo = W / 2;
+    const long total = (long)B * Ho * Wo * cv;
+    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+        int c = (idx % cv) * N;
+        long p = idx / cv;
+        int wo = p % Wo, ho = (p / Wo) % Ho, b = p / ((long)Wo * Ho);
+        const T* base = x + (((long)b * H + 2 * ho) * W + 2 * wo) * C + c;
+        Vec16<T> v00, v01, v10, v11, o;
+        v00.load(base); v01.load(base + C); v10.load(base + (long)W * C); v11.load(base + (long)W * C + C);
+#pragma unroll
+        for (int i = 0; i < N; ++i) o.set(i, fmaxf(fmaxf(v00.get(i), v01.get(i)), fmaxf(v10.get(i), v11.get(i))));
+        o.store(y + p * C + c);
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void maxpool_bwd_kernel(const T* __restrict__ x, const T* __restrict__ dy, T* __restrict__ dx,
+                                                          int B, int H, int W, int C) {
+    constexpr int N = Vec16<T>::N;
+    const int cv = C / N, Ho = H / 2, Wo = W / 2;
+    const long total = (long)B * Ho * Wo * cv;
+    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+        int c = (idx % cv) * N;
+        long p = idx / cv;
+        int wo = p % Wo, ho = (p / Wo) % Ho, b = p / ((long)Wo * Ho);
+        long off = (((long)b * H + 2 * ho) * W + 2 * wo) * C + c;
+        Vec16<T> v[4], g, o[4];
+        v[0].load(x + off); v[1].load(x + off + C); v[2].load(x + off + (long)W * C); v[3].load(x + off + (long)W * C + C);
+        g.load(dy + p * C + c);
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+            int best = 0;
+            float m = v[0].get(i);
+#pragma unroll
+            for (int k = 1; k < 4; ++k) {
+                float t = v[k].get(i);
+                if (t > m) { m = t; best = k; }
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) o[k].set(i, k == best ? g.get(i) : 0.f);
+        }
+        o[0].store(dx + off); o[1].store(dx + off + C); o[2].store(dx + off + (long)W * C); o[3].store(dx + off + (long)W * C + C);
+    }
+}
+
+static inline int ew_grid(long total) {
+    long g = (total + 255) / 256;
+    return (int)(g < 1 ? 1 : (g > 8192 ? 8192 : g));
+}
+
+extern "C" int mu_maxpool2_fwd(const void* x, void* y, int B, int H, int W, int C, int dtype, void* stream) {
+    if (!x || !y || B <= 0 || (H & 1) || (W & 1) || C % 8) return MU_ERR_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == MU_F32) {
+        long total = (long)B * (H / 2) * (W / 2) * (C / 4);
+        maxpool_fwd_kernel<float><<<ew_grid(total), 256, 0, st>>>((const float*)x, (float*)y, B, H, W, C);
+    } else if (dtype == MU_F16) {
+        long total = (long)B * (H / 2) * (W / 2) * (C / 8);
+        maxpool_fwd_kernel<h16><<<ew_grid(total), 256, 0, st>>>((const h16*)x, (h16*)y, B, H, W, C);
+    } else return MU_ERR_ARG;
+    MU_CHECK_LAUNCH();
+    return MU_OK;
+}
+
+extern "C" int mu_maxpool2_bwd(const void* x, const void* dy, void* dx, int B, int H, int W, int C, int dtype, void* stream) {
+    if (!x || !dy || !dx || B <= 0 || (H & 1) || (W & 1) || C % 8) return MU_ERR_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == MU_F32) {
+        long total = (long)B * (H / 2) * (W / 2) * (C / 4);
+        maxpool_bwd_kernel<float><<<ew_grid(total), 256, 0, st>>>((const float*)x, (const float*)dy, (float*)dx, B, H, W, C);
+    } else if (dtype == MU_F16) {
+        long total = (long)B * (H / 2) * (W / 2) * (C / 8);
+        maxpool_bwd_kernel<h16><<<ew_grid(total), 256, 0, st>>>((const h16*)x, (const h16*)dy, (h16*)dx, B, H, W, C);
+    } else return MU_ERR_ARG;
+    MU_CHECK_LAUNCH();
+    return MU_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// bilinear x2 upsample (align_corners=True) fused with the channel concat [skip, up]
+//   y[b, ho, wo, 0:Cs]      = skip[b, ho, wo, :]
+//   y[b, ho, wo, Cs:Cs+Cx]  = lerp of x[b, h0/h1, w0/w1, :]
+// src = dst * (in-1)/(out-1)  (aten area_pixel_compute_source_index, align_corners branch)
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ void lerp_axis(int d, float scale, int n_in, int& i0, int& i1, float& f) {
+    float s = scale * (float)d;
+    i0 = (int)s;
+    if (i0 > n_in - 1) i0 = n_in - 1;
+    i1 = i0 + (i0 < n_in - 1 ? 1 : 0);
+    f = s - (float)i0;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void upcat_fwd_kernel(const T* __restrict__ x, const T* __restrict__ skip, T* __restrict__ y,
+                                                        int B, int h, int w, int Cx, int Cs) {
+    constexpr int N = Vec16<T>::N;
+    const int Ho = 2 * h, Wo = 2 * w, Ct = Cx + Cs, cv = Ct / N;
+    const float sh = h > 1 ? (float)(h - 1) / (float)(Ho - 1) : 0.f, sw = w > 1 ? (float)(w - 1) / (float)(Wo - 1) : 0.f;
+    const long total = (long)B * Ho * Wo * cv;
+    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+        int c = (idx % cv) * N;
+        long p = idx / cv;
+        Vec16<T> o;
+        if (c < Cs) {
+            o.load(skip + p * Cs + c);
+        } else {
+            int wo = p % Wo, ho = (p / Wo) % Ho, b = p / ((long)Wo * Ho);
+            int h0, h1, w0, w1; float fh, fw;
+            lerp_axis(ho, sh, h, h0, h1, fh);
+            lerp_axis(wo, sw, w, w0, w1, fw);
+            const T* xb = x + (long)b * h * w * Cx + (c - Cs);
+            Vec16<T> a00, a01, a10, a11;
+            a00.load(xb + ((long)h0 * w + w0) * Cx); a01.load(xb + ((long)h0 * w + w1) * Cx);
+            a10.load(xb + ((long)h1 * w + w0) * Cx); a11.load(xb + ((long)h1 * w + w1) * Cx);
+#pragma unroll
+            for (int i = 0; i < N; ++i) {
+                // same association as the oracle: rows first (over h), then columns
+                float r0 = a00.get(i) * (1.f - fh) + a10.get(i) * fh;
+                float r1 = a01.get(i) * (1.f - fh) + a11.get(i) * fh;
+                o.set(i, r0 * (1.f - fw) + r1 * fw);
+            }
+        }
+        o.store(y + p * Ct + c);
+    }
+}
+
+// backward: dskip = dy[..., :Cs];  dx = bilinear^T(dy[..., Cs:]) as a deterministic gather
+template <typename T>
+__global__ __launch_bounds__(256) void upcat_bwd_kernel(const T* __restrict__ dy, T* __restrict__ dx, T* __restrict__ dskip,
+                                                        int B, int h, int w, int Cx, int Cs) {
+    constexpr int N = Vec16<T>::N;
+    const int Ho = 2 * h, Wo = 2 * w, Ct = Cx + Cs;
+    const float sh = h > 1 ? (float)(h - 1) / (float)(Ho - 1) : 0.f, sw = w > 1 ? (float)(w - 1) / (float)(Wo - 1) : 0.f;
+    const int cvs = Cs / N, cvx = Cx / N;
+    const long n_skip = (long)B * Ho * Wo * cvs, n_x = (long)B * h * w * cvx;
+    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < n_skip + n_x; idx += (long)gridDim.x * 256) {
+        if (idx < n_skip) {
+            int c = (idx % cvs) * N;
+            long p = idx / cvs;
+            Vec16<T> v;
+            v.load(dy + p * Ct + c);
+            v.store(dskip + p * Cs + c);
+            continue;
+        }
+        long j = idx - n_skip;
+        int c = (j % cvx) * N;
+        long p = j / cvx;
+        int wi = p % w, hi = (p / w) % h, b = p / ((long)w * h);
+        float acc[N];
+#pragma unroll
+        for (int i = 0; i < N; ++i) acc[i] = 0.f;
+        // destination rows whose source interval touches hi lie within [2hi-2, 2hi+3]
+        for (int ho = max(0, 2 * hi - 2); ho <= min(Ho - 1, 2 * hi + 3); ++ho) {
+            int h0, h1; float fh;
+            lerp_axis(ho, sh, h, h0, h1, fh);
+            float wh = (h0 == hi ? 1.f - fh : 0.f) + (h1 == hi ? fh : 0.f);
+            if (h0 == hi && h1 == hi) wh = 1.f;
+            if (wh == 0.f) continue;
+            for (int wo = max(0, 2 * wi - 2); wo <= min(Wo - 1, 2 * wi + 3); ++wo) {
+                int w0, w1; float fw;
+                lerp_axis(wo, sw, w, w0, w1, fw);
+                float ww = (w0 == wi ? 1.f - fw : 0.f) + (w1 == wi ? fw : 0.f);
+                if (w0 == wi && w1 == wi) ww = 1.f;
+                if (ww == 0.f) continue;
+                Vec16<T> g;
+                g.load(dy + (((long)b * Ho + ho) * Wo + wo) * Ct + Cs + c);
+                float wt = wh * ww;
+#pragma unroll
+                for (int i = 0; i < N; ++i) acc[i] += wt * g.get(i);
+            }
+        }
+        Vec16<T> o;
+#pragma unroll
+        for (int i = 0; i < N; ++i) o.set(i, acc[i]);
+        o.store(dx + p * Cx + c);
+    }
+}
+
+extern "C" int mu_upcat_fwd(const void* x, const void* skip, void* y, int B, int h, int w, int Cx, int Cs, int dtype, void* stream) {
+    if (!x || !skip || !y || B <= 0 || h <= 0 || w <= 0 || Cx % 8 || Cs % 8) return MU_ERR_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == MU_F32) {
+        long total = (long)B * 4 * h * w * ((Cx + Cs) / 4);
+        upcat_fwd_kernel<float><<<ew_grid(total), 256, 0, st>>>((const float*)x, (const float*)skip, (float*)y, B, h, w, Cx, Cs);
+    } else if (dtype == MU_F16) {
+        long total = (long)B * 4 * h * w * ((Cx + Cs) / 8);
+        upcat_fwd_kernel<h16><<<ew_grid(total), 256, 0, st>>>((const h16*)x, (const h16*)skip, (h16*)y, B, h, w, Cx, Cs);
+    } else return MU_ERR_ARG;
+    MU_CHECK_LAUNCH();
+    return MU_OK;
+}
+
+extern "C" int mu_upcat_bwd(const void* dy, void* dx, void* dskip, int B, int h, int w, int Cx, int Cs, int dtype, void* stream) {
+    if (!dy || !dx || !dskip || B <= 0 || h <= 0 || w <= 0 || Cx % 8 || Cs % 8) return MU_ERR_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == MU_F32) {
+        long total = (long)B * 4 * h * w * (Cs / 4) + (long)B * h * w * (Cx / 4);
+        upcat_bwd_kernel<float><<<ew_grid(total), 256, 0, st>>>((const float*)dy, (float*)dx, (float*)dskip, B, h, w, Cx, Cs);
+    } else if (dtype == MU_F16) {
+        long total = (long)B * 4 * h * w * (Cs / 8) + (long)B * h * w * (Cx / 8);
+        upcat_bwd_kernel<h16><<<ew_grid(total), 256, 0, st>>>((const h16*)dy, (h16*)dx, (h16*)dskip, B, h, w, Cx, Cs);
+    } else return MU_ERR_ARG;
+    MU_CHECK_LAUNCH();
+    return MU_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// Dropout: y = x * keep / (1-p).  keep is either an explicit uint8 mask (parity tests inject
+// the reference's captured mask) or drawn from a counter-based generator keyed on
+// (seed, element index) so the backward regenerates it instead of storing it.
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint64_t splitmix64(uint64_t z) {
+    z += 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void dropout_kernel(const T* __restrict__ x, T* __restrict__ y, long nvec, float p, float scale,
+                                                      uint64_t seed, const uint8_t* __restrict__ mask, uint8_t* __restrict__ mask_out) {
+    constexpr int N = Vec16<T>::N;
+    const uint32_t thr = (uint32_t)(p * 65536.0f);
+    for (long v = (long)blockIdx.x * 256 + threadIdx.x; v < nvec; v += (long)gridDim.x * 256) {
+        Vec16<T> a, o;
+        a.load(x + v * N);
+        uint64_t r0 = 0, r1 = 0;
+        if (!mask) {
+            r0 = splitmix64(seed ^ (uint64_t)(2 * v) * 0xD6E8FEB86659FD93ull);
+            r1 = splitmix64(seed ^ (uint64_t)(2 * v + 1) * 0xD6E8FEB86659FD93ull);
+        }
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+            bool keep;
+            if (mask) keep = mask[v * N + i] != 0;
+            else {
+                uint32_t r = (uint32_t)(((i < 4 ? r0 : r1) >> (16 * (i & 3))) & 0xFFFFu);
+                keep = r >= thr;
+            }
+            if (mask_out) mask_out[v * N + i] = keep ? 1 : 0;
+            o.set(i, keep ? a.get(i) * scale : 0.f);
+        }
+        o.store(y + v * N);
+    }
+}
+
+extern "C" int mu_dropout(const void* x, void* y, long n, float p, unsigned long long seed, const unsigned char* mask,
+                          unsigned char* mask_out, int dtype, void* stream) {
+    if (!x || !y || n <= 0 || p < 0.f || p >= 1.f) return MU_ERR_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    float scale = 1.0f / (1.0f - p);
+    if (dtype == MU_F32) {
+        if (n % 4) return MU_ERR_SHAPE;
+        dropout_kernel<float><<<ew_grid(n / 4), 256, 0, st>>>((const float*)x, (float*)y, n / 4, p, scale, seed, mask, mask_out);
+    } else if (dtype == MU_F16) {
+        if (n % 8) return MU_ERR_SHAPE;
+        dropout_kernel<h16><<<ew_grid(n / 8), 256, 0, st>>>((const h16*)x, (h16*)y, n / 8, p, scale, seed, mask, mask_out);
+    } else return MU_ERR_ARG;
+    MU_CHECK_LAUNCH();
+    return MU_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// column sums of a [M, C] matrix (row stride ld) -> fp32 [C]   (bias gradients)
+// two stages, fp64 partials, deterministic.
+// ------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void colsum_partial_kernel(const T* __restrict__ x, long M, int C, long ld, double* __restrict__ part) {
+    // thread -> column (tid % C-chunk), rows strided
+    const int cols_per_pass = C < 256 ? C : 256;
+    const int rpi = 256 / cols_per_pass;
+    const int tc = threadIdx.x % cols_per_pass, tr = threadIdx.x / cols_per_pass;
+    __shared__ double sh[256];
+    const long rows_per_blk = (M + gridDim.x - 1) / gridDim.x;
+    const long r0 = (long)blockIdx.x * rows_per_blk, r1 = (r0 + rows_per_blk < M ? r0 + rows_per_blk : M);
+    for (int cbase = 0; cbase < C; cbase += cols_per_pass) {
+        int c = cbase + tc;
+        double s = 0.0;
+        if (tr < rpi && c < C)
+            for (long r = r0 + tr; r < r1; r += rpi) s += (double)(float)x[r * ld + c];
+        sh[threadIdx.x] = s;
+        __syncthreads();
+        if (tr == 0 && c < C) {
+            double t = 0.0;
+            for (int k = 0; k < rpi; ++k) t += sh[k * cols_per_pass + tc];
+            part[(long)blockIdx.x * C + c] = t;
+        }
+        __syncthreads();
+    }
+}
+__global__ void colsum_final_kernel(const double* __restrict__ part, int nblk, int C, float* __restrict__ out) {
+    int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    double s = 0.0;
+    for (int b = 0; b < nblk; ++b) s += part[(long)b * C + c];
+    out[c] = (float)s;
+}
+
+extern "C" long mu_colsum_workspace_bytes(int C) { return (long)512 * C * sizeof(double); }
+
+extern "C" int mu_colsum(const void* x, long M, int C, long ld, float* out, void* workspace, long ws_bytes, int dtype, void* stream) {
+    if (!x || !out || !workspace || M <= 0 || C <= 0 || ld < C) return MU_ERR_ARG;
+    if (ws_bytes < mu_colsum_workspace_bytes(C)) return MU_ERR_WORKSPACE;
+    int nblk = (int)(M / 64 < 1 ? 1 : (M / 64 > 512 ? 512 : M / 64));
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == MU_F32) colsum_partial_kernel<float><<<nblk, 256, 0, st>>>((const float*)x, M, C, ld, (double*)workspace);
+    else if (dtype == MU_F16) colsum_partial_kernel<h16><<<nblk, 256, 0, st>>>((const h16*)x, M, C, ld, (double*)workspace);
+    else return MU_ERR_ARG;
+    colsum_final_kernel<<<mu_cdiv(C, 64), 64, 0, st>>>((const double*)workspace, nblk, C, out);
+    MU_CHECK_LAUNCH();
+    return MU_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// out = a + b (residual-branch gradient join of the attention block)
+// ------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void add_kernel(const T* __restrict__ a, const T* __restrict__ b, T* __restrict__ o, long nvec) {
+    constexpr int N = Vec16<T>::N;
+    for (long v = (long)blockIdx.x * 256 + threadIdx.x; v < nvec; v += (long)gridDim.x * 256) {
+        Vec16<T> x, y, z;
+        x.load(a + v * N); y.load(b + v * N);
+#pragma unroll
+        for (int i = 0; i < N; ++i) z.set(i, x.get(i) + y.get(i));
+        z.store(o + v * N);
+    }
+}
+extern "C" int mu_add(const void* a, const void* b, void* out, long n, int dtype, void* stream) {
+    if (!a || !b || !out || n <= 0) return MU_ERR_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == MU_F32) { if (n % 4) return MU_ERR_SHAPE; add_kernel<float><<<ew_grid(n / 4), 256, 0, st>>>((const float*)a, (const float*)b, (float*)out, n / 4); }
+    else if (dtype == MU_F16) { if (n % 8) return MU_ERR_SHAPE; add_kernel<h16><<<ew_grid(n / 8), 256, 0, st>>>((const h16*)a, (const h16*)b, (h16*)out, n / 8); }
+    else return MU_ERR_ARG;
+    MU_CHECK_LAUNCH();
+    return MU_OK;
+}

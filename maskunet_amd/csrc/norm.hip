@@ -1,0 +1,466 @@
+// BatchNorm2d (+GELU/ReLU, +residual) and per-sample LayerNorm kernels, NHWC rows [M, C].
+// Reference ops replaced: nn.BatchNorm2d / nn.GELU / F.gelu(x + block(x)) in ConvBlock
+// (ade_semantic.py:198-210), the trailing BatchNorm2d of DownSample/UpSample (:219,240),
+// final_layer BN+ReLU (:285-286) and nn.LayerNorm([64,128,128]) (:281,311).
+// Statistics are accumulated in fp64 (sum, sum of squares) so the biased variance is exact to
+// fp32 rounding regardless of mean/variance ratio; everything else is fp32 math on T storage.
+#include "common.h"
+#include "../../include/maskunet_hip.h"
+
+#define MU_STAT_MAXBLK 1024
+
+// ------------------------------------------------------------------------------------------
+// per-channel partial sums over a block of rows.
+// MODE 0: (sum x, sum x^2)                                  -> BN forward statistics
+// MODE 1: dz = g * act'(pre), writes dz to dzbuf, sums (dz, dz*xhat) -> BN backward
+// layout of thread work: tc = channel vector chunk, tr = row lane; LDS [tr][C][2] reduce.
+// ------------------------------------------------------------------------------------------
+template <typename T, int MODE>
+__global__ __launch_bounds__(256) void bn_partial_kernel(const T* __restrict__ x, const T* __restrict__ g, const T* __restrict__ res,
+                                                         T* __restrict__ dzbuf, long M, int C, long ld,
+                                                         const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                         const float* __restrict__ gamma, const float* __restrict__ beta, int act,
+                                                         double* __restrict__ part) {
+    constexpr int N = Vec16<T>::N;
+    extern __shared__ __attribute__((aligned(16))) double sh[];   // [rpi][C][2]
+    const int cv = C / N;
+    const int rpi = 256 / cv;
+    const int tc = threadIdx.x % cv, tr = threadIdx.x / cv;
+    const long rows_per_blk = (M + gridDim.x - 1) / gridDim.x;
+    const long r0 = (long)blockIdx.x * rows_per_blk, r1 = (r0 + rows_per_blk < M ? r0 + rows_per_blk : M);
+    double s0[N], s1[N];
+#pragma unroll
+    for (int i = 0; i < N; ++i) { s0[i] = 0.0; s1[i] = 0.0; }
+    if (tr < rpi) {
+        const int c = tc * N;
+        float mu[N], rs[N], ga[N], be[N];
+        if (MODE == 1) {
+#pragma unroll
+            for (int i = 0; i < N; ++i) { mu[i] = mean[c + i]; rs[i] = rstd[c + i]; ga[i] = gamma[c + i]; be[i] = beta[c + i]; }
+        }
+        for (long r = r0 + tr; r < r1; r += rpi) {
+            Vec16<T> xv;
+            xv.load(x + r * ld + c);
+            if (MODE == 0) {
+#pragma unroll
+                for (int i = 0; i < N; ++i) {
+                    double v = (double)xv.get(i);
+                    s0[i] += v;
+                    s1[i] += v * v;
+                }
+            } else {
+                Vec16<T> gv, rv, dz;
+                gv.load(g + r * ld + c);
+                if (res) rv.load(res + r * ld + c);
+#pragma unroll
+                for (int i = 0; i < N; ++i) {
+                    float xh = (xv.get(i) - mu[i]) * rs[i];
+                    float pre = xh * ga[i] + be[i] + (res ? rv.get(i) : 0.f);
+                    float d = gv.get(i) * mu_act_grad(pre, act);
+                    dz.set(i, d);
+                    d = dz.get(i);       // the value the apply pass will re-read (rounded to T)
+                    s0[i] += (double)d;
+                    s1[i] += (double)d * (double)xh;
+                }
+                dz.store(dzbuf + r * ld + c);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+            sh[((long)tr * C + c + i) * 2 + 0] = s0[i];
+            sh[((long)tr * C + c + i) * 2 + 1] = s1[i];
+        }
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < C; c += 256) {
+        double a = 0.0, b = 0.0;
+        for (int k = 0; k < rpi; ++k) { a += sh[((long)k * C + c) * 2]; b += sh[((long)k * C + c) * 2 + 1]; }
+        part[((long)blockIdx.x * C + c) * 2] = a;
+        part[((long)blockIdx.x * C + c) * 2 + 1] = b;
+    }
+}
+
+// BN forward finalize: mean, rstd (biased var) + running-stat update (unbiased var, momentum)
+__global__ void bn_fwd_final_kernel(const double* __restrict__ part, int nblk, int C, long M, float eps, float momentum,
+                                    float* __restrict__ mean, float* __restrict__ rstd, float* __restrict__ running_mean,
+                                    float* __restrict__ running_var, int c_valid) {
+    int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    double s = 0.0, q = 0.0;
+    for (int b = 0; b < nblk; ++b) { s += part[((long)b * C + c) * 2]; q += part[((long)b * C + c) * 2 + 1]; }
+    double m = s / (double)M;
+    double var = q / (double)M - m * m;
+    if (var < 0.0) var = 0.0;
+    mean[c] = (float)m;
+    rstd[c] = (float)(1.0 / sqrt(var + (double)eps));
+    if (running_mean && c < c_valid) {
+        double unb = M > 1 ? var * ((double)M / (double)(M - 1)) : var;
+        running_mean[c] = (float)((1.0 - (double)momentum) * (double)running_mean[c] + (double)momentum * m);
+        running_var[c] = (float)((1.0 - (double)momentum) * (double)running_var[c] + (double)momentum * unb);
+    }
+}
+
+// eval mode: (mean, rstd) from running statistics; padded channels get (0, 1)
+__global__ void bn_eval_stats_kernel(const float* __restrict__ running_mean, const float* __restrict__ running_var, float eps,
+                                     float* __restrict__ mean, float* __restrict__ rstd, int C, int c_valid) {
+    int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    if (c < c_valid) { mean[c] = running_mean[c]; rstd[c] = 1.0f / sqrtf(running_var[c] + eps); }
+    else { mean[c] = 0.f; rstd[c] = 1.f; }
+}
+
+// BN backward finalize: dgamma = sum dz*xhat, dbeta = sum dz; s1 = dbeta/M, s2 = dgamma/M (0 in eval)
+__global__ void bn_bwd_final_kernel(const double* __restrict__ part, int nblk, int C, long M, int training,
+                                    float* __restrict__ dgamma, float* __restrict__ dbeta, float* __restrict__ s1, float* __restrict__ s2) {
+    int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    double a = 0.0, b = 0.0;
+    for (int k = 0; k < nblk; ++k) { a += part[((long)k * C + c) * 2]; b += part[((long)k * C + c) * 2 + 1]; }
+    dbeta[c] = (float)a;
+    dgamma[c] = (float)b;
+    s1[c] = training ? (float)(a / (double)M) : 0.f;
+    s2[c] = training ? (float)(b / (double)M) : 0.f;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void bn_act_fwd_kernel(const T* __restrict__ x, const T* __restrict__ res, T* __restrict__ y, long M,
+                                                         int C, long ld, const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                         const float* __restrict__ gamma, const float* __restrict__ beta, int act) {
+    constexpr int N = Vec16<T>::N;
+    const int cv = C / N;
+    const long total = M * cv;
+    int last_tc = -1;
+    float a[N], b[N];
+    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+        const int tc = idx % cv;
+        const long r = idx / cv;
+        const int c = tc * N;
+        if (tc != last_tc) {
+#pragma unroll
+            for (int i = 0; i < N; ++i) {
+                a[i] = rstd[c + i] * gamma[c + i];
+                b[i] = beta[c + i] - mean[c + i] * a[i];
+            }
+            last_tc = tc;
+        }
+        Vec16<T> xv, rv, o;
+        xv.load(x + r * ld + c);
+        if (res) rv.load(res + r * ld + c);
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+            float pre = xv.get(i) * a[i] + b[i] + (res ? rv.get(i) : 0.f);
+            o.set(i, mu_act(pre, act));
+        }
+        o.store(y + r * ld + c);
+    }
+}
+
+// dx = gamma*rstd*(dz - s1 - xhat*s2)   (dz read from dzbuf; may alias dx)
+template <typename T>
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__ x, const T* dzbuf, T* dx, long M, int C, long ld,
+                                                           const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                           const float* __restrict__ gamma, const float* __restrict__ s1,
+                                                           const float* __restrict__ s2) {
+    constexpr int N = Vec16<T>::N;
+    const int cv = C / N;
+    const long total = M * cv;
+    int last_tc = -1;
+    float mu[N], rs[N], gr[N], a1[N], a2[N];
+    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+        const int tc = idx % cv;
+        const long r = idx / cv;
+        const int c = tc * N;
+        if (tc != last_tc) {
+#pragma unroll
+            for (int i = 0; i < N; ++i) {
+                mu[i] = mean[c + i]; rs[i] = rstd[c + i]; gr[i] = gamma[c + i] * rs[i]; a1[i] = s1[c + i]; a2[i] = s2[c + i];
+            }
+            last_tc = tc;
+        }
+        Vec16<T> xv, dz, o;
+        xv.load(x + r * ld + c);
+        dz.load(dzbuf + r * ld + c);
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+            float xh = (xv.get(i) - mu[i]) * rs[i];
+            o.set(i, gr[i] * (dz.get(i) - a1[i] - xh * a2[i]));
+        }
+        o.store(dx + r * ld + c);
+    }
+}
+
+static inline int stat_blocks(long M) {
+    long b = M / 32;
+    return (int)(b < 1 ? 1 : (b > MU_STAT_MAXBLK ? MU_STAT_MAXBLK : b));
+}
+static inline int ew_grid(long total) {
+    long g = (total + 255) / 256;
+    // multiple of 5 keeps the channel chunk loop-invariant for C=160 (20/40 chunks per row)
+    g = g < 1 ? 1 : (g > 10240 ? 10240 : g);
+    return (int)g;
+}
+
+extern "C" long mu_bn_workspace_bytes(int C) { return (long)MU_STAT_MAXBLK * C * 2 * sizeof(double) + 2L * C * sizeof(float); }
+
+template <typename T>
+static int bn_train_stats_t(const T* x, long M, int C, long ld, float* mean, float* rstd, float* rmean, float* rvar, int c_valid,
+                            float momentum, float eps, void* ws, hipStream_t st) {
+    constexpr int N = Vec16<T>::N;
+    int cv = C / N;
+    if (cv > 256) return MU_ERR_SHAPE;
+    int rpi = 256 / cv;
+    int nblk = stat_blocks(M);
+    size_t lds = (size_t)rpi * C * 2 * sizeof(double);
+    bn_partial_kernel<T, 0><<<nblk, 256, lds, st>>>(x, nullptr, nullptr, nullptr, M, C, ld, nullptr, nullptr, nullptr, nullptr, 0, (double*)ws);
+    bn_fwd_final_kernel<<<mu_cdiv(C, 64), 64, 0, st>>>((const double*)ws, nblk, C, M, eps, momentum, mean, rstd, rmean, rvar, c_valid);
+    return MU_OK;
+}
+
+extern "C" int mu_bn_train_stats(const void* x, long M, int C, long ld, float* mean, float* rstd, float* running_mean,
+                                 float* running_var, int c_valid, float momentum, float eps, void* workspace, long ws_bytes,
+                                 int dtype, void* stream) {
+    if (!x || !mean || !rstd || !workspace || M <= 0 || C <= 0 || C % 8 || ld < C) return MU_ERR_ARG;
+    if (ws_bytes < mu_bn_workspace_bytes(C)) return MU_ERR_WORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    int rc;
+    if (dtype == MU_F32) rc = bn_train_stats_t<float>((const float*)x, M, C, ld, mean, rstd, running_mean, running_var, c_valid, momentum, eps, workspace, st);
+    else if (dtype == MU_F16) rc = bn_train_stats_t<h16>((const h16*)x, M, C, ld, mean, rstd, running_mean, running_var, c_valid, momentum, eps, workspace, st);
+    else return MU_ERR_ARG;
+    if (rc) return rc;
+    MU_CHECK_LAUNCH();
+    return MU_OK;
+}
+
+extern "C" int mu_bn_eval_stats(const float* running_mean, const float* running_var, float eps, float* mean, float* rstd, int C,
+                                int c_valid, void* stream) {
+    if (!running_mean || !running_var || !mean || !rstd || C <= 0) return MU_ERR_ARG;
+    bn_eval_stats_kernel<<<mu_cdiv(C, 64), 64, 0, (hipStream_t)stream>>>(running_mean, running_var, eps, mean, rstd, C, c_valid);
+    MU_CHECK_LAUNCH();
+    return MU_OK;
+}
+
+extern "C" int mu_bn_act_fwd(const void* x, const void* res, void* y, long M, int C, long ld, const float* mean, const float* rstd,
+                             const float* gamma, const float* beta, int act, int dtype, void* stream) {
+    if (!x || !y || !mean || !rstd || !gamma || !beta || M <= 0 || C <= 0 || C % 8 || ld < C) return MU_ERR_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == MU_F32)
+        bn_act_fwd_kernel<float><<<ew_grid(M * (C / 4)), 256, 0, st>>>((const float*)x, (const float*)res, (float*)y, M, C, ld, mean, rstd, gamma, beta, act);
+    else if (dtype == MU_F16)
+        bn_act_fwd_kernel<h16><<<ew_grid(M * (C / 8)), 256, 0, st>>>((const h16*)x, (const h16*)res, (h16*)y, M, C, ld, mean, rstd, gamma, beta, act);
+    else return MU_ERR_ARG;
+    MU_CHECK_LAUNCH();
+    return MU_OK;
+}
+
+template <typename T>
+static int bn_act_bwd_t(const T* x, const T* res, const T* g, T* dx, T* dres, long M, int C, long ld, const float* mean,
+                        const float* rstd, const float* gamma, const float* beta, int act, int training, float* dgamma,
+                        float* dbeta, void* ws, hipStream_t st) {
+    constexpr int N = Vec16<T>::N;
+    int cv = C / N;
+    if (cv > 256) return MU_ERR_SHAPE;
+    int rpi = 256 / cv;
+    int nblk = stat_blocks(M);
+    size_t lds = (size_t)rpi * C * 2 * sizeof(double);
+    double* part = (double*)ws;
+    float* s1 = (float*)((char*)ws + (size_t)MU_STAT_MAXBLK * C * 2 * sizeof(double));
+    float* s2 = s1 + C;
+    T* dzbuf = res ? dres : dx;     // d(residual) == dz exactly, so it doubles as the dz buffer
+    bn_partial_kernel<T, 1><<<nblk, 256, lds, st>>>(x, g, res, dzbuf, M, C, ld, mean, rstd, gamma, beta, act, part);
+    bn_bwd_final_kernel<<<mu_cdiv(C, 64), 64, 0, st>>>(part, nblk, C, M, training, dgamma, dbeta, s1, s2);
+    bn_bwd_apply_kernel<T><<<ew_grid(M * cv), 256, 0, st>>>(x, dzbuf, dx, M, C, ld, mean, rstd, gamma, s1, s2);
+    return MU_OK;
+}
+
+extern "C" int mu_bn_act_bwd(const void* x, const void* res, const void* grad_out, void* dx, void* dres, long M, int C, long ld,
+                             const float* mean, const float* rstd, const float* gamma, const float* beta, int act, int training,
+                             float* dgamma, float* dbeta, void* workspace, long ws_bytes, int dtype, void* stream) {
+    if (!x || !grad_out || !dx || !mean || !rstd || !gamma || !beta || !dgamma || !dbeta || !workspace) return MU_ERR_ARG;
+    if ((res != nullptr) != (dres != nullptr)) return MU_ERR_ARG;
+    if (M <= 0 || C <= 0 || C % 8 || ld < C) return MU_ERR_ARG;
+    if (ws_bytes < mu_bn_workspace_bytes(C)) return MU_ERR_WORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    int rc;
+    if (dtype == MU_F32)
+        rc = bn_act_bwd_t<float>((const float*)x, (const float*)res, (const float*)grad_out, (float*)dx, (float*)dres, M, C, ld, mean, rstd, gamma, beta, act, training, dgamma, dbeta, workspace, st);
+    else if (dtype == MU_F16)
+        rc = bn_act_bwd_t<h16>((const h16*)x, (const h16*)res, (const h16*)grad_out, (h16*)dx, (h16*)dres, M, C, ld, mean, rstd, gamma, beta, act, training, dgamma, dbeta, workspace, st);
+    else return MU_ERR_ARG;
+    if (rc) return rc;
+    MU_CHECK_LAUNCH();
+    return MU_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// per-sample LayerNorm over L = C*H*W elements with a full-shape affine (nn.LayerNorm([64,H,W])).
+// x, y, dy, dx: [B, L] in T;  w, b, dw, db: fp32 [L].
+// ------------------------------------------------------------------------------------------
+#define LN_CHUNKS 128     // partial-sum blocks per sample
+
+// MODE 0: (sum x, sum x^2);  MODE 1: (sum dy*w, sum dy*w*xhat)
+template <typename T, int MODE>
+__global__ __launch_bounds__(256) void lns_partial_kernel(const T* __restrict__ x, const T* __restrict__ dy, const float* __restrict__ w,
+                                                          const float* __restrict__ mean, const float* __restrict__ rstd, long L,
+                                                          double* __restrict__ part) {
+    constexpr int N = Vec16<T>::N;
+    const int b = blockIdx.y;
+    const long nvec = L / N;
+    const long per = (nvec + gridDim.x - 1) / gridDim.x;
+    const long v0 = (long)blockIdx.x * per, v1 = (v0 + per < nvec ? v0 + per : nvec);
+    const T* xb = x + (long)b * L;
+    double s0 = 0.0, s1 = 0.0;
+    float mu = 0.f, rs = 0.f;
+    if (MODE == 1) { mu = mean[b]; rs = rstd[b]; }
+    for (long v = v0 + threadIdx.x; v < v1; v += 256) {
+        Vec16<T> xv;
+        xv.load(xb + v * N);
+        if (MODE == 0) {
+#pragma unroll
+            for (int i = 0; i < N; ++i) { double t = (double)xv.get(i); s0 += t; s1 += t * t; }
+        } else {
+            Vec16<T> gv;
+            gv.load(dy + (long)b * L + v * N);
+#pragma unroll
+            for (int i = 0; i < N; ++i) {
+                float gw = gv.get(i) * w[v * N + i];
+                float xh = (xv.get(i) - mu) * rs;
+                s0 += (double)gw;
+                s1 += (double)gw * (double)xh;
+            }
+        }
+    }
+    s0 = wave_sum_d(s0);
+    s1 = wave_sum_d(s1);
+    __shared__ double sh[8];
+    const int wid = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (lane == 0) { sh[wid * 2] = s0; sh[wid * 2 + 1] = s1; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double a = sh[0] + sh[2] + sh[4] + sh[6], c = sh[1] + sh[3] + sh[5] + sh[7];
+        part[((long)b * gridDim.x + blockIdx.x) * 2] = a;
+        part[((long)b * gridDim.x + blockIdx.x) * 2 + 1] = c;
+    }
+}
+
+__global__ void lns_final_kernel(const double* __restrict__ part, int nchunk, long L, float eps, int mode, float* __restrict__ o0,
+                                 float* __restrict__ o1, int B) {
+    int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    double a = 0.0, c = 0.0;
+    for (int k = 0; k < nchunk; ++k) { a += part[((long)b * nchunk + k) * 2]; c += part[((long)b * nchunk + k) * 2 + 1]; }
+    if (mode == 0) {
+        double m = a / (double)L, var = c / (double)L - m * m;
+        if (var < 0.0) var = 0.0;
+        o0[b] = (float)m;
+        o1[b] = (float)(1.0 / sqrt(var + (double)eps));
+    } else {
+        o0[b] = (float)(a / (double)L);
+        o1[b] = (float)(c / (double)L);
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void lns_fwd_apply_kernel(const T* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
+                                                            const float* __restrict__ mean, const float* __restrict__ rstd, T* __restrict__ y,
+                                                            long L, int B) {
+    constexpr int N = Vec16<T>::N;
+    const long nvec = L / N;
+    for (long v = (long)blockIdx.x * 256 + threadIdx.x; v < nvec; v += (long)gridDim.x * 256) {
+        float wv[N], bv[N];
+#pragma unroll
+        for (int i = 0; i < N; ++i) { wv[i] = w[v * N + i]; bv[i] = bias[v * N + i]; }
+        for (int b = 0; b < B; ++b) {
+            const float mu = mean[b], rs = rstd[b];
+            Vec16<T> xv, o;
+            xv.load(x + (long)b * L + v * N);
+#pragma unroll
+            for (int i = 0; i < N; ++i) o.set(i, (xv.get(i) - mu) * rs * wv[i] + bv[i]);
+            o.store(y + (long)b * L + v * N);
+        }
+    }
+}
+
+// dx = rstd*(dy*w - m1 - xhat*m2);  dw[f] = sum_b dy*xhat;  db[f] = sum_b dy
+template <typename T>
+__global__ __launch_bounds__(256) void lns_bwd_apply_kernel(const T* __restrict__ x, const T* __restrict__ dy, const float* __restrict__ w,
+                                                            const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                            const float* __restrict__ m1, const float* __restrict__ m2, T* __restrict__ dx,
+                                                            float* __restrict__ dw, float* __restrict__ db, long L, int B) {
+    constexpr int N = Vec16<T>::N;
+    const long nvec = L / N;
+    for (long v = (long)blockIdx.x * 256 + threadIdx.x; v < nvec; v += (long)gridDim.x * 256) {
+        float wv[N], aw[N], ab[N];
+#pragma unroll
+        for (int i = 0; i < N; ++i) { wv[i] = w[v * N + i]; aw[i] = 0.f; ab[i] = 0.f; }
+        for (int b = 0; b < B; ++b) {
+            const float mu = mean[b], rs = rstd[b], a1 = m1[b], a2 = m2[b];
+            Vec16<T> xv, gv, o;
+            xv.load(x + (long)b * L + v * N);
+            gv.load(dy + (long)b * L + v * N);
+#pragma unroll
+            for (int i = 0; i < N; ++i) {
+                float xh = (xv.get(i) - mu) * rs, g = gv.get(i);
+                aw[i] += g * xh;
+                ab[i] += g;
+                o.set(i, rs * (g * wv[i] - a1 - xh * a2));
+            }
+            o.store(dx + (long)b * L + v * N);
+        }
+#pragma unroll
+        for (int i = 0; i < N; ++i) { dw[v * N + i] = aw[i]; db[v * N + i] = ab[i]; }
+    }
+}
+
+extern "C" long mu_ln_sample_workspace_bytes(int B) { return (long)B * LN_CHUNKS * 2 * sizeof(double) + 2L * B * sizeof(float); }
+
+template <typename T>
+static int lns_fwd_t(const T* x, const float* w, const float* b, T* y, float* mean, float* rstd, int B, long L, float eps, void* ws,
+                     hipStream_t st) {
+    constexpr int N = Vec16<T>::N;
+    dim3 grid(LN_CHUNKS, B);
+    lns_partial_kernel<T, 0><<<grid, 256, 0, st>>>(x, nullptr, nullptr, nullptr, nullptr, L, (double*)ws);
+    lns_final_kernel<<<mu_cdiv(B, 64), 64, 0, st>>>((const double*)ws, LN_CHUNKS, L, eps, 0, mean, rstd, B);
+    long nvec = L / N;
+    int g = (int)((nvec + 255) / 256 > 8192 ? 8192 : (nvec + 255) / 256);
+    lns_fwd_apply_kernel<T><<<g, 256, 0, st>>>(x, w, b, mean, rstd, y, L, B);
+    return MU_OK;
+}
+
+extern "C" int mu_ln_sample_fwd(const void* x, const float* w, const float* b, void* y, float* mean, float* rstd, int B, long L,
+                                float eps, void* workspace, long ws_bytes, int dtype, void* stream) {
+    if (!x || !w || !b || !y || !mean || !rstd || !workspace || B <= 0 || L <= 0 || L % 8) return MU_ERR_ARG;
+    if (ws_bytes < mu_ln_sample_workspace_bytes(B)) return MU_ERR_WORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == MU_F32) lns_fwd_t<float>((const float*)x, w, b, (float*)y, mean, rstd, B, L, eps, workspace, st);
+    else if (dtype == MU_F16) lns_fwd_t<h16>((const h16*)x, w, b, (h16*)y, mean, rstd, B, L, eps, workspace, st);
+    else return MU_ERR_ARG;
+    MU_CHECK_LAUNCH();
+    return MU_OK;
+}
+
+template <typename T>
+static int lns_bwd_t(const T* x, const T* dy, const float* w, const float* mean, const float* rstd, T* dx, float* dw, float* db,
+                     int B, long L, void* ws, hipStream_t st) {
+    constexpr int N = Vec16<T>::N;
+    dim3 grid(LN_CHUNKS, B);
+    float* m1 = (float*)((char*)ws + (size_t)B * LN_CHUNKS * 2 * sizeof(double));
+    float* m2 = m1 + B;
+    lns_partial_kernel<T, 1><<<grid, 256, 0, st>>>(x, dy, w, mean, rstd, L, (double*)ws);
+    lns_final_kernel<<<mu_cdiv(B, 64), 64, 0, st>>>((const double*)ws, LN_CHUNKS, L, 0.f, 1, m1, m2, B);
+    long nvec = L / N;
+    int g = (int)((nvec + 255) / 256 > 8192 ? 8192 : (nvec + 255) / 256);
+    lns_bwd_apply_kernel<T><<<g, 256, 0, st>>>(x, dy, w, mean, rstd, m1, m2, dx, dw, db, L, B);
+    return MU_OK;
+}
+
+extern "C" int mu_ln_sample_bwd(const void* x, const void* dy, const float* w, const float* mean, const float* rstd, void* dx,
+                                float* dw, float* db, int B, long L, void* workspace, long ws_bytes, int dtype, void* stream) {
+    if (!x || !dy || !w || !mean || !rstd || !dx || !dw || !db || !workspace || B <= 0 || L <= 0 || L % 8) return MU_ERR_ARG;
+    if (ws_bytes < mu_ln_sample_workspace_bytes(B)) return MU_ERR_WORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == MU_F32) lns_bwd_t<float>((const float*)x, (const float*)dy, w, mean, rstd, (float*)dx, dw, db, B, L, workspace, st);
+    else if (dtype == MU_F16) lns_bwd_t<h16>((const h16*)x, (const h16*)dy, w, mean, rstd, (h16*)dx, dw, db, B, L, workspace, st);
+    else return MU_ERR_ARG;
+    MU_CHECK_LAUNCH();
+    return MU_OK;
+}

@@ -1,0 +1,149 @@
+"""Data parallelism for the MaskAttn-UNet path: one process per GPU, replicated weights, batch sharded on
+dim 0, ONE exchange per step = bucketed all-reduce (mean) of the parameter gradients over RCCL/xGMI.
+
+Replaces the reference's ``torch.nn.DataParallel(model)`` (code/ade20k/ade_semantic.py:373), whose implicit
+per-forward broadcast / scatter / gather / reduce-add collapses to a single gradient all-reduce:
+  * BatchNorm statistics stay per replica (the reference has no SyncBN) -- faithful semantics;
+  * parameters that never receive gradients (``emb_layer``; ``boundary_head`` under the reference loss)
+    are skipped identically on every rank;
+  * buckets are launched from post-accumulate-grad hooks as soon as all their gradients exist, on a side
+    stream, so the all-reduce of late layers overlaps the backward of early layers.
+The collective backend is whatever ``torch.distributed`` was initialised with: "nccl" (= RCCL) on GPUs,
+"gloo" in the CPU tests.
+"""
+from __future__ import annotations
+
+from typing import List
+
+import torch
+import torch.distributed as dist
+import torch.nn as nn
+
+
+def shard_batch(global_batch: int, world_size: int, rank: int):
+    """[start, stop) of this rank's slice of a global batch (dim 0), remainder spread over the first ranks --
+    the split nn.DataParallel's scatter performs."""
+    base, rem = divmod(global_batch, world_size)
+    start = rank * base + min(rank, rem)
+    return start, start + base + (1 if rank < rem else 0)
+
+
+class _Bucket:
+    def __init__(self, params: List[nn.Parameter]):
+        self.params = params
+        self.numel = sum(p.numel() for p in params)
+        self.pending = 0
+        self.flat = None
+        self.work = None
+
+
+class DataParallel(nn.Module):
+    """``model = DataParallel(model)``; use like the wrapped module; call ``finish_gradient_sync()`` (or
+    ``sync_gradients()``) after ``loss.backward()`` and before ``optimizer.step()``.  ``state_dict`` keys carry the
+    ``module.`` prefix exactly like nn.DataParallel checkpoints (ade_semantic.py:412; stripped on load at
+    ade_panoptic.py:434)."""
+
+    def __init__(self, module: nn.Module, bucket_mb: float = 32.0, overlap: bool = True, process_group=None):
+        super().__init__()
+        self.module = module
+        self.group = process_group
+        self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        self.overlap = overlap and self.world > 1
+        if self.world > 1:
+            self.broadcast_parameters()
+        # buckets in reverse registration order (roughly the order gradients become ready)
+        params = [p for p in module.parameters() if p.requires_grad]
+        self.buckets: List[_Bucket] = []
+        cur, cur_bytes, cap = [], 0, int(bucket_mb * (1 << 20))
+        for p in reversed(params):
+            cur.append(p)
+            cur_bytes += p.numel() * 4
+            if cur_bytes >= cap:
+                self.buckets.append(_Bucket(cur))
+                cur, cur_bytes = [], 0
+        if cur:
+            self.buckets.append(_Bucket(cur))
+        self._bucket_of = {id(p): b for b in self.buckets for p in b.params}
+        self._comm_stream = None
+        self._hooks = []
+        if self.overlap:
+            for p in params:
+                self._hooks.append(p.register_post_accumulate_grad_hook(self._on_grad))
+        self._armed = False
+
+    # ------------------------------------------------------------------------------------------
+    def broadcast_parameters(self, src: int = 0):
+        """Replicas start identical (nn.DataParallel re-broadcasts GPU0's parameters/buffers every forward)."""
+        for t in list(self.module.parameters()) + list(self.module.buffers()):
+            dist.broadcast(t.data, src, group=self.group)
+
+    def forward(self, *args, **kwargs):
+        self._arm()
+        return self.module(*args, **kwargs)
+
+    def _arm(self):
+        for b in self.buckets:
+            b.pending = len(b.params)
+            b.flat, b.work = None, None
+        self._armed = True
+
+    def _on_grad(self, p):
+        if not self._armed:
+            return
+        b = self._bucket_of[id(p)]
+        b.pending -= 1
+        if b.pending == 0:
+            self._launch(b)
+
+    def _launch(self, b: _Bucket):
+        grads = [p.grad for p in b.params if p.grad is not None]
+        if not grads:
+            return
+        dev = grads[0].device
+        if dev.type == "cuda":
+            if self._comm_stream is None:
+                self._comm_stream = torch.cuda.Stream(device=dev)
+            self._comm_stream.wait_stream(torch.cuda.current_stream(dev))
+            with torch.cuda.stream(self._comm_stream):
+                b.flat = torch.cat([g.reshape(-1).float() for g in grads])
+                b.work = dist.all_reduce(b.flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        else:
+            b.flat = torch.cat([g.reshape(-1).float() for g in grads])
+            b.work = dist.all_reduce(b.flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+
+    def finish_gradient_sync(self):
+        """Wait for the bucket all-reduces and write the averaged gradients back.  Buckets whose hooks did not
+        all fire (parameters without gradients this step) are reduced here with what they have."""
+        if self.world == 1:
+            self._armed = False
+            return
+        for b in self.buckets:
+            if b.work is None:
+                self._launch(b)
+        for b in self.buckets:
+            if b.work is None:
+                continue
+            b.work.wait()
+            grads = [p.grad for p in b.params if p.grad is not None]
+            dev = grads[0].device
+            ctx = torch.cuda.stream(self._comm_stream) if dev.type == "cuda" else _null()
+            with ctx:
+                b.flat.div_(self.world)
+                off = 0
+                for g in grads:
+                    n = g.numel()
+                    g.copy_(b.flat[off:off + n].view_as(g))
+                    off += n
+        if self._comm_stream is not None:
+            torch.cuda.current_stream().wait_stream(self._comm_stream)
+        self._armed = False
+
+    sync_gradients = finish_gradient_sync
+
+
+class _null:
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        return False

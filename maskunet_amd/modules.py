@@ -1,0 +1,371 @@
+"""nn.Module surface of the reference (code/ade20k/ade_semantic.py:152-314 and
+code/cityscapes/city_instance.py:216-276), backed by the HIP kernels.
+
+Same class names, constructor signatures, forward signatures, error behaviour and ``state_dict``
+keys/shapes as the reference, so its training scripts and checkpoints work unchanged; the
+``north_star`` aliases (DoubleConv, Down, Up, MaskAttention, OutConv) are exported too.
+
+The torch sub-modules (nn.Conv2d, nn.BatchNorm2d, nn.Linear, nn.LayerNorm ...) are used purely as
+PARAMETER CONTAINERS -- they give identical parameter names, shapes and default initialisation
+ -- their ``forward`` is never called.  Every forward here runs HIP kernels through
+``maskunet_amd.ops``; CPU tensors raise (there is no fallback).
+
+Public ``forward`` takes and returns NCHW tensors like the reference.  Inside a UNet the blocks
+talk NHWC (``forward_nhwc``) in the compute dtype so no layout conversion happens between them.
+"""
+from __future__ import annotations
+
+import torch
+import torch.nn as nn
+
+from . import ops
+from ._lib import ACT_GELU, ACT_NONE, ACT_RELU
+
+_DEFAULT_DTYPE = torch.float32
+
+
+def set_default_compute_dtype(dtype):
+    """Compute/storage dtype of activations for modules created afterwards: torch.float32 (parity
+    path, exact-fp32 MFMA) or torch.float16 (fp16 storage, fp32 accumulate)."""
+    global _DEFAULT_DTYPE
+    if dtype not in (torch.float32, torch.float16):
+        raise TypeError("compute dtype must be torch.float32 or torch.float16")
+    _DEFAULT_DTYPE = dtype
+
+
+class _HipModule(nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.compute_dtype = _DEFAULT_DTYPE
+
+    def set_compute_dtype(self, dtype):
+        if dtype not in (torch.float32, torch.float16):
+            raise TypeError("compute dtype must be torch.float32 or torch.float16")
+        for m in self.modules():
+            if isinstance(m, _HipModule):
+                m.compute_dtype = dtype
+        return self
+
+    def _check_device(self, x):
+        if not x.is_cuda:
+            raise RuntimeError("maskunet_amd modules run on the GPU only (HIP kernels, no CPU fallback); "
+                               "move the model and inputs to cuda")
+
+
+class Mask2FormerAttention(_HipModule):
+    """ade_semantic.py:152-190.  ``mask`` keeps the reference's attribute semantics: ``None`` until the first
+    forward, then an additive {0,-inf} key mask cached while H*W is unchanged; it can be injected from outside
+    in the reference's own form ([B,N,N] expand view, or anything indexable as mask[:,0,:]) or via
+    ``set_keep_mask`` ([B,N], 1 = key visible).  ``mask_mode='resample'`` redraws it on every forward (what the
+    reference does under multi-GPU nn.DataParallel)."""
+
+    def __init__(self, channels, size):
+        super().__init__()
+        self.channels = channels
+        self.size = size
+        self.query = nn.Linear(channels, channels)
+        self.key = nn.Linear(channels, channels)
+        self.value = nn.Linear(channels, channels)
+        self.norm = nn.LayerNorm([channels])
+        self.mask_mode = "fixed"
+        self._keep = None
+        self._kidx = None
+        self._kcnt = None
+
+    # -- mask state -----------------------------------------------------------------------------
+    @property
+    def mask(self):
+        if self._keep is None:
+            return None
+        keep = self._keep
+        add = torch.where(keep > 0, torch.zeros((), device=keep.device), torch.full((), -float("inf"), device=keep.device))
+        return add.unsqueeze(1).expand(-1, keep.shape[1], -1)
+
+    @mask.setter
+    def mask(self, value):
+        if value is None:
+            self._keep = self._kidx = self._kcnt = None
+            return
+        if value.dim() == 3:
+            value = value[:, 0, :]
+        self.set_keep_mask(value == 0 if value.is_floating_point() else value)
+
+    def set_keep_mask(self, keep):
+        """keep: [B,N], non-zero = key visible.  Builds the compacted kept-key index list on device."""
+        keep = (keep != 0).to(torch.uint8)
+        self._keep = keep
+        self._kidx = self._kcnt = None
+
+    def _compact(self, device):
+        if self._kidx is None or self._kidx.device != device:
+            keep = self._keep.to(device)
+            self._keep = keep
+            # stable sort puts kept keys first, in ascending key order
+            self._kidx = torch.argsort(keep, dim=1, descending=True, stable=True).to(torch.int32).contiguous()
+            self._kcnt = keep.sum(dim=1, dtype=torch.int32).contiguous()
+        return self._kidx, self._kcnt
+
+    def _mask_for(self, x_nhwc):
+        B, H, W, _ = x_nhwc.shape
+        N = H * W
+        if self._keep is None or self._keep.shape[-1] != N or self.mask_mode == "resample":
+            # same draw as the reference (ade_semantic.py:178): randint(0,2,(B,H,W)) on the input's device
+            binary = torch.randint(0, 2, (B, H, W), device=x_nhwc.device)
+            self.set_keep_mask(binary.view(B, -1))
+        kidx, kcnt = self._compact(x_nhwc.device)
+        if kidx.shape[0] != B:
+            if kidx.shape[0] == 1:      # reference: a cached batch-1 mask broadcasts
+                kidx, kcnt = kidx.expand(B, -1).contiguous(), kcnt.expand(B).contiguous()
+            else:
+                raise RuntimeError(f"The size of tensor a ({B}) must match the size of tensor b ({kidx.shape[0]}) at "
+                                   "non-singleton dimension 0")
+        return kidx, kcnt
+
+    # -- forward --------------------------------------------------------------------------------
+    def forward_nhwc(self, x, scramble=True):
+        if x.shape[-1] != self.channels:
+            raise ValueError("Input channel size does not match initialized channel size.")
+        kidx, kcnt = self._mask_for(x)
+        return ops.mask_attention(x, self.query, self.key, self.value, self.norm, kidx, kcnt, scramble)
+
+    def forward(self, x):
+        batch_size, channels, height, width = x.size()
+        if channels != self.channels:
+            raise ValueError("Input channel size does not match initialized channel size.")
+        self._check_device(x)
+        if channels % 32:
+            raise RuntimeError("maskunet_amd: attention channels must be a multiple of 32")
+        y = self.forward_nhwc(ops.to_nhwc(x, self.compute_dtype), scramble=False)    # [B,N,C] token-major
+        # the reference returns this buffer re-viewed as [B,C,H,W] (ade_semantic.py:190)
+        return y.view(batch_size, channels, height, width).to(x.dtype)
+
+
+class ConvBlock(_HipModule):
+    """ade_semantic.py:192-210."""
+
+    def __init__(self, in_channels, out_channels, mid_channels=None, residual=False):
+        super().__init__()
+        self.residual = residual
+        if not mid_channels:
+            mid_channels = out_channels
+        self.conv_block = nn.Sequential(
+            nn.Conv2d(in_channels, mid_channels, kernel_size=3, padding=1, bias=False),
+            nn.BatchNorm2d(mid_channels),
+            nn.GELU(),
+            nn.Conv2d(mid_channels, out_channels, kernel_size=3, padding=1, bias=False),
+            nn.BatchNorm2d(out_channels),
+        )
+
+    def forward_nhwc(self, x):
+        cb = self.conv_block
+        y = ops.conv(x, cb[0].weight)
+        y = ops.bn_act(y, cb[1], ACT_GELU)
+        y = ops.conv(y, cb[3].weight)
+        if self.residual:
+            return ops.bn_act(y, cb[4], ACT_GELU, res=x)      # gelu(x + BN(conv(...)))  (:208)
+        return ops.bn_act(y, cb[4], ACT_NONE)
+
+    def forward(self, x):
+        self._check_device(x)
+        cout = self.conv_block[3].out_channels
+        return ops.to_nchw(self.forward_nhwc(ops.to_nhwc(x, self.compute_dtype)), cout, x.dtype)
+
+
+class DownSample(_HipModule):
+    """ade_semantic.py:212-229.  emb_layer is dead weight kept for checkpoint compatibility (:222-225)."""
+
+    def __init__(self, in_channels, out_channels, emb_dim=256):
+        super().__init__()
+        self.maxpool_conv = nn.Sequential(
+            nn.MaxPool2d(2),
+            ConvBlock(in_channels, in_channels, residual=True),
+            ConvBlock(in_channels, out_channels),
+            nn.BatchNorm2d(out_channels),
+        )
+        self.emb_layer = nn.Sequential(nn.SiLU(), nn.Linear(emb_dim, out_channels))
+        self.out_channels = out_channels
+
+    def forward_nhwc(self, x):
+        mc = self.maxpool_conv
+        x = ops.maxpool2(x)
+        x = mc[1].forward_nhwc(x)
+        x = mc[2].forward_nhwc(x)
+        return ops.bn_act(x, mc[3], ACT_NONE)
+
+    def forward(self, x):
+        self._check_device(x)
+        return ops.to_nchw(self.forward_nhwc(ops.to_nhwc(x, self.compute_dtype)), self.out_channels, x.dtype)
+
+
+class UpSample(_HipModule):
+    """ade_semantic.py:231-256."""
+
+    def __init__(self, in_channels, out_channels, emb_dim=256):
+        super().__init__()
+        self.upsample = nn.Upsample(scale_factor=2, mode="bilinear", align_corners=True)
+        self.out_channels = out_channels
+        self.conv = nn.Sequential(
+            ConvBlock(in_channels, in_channels, residual=True),
+            ConvBlock(in_channels, out_channels, in_channels // 2),
+            nn.BatchNorm2d(out_channels),
+        )
+        self.emb_layer = nn.Sequential(nn.SiLU(), nn.Linear(emb_dim, out_channels))
+
+    def forward_nhwc(self, x, skip_x):
+        x = ops.upcat(x, skip_x)                 # cat([skip_x, up(x)], dim=1)  (:250-253)
+        x = self.conv[0].forward_nhwc(x)
+        x = self.conv[1].forward_nhwc(x)
+        return ops.bn_act(x, self.conv[2], ACT_NONE)
+
+    def forward(self, x, skip_x):
+        self._check_device(x)
+        if x.shape[1] % 32 or skip_x.shape[1] % 32:
+            raise RuntimeError("maskunet_amd: stand-alone UpSample needs channel counts that are multiples of 32")
+        y = self.forward_nhwc(ops.to_nhwc(x, self.compute_dtype), ops.to_nhwc(skip_x, self.compute_dtype))
+        return ops.to_nchw(y, self.out_channels, x.dtype)
+
+
+class _Head(nn.Sequential):
+    """Conv2d 1x1 (bias) -> BatchNorm2d -> ReLU container with the reference's Sequential indices."""
+
+
+def _head_1x1_bn_relu(seq, x):
+    y = ops.conv(x, seq[0].weight, seq[0].bias)
+    return ops.bn_act(y, seq[1], ACT_RELU)
+
+
+class UNet(_HipModule):
+    """ade_semantic.py:258-314 (1-head) and city_instance.py:216-276 (3-head, when ``embed_dim`` is given).
+
+    ``UNet(c_in, c_out)`` -> forward returns [B,c_out,H,W]; ``UNet(c_in, c_out, embed_dim)`` -> forward returns
+    (semantic, boundary, embeddings).  ``hw`` (keyword, default 128) sizes ``norm = LayerNorm([64,hw,hw])``; the
+    reference hard-codes 128 (:281)."""
+
+    def __init__(self, c_in=3, c_out=3, embed_dim=None, *, hw=128):
+        super().__init__()
+        self.c_out = c_out
+        self.initial_conv = ConvBlock(c_in, 64)
+        self.downsample1 = DownSample(64, 128)
+        self.self_attention1 = Mask2FormerAttention(128, 128)
+        self.downsample2 = DownSample(128, 256)
+        self.self_attention2 = Mask2FormerAttention(256, 256)
+        self.downsample3 = DownSample(256, 256)
+        self.self_attention3 = Mask2FormerAttention(256, 256)
+
+        self.bottom1 = ConvBlock(256, 512)
+        self.bottom2 = ConvBlock(512, 512)
+        self.bottom3 = ConvBlock(512, 256)
+
+        self.dropout = nn.Dropout(0.3)
+
+        self.upsample1 = UpSample(512, 128)
+        self.self_attention4 = Mask2FormerAttention(128, 128)
+        self.upsample2 = UpSample(256, 64)
+        self.self_attention5 = Mask2FormerAttention(64, 64)
+        self.upsample3 = UpSample(128, 64)
+        self.self_attention6 = Mask2FormerAttention(64, 64)
+        self.norm = nn.LayerNorm([64, hw, hw])
+        self.final_layer = nn.Sequential(nn.Conv2d(64, c_out, kernel_size=1), nn.BatchNorm2d(c_out), nn.ReLU())
+        self.three_head = embed_dim is not None
+        if self.three_head:
+            self.boundary_head = nn.Sequential(
+                nn.Conv2d(c_out, 32, kernel_size=3, padding=1), nn.BatchNorm2d(32), nn.ReLU(), nn.Conv2d(32, 1, kernel_size=1))
+            self.embedding_head = nn.Sequential(nn.Conv2d(64, embed_dim, kernel_size=1), nn.BatchNorm2d(embed_dim), nn.ReLU())
+            self.embed_dim = embed_dim
+        # test hook: explicit dropout keep-masks (NHWC uint8) for the two dropout sites
+        self.dropout_masks = None
+
+    def attention_blocks(self):
+        return [getattr(self, f"self_attention{i}") for i in range(1, 7)]
+
+    def set_keep_masks(self, keeps):
+        """Inject the six key keep-masks ([B,N_k] each) -- parity tests and reproducible benches."""
+        for blk, k in zip(self.attention_blocks(), keeps):
+            blk.set_keep_mask(k)
+
+    def set_mask_mode(self, mode):
+        if mode not in ("fixed", "resample"):
+            raise ValueError("mask_mode must be 'fixed' or 'resample'")
+        for blk in self.attention_blocks():
+            blk.mask_mode = mode
+
+    def _drop(self, x, i):
+        m = None if self.dropout_masks is None else self.dropout_masks[i]
+        return ops.dropout(x, self.dropout.p, self.training, m)
+
+    def forward_nhwc(self, x):
+        """x: NHWC [B,H,W,32] (3 real channels) -> tuple of NHWC head outputs (padded channels)."""
+        x1 = self.initial_conv.forward_nhwc(x)
+        x2 = self.downsample1.forward_nhwc(x1)
+        x2 = self.self_attention1.forward_nhwc(x2)
+        x3 = self.downsample2.forward_nhwc(x2)
+        x3 = self.self_attention2.forward_nhwc(x3)
+        x4 = self.downsample3.forward_nhwc(x3)
+        x4 = self.self_attention3.forward_nhwc(x4)
+
+        x4 = self.bottom1.forward_nhwc(x4)
+        x4 = self.bottom2.forward_nhwc(x4)
+        x4 = self.bottom3.forward_nhwc(x4)
+
+        y = self.upsample1.forward_nhwc(x4, x3)
+        y = self._drop(y, 0)
+        y = self.self_attention4.forward_nhwc(y)
+        y = self.upsample2.forward_nhwc(y, x2)
+        y = self._drop(y, 1)
+        y = self.self_attention5.forward_nhwc(y)
+        y = self.upsample3.forward_nhwc(y, x1)
+        B, H, W, _ = y.shape
+        # attention 6 feeds the per-sample LayerNorm, which works on the NCHW-flat memory == the
+        # token-major buffer itself, so the scramble transpose is skipped here (:310-311)
+        y = self.self_attention6.forward_nhwc(y, scramble=False)             # [B,N,64] == NCHW-flat [B,64,H,W]
+        if tuple(self.norm.normalized_shape) != (64, H, W):
+            raise RuntimeError(f"Given normalized_shape={list(self.norm.normalized_shape)}, expected input with shape "
+                               f"[*, 64, {H}, {W}]")
+        y = ops.ln_sample(y.view(B, -1), self.norm.weight, self.norm.bias, self.norm.eps)
+        y = ops.to_nhwc(y.view(B, 64, H, W), self.compute_dtype)             # NCHW-flat -> NHWC for the 1x1 heads
+        sem = _head_1x1_bn_relu(self.final_layer, y)
+        if not self.three_head:
+            return (sem,)
+        emb = _head_1x1_bn_relu(self.embedding_head, y)
+        bh = self.boundary_head
+        b = ops.conv(sem, bh[0].weight, bh[0].bias)
+        b = ops.bn_act(b, bh[1], ACT_RELU)
+        b = ops.conv(b, bh[3].weight, bh[3].bias)
+        return sem, b, emb
+
+    def forward(self, x):
+        self._check_device(x)
+        outs = self.forward_nhwc(ops.to_nhwc(x, self.compute_dtype))
+        sem = ops.to_nchw(outs[0], self.c_out, torch.float32)
+        if not self.three_head:
+            return sem
+        return sem, ops.to_nchw(outs[1], 1, torch.float32), ops.to_nchw(outs[2], self.embed_dim, torch.float32)
+
+
+class InstanceUNet(UNet):
+    """The 3-head UNet of code/cityscapes/city_instance.py:216-276 with its own constructor signature
+    ``UNet(c_in=3, c_out=3, embed_dim=16)``."""
+
+    def __init__(self, c_in=3, c_out=3, embed_dim=16, *, hw=128):
+        super().__init__(c_in, c_out, embed_dim, hw=hw)
+
+
+# north_star aliases -------------------------------------------------------------------------------
+DoubleConv = ConvBlock
+Down = DownSample
+Up = UpSample
+MaskAttention = Mask2FormerAttention
+
+
+class OutConv(_HipModule):
+    """Alias-style wrapper for the reference's ``final_layer`` (Conv1x1 -> BN -> ReLU, ade_semantic.py:283-287)."""
+
+    def __init__(self, in_channels, out_channels):
+        super().__init__()
+        self.final_layer = nn.Sequential(nn.Conv2d(in_channels, out_channels, kernel_size=1), nn.BatchNorm2d(out_channels), nn.ReLU())
+        self.out_channels = out_channels
+
+    def forward(self, x):
+        self._check_device(x)
+        y = _head_1x1_bn_relu(self.final_layer, ops.to_nhwc(x, self.compute_dtype))
+        return ops.to_nchw(y, self.out_channels, x.dtype)

@@ -1,0 +1,433 @@
+"""torch.autograd.Function ops over the C ABI (include/maskunet_hip.h).  All activations here are
+NHWC tensors [B,H,W,C] (or token-major [B,N,C]) in the compute dtype (fp32 or fp16) whose channel
+count is a multiple of 32; parameters are the fp32 torch parameters in reference layout (OIHW).
+
+Each op cites the reference lines it replaces.  There is no eager/CPU fallback anywhere: every path
+ends in `_lib.call`, which raises if the HIP library is missing or a kernel reports an error.
+"""
+from __future__ import annotations
+
+import torch
+import torch.nn.functional as F
+from torch.autograd.function import once_differentiable
+
+from . import _lib
+from ._lib import ACT_GELU, ACT_NONE, ACT_RELU, call, dt, ptr, stream, workspace  # noqa: F401
+
+
+def pad32(c: int) -> int:
+    return (c + 31) // 32 * 32
+
+
+def _pad_vec(v, n, fill):
+    """fp32 per-channel vector padded to n entries (pad value `fill`)."""
+    v = v.detach().float()
+    if v.numel() == n:
+        return v.contiguous()
+    return F.pad(v, (0, n - v.numel()), value=fill)
+
+
+# ------------------------------------------------------------------------------------------------
+# layout conversion at the module boundary
+# ------------------------------------------------------------------------------------------------
+class _ToNHWC(torch.autograd.Function):
+    """NCHW fp32/fp16 [B,C,H,W] -> NHWC [B,H,W,pad32(C)] in the compute dtype (zero padded)."""
+
+    @staticmethod
+    def forward(ctx, x, dtype):
+        B, C, H, W = x.shape
+        x = x.contiguous()
+        Cp = pad32(C)
+        alloc = torch.zeros if Cp != C else torch.empty
+        y = alloc((B, H, W, Cp), dtype=dtype, device=x.device)
+        call("mu_transpose", ptr(x), dt(x), H * W, ptr(y), dt(y), Cp, B, C, H * W, stream())
+        ctx.C, ctx.in_dtype = C, x.dtype
+        return y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g):
+        g = g.contiguous()
+        B, H, W, Cp = g.shape
+        gx = torch.empty((B, ctx.C, H, W), dtype=ctx.in_dtype, device=g.device)
+        call("mu_transpose", ptr(g), dt(g), Cp, ptr(gx), dt(gx), H * W, B, H * W, ctx.C, stream())
+        return gx, None
+
+
+class _ToNCHW(torch.autograd.Function):
+    """NHWC [B,H,W,Cp] -> NCHW [B,C,H,W] (first C channels) in `out_dtype`."""
+
+    @staticmethod
+    def forward(ctx, x, C, out_dtype):
+        x = x.contiguous()
+        B, H, W, Cp = x.shape
+        y = torch.empty((B, C, H, W), dtype=out_dtype, device=x.device)
+        call("mu_transpose", ptr(x), dt(x), Cp, ptr(y), dt(y), H * W, B, H * W, C, stream())
+        ctx.Cp, ctx.in_dtype = Cp, x.dtype
+        return y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g):
+        g = g.contiguous()
+        B, C, H, W = g.shape
+        alloc = torch.zeros if ctx.Cp != C else torch.empty
+        gx = alloc((B, H, W, ctx.Cp), dtype=ctx.in_dtype, device=g.device)
+        call("mu_transpose", ptr(g), dt(g), H * W, ptr(gx), dt(gx), ctx.Cp, B, C, H * W, stream())
+        return gx, None, None
+
+
+def to_nhwc(x, dtype):
+    if x.dtype not in (torch.float32, torch.float16):
+        x = x.float()
+    return _ToNHWC.apply(x, dtype)
+
+
+def to_nchw(x, C, out_dtype=torch.float32):
+    return _ToNCHW.apply(x, C, out_dtype)
+
+
+# ------------------------------------------------------------------------------------------------
+# convolution / linear
+# ------------------------------------------------------------------------------------------------
+def _prep_weight(w, dtype, rows_pad, cols_pad, mode):
+    O, I = w.shape[0], w.shape[1]
+    taps = w.shape[2] * w.shape[3] if w.dim() == 4 else 1
+    dst = torch.empty((taps, rows_pad, cols_pad), dtype=dtype, device=w.device)
+    wf = w.detach().float().contiguous()
+    call("mu_prep_weight", ptr(wf), ptr(dst), dt(dtype), O, I, taps, rows_pad, cols_pad, mode, stream())
+    return dst
+
+
+def _conv_raw(x, wprep, bias_p, Cout_p, taps):
+    B, H, W, Cin_p = x.shape
+    y = torch.empty((B, H, W, Cout_p), dtype=x.dtype, device=x.device)
+    call("mu_conv_fwd", ptr(x), ptr(wprep), ptr(bias_p), ptr(y), B, H, W, Cin_p, Cout_p, taps, Cin_p, Cout_p, dt(x), stream())
+    return y
+
+
+def _wgrad_raw(x, gy, w_shape, taps):
+    B, H, W, Cin_p = x.shape
+    Cout_p = gy.shape[-1]
+    O, I = w_shape[0], w_shape[1]
+    gw = torch.empty(w_shape, dtype=torch.float32, device=x.device)
+    nbytes = _lib.load().mu_conv_wgrad_workspace_bytes(B, H, W, Cin_p, Cout_p, taps)
+    ws = workspace(nbytes, x.device)
+    call("mu_conv_wgrad", ptr(x), ptr(gy), ptr(gw), B, H, W, Cin_p, Cout_p, taps, I, O, Cin_p, Cout_p, ptr(ws), ws.numel(),
+         dt(x), stream())
+    return gw
+
+
+def _colsum(gy, n_valid):
+    C = gy.shape[-1]
+    M = gy.numel() // C
+    out = torch.empty(C, dtype=torch.float32, device=gy.device)
+    ws = workspace(_lib.load().mu_colsum_workspace_bytes(C), gy.device)
+    call("mu_colsum", ptr(gy), M, C, C, ptr(out), ptr(ws), ws.numel(), dt(gy), stream())
+    return out[:n_valid]
+
+
+class _Conv(torch.autograd.Function):
+    """nn.Conv2d k=3/pad=1 or k=1, NHWC (ade_semantic.py:199,202,284; city_instance.py:243-249)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        x = x.contiguous()
+        O, I = weight.shape[0], weight.shape[1]
+        taps = weight.shape[2] * weight.shape[3]
+        Cin_p, Cout_p = x.shape[-1], pad32(O)
+        if pad32(I) != Cin_p:
+            raise RuntimeError(f"conv: input has {Cin_p} (padded) channels, weight expects {I}")
+        wprep = _prep_weight(weight, x.dtype, Cout_p, Cin_p, 0)
+        bias_p = _pad_vec(bias, Cout_p, 0.0) if bias is not None else None
+        y = _conv_raw(x, wprep, bias_p, Cout_p, taps)
+        ctx.save_for_backward(x, weight)
+        ctx.has_bias, ctx.taps = bias is not None, taps
+        return y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, gy):
+        x, weight = ctx.saved_tensors
+        gy = gy.contiguous()
+        O, I = weight.shape[0], weight.shape[1]
+        gx = gw = gb = None
+        if ctx.needs_input_grad[0]:
+            wd = _prep_weight(weight, gy.dtype, x.shape[-1], gy.shape[-1], 1)
+            gx = _conv_raw(gy, wd, None, x.shape[-1], ctx.taps)
+        if ctx.needs_input_grad[1]:
+            gw = _wgrad_raw(x, gy, tuple(weight.shape), ctx.taps)
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            gb = _colsum(gy, O)
+        return gx, gw, gb
+
+
+def conv(x, weight, bias=None):
+    return _Conv.apply(x, weight, bias)
+
+
+# ------------------------------------------------------------------------------------------------
+# BatchNorm2d (+ activation, + residual)
+# ------------------------------------------------------------------------------------------------
+class _BNAct(torch.autograd.Function):
+    """act(res + BatchNorm2d(x)): ade_semantic.py:200-201 (BN,GELU), :204,208 (BN, +x, GELU), :219,240 (BN),
+    :285-286 (BN, ReLU).  Training uses batch statistics and updates the running buffers in place."""
+
+    @staticmethod
+    def forward(ctx, x, res, gamma, beta, running_mean, running_var, training, momentum, eps, act):
+        x = x.contiguous()
+        C = x.shape[-1]
+        M = x.numel() // C
+        cv = gamma.numel()
+        g_p, b_p = _pad_vec(gamma, C, 1.0), _pad_vec(beta, C, 0.0)
+        mean = torch.empty(C, dtype=torch.float32, device=x.device)
+        rstd = torch.empty_like(mean)
+        ws = workspace(_lib.load().mu_bn_workspace_bytes(C), x.device)
+        if training:
+            rm = running_mean if running_mean is not None else None
+            rv = running_var if running_var is not None else None
+            call("mu_bn_train_stats", ptr(x), M, C, C, ptr(mean), ptr(rstd), ptr(rm), ptr(rv), cv, float(momentum), float(eps),
+                 ptr(ws), ws.numel(), dt(x), stream())
+        else:
+            call("mu_bn_eval_stats", ptr(running_mean), ptr(running_var), float(eps), ptr(mean), ptr(rstd), C, cv, stream())
+        y = torch.empty_like(x)
+        if res is not None:
+            res = res.contiguous()
+        call("mu_bn_act_fwd", ptr(x), ptr(res), ptr(y), M, C, C, ptr(mean), ptr(rstd), ptr(g_p), ptr(b_p), act, dt(x), stream())
+        ctx.save_for_backward(x, res, mean, rstd, g_p, b_p)
+        ctx.act, ctx.training, ctx.cv = act, bool(training), cv
+        return y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, gy):
+        x, res, mean, rstd, g_p, b_p = ctx.saved_tensors
+        gy = gy.contiguous()
+        C = x.shape[-1]
+        M = x.numel() // C
+        dx = torch.empty_like(x)
+        dres = torch.empty_like(x) if res is not None else None
+        dgamma = torch.empty(C, dtype=torch.float32, device=x.device)
+        dbeta = torch.empty_like(dgamma)
+        ws = workspace(_lib.load().mu_bn_workspace_bytes(C), x.device)
+        call("mu_bn_act_bwd", ptr(x), ptr(res), ptr(gy), ptr(dx), ptr(dres), M, C, C, ptr(mean), ptr(rstd), ptr(g_p), ptr(b_p),
+             ctx.act, int(ctx.training), ptr(dgamma), ptr(dbeta), ptr(ws), ws.numel(), dt(x), stream())
+        return dx, dres, dgamma[:ctx.cv], dbeta[:ctx.cv], None, None, None, None, None, None
+
+
+def bn_act(x, bn, act=ACT_NONE, res=None):
+    """Apply the BatchNorm2d parameter container `bn` (an nn.BatchNorm2d used only for its
+    parameters/buffers/flags) followed by `act`, optionally adding `res` before the activation."""
+    training = bn.training or bn.running_mean is None
+    if bn.training and bn.num_batches_tracked is not None:
+        bn.num_batches_tracked.add_(1)
+    momentum = 0.1 if bn.momentum is None else bn.momentum
+    return _BNAct.apply(x, res, bn.weight, bn.bias, bn.running_mean, bn.running_var, training, momentum, bn.eps, act)
+
+
+# ------------------------------------------------------------------------------------------------
+# pooling / resampling / dropout
+# ------------------------------------------------------------------------------------------------
+class _MaxPool2(torch.autograd.Function):
+    """nn.MaxPool2d(2) (ade_semantic.py:216)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        x = x.contiguous()
+        B, H, W, C = x.shape
+        y = torch.empty((B, H // 2, W // 2, C), dtype=x.dtype, device=x.device)
+        call("mu_maxpool2_fwd", ptr(x), ptr(y), B, H, W, C, dt(x), stream())
+        ctx.save_for_backward(x)
+        return y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, gy):
+        (x,) = ctx.saved_tensors
+        gy = gy.contiguous()
+        B, H, W, C = x.shape
+        dx = torch.empty_like(x)
+        call("mu_maxpool2_bwd", ptr(x), ptr(gy), ptr(dx), B, H, W, C, dt(x), stream())
+        return dx
+
+
+def maxpool2(x):
+    return _MaxPool2.apply(x)
+
+
+class _UpCat(torch.autograd.Function):
+    """cat([skip, bilinear_x2(x, align_corners=True)], dim=C) (ade_semantic.py:235,250-253)."""
+
+    @staticmethod
+    def forward(ctx, x, skip):
+        x, skip = x.contiguous(), skip.contiguous()
+        B, h, w, Cx = x.shape
+        Cs = skip.shape[-1]
+        if skip.shape[:3] != (B, 2 * h, 2 * w):
+            raise RuntimeError(f"upsample/concat: skip {tuple(skip.shape)} does not match 2x of {tuple(x.shape)}")
+        y = torch.empty((B, 2 * h, 2 * w, Cs + Cx), dtype=x.dtype, device=x.device)
+        call("mu_upcat_fwd", ptr(x), ptr(skip), ptr(y), B, h, w, Cx, Cs, dt(x), stream())
+        ctx.dims = (B, h, w, Cx, Cs)
+        return y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, gy):
+        B, h, w, Cx, Cs = ctx.dims
+        gy = gy.contiguous()
+        dx = torch.empty((B, h, w, Cx), dtype=gy.dtype, device=gy.device)
+        dskip = torch.empty((B, 2 * h, 2 * w, Cs), dtype=gy.dtype, device=gy.device)
+        call("mu_upcat_bwd", ptr(gy), ptr(dx), ptr(dskip), B, h, w, Cx, Cs, dt(gy), stream())
+        return dx, dskip
+
+
+def upcat(x, skip):
+    return _UpCat.apply(x, skip)
+
+
+class _Dropout(torch.autograd.Function):
+    """nn.Dropout(p) in training (ade_semantic.py:273,304,307).  mask (uint8, same shape) overrides the generator."""
+
+    @staticmethod
+    def forward(ctx, x, p, seed, mask):
+        x = x.contiguous()
+        y = torch.empty_like(x)
+        if mask is not None:
+            mask = mask.to(device=x.device, dtype=torch.uint8).contiguous()
+        call("mu_dropout", ptr(x), ptr(y), x.numel(), float(p), int(seed), ptr(mask), None, dt(x), stream())
+        ctx.p, ctx.seed = p, seed
+        ctx.save_for_backward(mask)
+        return y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, gy):
+        (mask,) = ctx.saved_tensors
+        gy = gy.contiguous()
+        gx = torch.empty_like(gy)
+        call("mu_dropout", ptr(gy), ptr(gx), gy.numel(), float(ctx.p), int(ctx.seed), ptr(mask), None, dt(gy), stream())
+        return gx, None, None, None
+
+
+def dropout(x, p, training, mask=None):
+    if not training or (p == 0.0 and mask is None):
+        return x
+    seed = int(torch.randint(0, 2 ** 62, (1,), dtype=torch.int64).item())   # CPU generator: honours torch.manual_seed
+    return _Dropout.apply(x, p, seed, mask)
+
+
+# ------------------------------------------------------------------------------------------------
+# per-sample LayerNorm with full-shape affine
+# ------------------------------------------------------------------------------------------------
+class _LNSample(torch.autograd.Function):
+    """nn.LayerNorm([64,H,W]) applied to the NCHW-flat memory [B, L] (ade_semantic.py:281,311)."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, eps):
+        x = x.contiguous()
+        B = x.shape[0]
+        L = x.numel() // B
+        wf, bf = w.detach().float().contiguous().view(-1), b.detach().float().contiguous().view(-1)
+        y = torch.empty_like(x)
+        mean = torch.empty(B, dtype=torch.float32, device=x.device)
+        rstd = torch.empty_like(mean)
+        ws = workspace(_lib.load().mu_ln_sample_workspace_bytes(B), x.device)
+        call("mu_ln_sample_fwd", ptr(x), ptr(wf), ptr(bf), ptr(y), ptr(mean), ptr(rstd), B, L, float(eps), ptr(ws), ws.numel(),
+             dt(x), stream())
+        ctx.save_for_backward(x, wf, mean, rstd)
+        ctx.wshape = tuple(w.shape)
+        return y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, gy):
+        x, wf, mean, rstd = ctx.saved_tensors
+        gy = gy.contiguous()
+        B = x.shape[0]
+        L = x.numel() // B
+        dx = torch.empty_like(x)
+        dw = torch.empty(L, dtype=torch.float32, device=x.device)
+        db = torch.empty_like(dw)
+        ws = workspace(_lib.load().mu_ln_sample_workspace_bytes(B), x.device)
+        call("mu_ln_sample_bwd", ptr(x), ptr(gy), ptr(wf), ptr(mean), ptr(rstd), ptr(dx), ptr(dw), ptr(db), B, L, ptr(ws),
+             ws.numel(), dt(x), stream())
+        return dx, dw.view(ctx.wshape), db.view(ctx.wshape), None
+
+
+def ln_sample(x, w, b, eps):
+    return _LNSample.apply(x, w, b, eps)
+
+
+# ------------------------------------------------------------------------------------------------
+# masked attention block
+# ------------------------------------------------------------------------------------------------
+def _transpose_tokens(src, R, C):
+    """[B, R, C] -> [B, C, R] (same dtype)."""
+    B = src.shape[0]
+    dst = torch.empty((B, C, R), dtype=src.dtype, device=src.device)
+    call("mu_transpose", ptr(src), dt(src), C, ptr(dst), dt(dst), R, B, R, C, stream())
+    return dst
+
+
+class _MaskAttention(torch.autograd.Function):
+    """Mask2FormerAttention.forward (ade_semantic.py:163-190) on an NHWC activation.
+
+    NHWC *is* the reference's token-major [B,N,C] view of x (:168), so the input needs no permute.  The
+    reference then re-reads the [B,N,C] result as NCHW memory (:190); in NHWC terms that is a [C,N]->[N,C]
+    transpose of each image's flat buffer, done here with mu_transpose (`scramble=True`), or skipped when the
+    consumer wants the NCHW-flat memory itself (the final LayerNorm, :311)."""
+
+    @staticmethod
+    def forward(ctx, x, wq, bq, wk, bk, wv, bv, lnw, lnb, kidx, kcnt, eps, scramble):
+        x = x.contiguous()
+        B, H, W, C = x.shape
+        N = H * W
+        wqkv = torch.cat([wq.detach(), wk.detach(), wv.detach()], 0).float().view(3 * C, C, 1, 1)
+        bqkv = torch.cat([bq.detach(), bk.detach(), bv.detach()], 0).float().contiguous()
+        wprep = _prep_weight(wqkv, x.dtype, 3 * C, C, 0)
+        qkv = _conv_raw(x, wprep, bqkv, 3 * C, 1)                      # [B,H,W,3C] == [B,N,3C]
+        out = torch.empty((B, N, C), dtype=x.dtype, device=x.device)
+        oattn = torch.empty_like(out)
+        lse2 = torch.empty((B, N), dtype=torch.float32, device=x.device)
+        mean, rstd = torch.empty_like(lse2), torch.empty_like(lse2)
+        g, b_ = lnw.detach().float().contiguous(), lnb.detach().float().contiguous()
+        call("mu_attn_fwd", ptr(qkv), ptr(x), ptr(kidx), ptr(kcnt), ptr(g), ptr(b_), ptr(out), ptr(oattn), ptr(lse2), ptr(mean),
+             ptr(rstd), B, N, C, kidx.shape[1], float(eps), dt(x), stream())
+        ctx.save_for_backward(x, qkv, oattn, lse2, mean, rstd, g, wqkv, kidx, kcnt)
+        ctx.scramble, ctx.dims = scramble, (B, H, W, C)
+        if scramble:
+            return _transpose_tokens(out.view(B, C, N), C, N).view(B, H, W, C)
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, gout):
+        x, qkv, oattn, lse2, mean, rstd, g, wqkv, kidx, kcnt = ctx.saved_tensors
+        B, H, W, C = ctx.dims
+        N = H * W
+        gout = gout.contiguous()
+        if ctx.scramble:
+            gout = _transpose_tokens(gout.view(B, N, C), N, C)      # back to token-major flat [B, (N,C)]
+        dY = torch.empty((B, N, C), dtype=x.dtype, device=x.device)
+        dqkv = torch.empty((B, N, 3 * C), dtype=x.dtype, device=x.device)
+        delta = torch.empty((B, N), dtype=torch.float32, device=x.device)
+        dg = torch.empty(C, dtype=torch.float32, device=x.device)
+        db = torch.empty_like(dg)
+        ws = workspace(_lib.load().mu_attn_bwd_workspace_bytes(C), x.device)
+        call("mu_attn_bwd", ptr(qkv), ptr(x), ptr(oattn), ptr(gout), ptr(kidx), ptr(kcnt), ptr(lse2), ptr(mean), ptr(rstd), ptr(g),
+             ptr(dY), ptr(delta), ptr(dqkv), ptr(dg), ptr(db), B, N, C, kidx.shape[1], ptr(ws), ws.numel(), dt(x), stream())
+        dqkv4 = dqkv.view(B, H, W, 3 * C)
+        gx = None
+        if ctx.needs_input_grad[0]:
+            wd = _prep_weight(wqkv, x.dtype, C, 3 * C, 1)
+            gx = _conv_raw(dqkv4, wd, None, C, 1)
+            call("mu_add", ptr(gx), ptr(dY), ptr(gx), gx.numel(), dt(gx), stream())
+        gw = _wgrad_raw(x, dqkv4, (3 * C, C, 1, 1), 1).view(3 * C, C)
+        gb = _colsum(dqkv4, 3 * C)
+        return (gx, gw[:C], gb[:C], gw[C:2 * C], gb[C:2 * C], gw[2 * C:], gb[2 * C:], dg, db, None, None, None, None)
+
+
+def mask_attention(x, q, k, v, norm, kidx, kcnt, scramble=True):
+    """q,k,v: nn.Linear containers; norm: nn.LayerNorm([C]) container."""
+    return _MaskAttention.apply(x, q.weight, q.bias, k.weight, k.bias, v.weight, v.bias, norm.weight, norm.bias, kidx, kcnt,
+                                norm.eps, scramble)

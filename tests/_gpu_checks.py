@@ -1,0 +1,481 @@
+"""Shared GPU parity checks: every function runs HIP ops (through maskunet_amd -> C ABI) and the CPU
+oracle / stock torch reference on the same seeded inputs and returns [(name, err, tol)] where err is the
+max abs error normalised by max(1, |ref|_max).  Used by the pytest files and by tests/gpu_report.py.
+
+Tolerances: fp32 compute 1e-3 (the north_star gate; observed errors are ~1e-5), fp16 compute 3e-2
+(fp16 storage, fp32 accumulate; BASELINE.md expects ~1e-2-class errors for half precision).
+"""
+import math
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+from oracle import maskunet_oracle as O
+
+TOL = {torch.float32: 1e-3, torch.float16: 3e-2}
+DEV = "cuda"
+
+
+def _err(got, ref):
+    got = got.detach().float().cpu()
+    ref = ref.detach().float().cpu()
+    assert got.shape == ref.shape, (got.shape, ref.shape)
+    if not torch.isfinite(got).all():
+        return float("inf")
+    scale = max(1.0, float(ref.abs().max()))
+    return float((got - ref).abs().max()) / scale
+
+
+def _rel_err(got, ref):
+    """error relative to the reference's own max (for gradients whose scale is far from 1)."""
+    got = got.detach().float().cpu()
+    ref = ref.detach().float().cpu()
+    assert got.shape == ref.shape, (got.shape, ref.shape)
+    if not torch.isfinite(got).all():
+        return float("inf")
+    return float((got - ref).abs().max()) / max(float(ref.abs().max()), 1e-12)
+
+
+def _rnd(gen, *shape, scale=1.0):
+    return torch.from_numpy((gen.standard_normal(shape) * scale).astype(np.float32))
+
+
+def nhwc(x_nchw, dtype):
+    from maskunet_amd import ops
+    return ops.to_nhwc(x_nchw.to(DEV), dtype)
+
+
+# ------------------------------------------------------------------------------------------------
+def check_transpose(dtype):
+    from maskunet_amd import _lib
+    gen = np.random.default_rng(1)
+    out = []
+    for (B, R, C, sld, dld) in [(3, 70, 45, 45, 70), (2, 64, 150, 160, 64), (1, 130, 33, 40, 136)]:
+        src = torch.zeros(B, R, sld)
+        src[:, :, :C] = _rnd(gen, B, R, C)
+        s = src.to(DEV, dtype)
+        d = torch.zeros(B, C, dld, dtype=torch.float32, device=DEV)
+        _lib.call("mu_transpose", _lib.ptr(s), _lib.dt(s), sld, _lib.ptr(d), _lib.dt(d), dld, B, R, C, _lib.stream())
+        ref = torch.zeros(B, C, dld)
+        ref[:, :, :R] = s.float().cpu()[:, :, :C].transpose(1, 2)
+        out.append((f"transpose{(B, R, C)}", _err(d, ref), 1e-6))
+    return out
+
+
+def check_layout_roundtrip(dtype):
+    from maskunet_amd import ops
+    gen = np.random.default_rng(2)
+    x = _rnd(gen, 2, 19, 6, 10).to(DEV).requires_grad_(True)
+    y = ops.to_nhwc(x, dtype)
+    assert y.shape == (2, 6, 10, 32)
+    z = ops.to_nchw(y, 19, torch.float32)
+    g = _rnd(gen, 2, 19, 6, 10).to(DEV)
+    z.backward(g)
+    tol = 1e-6 if dtype == torch.float32 else 2e-3
+    return [("layout fwd", _err(z, x), tol), ("layout pad zero", float(y[..., 19:].abs().max()), 0.0),
+            ("layout bwd", _err(x.grad, g), tol)]
+
+
+def check_conv(dtype, cases=None):
+    from maskunet_amd import ops
+    gen = np.random.default_rng(3)
+    out = []
+    cases = cases or [(2, 12, 12, 32, 32, 3), (1, 16, 16, 64, 128, 3), (2, 8, 8, 128, 64, 3), (1, 10, 6, 19, 32, 3),
+                      (1, 8, 8, 64, 150, 1), (2, 9, 7, 256, 256, 3), (1, 16, 16, 3, 64, 3), (2, 8, 8, 32, 1, 1),
+                      (1, 6, 6, 512, 256, 3)]
+    for (B, H, W, Cin, Cout, k) in cases:
+        x = _rnd(gen, B, Cin, H, W)
+        w = _rnd(gen, Cout, Cin, k, k, scale=1.0 / math.sqrt(Cin * k * k))
+        b = _rnd(gen, Cout, scale=0.1) if k == 1 else None
+        g = _rnd(gen, B, Cout, H, W)
+        # reference on CPU (inputs rounded to the storage dtype so only accumulation differs)
+        xr = x.to(dtype).float().clone().requires_grad_(True)
+        wr = w.clone().requires_grad_(True)
+        br = b.clone().requires_grad_(True) if b is not None else None
+        yr = F.conv2d(xr, wr, br, padding=k // 2)
+        yr.backward(g.to(dtype).float())
+        xd = x.to(DEV).requires_grad_(True)
+        wd = w.to(DEV).requires_grad_(True)
+        bd = b.to(DEV).requires_grad_(True) if b is not None else None
+        y = ops.to_nchw(ops.conv(ops.to_nhwc(xd, dtype), wd, bd), Cout, torch.float32)
+        y.backward(g.to(DEV))
+        tol = TOL[dtype]
+        tag = f"conv{(B, H, W, Cin, Cout, k)}"
+        out += [(tag + " y", _err(y, yr), tol), (tag + " dx", _rel_err(xd.grad, xr.grad), tol),
+                (tag + " dw", _rel_err(wd.grad, wr.grad), tol)]
+        if b is not None:
+            out.append((tag + " db", _rel_err(bd.grad, br.grad), tol))
+    return out
+
+
+def check_bn_act(dtype):
+    from maskunet_amd import ops, _lib
+    import torch.nn as nn
+    gen = np.random.default_rng(4)
+    out = []
+    for (B, C, H, W, act, use_res, training) in [(2, 32, 6, 6, _lib.ACT_GELU, False, True), (2, 19, 8, 8, _lib.ACT_RELU, False, True),
+                                                 (3, 64, 5, 7, _lib.ACT_GELU, True, True), (2, 150, 4, 4, _lib.ACT_NONE, False, True),
+                                                 (2, 64, 6, 6, _lib.ACT_GELU, True, False), (1, 512, 16, 16, _lib.ACT_NONE, False, True)]:
+        x = _rnd(gen, B, C, H, W) * 1.5 + 0.3
+        r = _rnd(gen, B, C, H, W) if use_res else None
+        g = _rnd(gen, B, C, H, W)
+        bn_ref = nn.BatchNorm2d(C)
+        with torch.no_grad():
+            bn_ref.weight.copy_(torch.from_numpy(gen.uniform(0.5, 1.5, C).astype(np.float32)))
+            bn_ref.bias.copy_(torch.from_numpy(gen.uniform(-0.2, 0.2, C).astype(np.float32)))
+            bn_ref.running_mean.copy_(_rnd(gen, C, scale=0.1))
+            bn_ref.running_var.copy_(torch.from_numpy(gen.uniform(0.5, 1.5, C).astype(np.float32)))
+        bn_dev = nn.BatchNorm2d(C)
+        bn_dev.load_state_dict(bn_ref.state_dict())
+        bn_dev.to(DEV)
+        bn_ref.train(training)
+        bn_dev.train(training)
+        xr = x.to(dtype).float().clone().requires_grad_(True)
+        rr = r.to(dtype).float().clone().requires_grad_(True) if use_res else None
+        pre = bn_ref(xr) + (rr if use_res else 0)
+        yr = {_lib.ACT_GELU: F.gelu, _lib.ACT_RELU: torch.relu, _lib.ACT_NONE: lambda t: t}[act](pre)
+        yr.backward(g.to(dtype).float())
+        xd = x.to(DEV).requires_grad_(True)
+        rd = r.to(DEV).requires_grad_(True) if use_res else None
+        y = ops.bn_act(ops.to_nhwc(xd, dtype), bn_dev, act, res=ops.to_nhwc(rd, dtype) if use_res else None)
+        y = ops.to_nchw(y, C, torch.float32)
+        y.backward(g.to(DEV))
+        tol = TOL[dtype]
+        tag = f"bn{(B, C, H, W)}a{act}r{int(use_res)}t{int(training)}"
+        out += [(tag + " y", _err(y, yr), tol), (tag + " dx", _rel_err(xd.grad, xr.grad), tol),
+                (tag + " dgamma", _rel_err(bn_dev.weight.grad, bn_ref.weight.grad), tol),
+                (tag + " dbeta", _rel_err(bn_dev.bias.grad, bn_ref.bias.grad), tol),
+                (tag + " rmean", _err(bn_dev.running_mean, bn_ref.running_mean), tol),
+                (tag + " rvar", _err(bn_dev.running_var, bn_ref.running_var), tol)]
+        if use_res:
+            out.append((tag + " dres", _rel_err(rd.grad, rr.grad), tol))
+    return out
+
+
+def check_pool_up(dtype):
+    from maskunet_amd import ops
+    gen = np.random.default_rng(5)
+    out = []
+    tol = TOL[dtype]
+    x = _rnd(gen, 2, 64, 12, 8)
+    g = _rnd(gen, 2, 64, 6, 4)
+    xr = x.to(dtype).float().clone().requires_grad_(True)
+    yr = F.max_pool2d(xr, 2)
+    yr.backward(g.to(dtype).float())
+    xd = x.to(DEV).requires_grad_(True)
+    y = ops.to_nchw(ops.maxpool2(ops.to_nhwc(xd, dtype)), 64, torch.float32)
+    y.backward(g.to(DEV))
+    out += [("maxpool y", _err(y, yr), tol), ("maxpool dx", _rel_err(xd.grad, xr.grad), tol)]
+    for (B, Cx, Cs, h, w) in [(2, 32, 64, 5, 7), (1, 256, 256, 16, 16), (2, 64, 32, 1, 3)]:
+        x = _rnd(gen, B, Cx, h, w)
+        s = _rnd(gen, B, Cs, 2 * h, 2 * w)
+        g = _rnd(gen, B, Cs + Cx, 2 * h, 2 * w)
+        xr = x.to(dtype).float().clone().requires_grad_(True)
+        sr = s.to(dtype).float().clone().requires_grad_(True)
+        yr = torch.cat([sr, F.interpolate(xr, scale_factor=2, mode="bilinear", align_corners=True)], 1)
+        yr.backward(g.to(dtype).float())
+        xd, sd = x.to(DEV).requires_grad_(True), s.to(DEV).requires_grad_(True)
+        y = ops.to_nchw(ops.upcat(ops.to_nhwc(xd, dtype), ops.to_nhwc(sd, dtype)), Cs + Cx, torch.float32)
+        y.backward(g.to(DEV))
+        tag = f"upcat{(B, Cx, Cs, h, w)}"
+        out += [(tag + " y", _err(y, yr), tol), (tag + " dx", _rel_err(xd.grad, xr.grad), tol),
+                (tag + " dskip", _rel_err(sd.grad, sr.grad), tol)]
+    return out
+
+
+def check_ln_sample(dtype):
+    from maskunet_amd import ops
+    gen = np.random.default_rng(6)
+    B, C, H, W = 3, 64, 16, 16
+    x = _rnd(gen, B, C, H, W) * 2 + 0.5
+    w = torch.from_numpy(gen.uniform(0.5, 1.5, (C, H, W)).astype(np.float32))
+    b = torch.from_numpy(gen.uniform(-0.2, 0.2, (C, H, W)).astype(np.float32))
+    g = _rnd(gen, B, C, H, W)
+    xr = x.to(dtype).float().clone().requires_grad_(True)
+    wr, br = w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    yr = F.layer_norm(xr, (C, H, W), wr, br, 1e-5)
+    yr.backward(g.to(dtype).float())
+    xd = x.to(DEV).to(dtype).requires_grad_(True)
+    wd, bd = w.to(DEV).requires_grad_(True), b.to(DEV).requires_grad_(True)
+    y = ops.ln_sample(xd.view(B, -1), wd, bd, 1e-5).view(B, C, H, W)
+    y.backward(g.to(DEV).to(dtype))
+    tol = TOL[dtype]
+    return [("ln_sample y", _err(y, yr), tol), ("ln_sample dx", _rel_err(xd.grad, xr.grad), tol),
+            ("ln_sample dw", _rel_err(wd.grad, wr.grad), tol), ("ln_sample db", _rel_err(bd.grad, br.grad), tol)]
+
+
+def check_dropout(dtype):
+    from maskunet_amd import ops
+    x = torch.ones(4, 8, 8, 64, device=DEV, dtype=dtype, requires_grad=True)
+    torch.manual_seed(5)
+    y = ops.dropout(x, 0.3, True)
+    keep = (y != 0)
+    frac = float(keep.float().mean())
+    y.sum().backward()
+    same = bool(((x.grad != 0) == keep).all())
+    val = float((y[keep].float() - 1 / 0.7).abs().max())
+    m = (torch.rand(4, 8, 8, 64) > 0.5).to(torch.uint8)
+    y2 = ops.dropout(x, 0.3, True, m)
+    ok_mask = bool(((y2 != 0).cpu() == (m != 0)).all())
+    return [("dropout keep frac", abs(frac - 0.7), 0.03), ("dropout scale", val, 2e-3), ("dropout bwd mask", 0.0 if same else 1.0, 0.0),
+            ("dropout explicit mask", 0.0 if ok_mask else 1.0, 0.0), ("dropout eval identity", 0.0 if ops.dropout(x, 0.3, False) is x else 1.0, 0.0)]
+
+
+def _attn_modules(C, gen):
+    import maskunet_amd
+    m = maskunet_amd.Mask2FormerAttention(C, C)
+    sd = {}
+    for k, v in m.state_dict().items():
+        if k.startswith("norm.weight"):
+            kind = "gamma"
+        elif k.startswith("norm.bias"):
+            kind = "beta"
+        elif k.endswith("weight"):
+            kind = "w"
+        else:
+            kind = "b%d" % C
+        sd[k] = O.make_tensor(gen, tuple(v.shape), kind)
+    m.load_state_dict(sd)
+    return m, sd
+
+
+def check_attention(dtype, cases=None):
+    gen = np.random.default_rng(7)
+    out = []
+    cases = cases or [(2, 8, 8, 32), (2, 16, 16, 64), (1, 24, 8, 128), (1, 16, 16, 256), (2, 40, 40, 64), (1, 12, 12, 128)]
+    for (B, H, W, C) in cases:
+        m, sd = _attn_modules(C, gen)
+        m.to(DEV).set_compute_dtype(dtype)
+        keep = torch.from_numpy(gen.integers(0, 2, size=(B, H * W)).astype(np.uint8))
+        keep[:, 0] = 1
+        x = _rnd(gen, B, C, H, W)
+        g = _rnd(gen, B, C, H, W)
+        p = {"m." + k: v.clone().requires_grad_(True) for k, v in sd.items()}
+        xr = x.to(dtype).float().clone().requires_grad_(True)
+        yr = O.mask_attention(xr, p, "m", keep)
+        yr.backward(g.to(dtype).float())
+        m.set_keep_mask(keep)
+        xd = x.to(DEV).requires_grad_(True)
+        y = m(xd)
+        y.backward(g.to(DEV))
+        tol = TOL[dtype]
+        tag = f"attn{(B, H, W, C)}"
+        out += [(tag + " y", _err(y, yr), tol), (tag + " dx", _rel_err(xd.grad, xr.grad), tol)]
+        for k, v in m.named_parameters():
+            gref = p["m." + k].grad
+            if k == "key.bias":        # analytically zero gradient (softmax shift invariance): absolute check
+                out.append((tag + " d" + k, float(v.grad.abs().max().cpu()), tol * float(p["m.query.bias"].grad.abs().max()) + 1e-6))
+            else:
+                out.append((tag + " d" + k, _rel_err(v.grad, gref), tol))
+    return out
+
+
+def check_attention_mask_semantics():
+    import maskunet_amd
+    m = maskunet_amd.Mask2FormerAttention(32, 32).to(DEV)
+    res = []
+    assert m.mask is None
+    x = torch.randn(2, 32, 8, 8, device=DEV)
+    y1 = m(x)
+    mk = m.mask
+    res.append(("mask lazily drawn [B,N,N] view", 0.0 if (mk is not None and tuple(mk.shape) == (2, 64, 64)) else 1.0, 0.0))
+    vals = torch.unique(mk)
+    res.append(("mask values {0,-inf}", 0.0 if all(v == 0 or v == -float("inf") for v in vals.tolist()) else 1.0, 0.0))
+    y2 = m(x)
+    res.append(("mask cached", _err(y2, y1), 0.0))
+    # inject in the reference's own form and compare with set_keep_mask
+    keep = (torch.rand(2, 64) > 0.4)
+    add = torch.where(keep, torch.zeros(()), torch.full((), -float("inf"))).unsqueeze(1).expand(-1, 64, -1)
+    m.mask = add.to(DEV)
+    ya = m(x)
+    m.set_keep_mask(keep.to(torch.uint8))
+    yb = m(x)
+    res.append(("mask inject forms agree", _err(ya, yb), 0.0))
+    try:
+        m(torch.randn(3, 32, 8, 8, device=DEV))
+        res.append(("batch mismatch raises", 1.0, 0.0))
+    except RuntimeError:
+        res.append(("batch mismatch raises", 0.0, 0.0))
+    try:
+        m(torch.randn(2, 64, 8, 8, device=DEV))
+        res.append(("channel mismatch raises", 1.0, 0.0))
+    except ValueError as e:
+        res.append(("channel mismatch raises", 0.0 if "Input channel size does not match" in str(e) else 1.0, 0.0))
+    m.mask_mode = "resample"
+    m(x)
+    k1 = m._keep.clone()
+    m(x)
+    res.append(("resample mode redraws", 0.0 if not torch.equal(k1, m._keep) else 1.0, 0.0))
+    return res
+
+
+# ------------------------------------------------------------------------------------------------
+def load_golden(name):
+    import os
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", name + ".npz"))
+    return {k: z[k] for k in z.files}
+
+
+def check_golden_module(name, dtype):
+    """Run a committed golden case (generated from the REAL reference) through the HIP modules."""
+    import maskunet_amd
+    rec = load_golden(name)
+    training = bool(rec["training"])
+    sd = {k[len("param/"):]: torch.from_numpy(v) for k, v in rec.items() if k.startswith("param/")}
+    if name.startswith("convblock_res"):
+        c = sd["conv_block.0.weight"].shape
+        mod = maskunet_amd.ConvBlock(c[1], c[0], residual=True)
+    elif name.startswith("convblock_mid"):
+        mod = maskunet_amd.ConvBlock(sd["conv_block.0.weight"].shape[1], sd["conv_block.3.weight"].shape[0], sd["conv_block.0.weight"].shape[0])
+    elif name.startswith("convblock"):
+        mod = maskunet_amd.ConvBlock(sd["conv_block.0.weight"].shape[1], sd["conv_block.3.weight"].shape[0])
+    elif name.startswith("down"):
+        mod = maskunet_amd.DownSample(sd["maxpool_conv.1.conv_block.0.weight"].shape[1], sd["maxpool_conv.3.weight"].shape[0])
+    elif name.startswith("up"):
+        mod = maskunet_amd.UpSample(sd["conv.0.conv_block.0.weight"].shape[1], sd["conv.2.weight"].shape[0])
+    elif name.startswith("attn"):
+        C = sd["query.weight"].shape[0]
+        mod = maskunet_amd.Mask2FormerAttention(C, C)
+    else:
+        raise KeyError(name)
+    mod.load_state_dict(sd)
+    mod.to(DEV).set_compute_dtype(dtype).train(training)
+    if "keep" in rec:
+        mod.set_keep_mask(torch.from_numpy(rec["keep"]))
+    ins = [torch.from_numpy(rec[f"in/{i}"]).to(DEV).requires_grad_(True) for i in range(2) if f"in/{i}" in rec]
+    out = mod(*ins)
+    out.backward(torch.from_numpy(rec["gout"]).to(DEV))
+    tol = TOL[dtype]
+    res = [(name + " out", _err(out, torch.from_numpy(rec["out"])), tol)]
+    for i, t in enumerate(ins):
+        res.append((name + f" gin{i}", _rel_err(t.grad, torch.from_numpy(rec[f"gin/{i}"])), tol))
+    gmax = max(float(np.abs(v).max()) for k, v in rec.items() if k.startswith("gparam/"))
+    for k, v in mod.named_parameters():
+        if "gparam/" + k in rec:
+            ref = torch.from_numpy(rec["gparam/" + k])
+            # compare against the largest parameter-gradient scale of the case: gamma/beta feeding a
+            # second BatchNorm and key.bias have analytically-zero gradients (pure rounding noise)
+            floor = (1e-3 if dtype == torch.float32 else 5e-2) * gmax
+            e = float((v.grad.detach().float().cpu() - ref).abs().max()) / max(float(ref.abs().max()), floor)
+            res.append((name + " d" + k, e, tol))
+    if training:
+        for k, v in mod.state_dict().items():
+            if "running" in k and "newstat/" + k in rec:
+                res.append((name + " " + k, _err(v, torch.from_numpy(rec["newstat/" + k])), tol))
+    return res
+
+
+def build_unet(c_out, three_head, seed, dtype, training, B):
+    import maskunet_amd
+    shapes = O.unet_state_shapes(3, c_out, three_head)
+    params = O.make_params(shapes, seed)
+    model = maskunet_amd.InstanceUNet(3, c_out, 16) if three_head else maskunet_amd.UNet(3, c_out)
+    model.load_state_dict(params)
+    model.to(DEV).set_compute_dtype(dtype).train(training)
+    model.dropout.p = 0.0
+    keeps = O.make_keeps(seed + 1, B)
+    model.set_keep_masks(keeps)
+    x, labels = O.make_inputs(seed + 2, B, c_out, ignore_frac=0.1 if three_head else 0.0)
+    return model, params, keeps, x, labels
+
+
+def check_unet_golden(name, dtype):
+    """Whole-model case against the committed slices/grad norms produced by the REAL reference."""
+    rec = load_golden(name)
+    three = name.startswith("unet3")
+    B, c_out, seed, training = int(rec["B"]), int(rec["c_out"]), int(rec["seed"]), bool(rec["training"])
+    model, params, keeps, x, labels = build_unet(c_out, three, seed, dtype, training, B)
+    scale = 1.0 if dtype == torch.float32 else 1024.0      # static loss scale for the fp16 backward
+    out = model(x.to(DEV))
+    outs = out if three else (out,)
+    tol = TOL[dtype]
+    res = []
+    for i, o in enumerate(outs):
+        res.append((f"{name} out{i} slice", _err(o[:, :, ::16, ::16], torch.from_numpy(rec[f"out{i}_slice"])), tol))
+        res.append((f"{name} out{i} sum", abs(float(o.double().sum()) - float(rec[f"out{i}_sum"])) / float(rec[f"out{i}_abssum"]), tol))
+    loss = F.cross_entropy(outs[0], labels.to(DEV), ignore_index=255 if three else -100)
+    if three:
+        loss = loss + 0.5 * out[2].square().mean() + 0.25 * out[1].square().mean()
+    res.append((f"{name} loss", abs(loss.item() - float(rec["loss"])) / max(1.0, abs(float(rec["loss"]))), tol))
+    if not training:
+        return res
+    (loss * scale).backward()
+    gmax = max(float(v) for k, v in rec.items() if k.startswith("gnorm/"))
+    worst = (0.0, "")
+    for k, v in model.named_parameters():
+        has = bool(rec["ghas/" + k])
+        assert (v.grad is not None) == has, k
+        if not has:
+            continue
+        gn = float((v.grad.double() / scale).norm())
+        ref = float(rec["gnorm/" + k])
+        e = abs(gn - ref) / max(ref, 1e-4 * gmax)
+        if e > worst[0]:
+            worst = (e, k)
+        if "g/" + k in rec:
+            r = torch.from_numpy(rec["g/" + k])
+            e2 = float((v.grad.float().cpu() / scale - r).abs().max()) / max(float(r.abs().max()), 1e-4 * gmax)
+            if e2 > worst[0]:
+                worst = (e2, k + " (full)")
+    gtol = 5e-3 if dtype == torch.float32 else 1e-1
+    res.append((f"{name} worst grad [{worst[1]}]", worst[0], gtol))
+    gsl = model.norm.weight.grad[:, ::16, ::16].float().cpu() / scale
+    res.append((f"{name} d norm.weight slice", _rel_err(gsl, torch.from_numpy(rec["g_slice/norm.weight"])), gtol))
+    gw0 = model.initial_conv.conv_block[0].weight.grad.float().cpu() / scale
+    res.append((f"{name} d initial conv w", _rel_err(gw0, torch.from_numpy(rec["g_slice/initial_conv.conv_block.0.weight"])), gtol))
+    for k, v in model.state_dict().items():
+        if "newstat/" + k in rec:
+            res.append((f"{name} {k}", _err(v, torch.from_numpy(rec["newstat/" + k])), tol))
+    return res
+
+
+def check_unet_vs_oracle(dtype, B=2, c_out=150, three_head=False, seed=300, with_dropout=True):
+    """Whole model vs the CPU oracle run live on the same seeded inputs, training mode, with explicit dropout masks."""
+    model, params, keeps, x, labels = build_unet(c_out, three_head, seed, dtype, True, B)
+    gen = np.random.default_rng(seed + 5)
+    if with_dropout:
+        model.dropout.p = 0.3
+        dm = [torch.from_numpy((gen.random((B, 128, 32, 32)) > 0.3).astype(np.uint8)),
+              torch.from_numpy((gen.random((B, 64, 64, 64)) > 0.3).astype(np.uint8))]
+        model.dropout_masks = [m.permute(0, 2, 3, 1).contiguous() for m in dm]    # NHWC for the HIP path
+    else:
+        dm = None
+    p = {k: (v.clone().requires_grad_(True) if v.dtype.is_floating_point and "running" not in k else v.clone()) for k, v in params.items()}
+    ns = {}
+    ref = O.unet_forward(p, x, keeps, training=True, dropout_masks=dm, new_stats=ns, three_head=three_head)
+    refs = ref if three_head else (ref,)
+    lref = O.pixel_cross_entropy(refs[0], labels, 255 if three_head else -100)
+    if three_head:
+        lref = lref + 0.5 * ref[2].square().mean() + 0.25 * ref[1].square().mean()
+    lref.backward()
+    out = model(x.to(DEV))
+    outs = out if three_head else (out,)
+    loss = F.cross_entropy(outs[0], labels.to(DEV), ignore_index=255 if three_head else -100)
+    if three_head:
+        loss = loss + 0.5 * out[2].square().mean() + 0.25 * out[1].square().mean()
+    scale = 1.0 if dtype == torch.float32 else 1024.0
+    (loss * scale).backward()
+    tol = TOL[dtype]
+    gtol = 5e-3 if dtype == torch.float32 else 1e-1
+    res = [(f"unet out{i} full", _err(o, r), tol) for i, (o, r) in enumerate(zip(outs, refs))]
+    res.append(("unet loss", abs(loss.item() - lref.item()) / max(1.0, abs(lref.item())), tol))
+    gmax = max(float(v.grad.abs().max()) for v in p.values() if v.requires_grad and v.grad is not None)
+    worst = (0.0, "")
+    for k, v in model.named_parameters():
+        r = p[k].grad
+        assert (v.grad is None) == (r is None), k
+        if r is None:
+            continue
+        e = float((v.grad.float().cpu() / scale - r).abs().max()) / max(float(r.abs().max()), 1e-3 * gmax)
+        if e > worst[0]:
+            worst = (e, k)
+    res.append((f"unet worst param grad [{worst[1]}]", worst[0], gtol))
+    worst = (0.0, "")
+    for k, v in model.state_dict().items():
+        if k in ns:
+            e = _err(v, ns[k])
+            if e > worst[0]:
+                worst = (e, k)
+    res.append((f"unet worst running stat [{worst[1]}]", worst[0], tol))
+    return res
