@@ -93,9 +93,22 @@ def stream():
     return torch.cuda.current_stream().cuda_stream
 
 
+# optional HIP-event probe (bench.py): {"names": (...), "match_int": int, "events": []} brackets the matching
+# entry points with events on the launch stream; None = off (no overhead).
+PROBE = None
+
+
 def call(name: str, *args):
     """Invoke an int-returning entry point and raise on a non-zero status."""
-    rc = getattr(load(), name)(*args)
+    probe = PROBE
+    if probe is not None and name in probe["names"] and probe["match_int"] in args:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        rc = getattr(load(), name)(*args)
+        e1.record()
+        probe["events"].append((name, e0, e1))
+    else:
+        rc = getattr(load(), name)(*args)
     if rc != 0:
         raise RuntimeError(f"maskunet_amd: {name} failed with {_ERR.get(rc, rc)}")
 

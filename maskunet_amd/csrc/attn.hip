@@ -333,10 +333,12 @@ __global__ __launch_bounds__(256) void attn_ln_bwd_kernel(const T* __restrict__ 
 }
 
 __global__ void attn_ln_bwd_final_kernel(const double* __restrict__ part, int nblk, int D, float* __restrict__ dgamma, float* __restrict__ dbeta) {
-    int c = blockIdx.x * blockDim.x + threadIdx.x;
+    const int c = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (c >= D) return;
     double a = 0.0, b = 0.0;
-    for (int k = 0; k < nblk; ++k) { a += part[((long)k * D + c) * 2]; b += part[((long)k * D + c) * 2 + 1]; }
+    for (int k = lane; k < nblk; k += 64) { a += part[((long)k * D + c) * 2]; b += part[((long)k * D + c) * 2 + 1]; }
+    a = wave_sum_d(a); b = wave_sum_d(b);
+    if (lane) return;
     dgamma[c] = (float)a;
     dbeta[c] = (float)b;
 }
@@ -598,7 +600,7 @@ static int attn_bwd_t(const T* qkv, const T* x, const T* oattn, const T* gout, c
     if (hipMemsetAsync(dqkv, 0, (size_t)rows * 3 * C * sizeof(T), st) != hipSuccess) return MU_ERR_LAUNCH;
 #define LAUNCH_BWD(DD, NKT)                                                                                                     \
     attn_ln_bwd_kernel<T, DD><<<nblk, 256, 0, st>>>(gout, oattn, x, mean, rstd, gamma, dY, delta, (double*)ws, rows);           \
-    attn_ln_bwd_final_kernel<<<mu_cdiv(DD, 64), 64, 0, st>>>((const double*)ws, nblk, DD, dgamma, dbeta);                       \
+    attn_ln_bwd_final_kernel<<<mu_cdiv(DD, 4), 256, 0, st>>>((const double*)ws, nblk, DD, dgamma, dbeta);                       \
     attn_bwd_dq_kernel<T, DD><<<gq, 256, 0, st>>>(qkv, dY, kidx, kcnt, lse2, delta, dqkv, N, nkmax, scale, sl2);                \
     attn_bwd_dkv_kernel<T, DD, NKT><<<dim3(mu_cdiv(nkmax, 64 * NKT), B), 256, 0, st>>>(qkv, dY, kidx, kcnt, lse2, delta, dqkv, N, \
                                                                                       nkmax, scale, sl2)

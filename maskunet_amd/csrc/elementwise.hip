@@ -378,57 +378,6 @@ extern "C" int mu_dropout(const void* x, void* y, long n, float p, unsigned long
 }
 
 // ------------------------------------------------------------------------------------------
-// column sums of a [M, C] matrix (row stride ld) -> fp32 [C]   (bias gradients)
-// two stages, fp64 partials, deterministic.
-// ------------------------------------------------------------------------------------------
-template <typename T>
-__global__ __launch_bounds__(256) void colsum_partial_kernel(const T* __restrict__ x, long M, int C, long ld, double* __restrict__ part) {
-    // thread -> column (tid % C-chunk), rows strided
-    const int cols_per_pass = C < 256 ? C : 256;
-    const int rpi = 256 / cols_per_pass;
-    const int tc = threadIdx.x % cols_per_pass, tr = threadIdx.x / cols_per_pass;
-    __shared__ double sh[256];
-    const long rows_per_blk = (M + gridDim.x - 1) / gridDim.x;
-    const long r0 = (long)blockIdx.x * rows_per_blk, r1 = (r0 + rows_per_blk < M ? r0 + rows_per_blk : M);
-    for (int cbase = 0; cbase < C; cbase += cols_per_pass) {
-        int c = cbase + tc;
-        double s = 0.0;
-        if (tr < rpi && c < C)
-            for (long r = r0 + tr; r < r1; r += rpi) s += (double)(float)x[r * ld + c];
-        sh[threadIdx.x] = s;
-        __syncthreads();
-        if (tr == 0 && c < C) {
-            double t = 0.0;
-            for (int k = 0; k < rpi; ++k) t += sh[k * cols_per_pass + tc];
-            part[(long)blockIdx.x * C + c] = t;
-        }
-        __syncthreads();
-    }
-}
-__global__ void colsum_final_kernel(const double* __restrict__ part, int nblk, int C, float* __restrict__ out) {
-    int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
-    double s = 0.0;
-    for (int b = 0; b < nblk; ++b) s += part[(long)b * C + c];
-    out[c] = (float)s;
-}
-
-extern "C" long mu_colsum_workspace_bytes(int C) { return (long)512 * C * sizeof(double); }
-
-extern "C" int mu_colsum(const void* x, long M, int C, long ld, float* out, void* workspace, long ws_bytes, int dtype, void* stream) {
-    if (!x || !out || !workspace || M <= 0 || C <= 0 || ld < C) return MU_ERR_ARG;
-    if (ws_bytes < mu_colsum_workspace_bytes(C)) return MU_ERR_WORKSPACE;
-    int nblk = (int)(M / 64 < 1 ? 1 : (M / 64 > 512 ? 512 : M / 64));
-    hipStream_t st = (hipStream_t)stream;
-    if (dtype == MU_F32) colsum_partial_kernel<float><<<nblk, 256, 0, st>>>((const float*)x, M, C, ld, (double*)workspace);
-    else if (dtype == MU_F16) colsum_partial_kernel<h16><<<nblk, 256, 0, st>>>((const h16*)x, M, C, ld, (double*)workspace);
-    else return MU_ERR_ARG;
-    colsum_final_kernel<<<mu_cdiv(C, 64), 64, 0, st>>>((const double*)workspace, nblk, C, out);
-    MU_CHECK_LAUNCH();
-    return MU_OK;
-}
-
-// ------------------------------------------------------------------------------------------
 // out = a + b (residual-branch gradient join of the attention block)
 // ------------------------------------------------------------------------------------------
 template <typename T>

@@ -84,10 +84,13 @@ __global__ __launch_bounds__(256) void bn_partial_kernel(const T* __restrict__ x
 __global__ void bn_fwd_final_kernel(const double* __restrict__ part, int nblk, int C, long M, float eps, float momentum,
                                     float* __restrict__ mean, float* __restrict__ rstd, float* __restrict__ running_mean,
                                     float* __restrict__ running_var, int c_valid) {
-    int c = blockIdx.x * blockDim.x + threadIdx.x;
+    // one wave per channel: lanes stride over the partial blocks, then a wave reduction
+    const int c = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (c >= C) return;
     double s = 0.0, q = 0.0;
-    for (int b = 0; b < nblk; ++b) { s += part[((long)b * C + c) * 2]; q += part[((long)b * C + c) * 2 + 1]; }
+    for (int b = lane; b < nblk; b += 64) { s += part[((long)b * C + c) * 2]; q += part[((long)b * C + c) * 2 + 1]; }
+    s = wave_sum_d(s); q = wave_sum_d(q);
+    if (lane) return;
     double m = s / (double)M;
     double var = q / (double)M - m * m;
     if (var < 0.0) var = 0.0;
@@ -112,10 +115,12 @@ __global__ void bn_eval_stats_kernel(const float* __restrict__ running_mean, con
 // BN backward finalize: dgamma = sum dz*xhat, dbeta = sum dz; s1 = dbeta/M, s2 = dgamma/M (0 in eval)
 __global__ void bn_bwd_final_kernel(const double* __restrict__ part, int nblk, int C, long M, int training,
                                     float* __restrict__ dgamma, float* __restrict__ dbeta, float* __restrict__ s1, float* __restrict__ s2) {
-    int c = blockIdx.x * blockDim.x + threadIdx.x;
+    const int c = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (c >= C) return;
     double a = 0.0, b = 0.0;
-    for (int k = 0; k < nblk; ++k) { a += part[((long)k * C + c) * 2]; b += part[((long)k * C + c) * 2 + 1]; }
+    for (int k = lane; k < nblk; k += 64) { a += part[((long)k * C + c) * 2]; b += part[((long)k * C + c) * 2 + 1]; }
+    a = wave_sum_d(a); b = wave_sum_d(b);
+    if (lane) return;
     dbeta[c] = (float)a;
     dgamma[c] = (float)b;
     s1[c] = training ? (float)(a / (double)M) : 0.f;
@@ -200,6 +205,37 @@ static inline int ew_grid(long total) {
     return (int)g;
 }
 
+__global__ void colsum_final_kernel(const double* __restrict__ part, int nblk, int C, float* __restrict__ out) {
+    const int c = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (c >= C) return;
+    double s = 0.0;
+    for (int b = lane; b < nblk; b += 64) s += part[((long)b * C + c) * 2];
+    s = wave_sum_d(s);
+    if (lane == 0) out[c] = (float)s;
+}
+
+extern "C" long mu_colsum_workspace_bytes(int C) { return (long)MU_STAT_MAXBLK * C * 2 * sizeof(double); }
+
+// out[c] = sum_r x[r][c]: bias gradients.  Same vectorised row sweep as the BN statistics.
+extern "C" int mu_colsum(const void* x, long M, int C, long ld, float* out, void* workspace, long ws_bytes, int dtype, void* stream) {
+    if (!x || !out || !workspace || M <= 0 || C <= 0 || C % 8 || ld < C) return MU_ERR_ARG;
+    if (ws_bytes < mu_colsum_workspace_bytes(C)) return MU_ERR_WORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    const int nblk = stat_blocks(M);
+    if (dtype == MU_F32) {
+        const int cv = C / 4;
+        if (cv > 256) return MU_ERR_SHAPE;
+        bn_partial_kernel<float, 0><<<nblk, 256, (size_t)(256 / cv) * C * 2 * sizeof(double), st>>>((const float*)x, nullptr, nullptr, nullptr, M, C, ld, nullptr, nullptr, nullptr, nullptr, 0, (double*)workspace);
+    } else if (dtype == MU_F16) {
+        const int cv = C / 8;
+        if (cv > 256) return MU_ERR_SHAPE;
+        bn_partial_kernel<h16, 0><<<nblk, 256, (size_t)(256 / cv) * C * 2 * sizeof(double), st>>>((const h16*)x, nullptr, nullptr, nullptr, M, C, ld, nullptr, nullptr, nullptr, nullptr, 0, (double*)workspace);
+    } else return MU_ERR_ARG;
+    colsum_final_kernel<<<mu_cdiv(C, 4), 256, 0, st>>>((const double*)workspace, nblk, C, out);
+    MU_CHECK_LAUNCH();
+    return MU_OK;
+}
+
 extern "C" long mu_bn_workspace_bytes(int C) { return (long)MU_STAT_MAXBLK * C * 2 * sizeof(double) + 2L * C * sizeof(float); }
 
 template <typename T>
@@ -212,7 +248,7 @@ static int bn_train_stats_t(const T* x, long M, int C, long ld, float* mean, flo
     int nblk = stat_blocks(M);
     size_t lds = (size_t)rpi * C * 2 * sizeof(double);
     bn_partial_kernel<T, 0><<<nblk, 256, lds, st>>>(x, nullptr, nullptr, nullptr, M, C, ld, nullptr, nullptr, nullptr, nullptr, 0, (double*)ws);
-    bn_fwd_final_kernel<<<mu_cdiv(C, 64), 64, 0, st>>>((const double*)ws, nblk, C, M, eps, momentum, mean, rstd, rmean, rvar, c_valid);
+    bn_fwd_final_kernel<<<mu_cdiv(C, 4), 256, 0, st>>>((const double*)ws, nblk, C, M, eps, momentum, mean, rstd, rmean, rvar, c_valid);
     return MU_OK;
 }
 
@@ -267,7 +303,7 @@ static int bn_act_bwd_t(const T* x, const T* res, const T* g, T* dx, T* dres, lo
     float* s2 = s1 + C;
     T* dzbuf = res ? dres : dx;     // d(residual) == dz exactly, so it doubles as the dz buffer
     bn_partial_kernel<T, 1><<<nblk, 256, lds, st>>>(x, g, res, dzbuf, M, C, ld, mean, rstd, gamma, beta, act, part);
-    bn_bwd_final_kernel<<<mu_cdiv(C, 64), 64, 0, st>>>(part, nblk, C, M, training, dgamma, dbeta, s1, s2);
+    bn_bwd_final_kernel<<<mu_cdiv(C, 4), 256, 0, st>>>(part, nblk, C, M, training, dgamma, dbeta, s1, s2);
     bn_bwd_apply_kernel<T><<<ew_grid(M * cv), 256, 0, st>>>(x, dzbuf, dx, M, C, ld, mean, rstd, gamma, s1, s2);
     return MU_OK;
 }
@@ -344,10 +380,12 @@ __global__ __launch_bounds__(256) void lns_partial_kernel(const T* __restrict__ 
 
 __global__ void lns_final_kernel(const double* __restrict__ part, int nchunk, long L, float eps, int mode, float* __restrict__ o0,
                                  float* __restrict__ o1, int B) {
-    int b = blockIdx.x * blockDim.x + threadIdx.x;
+    const int b = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (b >= B) return;
     double a = 0.0, c = 0.0;
-    for (int k = 0; k < nchunk; ++k) { a += part[((long)b * nchunk + k) * 2]; c += part[((long)b * nchunk + k) * 2 + 1]; }
+    for (int k = lane; k < nchunk; k += 64) { a += part[((long)b * nchunk + k) * 2]; c += part[((long)b * nchunk + k) * 2 + 1]; }
+    a = wave_sum_d(a); c = wave_sum_d(c);
+    if (lane) return;
     if (mode == 0) {
         double m = a / (double)L, var = c / (double)L - m * m;
         if (var < 0.0) var = 0.0;
@@ -419,7 +457,7 @@ static int lns_fwd_t(const T* x, const float* w, const float* b, T* y, float* me
     constexpr int N = Vec16<T>::N;
     dim3 grid(LN_CHUNKS, B);
     lns_partial_kernel<T, 0><<<grid, 256, 0, st>>>(x, nullptr, nullptr, nullptr, nullptr, L, (double*)ws);
-    lns_final_kernel<<<mu_cdiv(B, 64), 64, 0, st>>>((const double*)ws, LN_CHUNKS, L, eps, 0, mean, rstd, B);
+    lns_final_kernel<<<mu_cdiv(B, 4), 256, 0, st>>>((const double*)ws, LN_CHUNKS, L, eps, 0, mean, rstd, B);
     long nvec = L / N;
     int g = (int)((nvec + 255) / 256 > 8192 ? 8192 : (nvec + 255) / 256);
     lns_fwd_apply_kernel<T><<<g, 256, 0, st>>>(x, w, b, mean, rstd, y, L, B);
@@ -446,7 +484,7 @@ static int lns_bwd_t(const T* x, const T* dy, const float* w, const float* mean,
     float* m1 = (float*)((char*)ws + (size_t)B * LN_CHUNKS * 2 * sizeof(double));
     float* m2 = m1 + B;
     lns_partial_kernel<T, 1><<<grid, 256, 0, st>>>(x, dy, w, mean, rstd, L, (double*)ws);
-    lns_final_kernel<<<mu_cdiv(B, 64), 64, 0, st>>>((const double*)ws, LN_CHUNKS, L, 0.f, 1, m1, m2, B);
+    lns_final_kernel<<<mu_cdiv(B, 4), 256, 0, st>>>((const double*)ws, LN_CHUNKS, L, 0.f, 1, m1, m2, B);
     long nvec = L / N;
     int g = (int)((nvec + 255) / 256 > 8192 ? 8192 : (nvec + 255) / 256);
     lns_bwd_apply_kernel<T><<<g, 256, 0, st>>>(x, dy, w, mean, rstd, m1, m2, dx, dw, db, L, B);

@@ -1,0 +1,92 @@
+"""CPU, world_size 2, gloo: the data-parallel exchange step (maskunet_amd/dp.py).  The all-reduce logic is
+device-agnostic, so it is exercised here with real parameters of the model and synthetic gradients (the HIP
+forward itself needs a GPU)."""
+import os
+import socket
+
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from maskunet_amd.dp import DataParallel, shard_batch
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, overlap, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import maskunet_amd
+        torch.manual_seed(100 + rank)                      # different init per rank on purpose
+        model = maskunet_amd.DownSample(32, 64)
+        ddp = DataParallel(model, bucket_mb=0.05, overlap=overlap)
+        # replicas must be identical after construction (rank 0's weights)
+        ref = [torch.zeros_like(p) for p in model.parameters()]
+        for r, p in zip(ref, model.parameters()):
+            r.copy_(p.data)
+            dist.broadcast(r, 0)
+            assert torch.equal(r, p.data), "parameters not broadcast from rank 0"
+        assert len(ddp.buckets) > 1
+        ddp._arm()
+        # synthetic gradients: rank-dependent; emb_layer never gets one (dead weights)
+        expected = {}
+        for name, p in model.named_parameters():
+            if "emb_layer" in name:
+                continue
+            g0 = torch.full_like(p, 1.0) * (len(name) % 7 + 1)
+            expected[name] = g0 * 1.5                      # mean of g0*(rank+1) over ranks 0,1
+            p.grad = None
+            # emulate autograd: accumulate then fire the post-accumulate hook path
+            p.grad = g0 * (rank + 1)
+            if overlap:
+                ddp._on_grad(p)
+        ddp.finish_gradient_sync()
+        for name, p in model.named_parameters():
+            if "emb_layer" in name:
+                assert p.grad is None
+            else:
+                assert torch.allclose(p.grad, expected[name]), name
+        # state_dict keys carry the nn.DataParallel "module." prefix
+        assert all(k.startswith("module.") for k in ddp.state_dict().keys())
+        q.put((rank, "ok"))
+    except Exception as e:  # pragma: no cover
+        q.put((rank, repr(e)))
+    finally:
+        dist.destroy_process_group()
+
+
+def _run(overlap):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, overlap, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=180) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    assert sorted(res) == [(0, "ok"), (1, "ok")], res
+
+
+def test_gradient_allreduce_world2_overlap():
+    _run(True)
+
+
+def test_gradient_allreduce_world2_deferred():
+    _run(False)
+
+
+def test_shard_batch_partitions_like_scatter():
+    for gb, w in [(512, 8), (256, 8), (10, 4), (7, 2)]:
+        spans = [shard_batch(gb, w, r) for r in range(w)]
+        assert spans[0][0] == 0 and spans[-1][1] == gb
+        assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+        sizes = [b - a for a, b in spans]
+        assert max(sizes) - min(sizes) <= 1

@@ -1,0 +1,94 @@
+"""CPU: host-side logic of the drop-in boundary -- module names/signatures, state_dict contract,
+mask attribute semantics (8-b5), error behaviour, and that the product path refuses CPU tensors."""
+import pytest
+import torch
+
+import maskunet_amd
+from oracle import maskunet_oracle as O
+
+
+def test_state_dict_contract_1head():
+    m = maskunet_amd.UNet(3, 150)
+    shapes = O.unet_state_shapes(3, 150)            # verified against the real reference in make_golden.py
+    sd = m.state_dict()
+    assert list(sd.keys()) == [k for k, _, _ in shapes]
+    for k, shp, _ in shapes:
+        assert tuple(sd[k].shape) == tuple(shp), k
+    assert sum(p.numel() for p in m.parameters()) == 24920962
+
+
+def test_state_dict_contract_3head():
+    m = maskunet_amd.InstanceUNet(3, 19)
+    shapes = O.unet_state_shapes(3, 19, True)
+    assert list(m.state_dict().keys()) == [k for k, _, _ in shapes]
+    assert sum(p.numel() for p in m.parameters()) == 24918858
+
+
+def test_load_reference_style_checkpoint_with_module_prefix():
+    params = O.make_params(O.unet_state_shapes(3, 7), 5)
+    ckpt = {"module." + k: v for k, v in params.items()}             # nn.DataParallel checkpoint (ade_semantic.py:412)
+    m = maskunet_amd.UNet(3, 7)
+    m.load_state_dict({k.replace("module.", ""): v for k, v in ckpt.items()})     # ade_panoptic.py:434
+    assert torch.equal(m.state_dict()["bottom2.conv_block.3.weight"], params["bottom2.conv_block.3.weight"])
+
+
+def test_aliases_and_signatures():
+    assert maskunet_amd.DoubleConv is maskunet_amd.ConvBlock and maskunet_amd.Down is maskunet_amd.DownSample
+    assert maskunet_amd.Up is maskunet_amd.UpSample and maskunet_amd.MaskAttention is maskunet_amd.Mask2FormerAttention
+    cb = maskunet_amd.ConvBlock(8, 16, mid_channels=4, residual=True)
+    assert cb.conv_block[0].weight.shape == (4, 8, 3, 3) and cb.conv_block[3].weight.shape == (16, 4, 3, 3)
+    assert maskunet_amd.ConvBlock(8, 16, 0).conv_block[0].out_channels == 16      # `if not mid_channels` (:196)
+    d = maskunet_amd.DownSample(16, 32)
+    assert d.emb_layer[1].weight.shape == (32, 256)
+    u = maskunet_amd.UpSample(64, 16)
+    assert u.conv[1].conv_block[0].weight.shape == (32, 64, 3, 3)                  # mid = in // 2 (:239)
+    a = maskunet_amd.Mask2FormerAttention(64, 99)
+    assert a.size == 99 and a.channels == 64
+    assert maskunet_amd.OutConv(64, 5).final_layer[0].weight.shape == (5, 64, 1, 1)
+
+
+def test_mask_attribute_semantics_on_host():
+    a = maskunet_amd.Mask2FormerAttention(32, 32)
+    assert a.mask is None                                            # ade_semantic.py:160
+    keep = torch.tensor([[1, 0, 1, 1], [0, 0, 1, 0]], dtype=torch.uint8)
+    add = torch.where(keep > 0, torch.zeros(()), torch.full((), -float("inf"))).unsqueeze(1).expand(-1, 4, -1)
+    a.mask = add                                                     # the reference's own form (:180-181)
+    assert tuple(a.mask.shape) == (2, 4, 4) and torch.equal(a.mask, add)
+    assert a.mask.stride(1) == 0                                     # expand view: key-only mask
+    kidx, kcnt = a._compact(torch.device("cpu"))
+    assert kcnt.tolist() == [3, 1] and kidx[0, :3].tolist() == [0, 2, 3] and kidx[1, 0].item() == 2
+    a.mask = None
+    assert a.mask is None and a._kidx is None
+
+
+def test_cpu_tensors_are_refused_no_fallback():
+    m = maskunet_amd.UNet(3, 5)
+    with pytest.raises(RuntimeError, match="GPU only"):
+        m(torch.zeros(1, 3, 128, 128))
+    with pytest.raises(RuntimeError, match="GPU only"):
+        maskunet_amd.ConvBlock(32, 32)(torch.zeros(1, 32, 8, 8))
+
+
+def test_channel_mismatch_error_matches_reference():
+    a = maskunet_amd.Mask2FormerAttention(32, 32)
+    with pytest.raises(ValueError, match="Input channel size does not match initialized channel size."):
+        a(torch.zeros(1, 16, 4, 4))
+
+
+def test_product_never_imports_oracle():
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for dirpath, _, files in os.walk(os.path.join(root, "maskunet_amd")):
+        for f in files:
+            if f.endswith(".py"):
+                src = open(os.path.join(dirpath, f)).read()
+                assert "oracle" not in src.replace("no oracle", ""), f"{f} references the oracle"
+
+
+def test_compute_dtype_switch():
+    m = maskunet_amd.UNet(3, 5)
+    assert m.compute_dtype == torch.float32
+    m.set_compute_dtype(torch.float16)
+    assert m.downsample1.maxpool_conv[1].compute_dtype == torch.float16
+    with pytest.raises(TypeError):
+        m.set_compute_dtype(torch.bfloat16)
