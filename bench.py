@@ -42,10 +42,12 @@ def synth(B, c_out, hw, seed, device):
     return x.to(device), y.to(device), [k.to(device) for k in keeps]
 
 
-def cpu_baseline(c_out, hw, seconds_budget=30.0):
+def cpu_baseline(c_out, hw, seconds_budget=20.0):
     """Oracle (kind 'port') fwd+bwd, fp32, train mode, on all host cores; bounded sample B=1."""
     from oracle import maskunet_oracle as O
-    cores = os.cpu_count() or 1
+    # torch's intra-op scaling collapses with hundreds of threads on this path (256 threads on the GPU box's
+    # host: 232 s/iteration); 32 threads is the fastest setting found, `cores` reports the threads actually used
+    cores = min(os.cpu_count() or 1, 32)
     torch.set_num_threads(cores)
     B = 1
     shapes = O.unet_state_shapes(3, c_out, False, hw=hw)
@@ -57,7 +59,7 @@ def cpu_baseline(c_out, hw, seconds_budget=30.0):
     x, labels = O.make_inputs(3, B, c_out, hw)
     times = []
     t_all = time.time()
-    for it in range(4):
+    for it in range(3):
         t0 = time.time()
         out = O.unet_forward(p, x, keeps, training=True)
         loss = O.pixel_cross_entropy(out, labels)

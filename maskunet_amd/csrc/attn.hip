@@ -74,8 +74,21 @@ template <typename T> __device__ __forceinline__ typename AT<T>::Frag zero_frag(
     for (int i = 0; i < AT<T>::VN; ++i) f[i] = (T)0;
     return f;
 }
-__device__ __forceinline__ float grp_max(float v) { v = fmaxf(v, __shfl_xor(v, 16)); return fmaxf(v, __shfl_xor(v, 32)); }
-__device__ __forceinline__ float grp_sum(float v) { v += __shfl_xor(v, 16); return v + __shfl_xor(v, 32); }
+// reductions over the 4 lanes {r16 + 16g}: v_permlane16_swap / v_permlane32_swap exchange 16-/32-lane rows in
+// registers (no LDS round trip, unlike the ds_bpermute behind __shfl_xor).  swap(v, v) returns {own, partner} in
+// an order that depends on the row parity, so a symmetric combine needs no select.
+__device__ __forceinline__ float grp_max(float v) {
+    auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    v = fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+    r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+__device__ __forceinline__ float grp_sum(float v) {
+    auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    v = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+    r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
 
 template <typename T> __device__ __forceinline__ void store4(T* p, const float v[4]);
 template <> __device__ __forceinline__ void store4<h16>(h16* p, const float v[4]) {
@@ -248,6 +261,262 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const T* __restrict__ qkv
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     ov[r] = (y[dt][r] - mean) * rstd * gamma[c + r] + beta[c + r];
+                    av[r] = o[dt][t][r];
+                }
+                store4<T>(out + tok * D + c, ov);
+                store4<T>(oattn + tok * D + c, av);
+            }
+            if (g == 0) {
+                lse2[tok] = m[t] + log2f(ltot);
+                ln_mean[tok] = mean;
+                ln_rstd[tok] = rstd;
+            }
+        }
+    }
+}
+
+
+// ------------------------------------------------------------------------------------------
+// forward v2: same math as attn_fwd_kernel, restructured for throughput
+//  * K/V tiles (KT kept keys) arrive by LDS-DMA (global_load_lds_dwordx4 with per-lane gathered
+//    source rows; padded rows read a zero page), double-buffered: tile j+1 is in flight while tile j
+//    is processed; the XOR chunk swizzle sits on the source chunk and on every read, which makes
+//    both the ds_read_b128 row reads of K and the transposed reads of V conflict-free at C=64;
+//  * the softmax denominator is accumulated by the matrix core (a constant-ones A operand) instead
+//    of VALU adds + a final cross-lane reduce;
+//  * the O/l rescale runs only when some row's running max actually moved (wave-uniform branch);
+//  * key-range masking only in the final, partial tile.
+// ------------------------------------------------------------------------------------------
+__device__ __attribute__((aligned(16))) char mu_attn_zero_page[16];
+
+template <typename T, int D> struct SwzTile {
+    static constexpr int VN = AT<T>::VN;
+    static constexpr int ROWB = D * (int)sizeof(T);       // bytes per row
+    static constexpr int CPR = ROWB / 16;                 // 16-byte chunks per row
+    static constexpr int RPW = 1024 / ROWB;               // rows per wave LDS-DMA instruction
+    static constexpr int SW = CPR < 8 ? CPR - 1 : 7;
+    // element offset of (row, col) in the swizzled image
+    static __device__ __forceinline__ int off(int row, int col) {
+        return row * D + ((((col / VN) ^ (row & SW))) * VN) + (col % VN);
+    }
+};
+
+// Kept-key row indices of one KT-key tile for this lane's DMA rows (-1 = past the end -> zero page).  Loaded one
+// iteration AHEAD of the DMA that consumes them, so the dependent index->address chain never stalls the loop.
+template <typename T, int D, int KT, int NW> struct KvStage {
+    using Z = SwzTile<T, D>;
+    static constexpr int NI = KT / Z::RPW;                 // wave DMA instructions per tile (K and V each)
+    static constexpr int NPW = (NI + NW - 1) / NW;         // per wave
+    int idx[NPW];
+
+    __device__ __forceinline__ void load_idx(const int* kidx_b, int j0, int Nk, int wave, int lane) {
+        const int lrow = lane / Z::CPR;
+#pragma unroll
+        for (int n = 0; n < NPW; ++n) {
+            const int i = wave + NW * n;
+            const int j = j0 + i * Z::RPW + lrow;
+            idx[n] = (i < NI && j < Nk) ? kidx_b[j] : -1;
+        }
+    }
+    __device__ __forceinline__ void issue(T* Kt, T* Vt, const T* qkv_b, int wave, int lane) const {
+        const int lrow = lane / Z::CPR, lch = lane % Z::CPR;
+#pragma unroll
+        for (int n = 0; n < NPW; ++n) {
+            const int i = wave + NW * n;
+            if (i >= NI) break;                            // wave-uniform
+            const int row = i * Z::RPW + lrow;
+            const int sc = lch ^ (row & Z::SW);
+            const T* base = qkv_b + (long)(idx[n] < 0 ? 0 : idx[n]) * 3 * D + sc * Z::VN;
+            const void* ks = idx[n] < 0 ? (const void*)mu_attn_zero_page : (const void*)(base + D);
+            const void* vs = idx[n] < 0 ? (const void*)mu_attn_zero_page : (const void*)(base + 2 * D);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)ks,
+                                             (__attribute__((address_space(3))) void*)(Kt + i * Z::RPW * D), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)vs,
+                                             (__attribute__((address_space(3))) void*)(Vt + i * Z::RPW * D), 16, 0, 0);
+        }
+    }
+};
+
+// accumulator-operand A fragment from a swizzled tile: rows r0+4g+j (j<4) and r0+16+4g+j, column col0+r16
+template <typename T, int D> struct AccLd;
+template <int D> struct AccLd<h16, D> {
+    static __device__ __forceinline__ AT<h16>::AccA ld(const h16* tile, int r0, int col0, int g, int r16) {
+        using Z = SwzTile<h16, D>;
+        const int q = r16 >> 2, pc = r16 & 3;
+        auto lo = LDS_TR16(tile + Z::off(r0 + 4 * g + q, col0 + 4 * pc));
+        auto hi = LDS_TR16(tile + Z::off(r0 + 16 + 4 * g + q, col0 + 4 * pc));
+        AT<h16>::AccA a;
+        a.v = (h16x8){(h16)lo[0], (h16)lo[1], (h16)lo[2], (h16)lo[3], (h16)hi[0], (h16)hi[1], (h16)hi[2], (h16)hi[3]};
+        return a;
+    }
+    static __device__ __forceinline__ AT<h16>::AccA ones() {
+        AT<h16>::AccA a;
+        a.v = (h16x8)(h16)1.0f;
+        return a;
+    }
+};
+template <int D> struct AccLd<float, D> {
+    static __device__ __forceinline__ AT<float>::AccA ld(const float* tile, int r0, int col0, int g, int r16) {
+        using Z = SwzTile<float, D>;
+        AT<float>::AccA a;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            a.v[r] = tile[Z::off(r0 + 4 * g + r, col0 + r16)];
+            a.v[4 + r] = tile[Z::off(r0 + 16 + 4 * g + r, col0 + r16)];
+        }
+        return a;
+    }
+    static __device__ __forceinline__ AT<float>::AccA ones() {
+        AT<float>::AccA a;
+#pragma unroll
+        for (int r = 0; r < 8; ++r) a.v[r] = 1.0f;
+        return a;
+    }
+};
+
+template <typename T, int D, int KT, int NW>
+__global__ __launch_bounds__(NW * 64, (NW == 4 && D <= 64 && sizeof(T) == 2) ? 2 : 1) void attn_fwd2_kernel(const T* __restrict__ qkv, const T* __restrict__ x, const int* __restrict__ kidx,
+                                                        const int* __restrict__ kcnt, const float* __restrict__ gamma,
+                                                        const float* __restrict__ beta, T* __restrict__ out, T* __restrict__ oattn,
+                                                        float* __restrict__ lse2, float* __restrict__ ln_mean, float* __restrict__ ln_rstd,
+                                                        int N, int nkmax, float scale_log2, float eps) {
+    using A = AT<T>;
+    using Frag = typename A::Frag;
+    using Z = SwzTile<T, D>;
+    constexpr int VN = A::VN, KR = A::KR, NKS = D / KR, NDT = D / 16, NKT = KT / 16, NH = KT / 32;
+    __shared__ __attribute__((aligned(16))) T lds[2 * 2 * KT * D];      // [buf][K|V][KT][D]
+
+    const int b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r16 = lane & 15, g = lane >> 4;
+    const int q0 = blockIdx.x * (NW * 32) + wave * 32;
+    const T* qkv_b = qkv + (long)b * N * 3 * D;
+    const int Nk = kcnt[b];
+    const int* kidx_b = kidx + (long)b * nkmax;
+
+    KvStage<T, D, KT, NW> stg;
+    stg.load_idx(kidx_b, 0, Nk, wave, lane);
+    stg.issue(lds, lds + KT * D, qkv_b, wave, lane);
+    stg.load_idx(kidx_b, KT, Nk, wave, lane);            // indices of tile 1, consumed inside iteration 0
+
+    Frag qf[2][NKS];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        int qrow = q0 + t * 16 + r16;
+        if (qrow > N - 1) qrow = N - 1;
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks) qf[t][ks] = ld16<T>(qkv_b + (long)qrow * 3 * D + ks * KR + g * VN);
+    }
+    f32x4 o[NDT][2], lacc[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        lacc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int dt = 0; dt < NDT; ++dt) o[dt][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+    float m[2] = {-INFINITY, -INFINITY};
+    const typename A::AccA ones = AccLd<T, D>::ones();
+    __syncthreads();
+
+    int buf = 0;
+    for (int j0 = 0; j0 < Nk; j0 += KT, buf ^= 1) {
+        const T* Kt = lds + buf * 2 * KT * D;
+        const T* Vt = Kt + KT * D;
+        if (j0 + KT < Nk) {
+            T* Kn = lds + (buf ^ 1) * 2 * KT * D;
+            stg.issue(Kn, Kn + KT * D, qkv_b, wave, lane);                 // tile j+1 (indices loaded last iteration)
+            stg.load_idx(kidx_b, j0 + 2 * KT, Nk, wave, lane);            // indices of tile j+2
+        }
+        f32x4 s[NKT][2];
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks)
+#pragma unroll
+            for (int kt = 0; kt < NKT; ++kt) {
+                Frag a = ld16<T>(Kt + Z::off(kt * 16 + r16, ks * KR + g * VN));
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    if (ks == 0) s[kt][t] = (f32x4){0.f, 0.f, 0.f, 0.f};      // folds into a zero C operand
+                    A::mma_row(a, qf[t][ks], s[kt][t]);
+                }
+            }
+        const bool partial = j0 + KT > Nk;          // wave-uniform
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            if (partial) {
+#pragma unroll
+                for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (j0 + kt * 16 + 4 * g + r >= Nk) s[kt][t][r] = -INFINITY;
+            }
+            float mx = s[0][t][0];
+#pragma unroll
+            for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) mx = fmaxf(mx, s[kt][t][r]);
+            mx = grp_max(mx) * scale_log2;
+            if (!__all(mx <= m[t])) {                // some row's max moved: rescale (rare after the first tiles)
+                const float m_new = fmaxf(m[t], mx);
+                const float alpha = __builtin_amdgcn_exp2f(m[t] - m_new);
+                m[t] = m_new;
+                lacc[t] *= alpha;
+#pragma unroll
+                for (int dt = 0; dt < NDT; ++dt) o[dt][t] *= alpha;
+            }
+            const float nm = -m[t];
+#pragma unroll
+            for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) s[kt][t][r] = __builtin_amdgcn_exp2f(fmaf(s[kt][t][r], scale_log2, nm));
+        }
+#pragma unroll
+        for (int h = 0; h < NH; ++h) {
+#pragma unroll
+            for (int t = 0; t < 2; ++t) A::mma_acc(ones, s[2 * h][t], s[2 * h + 1][t], lacc[t]);
+#pragma unroll
+            for (int dt = 0; dt < NDT; ++dt) {
+                typename A::AccA va = AccLd<T, D>::ld(Vt, 32 * h, dt * 16, g, r16);
+#pragma unroll
+                for (int t = 0; t < 2; ++t) A::mma_acc(va, s[2 * h][t], s[2 * h + 1][t], o[dt][t]);
+            }
+        }
+        __syncthreads();        // tile j+1 landed (vmcnt(0)) and everyone is done reading tile j
+    }
+
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        const float ltot = lacc[t][0];           // every row of the ones-product holds the same column sum
+        const float inv = 1.0f / ltot;
+        const int qrow = q0 + t * 16 + r16;
+        const bool valid = qrow < N;
+        const long tok = (long)b * N + (valid ? qrow : 0);
+        float yv[NDT][4];
+        float sum = 0.f;
+#pragma unroll
+        for (int dt = 0; dt < NDT; ++dt) {
+            float xr[4] = {0.f, 0.f, 0.f, 0.f};
+            if (valid) load4<T>(x + tok * D + dt * 16 + 4 * g, xr);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                o[dt][t][r] *= inv;
+                yv[dt][r] = o[dt][t][r] + xr[r];
+                sum += yv[dt][r];
+            }
+        }
+        const float mean = grp_sum(sum) * (1.0f / D);
+        float sq = 0.f;
+#pragma unroll
+        for (int dt = 0; dt < NDT; ++dt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { const float d = yv[dt][r] - mean; sq += d * d; }
+        const float rstd = rsqrtf(grp_sum(sq) * (1.0f / D) + eps);
+        if (valid) {
+#pragma unroll
+            for (int dt = 0; dt < NDT; ++dt) {
+                const int c = dt * 16 + 4 * g;
+                float ov[4], av[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    ov[r] = (yv[dt][r] - mean) * rstd * gamma[c + r] + beta[c + r];
                     av[r] = o[dt][t][r];
                 }
                 store4<T>(out + tok * D + c, ov);
@@ -550,20 +819,290 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const T* __restrict__
     }
 }
 
+
+// ------------------------------------------------------------------------------------------
+// backward v2 kernels: LDS-DMA double-buffered tiles, swizzled images (see attn_fwd2_kernel)
+// ------------------------------------------------------------------------------------------
+template <typename T, int D, int KT, int NW>
+__global__ __launch_bounds__(NW * 64, (NW == 4 && D <= 64 && sizeof(T) == 2) ? 2 : 1) void attn_bwd_dq2_kernel(const T* __restrict__ qkv, const T* __restrict__ dY, const int* __restrict__ kidx,
+                                                           const int* __restrict__ kcnt, const float* __restrict__ lse2,
+                                                           const float* __restrict__ delta, T* __restrict__ dqkv, int N, int nkmax,
+                                                           float scale, float scale_log2) {
+    using A = AT<T>;
+    using Frag = typename A::Frag;
+    using Z = SwzTile<T, D>;
+    constexpr int VN = A::VN, KR = A::KR, NKS = D / KR, NDT = D / 16, NKT = KT / 16, NH = KT / 32;
+    __shared__ __attribute__((aligned(16))) T lds[2 * 2 * KT * D];
+
+    const int b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r16 = lane & 15, g = lane >> 4;
+    const int q0 = blockIdx.x * (NW * 32) + wave * 32;
+    const T* qkv_b = qkv + (long)b * N * 3 * D;
+    const int Nk = kcnt[b];
+    const int* kidx_b = kidx + (long)b * nkmax;
+
+    KvStage<T, D, KT, NW> stg;
+    stg.load_idx(kidx_b, 0, Nk, wave, lane);
+    stg.issue(lds, lds + KT * D, qkv_b, wave, lane);
+    stg.load_idx(kidx_b, KT, Nk, wave, lane);            // indices of tile 1, consumed inside iteration 0
+
+    Frag qf[2][NKS], dof[2][NKS];
+    float nlse[2], del_q[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        int qrow = q0 + t * 16 + r16;
+        if (qrow > N - 1) qrow = N - 1;
+        const long tok = (long)b * N + qrow;
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks) {
+            qf[t][ks] = ld16<T>(qkv_b + (long)qrow * 3 * D + ks * KR + g * VN);
+            dof[t][ks] = ld16<T>(dY + tok * D + ks * KR + g * VN);
+        }
+        nlse[t] = -lse2[tok];
+        del_q[t] = delta[tok];
+    }
+    f32x4 dq[NDT][2];
+#pragma unroll
+    for (int dt = 0; dt < NDT; ++dt)
+#pragma unroll
+        for (int t = 0; t < 2; ++t) dq[dt][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    __syncthreads();
+
+    int buf = 0;
+    for (int j0 = 0; j0 < Nk; j0 += KT, buf ^= 1) {
+        const T* Kt = lds + buf * 2 * KT * D;
+        const T* Vt = Kt + KT * D;
+        if (j0 + KT < Nk) {
+            T* Kn = lds + (buf ^ 1) * 2 * KT * D;
+            stg.issue(Kn, Kn + KT * D, qkv_b, wave, lane);                 // tile j+1 (indices loaded last iteration)
+            stg.load_idx(kidx_b, j0 + 2 * KT, Nk, wave, lane);            // indices of tile j+2
+        }
+        f32x4 s[NKT][2], dp[NKT][2];
+#pragma unroll
+        for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+            for (int t = 0; t < 2; ++t) { s[kt][t] = (f32x4){0.f, 0.f, 0.f, 0.f}; dp[kt][t] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks)
+#pragma unroll
+            for (int kt = 0; kt < NKT; ++kt) {
+                Frag ka = ld16<T>(Kt + Z::off(kt * 16 + r16, ks * KR + g * VN));
+                Frag va = ld16<T>(Vt + Z::off(kt * 16 + r16, ks * KR + g * VN));
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    A::mma_row(ka, qf[t][ks], s[kt][t]);
+                    A::mma_row(va, dof[t][ks], dp[kt][t]);
+                }
+            }
+        const bool partial = j0 + KT > Nk;
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float p = __builtin_amdgcn_exp2f(fmaf(s[kt][t][r], scale_log2, nlse[t]));
+                    if (partial && j0 + kt * 16 + 4 * g + r >= Nk) p = 0.f;
+                    s[kt][t][r] = p * (dp[kt][t][r] - del_q[t]) * scale;
+                }
+#pragma unroll
+        for (int h = 0; h < NH; ++h)
+#pragma unroll
+            for (int dt = 0; dt < NDT; ++dt) {
+                typename A::AccA ka = AccLd<T, D>::ld(Kt, 32 * h, dt * 16, g, r16);
+#pragma unroll
+                for (int t = 0; t < 2; ++t) A::mma_acc(ka, s[2 * h][t], s[2 * h + 1][t], dq[dt][t]);
+            }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        const int qrow = q0 + t * 16 + r16;
+        if (qrow >= N) continue;
+        T* dst = dqkv + ((long)b * N + qrow) * 3 * D;
+#pragma unroll
+        for (int dt = 0; dt < NDT; ++dt) {
+            float v[4] = {dq[dt][t][0], dq[dt][t][1], dq[dt][t][2], dq[dt][t][3]};
+            store4<T>(dst + dt * 16 + 4 * g, v);
+        }
+    }
+}
+
+// stage QT query rows of Q (from qkv, row stride 3D) and dO (from dY, row stride D), swizzled, by LDS-DMA
+template <typename T, int D, int QT>
+__device__ __forceinline__ void stage_qo_dma(T* Qt, T* Ot, const T* qkv_b, const T* dY_b, int q0, int N, int wave, int lane) {
+    using Z = SwzTile<T, D>;
+    constexpr int NI = QT / Z::RPW;
+    const int lrow = lane / Z::CPR, lch = lane % Z::CPR;
+#pragma unroll
+    for (int i = wave; i < NI; i += 4) {
+        const int row = i * Z::RPW + lrow;
+        const int q = q0 + row;
+        const int sc = lch ^ (row & Z::SW);
+        const void *qs = mu_attn_zero_page, *os = mu_attn_zero_page;
+        if (q < N) {
+            qs = qkv_b + (long)q * 3 * D + sc * Z::VN;
+            os = dY_b + (long)q * D + sc * Z::VN;
+        }
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)qs,
+                                         (__attribute__((address_space(3))) void*)(Qt + i * Z::RPW * D), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)os,
+                                         (__attribute__((address_space(3))) void*)(Ot + i * Z::RPW * D), 16, 0, 0);
+    }
+}
+
+template <typename T, int D, int NKT>
+__global__ __launch_bounds__(256, (D <= 64 && sizeof(T) == 2) ? 2 : 1) void attn_bwd_dkv2_kernel(const T* __restrict__ qkv, const T* __restrict__ dY, const int* __restrict__ kidx,
+                                                            const int* __restrict__ kcnt, const float* __restrict__ lse2,
+                                                            const float* __restrict__ delta, T* __restrict__ dqkv, int N, int nkmax,
+                                                            float scale, float scale_log2) {
+    using A = AT<T>;
+    using Frag = typename A::Frag;
+    using Z = SwzTile<T, D>;
+    constexpr int VN = A::VN, KR = A::KR, NKS = D / KR, NDT = D / 16, QT = 32;
+    __shared__ __attribute__((aligned(16))) T lds[2 * 2 * QT * D];
+
+    const int b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r16 = lane & 15, g = lane >> 4;
+    const int Nk = kcnt[b];
+    const int kb0 = blockIdx.x * (4 * NKT * 16);
+    if (kb0 >= Nk) return;
+    const int* kidx_b = kidx + (long)b * nkmax;
+    const T* qkv_b = qkv + (long)b * N * 3 * D;
+    const T* dY_b = dY + (long)b * N * D;
+    const float* lse_b = lse2 + (long)b * N;
+    const float* del_b = delta + (long)b * N;
+
+    stage_qo_dma<T, D, QT>(lds, lds + QT * D, qkv_b, dY_b, 0, N, wave, lane);
+
+    Frag kf[NKT][NKS], vf[NKT][NKS];
+    int keyrow[NKT];
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt) {
+        const int j = kb0 + (wave * NKT + kt) * 16 + r16;
+        keyrow[kt] = j < Nk ? kidx_b[j] : -1;
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks) {
+            if (keyrow[kt] >= 0) {
+                kf[kt][ks] = ld16<T>(qkv_b + (long)keyrow[kt] * 3 * D + D + ks * KR + g * VN);
+                vf[kt][ks] = ld16<T>(qkv_b + (long)keyrow[kt] * 3 * D + 2 * D + ks * KR + g * VN);
+            } else {
+                kf[kt][ks] = zero_frag<T>();
+                vf[kt][ks] = zero_frag<T>();
+            }
+        }
+    }
+    f32x4 dk[NDT][NKT], dv[NDT][NKT];
+#pragma unroll
+    for (int dt = 0; dt < NDT; ++dt)
+#pragma unroll
+        for (int kt = 0; kt < NKT; ++kt) { dk[dt][kt] = (f32x4){0.f, 0.f, 0.f, 0.f}; dv[dt][kt] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+
+    // per-lane row constants of the current tile: queries qt*16 + 4g + r  (N is a multiple of 4 here: H*W)
+    auto load_rows = [&](int q0, float4 (&ls)[2], float4 (&de)[2]) {
+#pragma unroll
+        for (int qt = 0; qt < 2; ++qt) {
+            int q = q0 + qt * 16 + 4 * g;
+            if (q > N - 4) q = N - 4;
+            ls[qt] = *reinterpret_cast<const float4*>(lse_b + q);
+            de[qt] = *reinterpret_cast<const float4*>(del_b + q);
+        }
+    };
+    float4 ls_c[2], de_c[2], ls_n[2], de_n[2];
+    load_rows(0, ls_c, de_c);
+    __syncthreads();
+
+    int buf = 0;
+    for (int q0 = 0; q0 < N; q0 += QT, buf ^= 1) {
+        const T* Qt = lds + buf * 2 * QT * D;
+        const T* Ot = Qt + QT * D;
+        const bool more = q0 + QT < N;
+        if (more) {
+            load_rows(q0 + QT, ls_n, de_n);           // issued BEFORE the DMA so their wait does not drain it
+            T* Qn = lds + (buf ^ 1) * 2 * QT * D;
+            stage_qo_dma<T, D, QT>(Qn, Qn + QT * D, qkv_b, dY_b, q0 + QT, N, wave, lane);
+        }
+        f32x4 s[2][NKT], dp[2][NKT];
+#pragma unroll
+        for (int qt = 0; qt < 2; ++qt)
+#pragma unroll
+            for (int kt = 0; kt < NKT; ++kt) { s[qt][kt] = (f32x4){0.f, 0.f, 0.f, 0.f}; dp[qt][kt] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks)
+#pragma unroll
+            for (int qt = 0; qt < 2; ++qt) {
+                Frag qa = ld16<T>(Qt + Z::off(qt * 16 + r16, ks * KR + g * VN));
+                Frag oa = ld16<T>(Ot + Z::off(qt * 16 + r16, ks * KR + g * VN));
+#pragma unroll
+                for (int kt = 0; kt < NKT; ++kt) {
+                    A::mma_row(qa, kf[kt][ks], s[qt][kt]);
+                    A::mma_row(oa, vf[kt][ks], dp[qt][kt]);
+                }
+            }
+        const bool partial = q0 + QT > N;
+#pragma unroll
+        for (int qt = 0; qt < 2; ++qt) {
+            const float lsv[4] = {ls_c[qt].x, ls_c[qt].y, ls_c[qt].z, ls_c[qt].w};
+            const float dev[4] = {de_c[qt].x, de_c[qt].y, de_c[qt].z, de_c[qt].w};
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const bool dead = partial && (q0 + qt * 16 + 4 * g + r >= N);
+#pragma unroll
+                for (int kt = 0; kt < NKT; ++kt) {
+                    float p = __builtin_amdgcn_exp2f(fmaf(s[qt][kt][r], scale_log2, -lsv[r]));
+                    if (dead) p = 0.f;
+                    s[qt][kt][r] = p;
+                    dp[qt][kt][r] = p * (dp[qt][kt][r] - dev[r]) * scale;
+                }
+            }
+        }
+#pragma unroll
+        for (int dt = 0; dt < NDT; ++dt) {
+            typename A::AccA oa = AccLd<T, D>::ld(Ot, 0, dt * 16, g, r16);
+            typename A::AccA qa = AccLd<T, D>::ld(Qt, 0, dt * 16, g, r16);
+#pragma unroll
+            for (int kt = 0; kt < NKT; ++kt) {
+                A::mma_acc(oa, s[0][kt], s[1][kt], dv[dt][kt]);
+                A::mma_acc(qa, dp[0][kt], dp[1][kt], dk[dt][kt]);
+            }
+        }
+        if (more) {
+#pragma unroll
+            for (int qt = 0; qt < 2; ++qt) { ls_c[qt] = ls_n[qt]; de_c[qt] = de_n[qt]; }
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt) {
+        if (keyrow[kt] < 0) continue;
+        T* dst = dqkv + ((long)b * N + keyrow[kt]) * 3 * D;
+#pragma unroll
+        for (int dt = 0; dt < NDT; ++dt) {
+            float kv[4] = {dk[dt][kt][0], dk[dt][kt][1], dk[dt][kt][2], dk[dt][kt][3]};
+            float vv[4] = {dv[dt][kt][0], dv[dt][kt][1], dv[dt][kt][2], dv[dt][kt][3]};
+            store4<T>(dst + D + dt * 16 + 4 * g, kv);
+            store4<T>(dst + 2 * D + dt * 16 + 4 * g, vv);
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------
 // host entry points
 // ------------------------------------------------------------------------------------------
 template <typename T>
 static int attn_fwd_t(const T* qkv, const T* x, const int* kidx, const int* kcnt, const float* gamma, const float* beta, T* out,
                       T* oattn, float* lse2, float* mean, float* rstd, int B, int N, int C, int nkmax, float eps, hipStream_t st) {
-    dim3 grid(mu_cdiv(N, 128), B);
     const float sl2 = (float)(1.4426950408889634 / sqrt((double)C));
-#define LAUNCH_FWD(DD) attn_fwd_kernel<T, DD><<<grid, 256, 0, st>>>(qkv, x, kidx, kcnt, gamma, beta, out, oattn, lse2, mean, rstd, N, nkmax, sl2, eps)
+    // 8 waves (256 queries) per block share each K/V tile when the image has enough queries: halves the L2->LDS traffic
+    const bool big = false;   // measured: 8-wave blocks are 8% SLOWER (the per-tile barrier over 8 waves costs more than the saved L2 traffic)
+#define LAUNCH_FWD(DD, KT)                                                                                                          \
+    if (big) attn_fwd2_kernel<T, DD, KT, 8><<<dim3(mu_cdiv(N, 256), B), 512, 0, st>>>(qkv, x, kidx, kcnt, gamma, beta, out, oattn, lse2, mean, rstd, N, nkmax, sl2, eps); \
+    else attn_fwd2_kernel<T, DD, KT, 4><<<dim3(mu_cdiv(N, 128), B), 256, 0, st>>>(qkv, x, kidx, kcnt, gamma, beta, out, oattn, lse2, mean, rstd, N, nkmax, sl2, eps)
     switch (C) {
-        case 32: LAUNCH_FWD(32); break;
-        case 64: LAUNCH_FWD(64); break;
-        case 128: LAUNCH_FWD(128); break;
-        case 256: LAUNCH_FWD(256); break;
+        case 32: LAUNCH_FWD(32, 64); break;
+        case 64: LAUNCH_FWD(64, 64); break;
+        case 128: LAUNCH_FWD(128, 64); break;
+        case 256: LAUNCH_FWD(256, 32); break;
         default: return MU_ERR_SHAPE;
     }
 #undef LAUNCH_FWD
@@ -601,14 +1140,16 @@ static int attn_bwd_t(const T* qkv, const T* x, const T* oattn, const T* gout, c
 #define LAUNCH_BWD(DD, NKT)                                                                                                     \
     attn_ln_bwd_kernel<T, DD><<<nblk, 256, 0, st>>>(gout, oattn, x, mean, rstd, gamma, dY, delta, (double*)ws, rows);           \
     attn_ln_bwd_final_kernel<<<mu_cdiv(DD, 4), 256, 0, st>>>((const double*)ws, nblk, DD, dgamma, dbeta);                       \
-    attn_bwd_dq_kernel<T, DD><<<gq, 256, 0, st>>>(qkv, dY, kidx, kcnt, lse2, delta, dqkv, N, nkmax, scale, sl2);                \
-    attn_bwd_dkv_kernel<T, DD, NKT><<<dim3(mu_cdiv(nkmax, 64 * NKT), B), 256, 0, st>>>(qkv, dY, kidx, kcnt, lse2, delta, dqkv, N, \
-                                                                                      nkmax, scale, sl2)
+    if (false) attn_bwd_dq2_kernel<T, DD, KTQ, 8><<<dim3(mu_cdiv(N, 256), B), 512, 0, st>>>(qkv, dY, kidx, kcnt, lse2, delta, dqkv, N, nkmax, scale, sl2); \
+    else attn_bwd_dq2_kernel<T, DD, KTQ, 4><<<gq, 256, 0, st>>>(qkv, dY, kidx, kcnt, lse2, delta, dqkv, N, nkmax, scale, sl2);  \
+    attn_bwd_dkv2_kernel<T, DD, NKT><<<dim3(mu_cdiv(nkmax, 64 * NKT), B), 256, 0, st>>>(qkv, dY, kidx, kcnt, lse2, delta, dqkv, N, \
+                                                                                       nkmax, scale, sl2)
+    if (N % 4) return MU_ERR_SHAPE;
     switch (C) {
-        case 32: LAUNCH_BWD(32, 2); break;
-        case 64: LAUNCH_BWD(64, 2); break;
-        case 128: LAUNCH_BWD(128, 2); break;
-        case 256: LAUNCH_BWD(256, 1); break;
+        case 32: { constexpr int KTQ = 64; LAUNCH_BWD(32, 2); } break;
+        case 64: { constexpr int KTQ = 64; LAUNCH_BWD(64, 2); } break;
+        case 128: { constexpr int KTQ = 32; LAUNCH_BWD(128, 2); } break;
+        case 256: { constexpr int KTQ = 32; LAUNCH_BWD(256, 1); } break;
         default: return MU_ERR_SHAPE;
     }
 #undef LAUNCH_BWD

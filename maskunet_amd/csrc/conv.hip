@@ -175,11 +175,153 @@ __global__ __launch_bounds__(256) void conv_nt_kernel(const T* __restrict__ x, c
     }
 }
 
+
+// ------------------------------------------------------------------------------------------
+// v2 of the same implicit GEMM for K rows of >= 128 bytes (Cin % 64 == 0 fp16, % 32 fp32):
+//  * BK = 128 bytes per stage (half the barriers of the 64-byte version);
+//  * both tiles go HBM/L2 -> LDS by LDS-DMA (global_load_lds_dwordx4): no VGPR staging and no
+//    ds_write pass, which was the LDS-pipe bottleneck of v1.  The LDS image is lane-linear
+//    (8 rows x 128 B per wave instruction); the XOR swizzle is applied to the per-lane SOURCE
+//    chunk and again on the fragment read (cdna guide rule 21).  Padding pixels of the 3x3
+//    halo and out-of-range rows read a 16-byte zero page instead of branching around the load.
+//  * double-buffered: stage s+1 is in flight while stage s is multiplied.
+// ------------------------------------------------------------------------------------------
+__device__ __attribute__((aligned(16))) char mu_zero_page[16];
+
+__device__ __forceinline__ void glds16(const void* gsrc, void* lds_wave_base) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
+                                     (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+
+template <typename T, int TM, int TN, int WR, int TAPS>
+__global__ __launch_bounds__(256) void conv_nt2_kernel(const T* __restrict__ x, const T* __restrict__ w, const float* __restrict__ bias,
+                                                       T* __restrict__ y, int B, int H, int W, int Cin, int Cout, long x_ld, long y_ld) {
+    using M_ = Mma<T>;
+    using Frag = typename M_::Frag;
+    constexpr int VN = M_::VN, KC = 8 * VN;                 // elements per 128-byte stage row
+    constexpr int WC = 4 / WR;
+    constexpr int BCO = WR * TM * 16, BPX = WC * TN * 16;
+    constexpr int PA = BCO / 32, PB = BPX / 32;            // staging passes (4 waves x 8 rows each)
+    static_assert(BCO % 32 == 0 && BPX % 32 == 0, "tiles must be multiples of 32 rows");
+    constexpr int STAGE = (BCO + BPX) * 128;
+
+    __shared__ __attribute__((aligned(16))) char lds[2 * STAGE];
+
+    const long Mtot = (long)B * H * W;
+    const int npb = (int)((Mtot + BPX - 1) / BPX), ncb = (Cout + BCO - 1) / BCO;
+    const int L = xcd_remap(blockIdx.x, npb * ncb);
+    const int cb = L % ncb, pb = L / ncb;
+    const int co0 = cb * BCO;
+    const long px0 = (long)pb * BPX;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wr = wave / WC, wc = wave % WC;
+    const int r16 = lane & 15, g = lane >> 4;
+    const int srow = lane >> 3, sch = lane & 7;             // staging: row within the wave's 8-row group, dest chunk
+
+    long prow[PB]; int ph[PB], pw[PB]; bool pok[PB];
+#pragma unroll
+    for (int i = 0; i < PB; ++i) {
+        const long p = px0 + (i * 4 + wave) * 8 + srow;
+        pok[i] = p < Mtot;
+        const long pp = pok[i] ? p : 0;
+        pw[i] = (int)(pp % W);
+        ph[i] = (int)((pp / W) % H);
+        prow[i] = pp;
+    }
+    const int kchunks = Cin / KC;
+    const int nsteps = TAPS * kchunks;
+
+    auto stage = [&](int s, int buf) {
+        const int tap = s / kchunks, ci0 = (s % kchunks) * KC;
+        const int dh = TAPS == 9 ? tap / 3 - 1 : 0, dw = TAPS == 9 ? tap % 3 - 1 : 0;
+        char* Ab = lds + buf * STAGE;
+        char* Bb = Ab + BCO * 128;
+#pragma unroll
+        for (int i = 0; i < PA; ++i) {
+            const int row = (i * 4 + wave) * 8 + srow, co = co0 + row;
+            const int sc = sch ^ (row & 7);
+            const void* src = co < Cout ? (const void*)(w + ((long)tap * Cout + co) * Cin + ci0 + sc * VN) : (const void*)mu_zero_page;
+            glds16(src, Ab + (i * 4 + wave) * 1024);
+        }
+#pragma unroll
+        for (int i = 0; i < PB; ++i) {
+            const int row = (i * 4 + wave) * 8 + srow;
+            const int sc = sch ^ (row & 7);
+            const int hh = ph[i] + dh, ww = pw[i] + dw;
+            const bool ok = pok[i] && hh >= 0 && hh < H && ww >= 0 && ww < W;
+            const void* src = ok ? (const void*)(x + (prow[i] + dh * W + dw) * x_ld + ci0 + sc * VN) : (const void*)mu_zero_page;
+            glds16(src, Bb + (i * 4 + wave) * 1024);
+        }
+    };
+
+    f32x4 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    stage(0, 0);
+    __syncthreads();
+    for (int s = 0; s < nsteps; ++s) {
+        const int buf = s & 1;
+        if (s + 1 < nsteps) stage(s + 1, buf ^ 1);
+        const char* Ab = lds + buf * STAGE;
+        const char* Bb = Ab + BCO * 128;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            Frag a[TM], b[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                const int row = (wr * TM + i) * 16 + r16;
+                a[i] = *reinterpret_cast<const Frag*>(Ab + row * 128 + (((kk * 4 + g) ^ (row & 7)) << 4));
+            }
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int row = (wc * TN + j) * 16 + r16;
+                b[j] = *reinterpret_cast<const Frag*>(Bb + row * 128 + (((kk * 4 + g) ^ (row & 7)) << 4));
+            }
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) M_::mma(a[i], b[j], acc[i][j]);
+        }
+        __syncthreads();          // drains the LDS-DMA of stage s+1 (vmcnt(0)) and fences the reads of stage s
+    }
+
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const long p = px0 + (wc * TN + j) * 16 + r16;
+        if (p >= Mtot) continue;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const int co = co0 + (wr * TM + i) * 16 + 4 * g;
+            if (co >= Cout) continue;
+            float v[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = acc[i][j][r] + (bias ? bias[co + r] : 0.f);
+            if constexpr (sizeof(T) == 2) {
+                h16x4 o = {(h16)v[0], (h16)v[1], (h16)v[2], (h16)v[3]};
+                *reinterpret_cast<h16x4*>(y + p * y_ld + co) = o;
+            } else {
+                *reinterpret_cast<float4*>(y + p * y_ld + co) = make_float4(v[0], v[1], v[2], v[3]);
+            }
+        }
+    }
+}
+
 template <typename T, int TAPS>
 static int conv_fwd_launch(const T* x, const T* w, const float* bias, T* y, int B, int H, int W, int Cin, int Cout, long x_ld,
                            long y_ld, hipStream_t st) {
     const long M = (long)B * H * W;
     const int npb = (int)((M + 127) / 128);
+    if ((Cin * (int)sizeof(T)) % 128 == 0 && Cout % 64 == 0) {         // LDS-DMA version
+        if (Cout % 128 == 0)
+            conv_nt2_kernel<T, 4, 4, 2, TAPS><<<npb * (Cout / 128), 256, 0, st>>>(x, w, bias, y, B, H, W, Cin, Cout, x_ld, y_ld);
+        else
+            conv_nt2_kernel<T, 4, 4, 1, TAPS><<<(int)((M + 255) / 256) * (Cout / 64), 256, 0, st>>>(x, w, bias, y, B, H, W, Cin, Cout, x_ld, y_ld);
+        return MU_OK;
+    }
     if (Cout % 128 == 0) {
         conv_nt_kernel<T, 4, 4, 2, TAPS><<<npb * (Cout / 128), 256, 0, st>>>(x, w, bias, y, B, H, W, Cin, Cout, x_ld, y_ld);
     } else if (Cout % 64 == 0) {
