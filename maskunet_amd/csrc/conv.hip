@@ -310,11 +310,151 @@ __global__ __launch_bounds__(256) void conv_nt2_kernel(const T* __restrict__ x, 
     }
 }
 
+
+// ------------------------------------------------------------------------------------------
+// v3 for 3x3: LDS-staged halo tile.  A block owns a TH x 16 spatial tile of one image; for every
+// 64-channel chunk the (TH+2) x 18 input halo is brought into LDS ONCE (LDS-DMA, zero page for the
+// padding ring) and re-used by all nine taps -- the tap shift is just a different row of the halo image
+// in the fragment read.  Only the 16 KB weight tile changes per tap.  Versus v2 this cuts the
+// activation L2->LDS traffic 9x (v2 is pinned at the ~10 TB/s L2->LDS ceiling on the Cin<=256 layers).
+// The next chunk's halo is streamed in 1/6 pieces behind the first six tap steps.
+// ------------------------------------------------------------------------------------------
+template <typename T, int TM, int TN, int WR>
+__global__ __launch_bounds__(256, 2) void conv_nt3_kernel(const T* __restrict__ x, const T* __restrict__ w, const float* __restrict__ bias,
+                                                       T* __restrict__ y, int B, int H, int W, int Cin, int Cout, long x_ld, long y_ld) {
+    using M_ = Mma<T>;
+    using Frag = typename M_::Frag;
+    constexpr int VN = M_::VN, KC = 8 * VN;
+    constexpr int WC = 4 / WR;
+    constexpr int BCO = WR * TM * 16;
+    constexpr int TH = WC * TN, TW = 16, HW_ = TW + 2;      // spatial tile TH x 16, halo row width 18
+    constexpr int HROWS = (TH + 2) * HW_;
+    constexpr int HINST = (HROWS + 7) / 8;                  // 8 halo rows (128 B each) per wave DMA instruction
+    constexpr int HPER = (HINST + 5) / 6;                   // instructions per piece (6 pieces), spread over 4 waves
+    constexpr int PA = BCO / 32;
+    constexpr int HBYTES = HINST * 1024, WBYTES = BCO * 128;
+
+    __shared__ __attribute__((aligned(16))) char lds[2 * HBYTES + 2 * WBYTES];
+    char* Hs = lds;
+    char* Ws = lds + 2 * HBYTES;
+
+    const int tiles_w = W / TW, tiles_h = H / TH;
+    const int ntile = B * tiles_h * tiles_w, ncb = Cout / BCO;
+    const int L = xcd_remap(blockIdx.x, ntile * ncb);
+    const int cb = L % ncb, tl = L / ncb;
+    const int co0 = cb * BCO;
+    const int tw_ = tl % tiles_w, th_ = (tl / tiles_w) % tiles_h, bimg = tl / (tiles_w * tiles_h);
+    const int h0 = th_ * TH, w0 = tw_ * TW;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wr = wave / WC, wc = wave % WC;
+    const int r16 = lane & 15, g = lane >> 4;
+    const int srow = lane >> 3, sch = lane & 7;
+
+    const int kchunks = Cin / KC;
+    const int nsteps = 9 * kchunks;
+
+    auto stage_w = [&](int s, int buf) {
+        const int tap = s % 9, ci0 = (s / 9) * KC;
+        char* Wb = Ws + buf * WBYTES;
+#pragma unroll
+        for (int i = 0; i < PA; ++i) {
+            const int row = (i * 4 + wave) * 8 + srow;
+            const int sc = sch ^ (row & 7);
+            glds16(w + ((long)tap * Cout + co0 + row) * Cin + ci0 + sc * VN, Wb + (i * 4 + wave) * 1024);
+        }
+    };
+    auto stage_h = [&](int inst, int ci0, int buf) {        // one wave instruction = halo rows 8*inst .. 8*inst+7
+        const int hr = inst * 8 + srow;
+        const int hy = hr / HW_, hx = hr - hy * HW_;
+        const int hh = h0 - 1 + hy, ww = w0 - 1 + hx;
+        const bool ok = hr < HROWS && hh >= 0 && hh < H && ww >= 0 && ww < W;
+        const int sc = sch ^ (hr & 7);
+        const void* src = ok ? (const void*)(x + (((long)bimg * H + hh) * W + ww) * x_ld + ci0 + sc * VN) : (const void*)mu_zero_page;
+        glds16(src, Hs + buf * HBYTES + inst * 1024);
+    };
+
+    f32x4 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    stage_w(0, 0);
+    for (int inst = wave; inst < HINST; inst += 4) stage_h(inst, 0, 0);
+    __syncthreads();
+
+    int s = 0;
+    for (int c = 0; c < kchunks; ++c) {
+        const char* Hb = Hs + (c & 1) * HBYTES;
+#pragma unroll 1
+        for (int t = 0; t < 9; ++t, ++s) {
+            if (s + 1 < nsteps) stage_w(s + 1, (s + 1) & 1);
+            if (t < 6 && c + 1 < kchunks) {
+#pragma unroll
+                for (int k = 0; k < (HPER + 3) / 4; ++k) {
+                    const int inst = t * HPER + k * 4 + wave;
+                    if (k * 4 + wave < HPER && inst < HINST) stage_h(inst, (c + 1) * KC, (c + 1) & 1);
+                }
+            }
+            const char* Wb = Ws + (s & 1) * WBYTES;
+            const int dh = t / 3, dw = t % 3;               // halo offsets (already include the -1 ring)
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+                Frag a[TM], b[TN];
+#pragma unroll
+                for (int i = 0; i < TM; ++i) {
+                    const int row = (wr * TM + i) * 16 + r16;
+                    a[i] = *reinterpret_cast<const Frag*>(Wb + row * 128 + (((kk * 4 + g) ^ (row & 7)) << 4));
+                }
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    const int hr = (wc * TN + j + dh) * HW_ + r16 + dw;
+                    b[j] = *reinterpret_cast<const Frag*>(Hb + hr * 128 + (((kk * 4 + g) ^ (hr & 7)) << 4));
+                }
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) M_::mma(a[i], b[j], acc[i][j]);
+            }
+            __syncthreads();
+        }
+    }
+
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const long p = ((long)bimg * H + h0 + wc * TN + j) * W + w0 + r16;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const int co = co0 + (wr * TM + i) * 16 + 4 * g;
+            float v[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = acc[i][j][r] + (bias ? bias[co + r] : 0.f);
+            if constexpr (sizeof(T) == 2) {
+                h16x4 o = {(h16)v[0], (h16)v[1], (h16)v[2], (h16)v[3]};
+                *reinterpret_cast<h16x4*>(y + p * y_ld + co) = o;
+            } else {
+                *reinterpret_cast<float4*>(y + p * y_ld + co) = make_float4(v[0], v[1], v[2], v[3]);
+            }
+        }
+    }
+}
+
 template <typename T, int TAPS>
 static int conv_fwd_launch(const T* x, const T* w, const float* bias, T* y, int B, int H, int W, int Cin, int Cout, long x_ld,
                            long y_ld, hipStream_t st) {
     const long M = (long)B * H * W;
     const int npb = (int)((M + 127) / 128);
+    if (TAPS == 9 && (Cin * (int)sizeof(T)) % 128 == 0 && W % 16 == 0) {     // halo-tile version
+        if (Cout % 128 == 0 && H % 8 == 0) {
+            conv_nt3_kernel<T, 4, 4, 2><<<B * (H / 8) * (W / 16) * (Cout / 128), 256, 0, st>>>(x, w, bias, y, B, H, W, Cin, Cout, x_ld, y_ld);
+            return MU_OK;
+        }
+        if (Cout % 64 == 0 && H % 8 == 0) {
+            conv_nt3_kernel<T, 4, 2, 1><<<B * (H / 8) * (W / 16) * (Cout / 64), 256, 0, st>>>(x, w, bias, y, B, H, W, Cin, Cout, x_ld, y_ld);
+            return MU_OK;
+        }
+    }
     if ((Cin * (int)sizeof(T)) % 128 == 0 && Cout % 64 == 0) {         // LDS-DMA version
         if (Cout % 128 == 0)
             conv_nt2_kernel<T, 4, 4, 2, TAPS><<<npb * (Cout / 128), 256, 0, st>>>(x, w, bias, y, B, H, W, Cin, Cout, x_ld, y_ld);
@@ -502,6 +642,133 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const T* __restrict__ x
         }
 }
 
+
+// ------------------------------------------------------------------------------------------
+// weight gradient v2 (fp16, 3x3, W % 32 == 0): one block accumulates the THREE taps of a kernel row
+// (dh fixed, dw = -1,0,+1).  A 32-pixel stage never crosses an image row, so the three shifted input
+// tiles are 32-row windows (offset 0,1,2) of ONE 34-row LDS window: the dy tile and the x window are
+// loaded once for 3x the MFMAs of v1 -> 3x fewer L2->LDS bytes per flop (v1 sits on the ~10 TB/s
+// L2->LDS ceiling).  Boundary columns (w = 0 / W-1) only touch window rows 0 / 33, each used by a single
+// tap, so they are zeroed at load time (zero page).  Tiles arrive by LDS-DMA, double-buffered; the LDS
+// image XORs the 32-byte chunk index with a row hash so the transposed reads are conflict-free.
+// ------------------------------------------------------------------------------------------
+template <int BCH> __device__ __forceinline__ int wg_hash(int row) {
+    return (BCH >= 128) ? ((row & 3) | (((row >> 3) & 1) << 2)) : (row & 3);
+}
+
+template <int TM, int TN, int WR>
+__global__ __launch_bounds__(256, 1) void conv_wgrad3_kernel(const h16* __restrict__ x, const h16* __restrict__ dy, float* __restrict__ part,
+                                                             int B, int H, int W, int Cin, int Cout, long x_ld, long dy_ld, int nsplit,
+                                                             long pix_per_split) {
+    constexpr int WC = 4 / WR;
+    constexpr int BCO = WR * TM * 16, BCI = WC * TN * 16;
+    static_assert(BCO == BCI, "square channel tiles");
+    constexpr int ROWB = BCO * 2, CPR = ROWB / 16, RPW = 1024 / ROWB;
+    constexpr int KP = 32, XR = (KP + 2 + RPW - 1) / RPW * RPW;   // pixels per stage; x-window rows allocated (34 used)
+    constexpr int NIA = KP / RPW, NIB = XR / RPW;          // DMA wave-instructions per tile
+    constexpr int STAGE = (KP + XR) * BCO;                 // elements per stage
+
+    __shared__ __attribute__((aligned(16))) h16 lds[2 * STAGE];
+
+    const long Mtot = (long)B * H * W;
+    const int nco = Cout / BCO, nci = Cin / BCI;
+    int bid = blockIdx.x;
+    const int split = bid % nsplit; bid /= nsplit;
+    const int cib = bid % nci; bid /= nci;
+    const int cob = bid % nco; bid /= nco;
+    const int dh = bid - 1;                                 // kernel row: taps 3*(dh+1) + {0,1,2}
+    const int co0 = cob * BCO, ci0 = cib * BCI;
+    const long p_begin = (long)split * pix_per_split;
+    const long p_end = p_begin + pix_per_split < Mtot ? p_begin + pix_per_split : Mtot;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wr = wave / WC, wc = wave % WC;
+    const int r16 = lane & 15, g = lane >> 4;
+    const int lrow = lane / CPR, c16 = lane % CPR;
+
+    auto stage = [&](long pbase, int buf) {
+        h16* At = lds + buf * STAGE;
+        h16* Bt = At + KP * BCO;
+#pragma unroll
+        for (int i = wave; i < NIA; i += 4) {
+            const int row = i * RPW + lrow;
+            const long pp = pbase + row;
+            const int sc = (((c16 >> 1) ^ wg_hash<BCO>(row)) << 1) | (c16 & 1);
+            const void* src = pp < p_end ? (const void*)(dy + pp * dy_ld + co0 + sc * 8) : (const void*)mu_zero_page;
+            glds16(src, At + i * RPW * BCO);
+        }
+        const int w0 = (int)(pbase % W);
+        const int hh = (int)((pbase / W) % H) + dh;
+        const bool rowok = hh >= 0 && hh < H;
+#pragma unroll
+        for (int i = wave; i < NIB; i += 4) {
+            const int row = i * RPW + lrow;                 // window row: flat pixel pbase + dh*W - 1 + row
+            const bool ok = rowok && row <= KP + 1 && (row >= 1 || w0 > 0) && (row <= KP || w0 + KP < W);
+            const int sc = (((c16 >> 1) ^ wg_hash<BCO>(row)) << 1) | (c16 & 1);
+            const void* src = ok ? (const void*)(x + (pbase + (long)dh * W - 1 + row) * x_ld + ci0 + sc * 8) : (const void*)mu_zero_page;
+            glds16(src, Bt + i * RPW * BCO);
+        }
+    };
+
+    f32x4 acc[3][TM][TN];
+#pragma unroll
+    for (int t = 0; t < 3; ++t)
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) acc[t][i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    const int nsteps = (int)((p_end - p_begin + KP - 1) / KP);
+    if (nsteps > 0) stage(p_begin, 0);
+    __syncthreads();
+    const int q = r16 >> 2, pc = r16 & 3;
+    for (int s = 0; s < nsteps; ++s) {
+        const int buf = s & 1;
+        if (s + 1 < nsteps) stage(p_begin + (long)(s + 1) * KP, buf ^ 1);
+        const h16* At = lds + buf * STAGE;
+        const h16* Bt = At + KP * BCO;
+        h16x8 a[TM];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const int col = (wr * TM + i) * 16 + 4 * pc;    // 4 halfs inside 32-byte chunk (col >> 4)
+            const int r0 = 8 * g + q, r1 = r0 + 4;
+            auto lo = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) fp16x4v*)(At + r0 * BCO + ((((col >> 4) ^ wg_hash<BCO>(r0)) << 4) | (col & 15))));
+            auto hi = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) fp16x4v*)(At + r1 * BCO + ((((col >> 4) ^ wg_hash<BCO>(r1)) << 4) | (col & 15))));
+            a[i] = (h16x8){(h16)lo[0], (h16)lo[1], (h16)lo[2], (h16)lo[3], (h16)hi[0], (h16)hi[1], (h16)hi[2], (h16)hi[3]};
+        }
+#pragma unroll
+        for (int t = 0; t < 3; ++t) {
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int col = (wc * TN + j) * 16 + 4 * pc;
+                const int r0 = 8 * g + q + t, r1 = r0 + 4;
+                auto lo = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) fp16x4v*)(Bt + r0 * BCO + ((((col >> 4) ^ wg_hash<BCO>(r0)) << 4) | (col & 15))));
+                auto hi = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) fp16x4v*)(Bt + r1 * BCO + ((((col >> 4) ^ wg_hash<BCO>(r1)) << 4) | (col & 15))));
+                h16x8 bf = (h16x8){(h16)lo[0], (h16)lo[1], (h16)lo[2], (h16)lo[3], (h16)hi[0], (h16)hi[1], (h16)hi[2], (h16)hi[3]};
+#pragma unroll
+                for (int i = 0; i < TM; ++i) acc[t][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[i], bf, acc[t][i][j], 0, 0, 0);
+            }
+        }
+        __syncthreads();
+    }
+
+#pragma unroll
+    for (int t = 0; t < 3; ++t) {
+        float* out = part + ((long)split * 9 + (dh + 1) * 3 + t) * Cout * Cin;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int ci = ci0 + (wc * TN + j) * 16 + r16;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int co = co0 + (wr * TM + i) * 16 + 4 * g + r;
+                    out[(long)co * Cin + ci] = acc[t][i][j][r];
+                }
+            }
+    }
+}
+
 // dst_oihw[o][i][t] = sum_split part[split][t][o][i]   (valid region only)
 __global__ void wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ dst, int nsplit, int taps, int Cout, int Cin,
                                     int O, int I) {
@@ -538,11 +805,32 @@ static inline void wgrad_tile(int Cin, int Cout, int* bco, int* bci) {
     *bco = m; *bci = m;
 }
 
+// v2 (3 taps per block) applies to fp16 3x3 layers with W % 32 == 0 and 64/128-wide channel tiles
+static inline bool wgrad3_ok(int W, int taps, int bt, int dtype) { return dtype == MU_F16 && taps == 9 && W % 32 == 0 && (bt == 128 || bt == 64); }
+static inline void wgrad3_plan(long M, int Cin, int Cout, int bt, int* nsplit, long* pps) {
+    long tiles = 3L * (Cout / bt) * (Cin / bt);
+    long want = 1024 / tiles;                 // one 256-thread block per CU (192 accumulator registers), ~4 waves of blocks
+    if (want < 1) want = 1;
+    long max_split = (M + 511) / 512;
+    if (want > max_split) want = max_split;
+    if (want > 256) want = 256;
+    long p = (M + want - 1) / want;
+    p = (p + 31) / 32 * 32;
+    *pps = p;
+    *nsplit = (int)((M + p - 1) / p);
+}
+
 extern "C" long mu_conv_wgrad_workspace_bytes(int B, int H, int W, int Cin, int Cout, int taps) {
     int bco, bci, nsplit; long pps;
     wgrad_tile(Cin, Cout, &bco, &bci);
     wgrad_plan((long)B * H * W, Cin, Cout, taps, bco, bci, &nsplit, &pps);
-    return (long)nsplit * taps * Cout * Cin * sizeof(float);
+    long a = (long)nsplit * taps * Cout * Cin * sizeof(float);
+    if (taps == 9 && W % 32 == 0 && (bco == 128 || bco == 64)) {
+        wgrad3_plan((long)B * H * W, Cin, Cout, bco, &nsplit, &pps);
+        long b = (long)nsplit * taps * Cout * Cin * sizeof(float);
+        if (b > a) a = b;
+    }
+    return a;
 }
 
 template <typename T, int TAPS>
@@ -566,10 +854,19 @@ extern "C" int mu_conv_wgrad(const void* x, const void* dy, float* dw_oihw, int 
     int bco, bci, nsplit; long pps;
     wgrad_tile(Cin, Cout, &bco, &bci);
     wgrad_plan((long)B * H * W, Cin, Cout, taps, bco, bci, &nsplit, &pps);
-    if (ws_bytes < (long)nsplit * taps * Cout * Cin * (long)sizeof(float)) return MU_ERR_WORKSPACE;
     hipStream_t st = (hipStream_t)stream;
     float* part = (float*)workspace;
-    if (dtype == MU_F16) {
+    if (wgrad3_ok(W, taps, bco, dtype)) {
+        wgrad3_plan((long)B * H * W, Cin, Cout, bco, &nsplit, &pps);
+        if (ws_bytes < (long)nsplit * taps * Cout * Cin * (long)sizeof(float)) return MU_ERR_WORKSPACE;
+        const int grid = 3 * (Cout / bco) * (Cin / bco) * nsplit;
+        if (bco == 128)
+            conv_wgrad3_kernel<4, 4, 2><<<grid, 256, 0, st>>>((const h16*)x, (const h16*)dy, part, B, H, W, Cin, Cout, x_ld, dy_ld, nsplit, pps);
+        else
+            conv_wgrad3_kernel<2, 2, 2><<<grid, 256, 0, st>>>((const h16*)x, (const h16*)dy, part, B, H, W, Cin, Cout, x_ld, dy_ld, nsplit, pps);
+    } else if (ws_bytes < (long)nsplit * taps * Cout * Cin * (long)sizeof(float)) {
+        return MU_ERR_WORKSPACE;
+    } else if (dtype == MU_F16) {
         if (taps == 9) wgrad_launch<h16, 9>((const h16*)x, (const h16*)dy, part, B, H, W, Cin, Cout, x_ld, dy_ld, bco, nsplit, pps, st);
         else wgrad_launch<h16, 1>((const h16*)x, (const h16*)dy, part, B, H, W, Cin, Cout, x_ld, dy_ld, bco, nsplit, pps, st);
     } else if (dtype == MU_F32) {

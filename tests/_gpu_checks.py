@@ -88,7 +88,9 @@ def check_conv(dtype, cases=None):
     out = []
     cases = cases or [(2, 12, 12, 32, 32, 3), (1, 16, 16, 64, 128, 3), (2, 8, 8, 128, 64, 3), (1, 10, 6, 19, 32, 3),
                       (1, 8, 8, 64, 150, 1), (2, 9, 7, 256, 256, 3), (1, 16, 16, 3, 64, 3), (2, 8, 8, 32, 1, 1),
-                      (1, 6, 6, 512, 256, 3)]
+                      (1, 6, 6, 512, 256, 3),
+                      # W % 32 == 0: exercises the 3-taps-per-block weight-gradient kernel (fp16) incl. row/image borders
+                      (2, 32, 32, 64, 64, 3), (1, 64, 32, 128, 128, 3), (2, 16, 64, 64, 128, 3), (1, 32, 32, 256, 128, 3)]
     for (B, H, W, Cin, Cout, k) in cases:
         x = _rnd(gen, B, Cin, H, W)
         w = _rnd(gen, Cout, Cin, k, k, scale=1.0 / math.sqrt(Cin * k * k))
