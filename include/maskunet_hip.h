@@ -121,7 +121,7 @@ int mu_attn_fwd(const void* qkv, const void* x, const int* kidx, const int* kcnt
                 void* stream);
 /* backward: grad_out [B,N,C] (wrt `out`) -> dY (grad wrt the pre-LayerNorm sum, i.e. the residual branch),
  * dqkv [B,N,3C] (masked keys get exact zeros), dgamma, dbeta.  delta [B,N] is scratch output. */
-long mu_attn_bwd_workspace_bytes(int C);
+long mu_attn_bwd_workspace_bytes(int B, int N, int C);
 int mu_attn_bwd(const void* qkv, const void* x, const void* oattn, const void* grad_out, const int* kidx, const int* kcnt,
                 const float* lse2, const float* ln_mean, const float* ln_rstd, const float* gamma, void* dY, float* delta, void* dqkv,
                 float* dgamma, float* dbeta, int B, int N, int C, int nkmax, void* workspace, long ws_bytes, int dtype, void* stream);

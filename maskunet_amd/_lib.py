@@ -46,7 +46,7 @@ SIGNATURES = {
     "mu_dropout": (I, [P, P, L, F, c_ulonglong, P, P, I, P]),
     "mu_add": (I, [P, P, P, L, I, P]),
     "mu_attn_fwd": (I, [P, P, P, P, P, P, P, P, P, P, P, I, I, I, I, F, I, P]),
-    "mu_attn_bwd_workspace_bytes": (L, [I]),
+    "mu_attn_bwd_workspace_bytes": (L, [I, I, I]),
     "mu_attn_bwd": (I, [P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, I, I, I, I, P, L, I, P]),
 }
 

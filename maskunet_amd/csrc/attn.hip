@@ -14,6 +14,8 @@
 // from a transposing LDS read (fp16: ds_read_b64_tr_b16) or plain column reads (fp32).
 #include "common.h"
 #include "../../include/maskunet_hip.h"
+#include <stdlib.h>
+#include <type_traits>
 
 typedef __fp16 fp16x4v __attribute__((__vector_size__(4 * sizeof(__fp16))));
 #define LDS_TR16(ptr) __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) fp16x4v*)(ptr))
@@ -318,6 +320,7 @@ template <typename T, int D, int KT, int NW> struct KvStage {
             idx[n] = (i < NI && j < Nk) ? kidx_b[j] : -1;
         }
     }
+    template <bool DOK = true, bool DOV = true>
     __device__ __forceinline__ void issue(T* Kt, T* Vt, const T* qkv_b, int wave, int lane) const {
         const int lrow = lane / Z::CPR, lch = lane % Z::CPR;
 #pragma unroll
@@ -329,10 +332,10 @@ template <typename T, int D, int KT, int NW> struct KvStage {
             const T* base = qkv_b + (long)(idx[n] < 0 ? 0 : idx[n]) * 3 * D + sc * Z::VN;
             const void* ks = idx[n] < 0 ? (const void*)mu_attn_zero_page : (const void*)(base + D);
             const void* vs = idx[n] < 0 ? (const void*)mu_attn_zero_page : (const void*)(base + 2 * D);
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)ks,
-                                             (__attribute__((address_space(3))) void*)(Kt + i * Z::RPW * D), 16, 0, 0);
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)vs,
-                                             (__attribute__((address_space(3))) void*)(Vt + i * Z::RPW * D), 16, 0, 0);
+            if (DOK) __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)ks,
+                                                      (__attribute__((address_space(3))) void*)(Kt + i * Z::RPW * D), 16, 0, 0);
+            if (DOV) __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)vs,
+                                                      (__attribute__((address_space(3))) void*)(Vt + i * Z::RPW * D), 16, 0, 0);
         }
     }
 };
@@ -374,8 +377,8 @@ template <int D> struct AccLd<float, D> {
     }
 };
 
-template <typename T, int D, int KT, int NW>
-__global__ __launch_bounds__(NW * 64, (NW == 4 && D <= 64 && sizeof(T) == 2) ? 2 : 1) void attn_fwd2_kernel(const T* __restrict__ qkv, const T* __restrict__ x, const int* __restrict__ kidx,
+template <typename T, int D, int KT, int NW, int OCC = 0>
+__global__ __launch_bounds__(NW * 64, OCC ? OCC : ((NW == 4 && D <= 64 && sizeof(T) == 2) ? 2 : 1)) void attn_fwd2_kernel(const T* __restrict__ qkv, const T* __restrict__ x, const int* __restrict__ kidx,
                                                         const int* __restrict__ kcnt, const float* __restrict__ gamma,
                                                         const float* __restrict__ beta, T* __restrict__ out, T* __restrict__ oattn,
                                                         float* __restrict__ lse2, float* __restrict__ ln_mean, float* __restrict__ ln_rstd,
@@ -393,38 +396,49 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 && D <= 64 && sizeof(T) == 2) ? 2
     const int Nk = kcnt[b];
     const int* kidx_b = kidx + (long)b * nkmax;
 
+    // LDS: [buf][K|V][KT][D].  The tile loop is unrolled by two with the buffer as a compile-time constant so every
+    // LDS address is (loop-invariant per-lane base) + (immediate): no address arithmetic is left in the loop.
     KvStage<T, D, KT, NW> stg;
     stg.load_idx(kidx_b, 0, Nk, wave, lane);
     stg.issue(lds, lds + KT * D, qkv_b, wave, lane);
     stg.load_idx(kidx_b, KT, Nk, wave, lane);            // indices of tile 1, consumed inside iteration 0
 
+    // Q fragments pre-multiplied by log2(e)/sqrt(C): the score MFMA then yields exponents directly
     Frag qf[2][NKS];
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
         int qrow = q0 + t * 16 + r16;
         if (qrow > N - 1) qrow = N - 1;
 #pragma unroll
-        for (int ks = 0; ks < NKS; ++ks) qf[t][ks] = ld16<T>(qkv_b + (long)qrow * 3 * D + ks * KR + g * VN);
+        for (int ks = 0; ks < NKS; ++ks) {
+            Frag f = ld16<T>(qkv_b + (long)qrow * 3 * D + ks * KR + g * VN);
+#pragma unroll
+            for (int e = 0; e < VN; ++e) f[e] = (T)((float)f[e] * scale_log2);
+            qf[t][ks] = f;
+        }
     }
-    f32x4 o[NDT][2], lacc[2];
+    f32x4 o[NDT][2], lacc[2], negm[2];
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
         lacc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        negm[t] = (f32x4){0.f, 0.f, 0.f, 0.f};           // running max m = 0 until the first tile fixes it
 #pragma unroll
         for (int dt = 0; dt < NDT; ++dt) o[dt][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
     }
-    float m[2] = {-INFINITY, -INFINITY};
     const typename A::AccA ones = AccLd<T, D>::ones();
     __syncthreads();
 
-    int buf = 0;
-    for (int j0 = 0; j0 < Nk; j0 += KT, buf ^= 1) {
-        const T* Kt = lds + buf * 2 * KT * D;
+    // one KT-key tile out of LDS buffer BUF.  S' = K (c Q)^T - m comes straight out of the matrix core (C operand =
+    // -m broadcast), so the common case is p = exp2(S') with no per-element subtract; only when some row's maximum
+    // moves (or on the very first tile) is the correction path taken.
+    auto tile = [&](auto BUFC, int j0) {
+        constexpr int BUF = decltype(BUFC)::value;
+        const T* Kt = lds + BUF * 2 * KT * D;
         const T* Vt = Kt + KT * D;
         if (j0 + KT < Nk) {
-            T* Kn = lds + (buf ^ 1) * 2 * KT * D;
-            stg.issue(Kn, Kn + KT * D, qkv_b, wave, lane);                 // tile j+1 (indices loaded last iteration)
-            stg.load_idx(kidx_b, j0 + 2 * KT, Nk, wave, lane);            // indices of tile j+2
+            T* Kn = lds + (BUF ^ 1) * 2 * KT * D;
+            stg.issue(Kn, Kn + KT * D, qkv_b, wave, lane);
+            stg.load_idx(kidx_b, j0 + 2 * KT, Nk, wave, lane);
         }
         f32x4 s[NKT][2];
 #pragma unroll
@@ -434,7 +448,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 && D <= 64 && sizeof(T) == 2) ? 2
                 Frag a = ld16<T>(Kt + Z::off(kt * 16 + r16, ks * KR + g * VN));
 #pragma unroll
                 for (int t = 0; t < 2; ++t) {
-                    if (ks == 0) s[kt][t] = (f32x4){0.f, 0.f, 0.f, 0.f};      // folds into a zero C operand
+                    if (ks == 0) s[kt][t] = negm[t];
                     A::mma_row(a, qf[t][ks], s[kt][t]);
                 }
             }
@@ -448,25 +462,38 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 && D <= 64 && sizeof(T) == 2) ? 2
                     for (int r = 0; r < 4; ++r)
                         if (j0 + kt * 16 + 4 * g + r >= Nk) s[kt][t][r] = -INFINITY;
             }
-            float mx = s[0][t][0];
+            // max_i32 on the float bit patterns orders all non-negative floats correctly and keeps every negative one
+            // below zero -- all the fast path needs ("did any score exceed the running max?"), without the
+            // canonicalising v_max hipcc puts in front of every fmaxf of an MFMA result.  The first tile takes the
+            // exact float maximum (it may be negative).
+            float mx;
+            if (j0 == 0) {
+                mx = fmaxf(fmaxf(s[0][t][0], s[0][t][1]), fmaxf(s[0][t][2], s[0][t][3]));
 #pragma unroll
-            for (int kt = 0; kt < NKT; ++kt)
+                for (int kt = 1; kt < NKT; ++kt) mx = fmaxf(fmaxf(mx, fmaxf(s[kt][t][0], s[kt][t][1])), fmaxf(s[kt][t][2], s[kt][t][3]));
+                mx = grp_max(mx);
+            } else {
+                int mi = __float_as_int(s[0][t][0]);
 #pragma unroll
-                for (int r = 0; r < 4; ++r) mx = fmaxf(mx, s[kt][t][r]);
-            mx = grp_max(mx) * scale_log2;
-            if (!__all(mx <= m[t])) {                // some row's max moved: rescale (rare after the first tiles)
-                const float m_new = fmaxf(m[t], mx);
-                const float alpha = __builtin_amdgcn_exp2f(m[t] - m_new);
-                m[t] = m_new;
+                for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) mi = max(mi, __float_as_int(s[kt][t][r]));
+                mx = grp_max(__int_as_float(mi < 0 ? (int)0x80000000 : mi));     // -0.0 stands for "nothing above the max"
+            }
+            if (j0 == 0 || !__all(mx <= 0.f)) {      // first tile, or some row's max moved (rare afterwards)
+                const float d = (j0 == 0) ? mx : fmaxf(mx, 0.f);
+                const float alpha = __builtin_amdgcn_exp2f(-d);
+                negm[t] -= d;
                 lacc[t] *= alpha;
 #pragma unroll
                 for (int dt = 0; dt < NDT; ++dt) o[dt][t] *= alpha;
+#pragma unroll
+                for (int kt = 0; kt < NKT; ++kt) s[kt][t] -= d;
             }
-            const float nm = -m[t];
 #pragma unroll
             for (int kt = 0; kt < NKT; ++kt)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) s[kt][t][r] = __builtin_amdgcn_exp2f(fmaf(s[kt][t][r], scale_log2, nm));
+                for (int r = 0; r < 4; ++r) s[kt][t][r] = __builtin_amdgcn_exp2f(s[kt][t][r]);
         }
 #pragma unroll
         for (int h = 0; h < NH; ++h) {
@@ -480,7 +507,12 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 && D <= 64 && sizeof(T) == 2) ? 2
             }
         }
         __syncthreads();        // tile j+1 landed (vmcnt(0)) and everyone is done reading tile j
+    };
+    for (int j0 = 0; j0 < Nk; j0 += 2 * KT) {
+        tile(std::integral_constant<int, 0>{}, j0);
+        if (j0 + KT < Nk) tile(std::integral_constant<int, 1>{}, j0 + KT);
     }
+    float m[2] = {-negm[0][0], -negm[1][0]};
 
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
@@ -540,7 +572,8 @@ template <typename T, int D>
 __global__ __launch_bounds__(256) void attn_ln_bwd_kernel(const T* __restrict__ gout, const T* __restrict__ oattn, const T* __restrict__ x,
                                                           const float* __restrict__ ln_mean, const float* __restrict__ ln_rstd,
                                                           const float* __restrict__ gamma, T* __restrict__ dY, float* __restrict__ delta,
-                                                          double* __restrict__ part, long rows) {
+                                                          double* __restrict__ part, long rows, const float* __restrict__ lse2,
+                                                          float* __restrict__ rowc, int N, float scale) {
     constexpr int VN = AT<T>::VN, LPR = D / VN, RPI = 256 / LPR;     // lanes per row, rows per block-iteration
     const int tid = threadIdx.x;
     const int lc = tid % LPR, lr = tid / LPR;
@@ -580,7 +613,16 @@ __global__ __launch_bounds__(256) void attn_ln_bwd_kernel(const T* __restrict__ 
         for (int o = 1; o < LPR; o <<= 1) dl += __shfl_xor(dl, o);
         if (ok) {
             dv.store(dY + r * D + c);
-            if (lc == 0) delta[r] = dl;
+            if (lc == 0) {
+                delta[r] = dl;
+                // row constants for the dK/dV sweep, grouped per 32-query tile: [b][tile][{-lse2, -delta/sqrt(C)}][32]
+                const long bb = r / N;
+                const int qn = (int)(r - bb * N);
+                const int ntile = (N + 31) >> 5;
+                float* rc = rowc + ((bb * ntile + (qn >> 5)) * 2) * 32 + (qn & 31);
+                rc[0] = -lse2[r];
+                rc[32] = -dl * scale;
+            }
         }
     }
     // column partials: reduce the RPI row-lanes of this block through LDS
@@ -846,8 +888,10 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 && D <= 64 && sizeof(T) == 2) ? 2
     stg.issue(lds, lds + KT * D, qkv_b, wave, lane);
     stg.load_idx(kidx_b, KT, Nk, wave, lane);            // indices of tile 1, consumed inside iteration 0
 
+    // Q pre-scaled by log2(e)/sqrt(C) and dO by 1/sqrt(C): with the row constants -lse2 and -delta/sqrt(C) as the
+    // MFMA C operands, the matrix core hands back the exponent of P and the scaled (dP - delta) directly.
     Frag qf[2][NKS], dof[2][NKS];
-    float nlse[2], del_q[2];
+    f32x4 nlse[2], ndel[2];
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
         int qrow = q0 + t * 16 + r16;
@@ -855,11 +899,16 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 && D <= 64 && sizeof(T) == 2) ? 2
         const long tok = (long)b * N + qrow;
 #pragma unroll
         for (int ks = 0; ks < NKS; ++ks) {
-            qf[t][ks] = ld16<T>(qkv_b + (long)qrow * 3 * D + ks * KR + g * VN);
-            dof[t][ks] = ld16<T>(dY + tok * D + ks * KR + g * VN);
+            Frag fq = ld16<T>(qkv_b + (long)qrow * 3 * D + ks * KR + g * VN);
+            Frag fo = ld16<T>(dY + tok * D + ks * KR + g * VN);
+#pragma unroll
+            for (int e = 0; e < VN; ++e) { fq[e] = (T)((float)fq[e] * scale_log2); fo[e] = (T)((float)fo[e] * scale); }
+            qf[t][ks] = fq;
+            dof[t][ks] = fo;
         }
-        nlse[t] = -lse2[tok];
-        del_q[t] = delta[tok];
+        const float l = -lse2[tok], d = -delta[tok] * scale;
+        nlse[t] = (f32x4){l, l, l, l};
+        ndel[t] = (f32x4){d, d, d, d};
     }
     f32x4 dq[NDT][2];
 #pragma unroll
@@ -868,20 +917,16 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 && D <= 64 && sizeof(T) == 2) ? 2
         for (int t = 0; t < 2; ++t) dq[dt][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
     __syncthreads();
 
-    int buf = 0;
-    for (int j0 = 0; j0 < Nk; j0 += KT, buf ^= 1) {
-        const T* Kt = lds + buf * 2 * KT * D;
+    auto tile = [&](auto BUFC, int j0) {
+        constexpr int BUF = decltype(BUFC)::value;
+        const T* Kt = lds + BUF * 2 * KT * D;
         const T* Vt = Kt + KT * D;
         if (j0 + KT < Nk) {
-            T* Kn = lds + (buf ^ 1) * 2 * KT * D;
-            stg.issue(Kn, Kn + KT * D, qkv_b, wave, lane);                 // tile j+1 (indices loaded last iteration)
-            stg.load_idx(kidx_b, j0 + 2 * KT, Nk, wave, lane);            // indices of tile j+2
+            T* Kn = lds + (BUF ^ 1) * 2 * KT * D;
+            stg.issue(Kn, Kn + KT * D, qkv_b, wave, lane);
+            stg.load_idx(kidx_b, j0 + 2 * KT, Nk, wave, lane);
         }
         f32x4 s[NKT][2], dp[NKT][2];
-#pragma unroll
-        for (int kt = 0; kt < NKT; ++kt)
-#pragma unroll
-            for (int t = 0; t < 2; ++t) { s[kt][t] = (f32x4){0.f, 0.f, 0.f, 0.f}; dp[kt][t] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
 #pragma unroll
         for (int ks = 0; ks < NKS; ++ks)
 #pragma unroll
@@ -890,6 +935,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 && D <= 64 && sizeof(T) == 2) ? 2
                 Frag va = ld16<T>(Vt + Z::off(kt * 16 + r16, ks * KR + g * VN));
 #pragma unroll
                 for (int t = 0; t < 2; ++t) {
+                    if (ks == 0) { s[kt][t] = nlse[t]; dp[kt][t] = ndel[t]; }
                     A::mma_row(ka, qf[t][ks], s[kt][t]);
                     A::mma_row(va, dof[t][ks], dp[kt][t]);
                 }
@@ -901,9 +947,9 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 && D <= 64 && sizeof(T) == 2) ? 2
             for (int kt = 0; kt < NKT; ++kt)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    float p = __builtin_amdgcn_exp2f(fmaf(s[kt][t][r], scale_log2, nlse[t]));
+                    float p = __builtin_amdgcn_exp2f(s[kt][t][r]);
                     if (partial && j0 + kt * 16 + 4 * g + r >= Nk) p = 0.f;
-                    s[kt][t][r] = p * (dp[kt][t][r] - del_q[t]) * scale;
+                    s[kt][t][r] = p * dp[kt][t][r];
                 }
 #pragma unroll
         for (int h = 0; h < NH; ++h)
@@ -914,6 +960,10 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 && D <= 64 && sizeof(T) == 2) ? 2
                 for (int t = 0; t < 2; ++t) A::mma_acc(ka, s[2 * h][t], s[2 * h + 1][t], dq[dt][t]);
             }
         __syncthreads();
+    };
+    for (int j0 = 0; j0 < Nk; j0 += 2 * KT) {
+        tile(std::integral_constant<int, 0>{}, j0);
+        if (j0 + KT < Nk) tile(std::integral_constant<int, 1>{}, j0 + KT);
     }
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
@@ -975,6 +1025,8 @@ __global__ __launch_bounds__(256, (D <= 64 && sizeof(T) == 2) ? 2 : 1) void attn
 
     stage_qo_dma<T, D, QT>(lds, lds + QT * D, qkv_b, dY_b, 0, N, wave, lane);
 
+    // this wave's keys live in registers: K pre-scaled by log2(e)/sqrt(C) (S comes out as the exponent of P once
+    // -lse2 is the C operand) and V by 1/sqrt(C) (dP comes out as (dP - delta)/sqrt(C) with -delta/sqrt(C) as C)
     Frag kf[NKT][NKS], vf[NKT][NKS];
     int keyrow[NKT];
 #pragma unroll
@@ -983,13 +1035,15 @@ __global__ __launch_bounds__(256, (D <= 64 && sizeof(T) == 2) ? 2 : 1) void attn
         keyrow[kt] = j < Nk ? kidx_b[j] : -1;
 #pragma unroll
         for (int ks = 0; ks < NKS; ++ks) {
+            Frag fk = zero_frag<T>(), fv = zero_frag<T>();
             if (keyrow[kt] >= 0) {
-                kf[kt][ks] = ld16<T>(qkv_b + (long)keyrow[kt] * 3 * D + D + ks * KR + g * VN);
-                vf[kt][ks] = ld16<T>(qkv_b + (long)keyrow[kt] * 3 * D + 2 * D + ks * KR + g * VN);
-            } else {
-                kf[kt][ks] = zero_frag<T>();
-                vf[kt][ks] = zero_frag<T>();
+                fk = ld16<T>(qkv_b + (long)keyrow[kt] * 3 * D + D + ks * KR + g * VN);
+                fv = ld16<T>(qkv_b + (long)keyrow[kt] * 3 * D + 2 * D + ks * KR + g * VN);
+#pragma unroll
+                for (int e = 0; e < VN; ++e) { fk[e] = (T)((float)fk[e] * scale_log2); fv[e] = (T)((float)fv[e] * scale); }
             }
+            kf[kt][ks] = fk;
+            vf[kt][ks] = fv;
         }
     }
     f32x4 dk[NDT][NKT], dv[NDT][NKT];
@@ -998,35 +1052,33 @@ __global__ __launch_bounds__(256, (D <= 64 && sizeof(T) == 2) ? 2 : 1) void attn
 #pragma unroll
         for (int kt = 0; kt < NKT; ++kt) { dk[dt][kt] = (f32x4){0.f, 0.f, 0.f, 0.f}; dv[dt][kt] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
 
-    // per-lane row constants of the current tile: queries qt*16 + 4g + r  (N is a multiple of 4 here: H*W)
-    auto load_rows = [&](int q0, float4 (&ls)[2], float4 (&de)[2]) {
+    // per-lane row constants of a tile: queries qt*16 + 4g + r  (N % 4 == 0)
+    auto load_rows = [&](int q0, f32x4 (&ls)[2], f32x4 (&de)[2]) {
 #pragma unroll
         for (int qt = 0; qt < 2; ++qt) {
             int q = q0 + qt * 16 + 4 * g;
             if (q > N - 4) q = N - 4;
-            ls[qt] = *reinterpret_cast<const float4*>(lse_b + q);
-            de[qt] = *reinterpret_cast<const float4*>(del_b + q);
+            const float4 a = *reinterpret_cast<const float4*>(lse_b + q);
+            const float4 d = *reinterpret_cast<const float4*>(del_b + q);
+            ls[qt] = (f32x4){-a.x, -a.y, -a.z, -a.w};
+            de[qt] = (f32x4){-d.x * scale, -d.y * scale, -d.z * scale, -d.w * scale};
         }
     };
-    float4 ls_c[2], de_c[2], ls_n[2], de_n[2];
+    f32x4 ls_c[2], de_c[2], ls_n[2], de_n[2];
     load_rows(0, ls_c, de_c);
     __syncthreads();
 
-    int buf = 0;
-    for (int q0 = 0; q0 < N; q0 += QT, buf ^= 1) {
-        const T* Qt = lds + buf * 2 * QT * D;
+    auto tile = [&](auto BUFC, int q0) {
+        constexpr int BUF = decltype(BUFC)::value;
+        const T* Qt = lds + BUF * 2 * QT * D;
         const T* Ot = Qt + QT * D;
         const bool more = q0 + QT < N;
         if (more) {
             load_rows(q0 + QT, ls_n, de_n);           // issued BEFORE the DMA so their wait does not drain it
-            T* Qn = lds + (buf ^ 1) * 2 * QT * D;
+            T* Qn = lds + (BUF ^ 1) * 2 * QT * D;
             stage_qo_dma<T, D, QT>(Qn, Qn + QT * D, qkv_b, dY_b, q0 + QT, N, wave, lane);
         }
         f32x4 s[2][NKT], dp[2][NKT];
-#pragma unroll
-        for (int qt = 0; qt < 2; ++qt)
-#pragma unroll
-            for (int kt = 0; kt < NKT; ++kt) { s[qt][kt] = (f32x4){0.f, 0.f, 0.f, 0.f}; dp[qt][kt] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
 #pragma unroll
         for (int ks = 0; ks < NKS; ++ks)
 #pragma unroll
@@ -1035,27 +1087,25 @@ __global__ __launch_bounds__(256, (D <= 64 && sizeof(T) == 2) ? 2 : 1) void attn
                 Frag oa = ld16<T>(Ot + Z::off(qt * 16 + r16, ks * KR + g * VN));
 #pragma unroll
                 for (int kt = 0; kt < NKT; ++kt) {
+                    if (ks == 0) { s[qt][kt] = ls_c[qt]; dp[qt][kt] = de_c[qt]; }
                     A::mma_row(qa, kf[kt][ks], s[qt][kt]);
                     A::mma_row(oa, vf[kt][ks], dp[qt][kt]);
                 }
             }
         const bool partial = q0 + QT > N;
 #pragma unroll
-        for (int qt = 0; qt < 2; ++qt) {
-            const float lsv[4] = {ls_c[qt].x, ls_c[qt].y, ls_c[qt].z, ls_c[qt].w};
-            const float dev[4] = {de_c[qt].x, de_c[qt].y, de_c[qt].z, de_c[qt].w};
+        for (int qt = 0; qt < 2; ++qt)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const bool dead = partial && (q0 + qt * 16 + 4 * g + r >= N);
 #pragma unroll
                 for (int kt = 0; kt < NKT; ++kt) {
-                    float p = __builtin_amdgcn_exp2f(fmaf(s[qt][kt][r], scale_log2, -lsv[r]));
+                    float p = __builtin_amdgcn_exp2f(s[qt][kt][r]);
                     if (dead) p = 0.f;
                     s[qt][kt][r] = p;
-                    dp[qt][kt][r] = p * (dp[qt][kt][r] - dev[r]) * scale;
+                    dp[qt][kt][r] *= p;
                 }
             }
-        }
 #pragma unroll
         for (int dt = 0; dt < NDT; ++dt) {
             typename A::AccA oa = AccLd<T, D>::ld(Ot, 0, dt * 16, g, r16);
@@ -1071,6 +1121,193 @@ __global__ __launch_bounds__(256, (D <= 64 && sizeof(T) == 2) ? 2 : 1) void attn
             for (int qt = 0; qt < 2; ++qt) { ls_c[qt] = ls_n[qt]; de_c[qt] = de_n[qt]; }
         }
         __syncthreads();
+    };
+    for (int q0 = 0; q0 < N; q0 += 2 * QT) {
+        tile(std::integral_constant<int, 0>{}, q0);
+        if (q0 + QT < N) tile(std::integral_constant<int, 1>{}, q0 + QT);
+    }
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt) {
+        if (keyrow[kt] < 0) continue;
+        T* dst = dqkv + ((long)b * N + keyrow[kt]) * 3 * D;
+#pragma unroll
+        for (int dt = 0; dt < NDT; ++dt) {
+            float kv[4] = {dk[dt][kt][0], dk[dt][kt][1], dk[dt][kt][2], dk[dt][kt][3]};
+            float vv[4] = {dv[dt][kt][0], dv[dt][kt][1], dv[dt][kt][2], dv[dt][kt][3]};
+            store4<T>(dst + D + dt * 16 + 4 * g, kv);
+            store4<T>(dst + 2 * D + dt * 16 + 4 * g, vv);
+        }
+    }
+}
+
+
+// ------------------------------------------------------------------------------------------
+// dK/dV v3: the query sweep is a 4-deep LDS ring fed by LDS-DMA three tiles ahead with COUNTED vmcnt waits and one
+// raw s_barrier per tile.  With one-tile-ahead double buffering (v2) every barrier waited for a DMA issued only
+// ~0.7 us earlier -- shorter than the L2/HBM round trip -- so the matrix cores idled at each tile.  Every
+// vector-memory op in the loop is an LDS-DMA (the row constants -lse2 and -delta/sqrt(C) come in through the same
+// ring), so the counted waits are exact: each wave issues exactly 3 DMA instructions per tile.
+// ------------------------------------------------------------------------------------------
+template <typename T, int D, int NKT>
+__global__ __launch_bounds__(256, (D <= 64 && sizeof(T) == 2) ? 2 : 1) void attn_bwd_dkv3_kernel(
+    const T* __restrict__ qkv, const T* __restrict__ dY, const int* __restrict__ kidx, const int* __restrict__ kcnt,
+    const float* __restrict__ rowc, T* __restrict__ dqkv, int N, int nkmax, float scale, float scale_log2) {
+    using A = AT<T>;
+    using Frag = typename A::Frag;
+    using Z = SwzTile<T, D>;
+    constexpr int VN = A::VN, KR = A::KR, NKS = D / KR, NDT = D / 16, QT = 32;
+    constexpr int NI = QT / Z::RPW;                          // DMA wave-instructions per tensor per tile
+    static_assert(NI == 4 || NI == 8 || NI == 16 || NI == 32 || NI == 2, "unexpected tile geometry");
+    constexpr int NPW = (NI + 3) / 4;                        // per wave (Q and dO each)
+    constexpr int STG = 2 * QT * D;                          // elements per ring slot (Q | dO)
+    constexpr int DKV_RING = (STG * (int)sizeof(T) <= 32768) ? 4 : 2;      // ring depth; prefetch distance = depth - 1
+    __shared__ __attribute__((aligned(16))) T lds[DKV_RING * STG];
+    __shared__ __attribute__((aligned(16))) float rcs[DKV_RING * 256 + 256];   // 1 KB per slot: [{-lse2},{-delta*scale}][32] in its first 256 B; + 1 KB dump
+
+    const int b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r16 = lane & 15, g = lane >> 4;
+    const int Nk = kcnt[b];
+    const int kb0 = blockIdx.x * (4 * NKT * 16);
+    if (kb0 >= Nk) return;
+    const int* kidx_b = kidx + (long)b * nkmax;
+    const T* qkv_b = qkv + (long)b * N * 3 * D;
+    const T* dY_b = dY + (long)b * N * D;
+    const int ntile = (N + QT - 1) / QT;
+    const float* rowc_b = rowc + (long)b * ntile * 64;
+
+    // exactly 2*NPW + 1 DMA instructions per wave per tile
+    auto issue = [&](int tile) {
+        const int slot = tile % DKV_RING;
+        T* Qt = lds + slot * STG;
+        T* Ot = Qt + QT * D;
+        const int lrow = lane / Z::CPR, lch = lane % Z::CPR;
+#pragma unroll
+        for (int n = 0; n < NPW; ++n) {
+            const int i = wave + 4 * n;
+            const int ii = i < NI ? i : 0;                   // (NI >= 4 for every instantiation: never clamps)
+            const int row = ii * Z::RPW + lrow;
+            const int q = tile * QT + row;
+            const int sc = lch ^ (row & Z::SW);
+            const void *qs = mu_attn_zero_page, *os = mu_attn_zero_page;
+            if (q < N) {
+                qs = qkv_b + (long)q * 3 * D + sc * Z::VN;
+                os = dY_b + (long)q * D + sc * Z::VN;
+            }
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)qs,
+                                             (__attribute__((address_space(3))) void*)(Qt + ii * Z::RPW * D), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)os,
+                                             (__attribute__((address_space(3))) void*)(Ot + ii * Z::RPW * D), 16, 0, 0);
+        }
+        // row constants: 16 lanes x 16 B = the tile's 64 floats.  Every wave issues one DMA so that all waves count the same
+        // number of vector-memory ops: wave 0's lanes >= 16 pad the rest of the slot, waves 1-3 write zeros to a dump area
+        const void* rs = (wave == 0 && lane < 16) ? (const void*)(rowc_b + (long)tile * 64 + lane * 4) : (const void*)mu_attn_zero_page;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)rs,
+                                         (__attribute__((address_space(3))) void*)(rcs + (wave == 0 ? slot * 256 : DKV_RING * 256)), 16, 0, 0);
+    };
+    constexpr int OPS = 2 * NPW + 1;
+
+    issue(0);
+    if (DKV_RING == 4) {
+        if (ntile > 1) issue(1);
+        if (ntile > 2) issue(2);
+    }
+
+    Frag kf[NKT][NKS], vf[NKT][NKS];
+    int keyrow[NKT];
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt) {
+        const int j = kb0 + (wave * NKT + kt) * 16 + r16;
+        keyrow[kt] = j < Nk ? kidx_b[j] : -1;
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks) {
+            Frag fk = zero_frag<T>(), fv = zero_frag<T>();
+            if (keyrow[kt] >= 0) {
+                fk = ld16<T>(qkv_b + (long)keyrow[kt] * 3 * D + D + ks * KR + g * VN);
+                fv = ld16<T>(qkv_b + (long)keyrow[kt] * 3 * D + 2 * D + ks * KR + g * VN);
+#pragma unroll
+                for (int e = 0; e < VN; ++e) { fk[e] = (T)((float)fk[e] * scale_log2); fv[e] = (T)((float)fv[e] * scale); }
+            }
+            kf[kt][ks] = fk;
+            vf[kt][ks] = fv;
+        }
+    }
+    f32x4 dk[NDT][NKT], dv[NDT][NKT];
+#pragma unroll
+    for (int dt = 0; dt < NDT; ++dt)
+#pragma unroll
+        for (int kt = 0; kt < NKT; ++kt) { dk[dt][kt] = (f32x4){0.f, 0.f, 0.f, 0.f}; dv[dt][kt] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+    // the prologue's ordinary loads (kidx, K, V) are complete here: the frags were consumed by the scaling above
+
+    auto tile = [&](auto SLOTC, int tl) {
+        constexpr int SLOT = decltype(SLOTC)::value;
+        // tile tl's DMAs were issued RING-1 issue-groups ago; newer groups still in flight: min(RING-2, tiles left after tl)
+        const int newer = ntile - 1 - tl;
+        if (DKV_RING == 4 && newer >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * OPS) : "memory");
+        else if (DKV_RING == 4 && newer == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(OPS) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                        // everyone's share of tile tl landed; tile tl-1 fully consumed
+        if (tl + DKV_RING - 1 < ntile) issue(tl + DKV_RING - 1);   // into the slot tile tl-1 just vacated
+        const T* Qt = lds + SLOT * STG;
+        const T* Ot = Qt + QT * D;
+        const float* rc = rcs + SLOT * 256;
+        f32x4 s[2][NKT], dp[2][NKT];
+#pragma unroll
+        for (int qt = 0; qt < 2; ++qt) {
+            const f32x4 nl = *reinterpret_cast<const f32x4*>(rc + qt * 16 + 4 * g);
+            const f32x4 nd = *reinterpret_cast<const f32x4*>(rc + 32 + qt * 16 + 4 * g);
+#pragma unroll
+            for (int kt = 0; kt < NKT; ++kt) { s[qt][kt] = nl; dp[qt][kt] = nd; }
+        }
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks)
+#pragma unroll
+            for (int qt = 0; qt < 2; ++qt) {
+                Frag qa = ld16<T>(Qt + Z::off(qt * 16 + r16, ks * KR + g * VN));
+                Frag oa = ld16<T>(Ot + Z::off(qt * 16 + r16, ks * KR + g * VN));
+#pragma unroll
+                for (int kt = 0; kt < NKT; ++kt) {
+                    A::mma_row(qa, kf[kt][ks], s[qt][kt]);
+                    A::mma_row(oa, vf[kt][ks], dp[qt][kt]);
+                }
+            }
+        if (tl * QT + QT > N) {                              // last, partial tile: padded queries contribute nothing
+#pragma unroll
+            for (int qt = 0; qt < 2; ++qt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (tl * QT + qt * 16 + 4 * g + r >= N) {
+#pragma unroll
+                        for (int kt = 0; kt < NKT; ++kt) { s[qt][kt][r] = -INFINITY; dp[qt][kt][r] = 0.f; }
+                    }
+        }
+#pragma unroll
+        for (int qt = 0; qt < 2; ++qt)
+#pragma unroll
+            for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float p = __builtin_amdgcn_exp2f(s[qt][kt][r]);
+                    s[qt][kt][r] = p;
+                    dp[qt][kt][r] *= p;
+                }
+#pragma unroll
+        for (int dt = 0; dt < NDT; ++dt) {
+            typename A::AccA oa = AccLd<T, D>::ld(Ot, 0, dt * 16, g, r16);
+            typename A::AccA qa = AccLd<T, D>::ld(Qt, 0, dt * 16, g, r16);
+#pragma unroll
+            for (int kt = 0; kt < NKT; ++kt) {
+                A::mma_acc(oa, s[0][kt], s[1][kt], dv[dt][kt]);
+                A::mma_acc(qa, dp[0][kt], dp[1][kt], dk[dt][kt]);
+            }
+        }
+    };
+    for (int tl = 0; tl < ntile; tl += DKV_RING) {
+        tile(std::integral_constant<int, 0>{}, tl);
+        if (tl + 1 < ntile) tile(std::integral_constant<int, 1>{}, tl + 1);
+        if constexpr (DKV_RING == 4) {
+            if (tl + 2 < ntile) tile(std::integral_constant<int, 2>{}, tl + 2);
+            if (tl + 3 < ntile) tile(std::integral_constant<int, 3>{}, tl + 3);
+        }
     }
 #pragma unroll
     for (int kt = 0; kt < NKT; ++kt) {
@@ -1098,6 +1335,15 @@ static int attn_fwd_t(const T* qkv, const T* x, const int* kidx, const int* kcnt
 #define LAUNCH_FWD(DD, KT)                                                                                                          \
     if (big) attn_fwd2_kernel<T, DD, KT, 8><<<dim3(mu_cdiv(N, 256), B), 512, 0, st>>>(qkv, x, kidx, kcnt, gamma, beta, out, oattn, lse2, mean, rstd, N, nkmax, sl2, eps); \
     else attn_fwd2_kernel<T, DD, KT, 4><<<dim3(mu_cdiv(N, 128), B), 256, 0, st>>>(qkv, x, kidx, kcnt, gamma, beta, out, oattn, lse2, mean, rstd, N, nkmax, sl2, eps)
+    if (C == 64 && sizeof(T) == 2 && getenv("MU_ATTN_VARIANT")) {       // tuning experiments (debug only)
+        const int v = atoi(getenv("MU_ATTN_VARIANT"));
+        dim3 g4(mu_cdiv(N, 128), B);
+        if (v == 1) { attn_fwd2_kernel<T, 64, 128, 4><<<g4, 256, 0, st>>>(qkv, x, kidx, kcnt, gamma, beta, out, oattn, lse2, mean, rstd, N, nkmax, sl2, eps); return MU_OK; }
+        if (v == 2) { attn_fwd2_kernel<T, 64, 32, 4><<<g4, 256, 0, st>>>(qkv, x, kidx, kcnt, gamma, beta, out, oattn, lse2, mean, rstd, N, nkmax, sl2, eps); return MU_OK; }
+        if (v == 3) { attn_fwd2_kernel<T, 64, 64, 4, 3><<<g4, 256, 0, st>>>(qkv, x, kidx, kcnt, gamma, beta, out, oattn, lse2, mean, rstd, N, nkmax, sl2, eps); return MU_OK; }
+        if (v == 4) { attn_fwd2_kernel<T, 64, 32, 4, 3><<<g4, 256, 0, st>>>(qkv, x, kidx, kcnt, gamma, beta, out, oattn, lse2, mean, rstd, N, nkmax, sl2, eps); return MU_OK; }
+        if (v == 5) { attn_fwd2_kernel<T, 64, 64, 4, 1><<<g4, 256, 0, st>>>(qkv, x, kidx, kcnt, gamma, beta, out, oattn, lse2, mean, rstd, N, nkmax, sl2, eps); return MU_OK; }
+    }
     switch (C) {
         case 32: LAUNCH_FWD(32, 64); break;
         case 64: LAUNCH_FWD(64, 64); break;
@@ -1125,25 +1371,29 @@ extern "C" int mu_attn_fwd(const void* qkv, const void* x, const int* kidx, cons
 }
 
 #define ATT_LN_MAXBLK 1024
-extern "C" long mu_attn_bwd_workspace_bytes(int C) { return (long)ATT_LN_MAXBLK * C * 2 * sizeof(double); }
+static inline long attn_ln_part_bytes(int C) { return (long)ATT_LN_MAXBLK * C * 2 * sizeof(double); }
+extern "C" long mu_attn_bwd_workspace_bytes(int B, int N, int C) {
+    return attn_ln_part_bytes(C) + (long)B * ((N + 31) / 32) * 64 * sizeof(float);
+}
 
 template <typename T>
 static int attn_bwd_t(const T* qkv, const T* x, const T* oattn, const T* gout, const int* kidx, const int* kcnt, const float* lse2,
                       const float* mean, const float* rstd, const float* gamma, T* dY, float* delta, T* dqkv, float* dgamma,
                       float* dbeta, int B, int N, int C, int nkmax, void* ws, hipStream_t st) {
     const long rows = (long)B * N;
+    float* rowc = (float*)((char*)ws + attn_ln_part_bytes(C));
     int nblk = (int)(rows / 64 < 1 ? 1 : (rows / 64 > ATT_LN_MAXBLK ? ATT_LN_MAXBLK : rows / 64));
     const float scale = (float)(1.0 / sqrt((double)C));
     const float sl2 = (float)(1.4426950408889634 / sqrt((double)C));
     dim3 gq(mu_cdiv(N, 128), B);
     if (hipMemsetAsync(dqkv, 0, (size_t)rows * 3 * C * sizeof(T), st) != hipSuccess) return MU_ERR_LAUNCH;
 #define LAUNCH_BWD(DD, NKT)                                                                                                     \
-    attn_ln_bwd_kernel<T, DD><<<nblk, 256, 0, st>>>(gout, oattn, x, mean, rstd, gamma, dY, delta, (double*)ws, rows);           \
+    attn_ln_bwd_kernel<T, DD><<<nblk, 256, 0, st>>>(gout, oattn, x, mean, rstd, gamma, dY, delta, (double*)ws, rows, lse2, rowc, N, scale); \
     attn_ln_bwd_final_kernel<<<mu_cdiv(DD, 4), 256, 0, st>>>((const double*)ws, nblk, DD, dgamma, dbeta);                       \
     if (false) attn_bwd_dq2_kernel<T, DD, KTQ, 8><<<dim3(mu_cdiv(N, 256), B), 512, 0, st>>>(qkv, dY, kidx, kcnt, lse2, delta, dqkv, N, nkmax, scale, sl2); \
     else attn_bwd_dq2_kernel<T, DD, KTQ, 4><<<gq, 256, 0, st>>>(qkv, dY, kidx, kcnt, lse2, delta, dqkv, N, nkmax, scale, sl2);  \
-    attn_bwd_dkv2_kernel<T, DD, NKT><<<dim3(mu_cdiv(nkmax, 64 * NKT), B), 256, 0, st>>>(qkv, dY, kidx, kcnt, lse2, delta, dqkv, N, \
-                                                                                       nkmax, scale, sl2)
+    attn_bwd_dkv3_kernel<T, DD, NKT><<<dim3(mu_cdiv(nkmax, 64 * NKT), B), 256, 0, st>>>(qkv, dY, kidx, kcnt, rowc, dqkv, N, nkmax, \
+                                                                                       scale, sl2)
     if (N % 4) return MU_ERR_SHAPE;
     switch (C) {
         case 32: { constexpr int KTQ = 64; LAUNCH_BWD(32, 2); } break;
@@ -1164,7 +1414,7 @@ extern "C" int mu_attn_bwd(const void* qkv, const void* x, const void* oattn, co
         !dgamma || !dbeta || !workspace)
         return MU_ERR_ARG;
     if (B <= 0 || N <= 0 || nkmax <= 0) return MU_ERR_ARG;
-    if (ws_bytes < mu_attn_bwd_workspace_bytes(C)) return MU_ERR_WORKSPACE;
+    if (ws_bytes < mu_attn_bwd_workspace_bytes(B, N, C)) return MU_ERR_WORKSPACE;
     hipStream_t st = (hipStream_t)stream;
     int rc;
     if (dtype == MU_F16)

@@ -413,7 +413,7 @@ class _MaskAttention(torch.autograd.Function):
         delta = torch.empty((B, N), dtype=torch.float32, device=x.device)
         dg = torch.empty(C, dtype=torch.float32, device=x.device)
         db = torch.empty_like(dg)
-        ws = workspace(_lib.load().mu_attn_bwd_workspace_bytes(C), x.device)
+        ws = workspace(_lib.load().mu_attn_bwd_workspace_bytes(B, N, C), x.device)
         call("mu_attn_bwd", ptr(qkv), ptr(x), ptr(oattn), ptr(gout), ptr(kidx), ptr(kcnt), ptr(lse2), ptr(mean), ptr(rstd), ptr(g),
              ptr(dY), ptr(delta), ptr(dqkv), ptr(dg), ptr(db), B, N, C, kidx.shape[1], ptr(ws), ws.numel(), dt(x), stream())
         dqkv4 = dqkv.view(B, H, W, 3 * C)

@@ -22,7 +22,7 @@ def main():
     dY = torch.empty_like(x); dqkv = torch.empty_like(qkv); delta = torch.empty_like(lse)
     dg = torch.empty(C, device=dev); db = torch.empty(C, device=dev)
     gout = torch.randn_like(x)
-    ws = _lib.workspace(_lib.load().mu_attn_bwd_workspace_bytes(C), torch.device(dev))
+    ws = _lib.workspace(_lib.load().mu_attn_bwd_workspace_bytes(B, N, C), torch.device(dev))
     st = _lib.stream()
     def fwd():
         _lib.call("mu_attn_fwd", qkv.data_ptr(), x.data_ptr(), kidx.data_ptr(), kcnt.data_ptr(), g.data_ptr(), b_.data_ptr(), out.data_ptr(), oattn.data_ptr(), lse.data_ptr(), mean.data_ptr(), rstd.data_ptr(), B, N, C, N, 1e-5, _lib.dt(x), st)

@@ -41,7 +41,7 @@ def test_workspace_queries_are_host_only():
     lib = _lib.load()
     assert lib.mu_bn_workspace_bytes(64) > 0
     assert lib.mu_conv_wgrad_workspace_bytes(2, 16, 16, 64, 64, 9) >= 9 * 64 * 64 * 4
-    assert lib.mu_attn_bwd_workspace_bytes(64) > 0
+    assert lib.mu_attn_bwd_workspace_bytes(2, 256, 64) > 0
     assert lib.mu_ln_sample_workspace_bytes(4) > 0
     assert lib.mu_colsum_workspace_bytes(64) > 0
 
