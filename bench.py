@@ -91,9 +91,15 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    ndev = torch.cuda.device_count()
+    backend = os.environ.get("MU_DIST_BACKEND", "nccl")      # "gloo" lets two ranks share one GPU in a debug run
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend)
+            local = local % max(ndev, 1)
     assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
@@ -124,9 +130,10 @@ def main():
 
     for _ in range(args.warmup):
         step()
-    # HIP-event probe on the dominant kernel group: the attention block at N = hw*hw (self_attention6)
+    # HIP-event probe on the dominant kernel: the dK/dV sweep (attn_bwd_dkv3_kernel) of self_attention6, N = hw*hw.
+    # mu_attn_bwd_phases(..., B, N, C, nkmax, ws, ws_bytes, dtype, phases, stream): args[16] = N, args[22] = phases
     N6 = args.hw * args.hw
-    _lib.PROBE = {"names": ("mu_attn_fwd", "mu_attn_bwd"), "match_int": N6, "events": []}
+    _lib.PROBE = {"pred": lambda name, a: name == "mu_attn_bwd_phases" and a[16] == N6 and a[22] == 4, "events": []}
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -149,15 +156,17 @@ def main():
     if rank == 0:
         imgs = args.batch * world * args.steps
         C6 = 64
-        flops_fwd = 4.0 * N6 * N6 * C6 * args.batch            # algorithmic QK^T + PV of the full N x N block
-        dur = {"mu_attn_fwd": [], "mu_attn_bwd": []}
-        for name, e0, e1 in probe["events"]:
-            dur[name].append(e0.elapsed_time(e1) * 1e-3)
-        tf = sum(dur["mu_attn_fwd"]) / max(len(dur["mu_attn_fwd"]), 1)
-        tb = sum(dur["mu_attn_bwd"]) / max(len(dur["mu_attn_bwd"]), 1)
-        # forward + backward (2.5x forward FLOPs: 5 products vs 2) of the same block, one launch group each
-        achieved = (flops_fwd + 2.5 * flops_fwd) / max(tf + tb, 1e-12) / 1e12
+        # algorithmic FLOPs of one launch: the four N x N x C products of the dK/dV sweep (S, dP, dV, dK) over the FULL
+        # key set, 4 * 2*N*N*C per image; the kernel executes ~half (masked keys are skipped)
+        flops = 8.0 * N6 * N6 * C6 * args.batch
+        durs = [e0.elapsed_time(e1) * 1e-3 for _, e0, e1 in probe["events"]]
+        tk = sum(durs) / max(len(durs), 1)
+        achieved = flops / max(tk, 1e-12) / 1e12
         peak = PEAK_MFMA_TFLOPS[args.dtype]
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "r01_dkv_traffic.json")      # PMC FETCH_SIZE/WRITE_SIZE pass (see file)
+        if os.path.exists(tpath) and args.batch == 64 and args.dtype == "fp16":
+            traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
         rec = {
             "metric": "128x128 images/sec (fwd+bwd)", "value": round(imgs / elapsed, 3), "unit": "images/sec",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 3),
@@ -167,10 +176,10 @@ def main():
                                    f"{'3-head' if args.three_head else '1-head'} MaskAttn-UNet fwd+bwd, train mode",
                        "global_batch": args.batch * world, "parallelism": f"dp{world}", "loss_scale": scale},
             "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
-                         "frac": round(achieved / peak, 4), "traffic": None,
-                         "kernel": "self_attention6 block (N=16384,C=64): attn_fwd + attn_bwd launch groups",
-                         "ms_fwd": round(tf * 1e3, 3), "ms_bwd": round(tb * 1e3, 3),
-                         "note": "algorithmic FLOPs of the full N x N block; kernels skip masked keys (~50%)"},
+                         "frac": round(achieved / peak, 4), "traffic": traffic,
+                         "kernel": f"attn_bwd_dkv3_kernel (self_attention6 dK/dV sweep, N={N6}, C=64)",
+                         "ms_per_launch": round(tk * 1e3, 3), "launches_timed": len(durs),
+                         "note": "algorithmic FLOPs = 8*N*N*C per image over the full key set; the kernel skips masked keys (~50%)"},
         }
         if world == 1 and not args.no_cpu_baseline:
             rec["cpu_baseline"] = cpu_baseline(args.c_out, args.hw)

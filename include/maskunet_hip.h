@@ -125,6 +125,12 @@ long mu_attn_bwd_workspace_bytes(int B, int N, int C);
 int mu_attn_bwd(const void* qkv, const void* x, const void* oattn, const void* grad_out, const int* kidx, const int* kcnt,
                 const float* lse2, const float* ln_mean, const float* ln_rstd, const float* gamma, void* dY, float* delta, void* dqkv,
                 float* dgamma, float* dbeta, int B, int N, int C, int nkmax, void* workspace, long ws_bytes, int dtype, void* stream);
+/* the same, one phase group at a time (bit mask): 1 = zero dqkv + LayerNorm backward / delta / dgamma,dbeta,
+ * 2 = dQ sweep, 4 = dK/dV sweep.  Phases 2 and 4 need phase 1's dY, delta and workspace contents. */
+int mu_attn_bwd_phases(const void* qkv, const void* x, const void* oattn, const void* grad_out, const int* kidx, const int* kcnt,
+                       const float* lse2, const float* ln_mean, const float* ln_rstd, const float* gamma, void* dY, float* delta,
+                       void* dqkv, float* dgamma, float* dbeta, int B, int N, int C, int nkmax, void* workspace, long ws_bytes,
+                       int dtype, int phases, void* stream);
 
 #ifdef __cplusplus
 }

@@ -48,6 +48,7 @@ SIGNATURES = {
     "mu_attn_fwd": (I, [P, P, P, P, P, P, P, P, P, P, P, I, I, I, I, F, I, P]),
     "mu_attn_bwd_workspace_bytes": (L, [I, I, I]),
     "mu_attn_bwd": (I, [P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, I, I, I, I, P, L, I, P]),
+    "mu_attn_bwd_phases": (I, [P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, I, I, I, I, P, L, I, I, P]),
 }
 
 _lib = None
@@ -93,7 +94,7 @@ def stream():
     return torch.cuda.current_stream().cuda_stream
 
 
-# optional HIP-event probe (bench.py): {"names": (...), "match_int": int, "events": []} brackets the matching
+# optional HIP-event probe (bench.py): {"pred": f(name, args) -> bool, "events": []} brackets the matching
 # entry points with events on the launch stream; None = off (no overhead).
 PROBE = None
 
@@ -101,7 +102,7 @@ PROBE = None
 def call(name: str, *args):
     """Invoke an int-returning entry point and raise on a non-zero status."""
     probe = PROBE
-    if probe is not None and name in probe["names"] and probe["match_int"] in args:
+    if probe is not None and probe["pred"](name, args):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         rc = getattr(load(), name)(*args)

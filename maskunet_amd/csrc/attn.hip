@@ -1379,21 +1379,21 @@ extern "C" long mu_attn_bwd_workspace_bytes(int B, int N, int C) {
 template <typename T>
 static int attn_bwd_t(const T* qkv, const T* x, const T* oattn, const T* gout, const int* kidx, const int* kcnt, const float* lse2,
                       const float* mean, const float* rstd, const float* gamma, T* dY, float* delta, T* dqkv, float* dgamma,
-                      float* dbeta, int B, int N, int C, int nkmax, void* ws, hipStream_t st) {
+                      float* dbeta, int B, int N, int C, int nkmax, void* ws, hipStream_t st, int phases) {
     const long rows = (long)B * N;
     float* rowc = (float*)((char*)ws + attn_ln_part_bytes(C));
     int nblk = (int)(rows / 64 < 1 ? 1 : (rows / 64 > ATT_LN_MAXBLK ? ATT_LN_MAXBLK : rows / 64));
     const float scale = (float)(1.0 / sqrt((double)C));
     const float sl2 = (float)(1.4426950408889634 / sqrt((double)C));
     dim3 gq(mu_cdiv(N, 128), B);
-    if (hipMemsetAsync(dqkv, 0, (size_t)rows * 3 * C * sizeof(T), st) != hipSuccess) return MU_ERR_LAUNCH;
+    if ((phases & 1) && hipMemsetAsync(dqkv, 0, (size_t)rows * 3 * C * sizeof(T), st) != hipSuccess) return MU_ERR_LAUNCH;
 #define LAUNCH_BWD(DD, NKT)                                                                                                     \
-    attn_ln_bwd_kernel<T, DD><<<nblk, 256, 0, st>>>(gout, oattn, x, mean, rstd, gamma, dY, delta, (double*)ws, rows, lse2, rowc, N, scale); \
-    attn_ln_bwd_final_kernel<<<mu_cdiv(DD, 4), 256, 0, st>>>((const double*)ws, nblk, DD, dgamma, dbeta);                       \
-    if (false) attn_bwd_dq2_kernel<T, DD, KTQ, 8><<<dim3(mu_cdiv(N, 256), B), 512, 0, st>>>(qkv, dY, kidx, kcnt, lse2, delta, dqkv, N, nkmax, scale, sl2); \
-    else attn_bwd_dq2_kernel<T, DD, KTQ, 4><<<gq, 256, 0, st>>>(qkv, dY, kidx, kcnt, lse2, delta, dqkv, N, nkmax, scale, sl2);  \
-    attn_bwd_dkv3_kernel<T, DD, NKT><<<dim3(mu_cdiv(nkmax, 64 * NKT), B), 256, 0, st>>>(qkv, dY, kidx, kcnt, rowc, dqkv, N, nkmax, \
-                                                                                       scale, sl2)
+    if (phases & 1) {                                                                                                           \
+        attn_ln_bwd_kernel<T, DD><<<nblk, 256, 0, st>>>(gout, oattn, x, mean, rstd, gamma, dY, delta, (double*)ws, rows, lse2, rowc, N, scale); \
+        attn_ln_bwd_final_kernel<<<mu_cdiv(DD, 4), 256, 0, st>>>((const double*)ws, nblk, DD, dgamma, dbeta);                   \
+    }                                                                                                                           \
+    if (phases & 2) attn_bwd_dq2_kernel<T, DD, KTQ, 4><<<gq, 256, 0, st>>>(qkv, dY, kidx, kcnt, lse2, delta, dqkv, N, nkmax, scale, sl2); \
+    if (phases & 4) attn_bwd_dkv3_kernel<T, DD, NKT><<<dim3(mu_cdiv(nkmax, 64 * NKT), B), 256, 0, st>>>(qkv, dY, kidx, kcnt, rowc, dqkv, N, nkmax, scale, sl2)
     if (N % 4) return MU_ERR_SHAPE;
     switch (C) {
         case 32: { constexpr int KTQ = 64; LAUNCH_BWD(32, 2); } break;
@@ -1406,10 +1406,10 @@ static int attn_bwd_t(const T* qkv, const T* x, const T* oattn, const T* gout, c
     return MU_OK;
 }
 
-extern "C" int mu_attn_bwd(const void* qkv, const void* x, const void* oattn, const void* grad_out, const int* kidx, const int* kcnt,
+extern "C" int mu_attn_bwd_phases(const void* qkv, const void* x, const void* oattn, const void* grad_out, const int* kidx, const int* kcnt,
                            const float* lse2, const float* ln_mean, const float* ln_rstd, const float* gamma, void* dY, float* delta,
                            void* dqkv, float* dgamma, float* dbeta, int B, int N, int C, int nkmax, void* workspace, long ws_bytes,
-                           int dtype, void* stream) {
+                           int dtype, int phases, void* stream) {
     if (!qkv || !x || !oattn || !grad_out || !kidx || !kcnt || !lse2 || !ln_mean || !ln_rstd || !gamma || !dY || !delta || !dqkv ||
         !dgamma || !dbeta || !workspace)
         return MU_ERR_ARG;
@@ -1418,11 +1418,19 @@ extern "C" int mu_attn_bwd(const void* qkv, const void* x, const void* oattn, co
     hipStream_t st = (hipStream_t)stream;
     int rc;
     if (dtype == MU_F16)
-        rc = attn_bwd_t<h16>((const h16*)qkv, (const h16*)x, (const h16*)oattn, (const h16*)grad_out, kidx, kcnt, lse2, ln_mean, ln_rstd, gamma, (h16*)dY, delta, (h16*)dqkv, dgamma, dbeta, B, N, C, nkmax, workspace, st);
+        rc = attn_bwd_t<h16>((const h16*)qkv, (const h16*)x, (const h16*)oattn, (const h16*)grad_out, kidx, kcnt, lse2, ln_mean, ln_rstd, gamma, (h16*)dY, delta, (h16*)dqkv, dgamma, dbeta, B, N, C, nkmax, workspace, st, phases);
     else if (dtype == MU_F32)
-        rc = attn_bwd_t<float>((const float*)qkv, (const float*)x, (const float*)oattn, (const float*)grad_out, kidx, kcnt, lse2, ln_mean, ln_rstd, gamma, (float*)dY, delta, (float*)dqkv, dgamma, dbeta, B, N, C, nkmax, workspace, st);
+        rc = attn_bwd_t<float>((const float*)qkv, (const float*)x, (const float*)oattn, (const float*)grad_out, kidx, kcnt, lse2, ln_mean, ln_rstd, gamma, (float*)dY, delta, (float*)dqkv, dgamma, dbeta, B, N, C, nkmax, workspace, st, phases);
     else return MU_ERR_ARG;
     if (rc) return rc;
     MU_CHECK_LAUNCH();
     return MU_OK;
+}
+
+extern "C" int mu_attn_bwd(const void* qkv, const void* x, const void* oattn, const void* grad_out, const int* kidx, const int* kcnt,
+                           const float* lse2, const float* ln_mean, const float* ln_rstd, const float* gamma, void* dY, float* delta,
+                           void* dqkv, float* dgamma, float* dbeta, int B, int N, int C, int nkmax, void* workspace, long ws_bytes,
+                           int dtype, void* stream) {
+    return mu_attn_bwd_phases(qkv, x, oattn, grad_out, kidx, kcnt, lse2, ln_mean, ln_rstd, gamma, dY, delta, dqkv, dgamma, dbeta, B, N, C,
+                              nkmax, workspace, ws_bytes, dtype, 7, stream);
 }

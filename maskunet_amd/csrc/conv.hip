@@ -809,7 +809,8 @@ static inline void wgrad_tile(int Cin, int Cout, int* bco, int* bci) {
 static inline bool wgrad3_ok(int W, int taps, int bt, int dtype) { return dtype == MU_F16 && taps == 9 && W % 32 == 0 && (bt == 128 || bt == 64); }
 static inline void wgrad3_plan(long M, int Cin, int Cout, int bt, int* nsplit, long* pps) {
     long tiles = 3L * (Cout / bt) * (Cin / bt);
-    long want = 1024 / tiles;                 // one 256-thread block per CU (192 accumulator registers), ~4 waves of blocks
+    long want = 512 / tiles;                  // one 256-thread block per CU (192 accumulator registers): ~2 rounds of blocks;
+                                              // fewer, longer splits also halve the fp32 slab traffic of the reduce
     if (want < 1) want = 1;
     long max_split = (M + 511) / 512;
     if (want > max_split) want = max_split;
