@@ -377,7 +377,7 @@ template <int D> struct AccLd<float, D> {
     }
 };
 
-template <typename T, int D, int KT, int NW, int OCC = 0>
+template <typename T, int D, int KT, int NW, int OCC = 0, int NQ = 2>
 __global__ __launch_bounds__(NW * 64, OCC ? OCC : ((NW == 4 && D <= 64 && sizeof(T) == 2) ? 2 : 1)) void attn_fwd2_kernel(const T* __restrict__ qkv, const T* __restrict__ x, const int* __restrict__ kidx,
                                                         const int* __restrict__ kcnt, const float* __restrict__ gamma,
                                                         const float* __restrict__ beta, T* __restrict__ out, T* __restrict__ oattn,
@@ -391,7 +391,7 @@ __global__ __launch_bounds__(NW * 64, OCC ? OCC : ((NW == 4 && D <= 64 && sizeof
 
     const int b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r16 = lane & 15, g = lane >> 4;
-    const int q0 = blockIdx.x * (NW * 32) + wave * 32;
+    const int q0 = blockIdx.x * (NW * NQ * 16) + wave * (NQ * 16);     // NQ 16-query tiles per wave
     const T* qkv_b = qkv + (long)b * N * 3 * D;
     const int Nk = kcnt[b];
     const int* kidx_b = kidx + (long)b * nkmax;
@@ -404,9 +404,9 @@ __global__ __launch_bounds__(NW * 64, OCC ? OCC : ((NW == 4 && D <= 64 && sizeof
     stg.load_idx(kidx_b, KT, Nk, wave, lane);            // indices of tile 1, consumed inside iteration 0
 
     // Q fragments pre-multiplied by log2(e)/sqrt(C): the score MFMA then yields exponents directly
-    Frag qf[2][NKS];
+    Frag qf[NQ][NKS];
 #pragma unroll
-    for (int t = 0; t < 2; ++t) {
+    for (int t = 0; t < NQ; ++t) {
         int qrow = q0 + t * 16 + r16;
         if (qrow > N - 1) qrow = N - 1;
 #pragma unroll
@@ -417,9 +417,9 @@ __global__ __launch_bounds__(NW * 64, OCC ? OCC : ((NW == 4 && D <= 64 && sizeof
             qf[t][ks] = f;
         }
     }
-    f32x4 o[NDT][2], lacc[2], negm[2];
+    f32x4 o[NDT][NQ], lacc[NQ], negm[NQ];
 #pragma unroll
-    for (int t = 0; t < 2; ++t) {
+    for (int t = 0; t < NQ; ++t) {
         lacc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
         negm[t] = (f32x4){0.f, 0.f, 0.f, 0.f};           // running max m = 0 until the first tile fixes it
 #pragma unroll
@@ -440,21 +440,21 @@ __global__ __launch_bounds__(NW * 64, OCC ? OCC : ((NW == 4 && D <= 64 && sizeof
             stg.issue(Kn, Kn + KT * D, qkv_b, wave, lane);
             stg.load_idx(kidx_b, j0 + 2 * KT, Nk, wave, lane);
         }
-        f32x4 s[NKT][2];
+        f32x4 s[NKT][NQ];
 #pragma unroll
         for (int ks = 0; ks < NKS; ++ks)
 #pragma unroll
             for (int kt = 0; kt < NKT; ++kt) {
                 Frag a = ld16<T>(Kt + Z::off(kt * 16 + r16, ks * KR + g * VN));
 #pragma unroll
-                for (int t = 0; t < 2; ++t) {
+                for (int t = 0; t < NQ; ++t) {
                     if (ks == 0) s[kt][t] = negm[t];
                     A::mma_row(a, qf[t][ks], s[kt][t]);
                 }
             }
         const bool partial = j0 + KT > Nk;          // wave-uniform
 #pragma unroll
-        for (int t = 0; t < 2; ++t) {
+        for (int t = 0; t < NQ; ++t) {
             if (partial) {
 #pragma unroll
                 for (int kt = 0; kt < NKT; ++kt)
@@ -498,12 +498,12 @@ __global__ __launch_bounds__(NW * 64, OCC ? OCC : ((NW == 4 && D <= 64 && sizeof
 #pragma unroll
         for (int h = 0; h < NH; ++h) {
 #pragma unroll
-            for (int t = 0; t < 2; ++t) A::mma_acc(ones, s[2 * h][t], s[2 * h + 1][t], lacc[t]);
+            for (int t = 0; t < NQ; ++t) A::mma_acc(ones, s[2 * h][t], s[2 * h + 1][t], lacc[t]);
 #pragma unroll
             for (int dt = 0; dt < NDT; ++dt) {
                 typename A::AccA va = AccLd<T, D>::ld(Vt, 32 * h, dt * 16, g, r16);
 #pragma unroll
-                for (int t = 0; t < 2; ++t) A::mma_acc(va, s[2 * h][t], s[2 * h + 1][t], o[dt][t]);
+                for (int t = 0; t < NQ; ++t) A::mma_acc(va, s[2 * h][t], s[2 * h + 1][t], o[dt][t]);
             }
         }
         __syncthreads();        // tile j+1 landed (vmcnt(0)) and everyone is done reading tile j
@@ -512,10 +512,12 @@ __global__ __launch_bounds__(NW * 64, OCC ? OCC : ((NW == 4 && D <= 64 && sizeof
         tile(std::integral_constant<int, 0>{}, j0);
         if (j0 + KT < Nk) tile(std::integral_constant<int, 1>{}, j0 + KT);
     }
-    float m[2] = {-negm[0][0], -negm[1][0]};
+    float m[NQ];
+#pragma unroll
+    for (int t = 0; t < NQ; ++t) m[t] = -negm[t][0];
 
 #pragma unroll
-    for (int t = 0; t < 2; ++t) {
+    for (int t = 0; t < NQ; ++t) {
         const float ltot = lacc[t][0];           // every row of the ones-product holds the same column sum
         const float inv = 1.0f / ltot;
         const int qrow = q0 + t * 16 + r16;
@@ -1332,6 +1334,13 @@ static int attn_fwd_t(const T* qkv, const T* x, const int* kidx, const int* kcnt
     const float sl2 = (float)(1.4426950408889634 / sqrt((double)C));
     // 8 waves (256 queries) per block share each K/V tile when the image has enough queries: halves the L2->LDS traffic
     const bool big = false;   // measured: 8-wave blocks are 8% SLOWER (the per-tile barrier over 8 waves costs more than the saved L2 traffic)
+    if (C == 64 && sizeof(T) == 2 && N >= 1024 && getenv("MU_FWD_NQ4")) {
+        // experiment kept for reference: 64 queries per wave (4 tiles) against 32-key tiles halves the K/V bytes per query through
+        // L2->LDS and LDS->VGPR at the same MFMA count, yet measures 4% SLOWER (3.06 vs 2.95 ms at N=16384): the forward is not
+        // bound by tile traffic
+        attn_fwd2_kernel<T, 64, 32, 4, 2, 4><<<dim3(mu_cdiv(N, 256), B), 256, 0, st>>>(qkv, x, kidx, kcnt, gamma, beta, out, oattn, lse2, mean, rstd, N, nkmax, sl2, eps);
+        return MU_OK;
+    }
 #define LAUNCH_FWD(DD, KT)                                                                                                          \
     if (big) attn_fwd2_kernel<T, DD, KT, 8><<<dim3(mu_cdiv(N, 256), B), 512, 0, st>>>(qkv, x, kidx, kcnt, gamma, beta, out, oattn, lse2, mean, rstd, N, nkmax, sl2, eps); \
     else attn_fwd2_kernel<T, DD, KT, 4><<<dim3(mu_cdiv(N, 128), B), 256, 0, st>>>(qkv, x, kidx, kcnt, gamma, beta, out, oattn, lse2, mean, rstd, N, nkmax, sl2, eps)
