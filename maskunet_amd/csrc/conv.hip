@@ -7,6 +7,7 @@
 // MFMA shapes: fp16 storage -> v_mfma_f32_16x16x32_f16, fp32 storage -> v_mfma_f32_16x16x4_f32
 // (exact fp32 FMA chain).  Both consume the same LDS image: rows of 64 bytes along K.
 #include "common.h"
+#include <stdlib.h>
 #include "../../include/maskunet_hip.h"
 
 template <typename T> struct Mma;
@@ -319,19 +320,20 @@ __global__ __launch_bounds__(256) void conv_nt2_kernel(const T* __restrict__ x, 
 // activation L2->LDS traffic 9x (v2 is pinned at the ~10 TB/s L2->LDS ceiling on the Cin<=256 layers).
 // The next chunk's halo is streamed in 1/6 pieces behind the first six tap steps.
 // ------------------------------------------------------------------------------------------
-template <typename T, int TM, int TN, int WR>
-__global__ __launch_bounds__(256, 2) void conv_nt3_kernel(const T* __restrict__ x, const T* __restrict__ w, const float* __restrict__ bias,
+template <typename T, int TM, int TN, int WR, int NWV = 4>
+__global__ __launch_bounds__(NWV * 64, NWV == 4 ? 2 : 1) void conv_nt3_kernel(const T* __restrict__ x, const T* __restrict__ w, const float* __restrict__ bias,
                                                        T* __restrict__ y, int B, int H, int W, int Cin, int Cout, long x_ld, long y_ld) {
     using M_ = Mma<T>;
     using Frag = typename M_::Frag;
     constexpr int VN = M_::VN, KC = 8 * VN;
-    constexpr int WC = 4 / WR;
+    constexpr int WC = NWV / WR;
     constexpr int BCO = WR * TM * 16;
     constexpr int TH = WC * TN, TW = 16, HW_ = TW + 2;      // spatial tile TH x 16, halo row width 18
     constexpr int HROWS = (TH + 2) * HW_;
     constexpr int HINST = (HROWS + 7) / 8;                  // 8 halo rows (128 B each) per wave DMA instruction
     constexpr int HPER = (HINST + 5) / 6;                   // instructions per piece (6 pieces), spread over 4 waves
-    constexpr int PA = BCO / 32;
+    constexpr int PA = BCO / (8 * NWV);
+    static_assert(BCO % (8 * NWV) == 0, "weight tile rows must split over the waves");
     constexpr int HBYTES = HINST * 1024, WBYTES = BCO * 128;
 
     __shared__ __attribute__((aligned(16))) char lds[2 * HBYTES + 2 * WBYTES];
@@ -359,9 +361,9 @@ __global__ __launch_bounds__(256, 2) void conv_nt3_kernel(const T* __restrict__ 
         char* Wb = Ws + buf * WBYTES;
 #pragma unroll
         for (int i = 0; i < PA; ++i) {
-            const int row = (i * 4 + wave) * 8 + srow;
+            const int row = (i * NWV + wave) * 8 + srow;
             const int sc = sch ^ (row & 7);
-            glds16(w + ((long)tap * Cout + co0 + row) * Cin + ci0 + sc * VN, Wb + (i * 4 + wave) * 1024);
+            glds16(w + ((long)tap * Cout + co0 + row) * Cin + ci0 + sc * VN, Wb + (i * NWV + wave) * 1024);
         }
     };
     auto stage_h = [&](int inst, int ci0, int buf) {        // one wave instruction = halo rows 8*inst .. 8*inst+7
@@ -381,7 +383,7 @@ __global__ __launch_bounds__(256, 2) void conv_nt3_kernel(const T* __restrict__ 
         for (int j = 0; j < TN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
     stage_w(0, 0);
-    for (int inst = wave; inst < HINST; inst += 4) stage_h(inst, 0, 0);
+    for (int inst = wave; inst < HINST; inst += NWV) stage_h(inst, 0, 0);
     __syncthreads();
 
     int s = 0;
@@ -392,9 +394,9 @@ __global__ __launch_bounds__(256, 2) void conv_nt3_kernel(const T* __restrict__ 
             if (s + 1 < nsteps) stage_w(s + 1, (s + 1) & 1);
             if (t < 6 && c + 1 < kchunks) {
 #pragma unroll
-                for (int k = 0; k < (HPER + 3) / 4; ++k) {
-                    const int inst = t * HPER + k * 4 + wave;
-                    if (k * 4 + wave < HPER && inst < HINST) stage_h(inst, (c + 1) * KC, (c + 1) & 1);
+                for (int k = 0; k < (HPER + NWV - 1) / NWV; ++k) {
+                    const int inst = t * HPER + k * NWV + wave;
+                    if (k * NWV + wave < HPER && inst < HINST) stage_h(inst, (c + 1) * KC, (c + 1) & 1);
                 }
             }
             const char* Wb = Ws + (s & 1) * WBYTES;
@@ -446,6 +448,12 @@ static int conv_fwd_launch(const T* x, const T* w, const float* bias, T* y, int 
     const long M = (long)B * H * W;
     const int npb = (int)((M + 127) / 128);
     if (TAPS == 9 && (Cin * (int)sizeof(T)) % 128 == 0 && W % 16 == 0) {     // halo-tile version
+        if (Cout % 128 == 0 && H % 16 == 0 && (long)B * H * W >= 262144 && getenv("MU_CONV_NW8")) {
+            // experiment kept for reference: 16x16 spatial tile, 8 waves -- the weight tile is shared by 256 pixels (half the
+            // L2->LDS bytes per flop) yet the step time is unchanged (45.39 vs 45.29 ms): v3 is no longer L2->LDS bound
+            conv_nt3_kernel<T, 4, 4, 2, 8><<<B * (H / 16) * (W / 16) * (Cout / 128), 512, 0, st>>>(x, w, bias, y, B, H, W, Cin, Cout, x_ld, y_ld);
+            return MU_OK;
+        }
         if (Cout % 128 == 0 && H % 8 == 0) {
             conv_nt3_kernel<T, 4, 4, 2><<<B * (H / 8) * (W / 16) * (Cout / 128), 256, 0, st>>>(x, w, bias, y, B, H, W, Cin, Cout, x_ld, y_ld);
             return MU_OK;
@@ -809,8 +817,9 @@ static inline void wgrad_tile(int Cin, int Cout, int* bco, int* bci) {
 static inline bool wgrad3_ok(int W, int taps, int bt, int dtype) { return dtype == MU_F16 && taps == 9 && W % 32 == 0 && (bt == 128 || bt == 64); }
 static inline void wgrad3_plan(long M, int Cin, int Cout, int bt, int* nsplit, long* pps) {
     long tiles = 3L * (Cout / bt) * (Cin / bt);
-    long want = 512 / tiles;                  // one 256-thread block per CU (192 accumulator registers): ~2 rounds of blocks;
-                                              // fewer, longer splits also halve the fp32 slab traffic of the reduce
+    // 128-wide tiles: one block per CU (192 accumulator registers) -> ~2 rounds of blocks; fewer, longer splits also halve
+    // the fp32 slab traffic of the reduce.  64-wide tiles run 5 waves/SIMD and want more blocks in flight.
+    long want = (bt == 128 ? 512 : 1536) / tiles;
     if (want < 1) want = 1;
     long max_split = (M + 511) / 512;
     if (want > max_split) want = max_split;
