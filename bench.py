@@ -86,6 +86,9 @@ def main():
     ap.add_argument("--loss-scale", type=float, default=1024.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--three-head", action="store_true")
+    ap.add_argument("--fused-loss", action="store_true",
+                    help="SURVEY 8-f1 path: fused NHWC cross-entropy on the internal logits instead of module output + torch CE")
+    ap.add_argument("--optimizer", action="store_true", help="also run the fused AdamW step (8-f2) inside the timed step")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -116,15 +119,25 @@ def main():
     net = maskunet_amd.DataParallel(model) if world > 1 else model
     scale = args.loss_scale if dtype == torch.float16 else 1.0
 
+    opt = maskunet_amd.FusedAdamW(model.parameters(), lr=5e-5, weight_decay=1e-1) if args.optimizer else None
+
     def step():
-        out = net(x)
-        sem = out[0] if args.three_head else out
-        loss = F.cross_entropy(sem, labels)
-        if args.three_head:
-            loss = loss + 0.5 * out[2].square().mean()
-        (loss * scale).backward()
+        if args.fused_loss and not args.three_head:
+            if world > 1:
+                net._arm()
+            loss = maskunet_amd.pixel_cross_entropy_nhwc(model.logits_nhwc(x), labels, args.c_out, grad_scale=scale)
+            loss.backward()
+        else:
+            out = net(x)
+            sem = out[0] if args.three_head else out
+            loss = F.cross_entropy(sem, labels)
+            if args.three_head:
+                loss = loss + 0.5 * out[2].square().mean()
+            (loss * scale).backward()
         if world > 1:
             net.finish_gradient_sync()
+        if opt is not None:
+            opt.step(grad_scale=scale)
         model.zero_grad(set_to_none=True)
         return loss
 
@@ -174,7 +187,8 @@ def main():
             "data": "synthetic",
             "config": {"workload": f"ADE20K-semantic shape {args.hw}x{args.hw}, c_out={args.c_out}, batch={args.batch}/GPU, "
                                    f"{'3-head' if args.three_head else '1-head'} MaskAttn-UNet fwd+bwd, train mode",
-                       "global_batch": args.batch * world, "parallelism": f"dp{world}", "loss_scale": scale},
+                       "global_batch": args.batch * world, "parallelism": f"dp{world}", "loss_scale": scale,
+                       "loss": "fused NHWC CE kernel" if args.fused_loss else "torch CE on module output", "optimizer_in_step": bool(opt)},
             "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
                          "frac": round(achieved / peak, 4), "traffic": traffic,
                          "kernel": f"attn_bwd_dkv3_kernel (self_attention6 dK/dV sweep, N={N6}, C=64)",

@@ -132,6 +132,27 @@ int mu_attn_bwd_phases(const void* qkv, const void* x, const void* oattn, const 
                        void* dqkv, float* dgamma, float* dbeta, int B, int N, int C, int nkmax, void* workspace, long ws_bytes,
                        int dtype, int phases, void* stream);
 
+/* ---- "next" rows: the steps either side of the path ------------------------------ */
+/* f1: nn.CrossEntropyLoss (ade_semantic.py:377,399; ignore_index: city_semantic.py:341) on NHWC logits [M, Cp] (C valid
+ * channels): mean loss over counted pixels -> loss[0], count[0]; lse[M] is saved for the backward. */
+long mu_ce_workspace_bytes(void);
+int mu_ce_fwd(const void* logits, const long* labels, long M, int Cp, int C, long ignore_index, float* lse, float* loss, float* count,
+              void* workspace, long ws_bytes, int dtype, void* stream);
+/* dlogits = (softmax - onehot) * grad_out[0] * grad_scale / count[0]; zeros for ignored pixels and padded channels */
+int mu_ce_bwd(const void* logits, const long* labels, const float* lse, const float* count, const float* grad_out, float grad_scale,
+              long M, int Cp, int C, long ignore_index, void* dlogits, int dtype, void* stream);
+/* f3: mean_iou (ade_semantic.py:128-146) without host syncs.  Element (pixel r, class c) is read at
+ * logits[(r / inner) * outer_stride + c * c_stride + (r % inner) * p_stride]; counts is scratch [3*C] uint32; out[0] = mean IoU. */
+int mu_mean_iou(const void* logits, const long* labels, long M, int C, long inner, long outer_stride, long c_stride, long p_stride,
+                float smooth, unsigned int* counts, float* out, int dtype, void* stream);
+/* f2: optim.AdamW step (ade_semantic.py:379,401) for every parameter in one launch.  table: device array of
+ * {float* p; const float* g; float* m; float* v; long n; float bc1; float bc2_sqrt;} (48 bytes; g may be NULL; bc1 = 1-beta1^t,
+ * bc2_sqrt = sqrt(1-beta2^t) for that tensor's own step count t); block_tensor/block_chunk: per-block (tensor index, chunk
+ * index) with chunks of mu_adamw_chunk() elements.  grad_scale_inv un-scales loss-scaled gradients. */
+int mu_adamw_chunk(void);
+int mu_adamw_multi(const void* table, const int* block_tensor, const int* block_chunk, int nblocks, float lr, float beta1, float beta2,
+                   float eps, float weight_decay, float grad_scale_inv, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -48,6 +48,12 @@ SIGNATURES = {
     "mu_attn_fwd": (I, [P, P, P, P, P, P, P, P, P, P, P, I, I, I, I, F, I, P]),
     "mu_attn_bwd_workspace_bytes": (L, [I, I, I]),
     "mu_attn_bwd": (I, [P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, I, I, I, I, P, L, I, P]),
+    "mu_ce_workspace_bytes": (L, []),
+    "mu_ce_fwd": (I, [P, P, L, I, I, L, P, P, P, P, L, I, P]),
+    "mu_ce_bwd": (I, [P, P, P, P, P, F, L, I, I, L, P, I, P]),
+    "mu_mean_iou": (I, [P, P, L, I, L, L, L, L, F, P, P, I, P]),
+    "mu_adamw_chunk": (I, []),
+    "mu_adamw_multi": (I, [P, P, P, I, F, F, F, F, F, F, P]),
     "mu_attn_bwd_phases": (I, [P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, I, I, I, I, P, L, I, I, P]),
 }
 

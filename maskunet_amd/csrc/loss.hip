@@ -1,0 +1,233 @@
+// "Next" rows of the scope table: the steps either side of the forward/backward path.
+//   f1  fused pixel-wise softmax cross-entropy on the NHWC (channel-padded) logits, forward + dlogits
+//       (nn.CrossEntropyLoss, ade_semantic.py:377,399; ignore_index=255 in city_semantic.py:341)
+//   f3  on-device mean IoU (mean_iou, ade_semantic.py:128-146): arg-max + per-class intersection / union counts,
+//       no host round trips (the reference syncs once per class, :139)
+#include "common.h"
+
+// ------------------------------------------------------------------------------------------
+// cross-entropy.  16 lanes cooperate on one pixel row (channels strided by 16*VN), 16 rows per block-iteration.
+// forward: lse[row], per-block partial (sum of losses, number of counted rows) in fp64 -> finalize -> mean loss.
+// backward: dlogits = (softmax - onehot) * gscale / count  (0 for ignored rows and for the channel padding).
+// ------------------------------------------------------------------------------------------
+#define CE_MAXBLK 1024
+
+template <typename T>
+__global__ __launch_bounds__(256) void ce_fwd_kernel(const T* __restrict__ logits, const long* __restrict__ labels, long M, int Cp,
+                                                     int C, long ignore_index, float* __restrict__ lse_out, double* __restrict__ part) {
+    constexpr int VN = Vec16<T>::N;
+    const int tid = threadIdx.x, l16 = tid & 15, rowl = tid >> 4;
+    double loss = 0.0, cnt = 0.0;
+    for (long r0 = (long)blockIdx.x * 16; r0 < M; r0 += (long)gridDim.x * 16) {
+        const long r = r0 + rowl;
+        const bool ok = r < M;
+        const long rr = ok ? r : M - 1;
+        const long lab = labels[rr];
+        float mx = -INFINITY;
+        for (int c = l16 * VN; c < Cp; c += 16 * VN) {
+            Vec16<T> v;
+            v.load(logits + rr * Cp + c);
+#pragma unroll
+            for (int i = 0; i < VN; ++i) if (c + i < C) mx = fmaxf(mx, v.get(i));
+        }
+#pragma unroll
+        for (int o = 1; o < 16; o <<= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+        float se = 0.f, tgt = 0.f;
+        for (int c = l16 * VN; c < Cp; c += 16 * VN) {
+            Vec16<T> v;
+            v.load(logits + rr * Cp + c);
+#pragma unroll
+            for (int i = 0; i < VN; ++i) {
+                if (c + i < C) {
+                    se += __expf(v.get(i) - mx);
+                    if (c + i == lab) tgt = v.get(i);
+                }
+            }
+        }
+#pragma unroll
+        for (int o = 1; o < 16; o <<= 1) { se += __shfl_xor(se, o); tgt += __shfl_xor(tgt, o); }
+        const float lse = mx + __logf(se);
+        if (ok && l16 == 0) {
+            lse_out[r] = lse;
+            if (lab != ignore_index) { loss += (double)(lse - tgt); cnt += 1.0; }
+        }
+    }
+    __shared__ double sh[32];
+    loss = wave_sum_d(loss);
+    cnt = wave_sum_d(cnt);
+    if ((tid & 63) == 0) { sh[(tid >> 6) * 2] = loss; sh[(tid >> 6) * 2 + 1] = cnt; }
+    __syncthreads();
+    if (tid == 0) {
+        part[blockIdx.x * 2] = sh[0] + sh[2] + sh[4] + sh[6];
+        part[blockIdx.x * 2 + 1] = sh[1] + sh[3] + sh[5] + sh[7];
+    }
+}
+
+__global__ void ce_final_kernel(const double* __restrict__ part, int nblk, float* __restrict__ loss, float* __restrict__ count) {
+    double a = 0.0, c = 0.0;
+    for (int i = threadIdx.x; i < nblk; i += 64) { a += part[i * 2]; c += part[i * 2 + 1]; }
+    a = wave_sum_d(a);
+    c = wave_sum_d(c);
+    if (threadIdx.x == 0) {
+        loss[0] = (float)(a / c);          // 0/0 = NaN when every pixel is ignored, as torch
+        count[0] = (float)c;
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void ce_bwd_kernel(const T* __restrict__ logits, const long* __restrict__ labels, const float* __restrict__ lse,
+                                                     const float* __restrict__ count, const float* __restrict__ gout, float gscale,
+                                                     long M, int Cp, int C, long ignore_index, T* __restrict__ dlogits) {
+    constexpr int VN = Vec16<T>::N;
+    const int cv = Cp / VN;
+    const long total = M * cv;
+    const float k = gout[0] * gscale / count[0];
+    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+        const long r = idx / cv;
+        const int c = (int)(idx % cv) * VN;
+        const long lab = labels[r];
+        Vec16<T> v, o;
+        v.load(logits + r * Cp + c);
+        const float l = lse[r];
+#pragma unroll
+        for (int i = 0; i < VN; ++i) {
+            float g = 0.f;
+            if (lab != ignore_index && c + i < C) g = (__expf(v.get(i) - l) - (c + i == lab ? 1.f : 0.f)) * k;
+            o.set(i, g);
+        }
+        o.store(dlogits + r * Cp + c);
+    }
+}
+
+extern "C" long mu_ce_workspace_bytes(void) { return (long)CE_MAXBLK * 2 * sizeof(double); }
+
+extern "C" int mu_ce_fwd(const void* logits, const long* labels, long M, int Cp, int C, long ignore_index, float* lse, float* loss,
+                         float* count, void* workspace, long ws_bytes, int dtype, void* stream) {
+    if (!logits || !labels || !lse || !loss || !count || !workspace || M <= 0 || C <= 0 || Cp < C || Cp % 8) return MU_ERR_ARG;
+    if (ws_bytes < mu_ce_workspace_bytes()) return MU_ERR_WORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    int nblk = (int)((M + 15) / 16 < CE_MAXBLK ? (M + 15) / 16 : CE_MAXBLK);
+    if (dtype == MU_F16) ce_fwd_kernel<h16><<<nblk, 256, 0, st>>>((const h16*)logits, labels, M, Cp, C, ignore_index, lse, (double*)workspace);
+    else if (dtype == MU_F32) ce_fwd_kernel<float><<<nblk, 256, 0, st>>>((const float*)logits, labels, M, Cp, C, ignore_index, lse, (double*)workspace);
+    else return MU_ERR_ARG;
+    ce_final_kernel<<<1, 64, 0, st>>>((const double*)workspace, nblk, loss, count);
+    MU_CHECK_LAUNCH();
+    return MU_OK;
+}
+
+extern "C" int mu_ce_bwd(const void* logits, const long* labels, const float* lse, const float* count, const float* grad_out,
+                         float grad_scale, long M, int Cp, int C, long ignore_index, void* dlogits, int dtype, void* stream) {
+    if (!logits || !labels || !lse || !count || !grad_out || !dlogits || M <= 0 || C <= 0 || Cp < C || Cp % 8) return MU_ERR_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == MU_F16) {
+        long total = M * (Cp / 8);
+        int g = (int)((total + 255) / 256 > 8192 ? 8192 : (total + 255) / 256);
+        ce_bwd_kernel<h16><<<g, 256, 0, st>>>((const h16*)logits, labels, lse, count, grad_out, grad_scale, M, Cp, C, ignore_index, (h16*)dlogits);
+    } else if (dtype == MU_F32) {
+        long total = M * (Cp / 4);
+        int g = (int)((total + 255) / 256 > 8192 ? 8192 : (total + 255) / 256);
+        ce_bwd_kernel<float><<<g, 256, 0, st>>>((const float*)logits, labels, lse, count, grad_out, grad_scale, M, Cp, C, ignore_index, (float*)dlogits);
+    } else return MU_ERR_ARG;
+    MU_CHECK_LAUNCH();
+    return MU_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// mean IoU.  counts[0][c] = #(pred==c && label==c), counts[1][c] = #(pred==c), counts[2][c] = #(label==c);
+// iou_c = (I + smooth) / (U + smooth) with U = P + L - I, averaged over classes with U > 0 (ade_semantic.py:135-146).
+// logits: row r = pixel, element (r, c) at logits[(r / inner) * outer_stride + c * c_stride + (r % inner) * p_stride]
+//   NHWC padded: inner = M, outer_stride = 0, c_stride = 1, p_stride = Cp;  NCHW: inner = H*W, outer = C*H*W, c_stride = H*W, p_stride = 1
+// softmax(y/0.5) is monotone, so the arg-max is taken on the logits (first maximum, as torch.argmax).
+// ------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void iou_count_kernel(const T* __restrict__ logits, const long* __restrict__ labels, long M, int C,
+                                                        long inner, long outer_stride, long c_stride, long p_stride,
+                                                        unsigned int* __restrict__ counts) {
+    extern __shared__ unsigned int sh[];          // [3][C]
+    for (int i = threadIdx.x; i < 3 * C; i += 256) sh[i] = 0;
+    __syncthreads();
+    for (long r = (long)blockIdx.x * 256 + threadIdx.x; r < M; r += (long)gridDim.x * 256) {
+        const T* base = logits + (r / inner) * outer_stride + (r % inner) * p_stride;
+        float best = (float)base[0];
+        int arg = 0;
+        for (int c = 1; c < C; ++c) {
+            const float v = (float)base[(long)c * c_stride];
+            if (v > best) { best = v; arg = c; }
+        }
+        const long lab = labels[r];
+        atomicAdd(&sh[C + arg], 1u);
+        if (lab >= 0 && lab < C) {
+            atomicAdd(&sh[2 * C + (int)lab], 1u);
+            if (lab == arg) atomicAdd(&sh[arg], 1u);
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 3 * C; i += 256) if (sh[i]) atomicAdd(&counts[i], sh[i]);
+}
+
+__global__ void iou_final_kernel(const unsigned int* __restrict__ counts, int C, float smooth, float* __restrict__ out) {
+    float s = 0.f, n = 0.f;
+    for (int c = threadIdx.x; c < C; c += 64) {
+        const float I = (float)counts[c], U = (float)counts[C + c] + (float)counts[2 * C + c] - (float)counts[c];
+        if (U > 0.f) { s += (I + smooth) / (U + smooth); n += 1.f; }
+    }
+    s = wave_sum(s);
+    n = wave_sum(n);
+    if (threadIdx.x == 0) out[0] = s / n;
+}
+
+extern "C" int mu_mean_iou(const void* logits, const long* labels, long M, int C, long inner, long outer_stride, long c_stride,
+                           long p_stride, float smooth, unsigned int* counts, float* out, int dtype, void* stream) {
+    if (!logits || !labels || !counts || !out || M <= 0 || C <= 0 || C > 4096 || inner <= 0) return MU_ERR_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    if (hipMemsetAsync(counts, 0, (size_t)3 * C * sizeof(unsigned int), st) != hipSuccess) return MU_ERR_LAUNCH;
+    int g = (int)((M + 255) / 256 > 2048 ? 2048 : (M + 255) / 256);
+    size_t lds = (size_t)3 * C * sizeof(unsigned int);
+    if (dtype == MU_F16) iou_count_kernel<h16><<<g, 256, lds, st>>>((const h16*)logits, labels, M, C, inner, outer_stride, c_stride, p_stride, counts);
+    else if (dtype == MU_F32) iou_count_kernel<float><<<g, 256, lds, st>>>((const float*)logits, labels, M, C, inner, outer_stride, c_stride, p_stride, counts);
+    else return MU_ERR_ARG;
+    iou_final_kernel<<<1, 64, 0, st>>>(counts, C, smooth, out);
+    MU_CHECK_LAUNCH();
+    return MU_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// f2: fused multi-tensor AdamW (optim.AdamW(lr, weight_decay), ade_semantic.py:379,401; torch semantics: decoupled decay,
+// bias-corrected moments).  One launch updates every parameter: a device table lists {p, g, m, v, n} per tensor and a
+// block map assigns (tensor, chunk) to each block.  grad_scale_inv un-scales fp16-loss-scaled gradients on the fly.
+// ------------------------------------------------------------------------------------------
+struct MuAdamEntry { float* p; const float* g; float* m; float* v; long n; float bc1; float bc2_sqrt; };   // 48 bytes
+// bc1 = 1 - beta1^t, bc2_sqrt = sqrt(1 - beta2^t) with the tensor's own step count t (torch keeps one counter per parameter)
+#define ADAM_CHUNK 4096
+
+__global__ __launch_bounds__(256) void adamw_kernel(const MuAdamEntry* __restrict__ table, const int* __restrict__ block_tensor,
+                                                    const int* __restrict__ block_chunk, float lr, float beta1, float beta2, float eps,
+                                                    float wd, float ginv) {
+    const MuAdamEntry e = table[block_tensor[blockIdx.x]];
+    if (!e.g) return;                               // parameter without a gradient this step
+    const long base = (long)block_chunk[blockIdx.x] * ADAM_CHUNK;
+    for (int i = threadIdx.x; i < ADAM_CHUNK; i += 256) {
+        const long k = base + i;
+        if (k >= e.n) break;
+        const float g = e.g[k] * ginv;
+        float p = e.p[k];
+        p *= 1.f - lr * wd;
+        const float m = beta1 * e.m[k] + (1.f - beta1) * g;
+        const float v = beta2 * e.v[k] + (1.f - beta2) * g * g;
+        e.m[k] = m;
+        e.v[k] = v;
+        const float denom = sqrtf(v) / e.bc2_sqrt + eps;
+        e.p[k] = p - (lr / e.bc1) * (m / denom);
+    }
+}
+
+extern "C" int mu_adamw_chunk(void) { return ADAM_CHUNK; }
+
+extern "C" int mu_adamw_multi(const void* table, const int* block_tensor, const int* block_chunk, int nblocks, float lr, float beta1,
+                              float beta2, float eps, float weight_decay, float grad_scale_inv, void* stream) {
+    if (!table || !block_tensor || !block_chunk || nblocks <= 0) return MU_ERR_ARG;
+    adamw_kernel<<<nblocks, 256, 0, (hipStream_t)stream>>>((const MuAdamEntry*)table, block_tensor, block_chunk, lr, beta1, beta2, eps,
+                                                           weight_decay, grad_scale_inv);
+    MU_CHECK_LAUNCH();
+    return MU_OK;
+}

@@ -1,0 +1,71 @@
+"""fused loss and metric kernels for the step right after the forward path.
+
+``pixel_cross_entropy_nhwc`` consumes the model's NHWC channel-padded logits directly (``UNet.forward_nhwc``), so the training
+step needs neither the NHWC->NCHW fp32 output conversion nor torch's log-softmax / nll kernels.  Same semantics as
+``nn.CrossEntropyLoss(ignore_index=...)`` in the reference scripts (ade_semantic.py:377,399; city_semantic.py:341).
+"""
+from __future__ import annotations
+
+import torch
+from torch.autograd.function import once_differentiable
+
+from . import _lib
+from ._lib import call, dt, ptr, stream, workspace
+
+
+class _PixelCE(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, logits, labels, n_classes, ignore_index, grad_scale):
+        logits = logits.contiguous()
+        labels = labels.contiguous().view(-1)
+        Cp = logits.shape[-1]
+        M = logits.numel() // Cp
+        if labels.numel() != M or labels.dtype != torch.int64:
+            raise RuntimeError("pixel_cross_entropy_nhwc: labels must be int64 with one entry per pixel")
+        lse = torch.empty(M, dtype=torch.float32, device=logits.device)
+        loss = torch.empty(1, dtype=torch.float32, device=logits.device)
+        count = torch.empty(1, dtype=torch.float32, device=logits.device)
+        ws = workspace(_lib.load().mu_ce_workspace_bytes(), logits.device)
+        call("mu_ce_fwd", ptr(logits), ptr(labels), M, Cp, n_classes, ignore_index, ptr(lse), ptr(loss), ptr(count), ptr(ws),
+             ws.numel(), dt(logits), stream())
+        ctx.save_for_backward(logits, labels, lse, count)
+        ctx.meta = (M, Cp, n_classes, ignore_index, grad_scale)
+        return loss.view(())
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g):
+        logits, labels, lse, count = ctx.saved_tensors
+        M, Cp, C, ignore_index, grad_scale = ctx.meta
+        dl = torch.empty_like(logits)
+        g = g.contiguous().float().view(1)
+        call("mu_ce_bwd", ptr(logits), ptr(labels), ptr(lse), ptr(count), ptr(g), float(grad_scale), M, Cp, C, ignore_index, ptr(dl),
+             dt(logits), stream())
+        return dl, None, None, None, None
+
+
+def pixel_cross_entropy_nhwc(logits_nhwc, labels, n_classes, ignore_index=-100, grad_scale=1.0):
+    """Mean cross-entropy over non-ignored pixels.  logits_nhwc: [B,H,W,Cp] (fp16/fp32, first n_classes channels valid);
+    labels: int64 [B,H,W].  grad_scale multiplies the backward only (static fp16 loss scale without touching the loss value)."""
+    return _PixelCE.apply(logits_nhwc, labels, int(n_classes), int(ignore_index), float(grad_scale))
+
+
+def mean_iou(y_pred, y_true, num_classes, smooth=1e-6):
+    """mean_iou of the reference (ade_semantic.py:128-146) on device, no host synchronisation.
+    y_pred: NCHW [B,C,H,W] (the module output) or NHWC channel-padded [B,H,W,Cp]; y_true: int64 [B,H,W]."""
+    y_pred = y_pred.contiguous()
+    labels = y_true.contiguous().view(-1)
+    M = labels.numel()
+    if y_pred.dim() != 4:
+        raise RuntimeError("mean_iou expects a 4-D prediction tensor")
+    if y_pred.shape[1] == num_classes and y_pred.shape[0] * y_pred.shape[2] * y_pred.shape[3] == M:   # NCHW
+        hw = y_pred.shape[2] * y_pred.shape[3]
+        inner, outer, cs, ps = hw, num_classes * hw, hw, 1
+    else:                                                                                              # NHWC padded
+        Cp = y_pred.shape[-1]
+        inner, outer, cs, ps = M, 0, 1, Cp
+    counts = torch.empty(3 * num_classes, dtype=torch.int32, device=y_pred.device)
+    out = torch.empty(1, dtype=torch.float32, device=y_pred.device)
+    call("mu_mean_iou", ptr(y_pred), ptr(labels), M, num_classes, inner, outer, cs, ps, float(smooth), ptr(counts), ptr(out),
+         dt(y_pred), stream())
+    return out.view(())

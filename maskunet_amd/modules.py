@@ -333,6 +333,12 @@ class UNet(_HipModule):
         b = ops.conv(b, bh[3].weight, bh[3].bias)
         return sem, b, emb
 
+    def logits_nhwc(self, x):
+        """Semantic head output as the internal NHWC channel-padded tensor [B,H,W,pad32(c_out)] (compute dtype) -- feed it to
+        ``maskunet_amd.pixel_cross_entropy_nhwc`` / ``mean_iou`` to skip the NCHW fp32 materialisation in a training step."""
+        self._check_device(x)
+        return self.forward_nhwc(ops.to_nhwc(x, self.compute_dtype))[0]
+
     def forward(self, x):
         self._check_device(x)
         outs = self.forward_nhwc(ops.to_nhwc(x, self.compute_dtype))

@@ -232,6 +232,19 @@ def pixel_cross_entropy(logits, labels, ignore_index: int = -100):
     return F.cross_entropy(logits, labels, ignore_index=ignore_index)
 
 
+def mean_iou(y_pred, y_true, num_classes, smooth=1e-6):
+    """mean_iou (ade_semantic.py:128-146): softmax(y/0.5) -> argmax -> per-class (I+s)/(U+s), classes with U == 0 skipped."""
+    pred = torch.argmax(torch.softmax(y_pred / 0.5, dim=1), dim=1)
+    ious = []
+    for c in range(num_classes):
+        inter = torch.sum((pred == c) & (y_true == c))
+        union = torch.sum((pred == c) | (y_true == c))
+        if union == 0:
+            continue
+        ious.append((inter.float() + smooth) / (union.float() + smooth))
+    return torch.mean(torch.stack(ious))
+
+
 # --------------------------------------------------------------------------------------
 # deterministic parameter / input recipe shared by the golden generator and the tests
 # --------------------------------------------------------------------------------------

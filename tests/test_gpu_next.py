@@ -1,0 +1,113 @@
+"""GPU tests for the "next" rows: fused pixel cross-entropy, on-device mean IoU, fused AdamW."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 1e-5), (torch.float16, 2e-3)])
+@pytest.mark.parametrize("C,ignore", [(150, -100), (19, 255), (133, 255)])
+def test_pixel_cross_entropy_matches_torch(dtype, tol, C, ignore):
+    import maskunet_amd
+    from maskunet_amd import ops
+    g = np.random.default_rng(C)
+    B, H, W = 2, 12, 10
+    logits = torch.from_numpy(g.standard_normal((B, C, H, W)).astype(np.float32) * 3)
+    labels = torch.from_numpy(g.integers(0, C, (B, H, W)))
+    if ignore == 255:
+        labels[torch.from_numpy(g.random((B, H, W)) < 0.2)] = 255
+    lr = logits.to(dtype).float().clone().requires_grad_(True)
+    ref = F.cross_entropy(lr, labels, ignore_index=ignore)
+    ref.backward()
+    ld = logits.cuda().requires_grad_(True)
+    nhwc = ops.to_nhwc(ld, dtype)
+    loss = maskunet_amd.pixel_cross_entropy_nhwc(nhwc, labels.cuda(), C, ignore)
+    (loss * 3.0).backward()
+    assert abs(loss.item() - ref.item()) <= tol * max(1.0, abs(ref.item()))
+    err = (ld.grad.cpu() / 3.0 - lr.grad).abs().max().item() / lr.grad.abs().max().item()
+    assert err <= 20 * tol, err
+
+
+def test_pixel_cross_entropy_grad_scale_and_padding():
+    import maskunet_amd
+    C, Cp = 19, 32
+    x = torch.randn(2, 4, 4, Cp, device="cuda", requires_grad=True)
+    lab = torch.randint(0, C, (2, 4, 4), device="cuda")
+    l1 = maskunet_amd.pixel_cross_entropy_nhwc(x, lab, C)
+    l1.backward()
+    g1 = x.grad.clone()
+    x.grad = None
+    l2 = maskunet_amd.pixel_cross_entropy_nhwc(x, lab, C, grad_scale=128.0)
+    l2.backward()
+    assert torch.allclose(l1, l2) and torch.allclose(x.grad, g1 * 128.0, rtol=1e-5, atol=1e-7)
+    assert float(x.grad[..., C:].abs().max()) == 0.0        # padded channels get exact zeros
+
+
+@pytest.mark.parametrize("layout", ["nchw", "nhwc"])
+def test_mean_iou_matches_reference_definition(layout):
+    import maskunet_amd
+    from maskunet_amd import ops
+    from oracle import maskunet_oracle as O
+    g = np.random.default_rng(3)
+    B, C, H, W = 2, 21, 16, 16
+    y = torch.from_numpy(g.standard_normal((B, C, H, W)).astype(np.float32))
+    t = torch.from_numpy(g.integers(0, C - 3, (B, H, W)))           # some classes absent from the labels
+    y[:, C - 1] = -10.0                                              # and one never predicted either -> union == 0, skipped
+    ref = O.mean_iou(y, t, C)
+    pred = y.cuda() if layout == "nchw" else ops.to_nhwc(y.cuda(), torch.float32)
+    got = maskunet_amd.mean_iou(pred, t.cuda(), C)
+    assert abs(got.item() - ref.item()) <= 1e-6
+
+
+def test_fused_adamw_matches_torch():
+    import maskunet_amd
+    torch.manual_seed(0)
+    shapes = [(64, 3, 3, 3), (64,), (150, 64, 1, 1), (5000,), (7,)]
+    ref_p = [torch.randn(s, device="cuda").requires_grad_(True) for s in shapes]
+    our_p = [p.detach().clone().requires_grad_(True) for p in ref_p]
+    ref = torch.optim.AdamW(ref_p, lr=5e-3, weight_decay=1e-1)
+    our = maskunet_amd.FusedAdamW(our_p, lr=5e-3, weight_decay=1e-1)
+    scale = 1024.0
+    for it in range(4):
+        for i, (a, b) in enumerate(zip(ref_p, our_p)):
+            if i == 4 and it % 2 == 0:            # a parameter that sometimes has no gradient
+                a.grad = b.grad = None
+                continue
+            gr = torch.randn_like(a)
+            a.grad = gr.clone()
+            b.grad = gr * scale                    # loss-scaled gradients, un-scaled inside the fused step
+        ref.step()
+        our.step(grad_scale=scale)
+    for a, b in zip(ref_p, our_p):
+        assert torch.allclose(a, b, rtol=2e-5, atol=2e-6), (a - b).abs().max()
+
+
+def test_training_step_with_fused_loss_and_optimizer():
+    """One fp16 training step through the fused-loss path equals the public-API path (module output + torch CE)."""
+    import maskunet_amd
+    from tests import _gpu_checks as G
+    model, params, keeps, x, labels = G.build_unet(19, False, 500, torch.float16, True, 2)
+    x, labels = x.cuda(), labels.cuda()
+    out = model(x)
+    l_ref = F.cross_entropy(out, labels)
+    (l_ref * 512.0).backward()
+    gref = {k: v.grad.clone() for k, v in model.named_parameters() if v.grad is not None}
+    model.zero_grad(set_to_none=True)
+    for bn in model.modules():
+        if isinstance(bn, torch.nn.BatchNorm2d):
+            bn.reset_running_stats()
+    loss = maskunet_amd.pixel_cross_entropy_nhwc(model.logits_nhwc(x), labels, 19, grad_scale=512.0)
+    loss.backward()
+    assert abs(loss.item() - l_ref.item()) <= 2e-3
+    worst = 0.0
+    for k, v in model.named_parameters():
+        if k in gref and float(gref[k].abs().max()) > 1e-3 * 512:
+            c = 1.0 - float((v.grad.double() * gref[k].double()).sum() / (v.grad.double().norm() * gref[k].double().norm()))
+            worst = max(worst, c)
+    assert worst <= 2e-2, worst
+    opt = maskunet_amd.FusedAdamW(model.parameters(), lr=1e-4, weight_decay=1e-2)
+    before = model.final_layer[0].weight.detach().clone()
+    opt.step(grad_scale=512.0)
+    assert not torch.equal(before, model.final_layer[0].weight)
