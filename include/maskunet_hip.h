@@ -149,6 +149,8 @@ int mu_mean_iou(const void* logits, const long* labels, long M, int C, long inne
  * {float* p; const float* g; float* m; float* v; long n; float bc1; float bc2_sqrt;} (48 bytes; g may be NULL; bc1 = 1-beta1^t,
  * bc2_sqrt = sqrt(1-beta2^t) for that tensor's own step count t); block_tensor/block_chunk: per-block (tensor index, chunk
  * index) with chunks of mu_adamw_chunk() elements.  grad_scale_inv un-scales loss-scaled gradients. */
+/* f4: uint8 HWC image bytes [npix, C] -> [0,1] floats in the NHWC compute layout [npix, Cp] (ToTensor, ade_semantic.py:85) */
+int mu_u8_to_nhwc(const unsigned char* src, void* dst, long npix, int C, int Cp, int dtype, void* stream);
 int mu_adamw_chunk(void);
 int mu_adamw_multi(const void* table, const int* block_tensor, const int* block_chunk, int nblocks, float lr, float beta1, float beta2,
                    float eps, float weight_decay, float grad_scale_inv, void* stream);

@@ -400,3 +400,30 @@ extern "C" int mu_add(const void* a, const void* b, void* out, long n, int dtype
     MU_CHECK_LAUNCH();
     return MU_OK;
 }
+
+// ------------------------------------------------------------------------------------------
+// decoded image bytes -> network input.  uint8 HWC (what cv2.imread/cvtColor/resize leave in memory,
+// ade_semantic.py:72-76) -> [0,1] float (ToTensor, :85) in the NHWC compute layout, channel-padded with zeros.
+// ------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void u8_to_nhwc_kernel(const uint8_t* __restrict__ src, T* __restrict__ dst, long npix, int C, int Cp) {
+    constexpr int N = Vec16<T>::N;
+    const int cv = Cp / N;
+    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < npix * cv; idx += (long)gridDim.x * 256) {
+        const long p = idx / cv;
+        const int c0 = (int)(idx % cv) * N;
+        Vec16<T> o;
+#pragma unroll
+        for (int i = 0; i < N; ++i) o.set(i, c0 + i < C ? (float)src[p * C + c0 + i] * (1.0f / 255.0f) : 0.f);
+        o.store(dst + p * Cp + c0);
+    }
+}
+extern "C" int mu_u8_to_nhwc(const unsigned char* src, void* dst, long npix, int C, int Cp, int dtype, void* stream) {
+    if (!src || !dst || npix <= 0 || C <= 0 || Cp < C || Cp % 8) return MU_ERR_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == MU_F32) u8_to_nhwc_kernel<float><<<ew_grid(npix * (Cp / 4)), 256, 0, st>>>(src, (float*)dst, npix, C, Cp);
+    else if (dtype == MU_F16) u8_to_nhwc_kernel<h16><<<ew_grid(npix * (Cp / 8)), 256, 0, st>>>(src, (h16*)dst, npix, C, Cp);
+    else return MU_ERR_ARG;
+    MU_CHECK_LAUNCH();
+    return MU_OK;
+}

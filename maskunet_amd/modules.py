@@ -339,9 +339,16 @@ class UNet(_HipModule):
         self._check_device(x)
         return self.forward_nhwc(ops.to_nhwc(x, self.compute_dtype))[0]
 
+    def forward_u8(self, images_u8_hwc):
+        """Forward from decoded image bytes: uint8 [B,H,W,3] (HWC) -> same outputs as ``forward(ToTensor(images))``."""
+        self._check_device(images_u8_hwc)
+        return self._finish(self.forward_nhwc(ops.u8_hwc_to_nhwc(images_u8_hwc, self.compute_dtype)))
+
     def forward(self, x):
         self._check_device(x)
-        outs = self.forward_nhwc(ops.to_nhwc(x, self.compute_dtype))
+        return self._finish(self.forward_nhwc(ops.to_nhwc(x, self.compute_dtype)))
+
+    def _finish(self, outs):
         sem = ops.to_nchw(outs[0], self.c_out, torch.float32)
         if not self.three_head:
             return sem

@@ -83,6 +83,18 @@ def to_nhwc(x, dtype):
     return _ToNHWC.apply(x, dtype)
 
 
+def u8_hwc_to_nhwc(img_u8, dtype):
+    """uint8 [B,H,W,C] image bytes (HWC, as decoded) -> [0,1] activations [B,H,W,pad32(C)] in the compute dtype
+    (the ToTensor() of the reference datasets, ade_semantic.py:85, without an fp32 NCHW detour).  No gradient."""
+    img_u8 = img_u8.contiguous()
+    if img_u8.dtype != torch.uint8 or img_u8.dim() != 4:
+        raise RuntimeError("u8_hwc_to_nhwc expects a uint8 [B,H,W,C] tensor")
+    B, H, W, C = img_u8.shape
+    y = torch.empty((B, H, W, pad32(C)), dtype=dtype, device=img_u8.device)
+    call("mu_u8_to_nhwc", ptr(img_u8), ptr(y), B * H * W, C, pad32(C), dt(y), stream())
+    return y
+
+
 def to_nchw(x, C, out_dtype=torch.float32):
     return _ToNCHW.apply(x, C, out_dtype)
 

@@ -111,3 +111,18 @@ def test_training_step_with_fused_loss_and_optimizer():
     before = model.final_layer[0].weight.detach().clone()
     opt.step(grad_scale=512.0)
     assert not torch.equal(before, model.final_layer[0].weight)
+
+
+def test_u8_input_pipeline_matches_totensor():
+    """8-f4: forward_u8(uint8 HWC) == forward(ToTensor(image)) (ade_semantic.py:72-76,85)."""
+    import maskunet_amd
+    from maskunet_amd import ops
+    img = torch.randint(0, 256, (2, 128, 128, 3), dtype=torch.uint8, device="cuda")
+    y = ops.u8_hwc_to_nhwc(img, torch.float32)
+    ref = img.float() / 255.0
+    assert torch.equal(y[..., :3], ref) and float(y[..., 3:].abs().max()) == 0.0
+    m = maskunet_amd.UNet(3, 5).cuda().eval()
+    m.set_keep_masks([torch.ones(2, n, dtype=torch.uint8) for n in (4096, 1024, 256, 1024, 4096, 16384)])
+    a = m.forward_u8(img)
+    b = m(ref.permute(0, 3, 1, 2).contiguous())
+    assert torch.allclose(a, b, atol=1e-5)
