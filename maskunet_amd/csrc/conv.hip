@@ -331,7 +331,7 @@ __global__ __launch_bounds__(NWV * 64, NWV == 4 ? 2 : 1) void conv_nt3_kernel(co
     constexpr int TH = WC * TN, TW = 16, HW_ = TW + 2;      // spatial tile TH x 16, halo row width 18
     constexpr int HROWS = (TH + 2) * HW_;
     constexpr int HINST = (HROWS + 7) / 8;                  // 8 halo rows (128 B each) per wave DMA instruction
-    constexpr int HPER = (HINST + 5) / 6;                   // instructions per piece (6 pieces), spread over 4 waves
+    static_assert((HINST + NWV - 1) / NWV <= 9, "halo does not fit the 9 tap steps");
     constexpr int PA = BCO / (8 * NWV);
     static_assert(BCO % (8 * NWV) == 0, "weight tile rows must split over the waves");
     constexpr int HBYTES = HINST * 1024, WBYTES = BCO * 128;
@@ -356,24 +356,36 @@ __global__ __launch_bounds__(NWV * 64, NWV == 4 ? 2 : 1) void conv_nt3_kernel(co
     const int kchunks = Cin / KC;
     const int nsteps = 9 * kchunks;
 
-    auto stage_w = [&](int s, int buf) {
-        const int tap = s % 9, ci0 = (s / 9) * KC;
-        char* Wb = Ws + buf * WBYTES;
+    // DMA source offsets are loop-invariant per lane too: precompute them once (element offsets, int), so a stage costs one
+    // scalar base update + one add per instruction instead of 64-bit multiply-adds.
+    int wl[PA];                                             // weights: (co0 + row) * Cin + swizzled chunk
 #pragma unroll
-        for (int i = 0; i < PA; ++i) {
-            const int row = (i * NWV + wave) * 8 + srow;
-            const int sc = sch ^ (row & 7);
-            glds16(w + ((long)tap * Cout + co0 + row) * Cin + ci0 + sc * VN, Wb + (i * NWV + wave) * 1024);
-        }
-    };
-    auto stage_h = [&](int inst, int ci0, int buf) {        // one wave instruction = halo rows 8*inst .. 8*inst+7
-        const int hr = inst * 8 + srow;
+    for (int i = 0; i < PA; ++i) {
+        const int row = (i * NWV + wave) * 8 + srow;
+        wl[i] = (co0 + row) * Cin + (sch ^ (row & 7)) * VN;
+    }
+    constexpr int HPW = (HINST + NWV - 1) / NWV;            // halo instructions owned by this wave: inst = k * NWV + wave
+    int hl[HPW];                                            // (hh * W + ww) * x_ld + swizzled chunk, or -1 for the zero ring
+#pragma unroll
+    for (int k = 0; k < HPW; ++k) {
+        const int hr = (k * NWV + wave) * 8 + srow;
         const int hy = hr / HW_, hx = hr - hy * HW_;
         const int hh = h0 - 1 + hy, ww = w0 - 1 + hx;
-        const bool ok = hr < HROWS && hh >= 0 && hh < H && ww >= 0 && ww < W;
-        const int sc = sch ^ (hr & 7);
-        const void* src = ok ? (const void*)(x + (((long)bimg * H + hh) * W + ww) * x_ld + ci0 + sc * VN) : (const void*)mu_zero_page;
-        glds16(src, Hs + buf * HBYTES + inst * 1024);
+        const bool ok = (k * NWV + wave) < HINST && hr < HROWS && hh >= 0 && hh < H && ww >= 0 && ww < W;
+        hl[k] = ok ? (int)(((long)hh * W + ww) * x_ld) + (sch ^ (hx & 7)) * VN : -1;
+    }
+    const T* xb = x + (long)bimg * H * W * x_ld;
+
+    auto stage_w = [&](int s, int buf) {
+        const int tap = s % 9, ci0 = (s / 9) * KC;
+        const T* wb = w + (long)tap * Cout * Cin + ci0;      // wave-uniform
+        char* Wb = Ws + buf * WBYTES;
+#pragma unroll
+        for (int i = 0; i < PA; ++i) glds16(wb + wl[i], Wb + (i * NWV + wave) * 1024);
+    };
+    auto stage_h = [&](int k, int ci0, int buf) {           // this wave's k-th halo instruction (rows 8*(k*NWV+wave) ..)
+        const void* src = hl[k] >= 0 ? (const void*)(xb + hl[k] + ci0) : (const void*)mu_zero_page;
+        glds16(src, Hs + buf * HBYTES + (k * NWV + wave) * 1024);
     };
 
     f32x4 acc[TM][TN];
@@ -382,44 +394,53 @@ __global__ __launch_bounds__(NWV * 64, NWV == 4 ? 2 : 1) void conv_nt3_kernel(co
 #pragma unroll
         for (int j = 0; j < TN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
+    // Loop-invariant per-lane LDS byte offsets: the inner loop then needs one scalar+vector add per fragment group and
+    // immediates for everything else (the generic index arithmetic cost more VALU time than the MFMAs).
+    //   weights: row = (wr*TM+i)*16 + r16 -> i*2048 is an immediate; chunk swizzle key r16 & 7
+    //   halo   : row = (wc*TN + j + dh)*18 + r16 + dw -> (j + dh)*2304 immediate/scalar; key (r16 + dw) & 7 depends on dw only
+    int aoff[2], boff[3][2];
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+        aoff[kk] = (wr * TM * 16 + r16) * 128 + (((kk * 4 + g) ^ (r16 & 7)) << 4);
+#pragma unroll
+        for (int dw = 0; dw < 3; ++dw) boff[dw][kk] = (wc * TN * HW_ + r16 + dw) * 128 + (((kk * 4 + g) ^ ((r16 + dw) & 7)) << 4);
+    }
+
     stage_w(0, 0);
-    for (int inst = wave; inst < HINST; inst += NWV) stage_h(inst, 0, 0);
+#pragma unroll
+    for (int k = 0; k < HPW; ++k)
+        if (k * NWV + wave < HINST) stage_h(k, 0, 0);
     __syncthreads();
 
     int s = 0;
     for (int c = 0; c < kchunks; ++c) {
-        const char* Hb = Hs + (c & 1) * HBYTES;
-#pragma unroll 1
-        for (int t = 0; t < 9; ++t, ++s) {
-            if (s + 1 < nsteps) stage_w(s + 1, (s + 1) & 1);
-            if (t < 6 && c + 1 < kchunks) {
+        const int hbuf = (c & 1) * HBYTES;
 #pragma unroll
-                for (int k = 0; k < (HPER + NWV - 1) / NWV; ++k) {
-                    const int inst = t * HPER + k * NWV + wave;
-                    if (k * NWV + wave < HPER && inst < HINST) stage_h(inst, (c + 1) * KC, (c + 1) & 1);
+        for (int dh = 0; dh < 3; ++dh) {
+#pragma unroll
+            for (int dw = 0; dw < 3; ++dw, ++s) {
+                const int t = dh * 3 + dw;
+                if (s + 1 < nsteps) stage_w(s + 1, (s + 1) & 1);
+                if (t < HPW && c + 1 < kchunks && t * NWV + wave < HINST)        // one halo piece of the next chunk per tap step
+                    stage_h(t, (c + 1) * KC, (c + 1) & 1);
+                const char* Wb = Ws + (s & 1) * WBYTES;
+                const char* Hb = Hs + hbuf + dh * (HW_ * 128);
+#pragma unroll
+                for (int kk = 0; kk < 2; ++kk) {
+                    Frag a[TM], b[TN];
+                    const char* wa = Wb + aoff[kk];
+                    const char* hb = Hb + boff[dw][kk];
+#pragma unroll
+                    for (int i = 0; i < TM; ++i) a[i] = *reinterpret_cast<const Frag*>(wa + i * 2048);
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) b[j] = *reinterpret_cast<const Frag*>(hb + j * (HW_ * 128));
+#pragma unroll
+                    for (int i = 0; i < TM; ++i)
+#pragma unroll
+                        for (int j = 0; j < TN; ++j) M_::mma(a[i], b[j], acc[i][j]);
                 }
+                __syncthreads();
             }
-            const char* Wb = Ws + (s & 1) * WBYTES;
-            const int dh = t / 3, dw = t % 3;               // halo offsets (already include the -1 ring)
-#pragma unroll
-            for (int kk = 0; kk < 2; ++kk) {
-                Frag a[TM], b[TN];
-#pragma unroll
-                for (int i = 0; i < TM; ++i) {
-                    const int row = (wr * TM + i) * 16 + r16;
-                    a[i] = *reinterpret_cast<const Frag*>(Wb + row * 128 + (((kk * 4 + g) ^ (row & 7)) << 4));
-                }
-#pragma unroll
-                for (int j = 0; j < TN; ++j) {
-                    const int hr = (wc * TN + j + dh) * HW_ + r16 + dw;
-                    b[j] = *reinterpret_cast<const Frag*>(Hb + hr * 128 + (((kk * 4 + g) ^ (hr & 7)) << 4));
-                }
-#pragma unroll
-                for (int i = 0; i < TM; ++i)
-#pragma unroll
-                    for (int j = 0; j < TN; ++j) M_::mma(a[i], b[j], acc[i][j]);
-            }
-            __syncthreads();
         }
     }
 
@@ -664,11 +685,11 @@ template <int BCH> __device__ __forceinline__ int wg_hash(int row) {
     return (BCH >= 128) ? ((row & 3) | (((row >> 3) & 1) << 2)) : (row & 3);
 }
 
-template <int TM, int TN, int WR>
-__global__ __launch_bounds__(256, 1) void conv_wgrad3_kernel(const h16* __restrict__ x, const h16* __restrict__ dy, float* __restrict__ part,
+template <int TM, int TN, int WR, int NWV = 4>
+__global__ __launch_bounds__(NWV * 64, 1) void conv_wgrad3_kernel(const h16* __restrict__ x, const h16* __restrict__ dy, float* __restrict__ part,
                                                              int B, int H, int W, int Cin, int Cout, long x_ld, long dy_ld, int nsplit,
                                                              long pix_per_split) {
-    constexpr int WC = 4 / WR;
+    constexpr int WC = NWV / WR;
     constexpr int BCO = WR * TM * 16, BCI = WC * TN * 16;
     static_assert(BCO == BCI, "square channel tiles");
     constexpr int ROWB = BCO * 2, CPR = ROWB / 16, RPW = 1024 / ROWB;
@@ -698,7 +719,7 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad3_kernel(const h16* __restri
         h16* At = lds + buf * STAGE;
         h16* Bt = At + KP * BCO;
 #pragma unroll
-        for (int i = wave; i < NIA; i += 4) {
+        for (int i = wave; i < NIA; i += NWV) {
             const int row = i * RPW + lrow;
             const long pp = pbase + row;
             const int sc = (((c16 >> 1) ^ wg_hash<BCO>(row)) << 1) | (c16 & 1);
@@ -709,7 +730,7 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad3_kernel(const h16* __restri
         const int hh = (int)((pbase / W) % H) + dh;
         const bool rowok = hh >= 0 && hh < H;
 #pragma unroll
-        for (int i = wave; i < NIB; i += 4) {
+        for (int i = wave; i < NIB; i += NWV) {
             const int row = i * RPW + lrow;                 // window row: flat pixel pbase + dh*W - 1 + row
             const bool ok = rowok && row <= KP + 1 && (row >= 1 || w0 > 0) && (row <= KP || w0 + KP < W);
             const int sc = (((c16 >> 1) ^ wg_hash<BCO>(row)) << 1) | (c16 & 1);
@@ -870,7 +891,9 @@ extern "C" int mu_conv_wgrad(const void* x, const void* dy, float* dw_oihw, int 
         wgrad3_plan((long)B * H * W, Cin, Cout, bco, &nsplit, &pps);
         if (ws_bytes < (long)nsplit * taps * Cout * Cin * (long)sizeof(float)) return MU_ERR_WORKSPACE;
         const int grid = 3 * (Cout / bco) * (Cin / bco) * nsplit;
-        if (bco == 128)
+        if (bco == 128 && !getenv("MU_WG_NW4"))     // 8 waves, 64x32 tile x 3 taps per wave (96 accumulators): 2 waves/SIMD
+            conv_wgrad3_kernel<4, 2, 2, 8><<<grid, 512, 0, st>>>((const h16*)x, (const h16*)dy, part, B, H, W, Cin, Cout, x_ld, dy_ld, nsplit, pps);
+        else if (bco == 128)
             conv_wgrad3_kernel<4, 4, 2><<<grid, 256, 0, st>>>((const h16*)x, (const h16*)dy, part, B, H, W, Cin, Cout, x_ld, dy_ld, nsplit, pps);
         else
             conv_wgrad3_kernel<2, 2, 2><<<grid, 256, 0, st>>>((const h16*)x, (const h16*)dy, part, B, H, W, Cin, Cout, x_ld, dy_ld, nsplit, pps);
