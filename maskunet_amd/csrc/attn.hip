@@ -942,17 +942,21 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 && D <= 64 && sizeof(T) == 2) ? 2
                     A::mma_row(va, dof[t][ks], dp[kt][t]);
                 }
             }
-        const bool partial = j0 + KT > Nk;
+        if (j0 + KT > Nk) {                          // wave-uniform: only the last, partial tile pays for key-range masking
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (j0 + kt * 16 + 4 * g + r >= Nk) { s[kt][t][r] = -INFINITY; dp[kt][t][r] = 0.f; }
+        }
 #pragma unroll
         for (int t = 0; t < 2; ++t)
 #pragma unroll
             for (int kt = 0; kt < NKT; ++kt)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    float p = __builtin_amdgcn_exp2f(s[kt][t][r]);
-                    if (partial && j0 + kt * 16 + 4 * g + r >= Nk) p = 0.f;
-                    s[kt][t][r] = p * dp[kt][t][r];
-                }
+                for (int r = 0; r < 4; ++r) s[kt][t][r] = __builtin_amdgcn_exp2f(s[kt][t][r]) * dp[kt][t][r];
 #pragma unroll
         for (int h = 0; h < NH; ++h)
 #pragma unroll

@@ -60,3 +60,36 @@ def test_state_dict_roundtrip_and_dp_prefix():
     m2.load_state_dict({k.replace("module.", ""): v for k, v in sd.items()})   # ade_panoptic.py:434
     for (k1, v1), (k2, v2) in zip(m.state_dict().items(), m2.state_dict().items()):
         assert k1 == k2 and torch.equal(v1, v2)
+
+
+def test_unet_other_resolution_vs_oracle():
+    """The path is not tied to 128x128 (configs[4] runs 256x256): a 64x64 model (hw=64) against the oracle, fp32."""
+    import numpy as np
+    import torch.nn.functional as F
+    import maskunet_amd
+    from oracle import maskunet_oracle as O
+    hw, c_out, B, seed = 64, 21, 2, 700
+    shapes = O.unet_state_shapes(3, c_out, False, hw=hw)
+    params = O.make_params(shapes, seed)
+    model = maskunet_amd.UNet(3, c_out, hw=hw)
+    model.load_state_dict(params)
+    model.cuda().train()
+    model.dropout.p = 0.0
+    keeps = O.make_keeps(seed + 1, B, hw)
+    model.set_keep_masks(keeps)
+    x, labels = O.make_inputs(seed + 2, B, c_out, hw)
+    p = {k: (v.clone().requires_grad_(True) if v.dtype.is_floating_point and "running" not in k else v.clone()) for k, v in params.items()}
+    ref = O.unet_forward(p, x, keeps, training=True)
+    O.pixel_cross_entropy(ref, labels).backward()
+    out = model(x.cuda())
+    F.cross_entropy(out, labels.cuda()).backward()
+    assert float((out.cpu() - ref).abs().max()) <= 1e-3
+    worst = 0.0
+    gmax = max(float(v.grad.abs().max()) for v in p.values() if v.requires_grad and v.grad is not None)
+    for k, v in model.named_parameters():
+        r = p[k].grad
+        if r is None or float(r.abs().max()) < 1e-3 * gmax:
+            continue
+        g = v.grad.float().cpu()
+        worst = max(worst, 1.0 - float((g.double() * r.double()).sum() / (g.double().norm() * r.double().norm())))
+    assert worst <= 1e-4, worst
