@@ -77,3 +77,12 @@ def test_error_codes_not_exceptions():
     assert lib.mu_conv_fwd(x.data_ptr(), x.data_ptr(), None, x.data_ptr(), 1, 4, 4, 48, 32, 9, 48, 32, 0, None) == -2
     with pytest.raises(RuntimeError, match="MU_ERR"):
         _lib.call("mu_maxpool2_fwd", x.data_ptr(), x.data_ptr(), 1, 3, 4, 48, 0, None)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_conv_persistent_tile_walk(dtype, monkeypatch):
+    """The persistent 3x3 kernel (blocks walk several spatial tiles with the DMA pipeline running across tile borders) is
+    normally selected only for big grids; force it on small ones (3 blocks per channel slice, uneven tile counts)."""
+    from tests import _gpu_checks as G
+    monkeypatch.setenv("MU_CONV_PERSIST_BLOCKS", "3")
+    _assert_all(G.check_conv(dtype, cases=[(2, 32, 32, 64, 128, 3), (1, 64, 48, 128, 128, 3), (3, 16, 16, 256, 256, 3), (2, 40, 16, 128, 256, 3)]))
