@@ -16,6 +16,23 @@
 #include "../../include/maskunet_hip.h"
 #include <stdlib.h>
 #include <type_traits>
+// Tuning knobs (overridable with -D for tests/ab_bench.py A/B runs).  Measured in-process, N=16384 C=64 B=64 fp16:
+//   dK/dV  : 3 waves/SIMD (168 VGPRs, 4 spilled) 4.70 ms vs 2 waves/SIMD 5.24 ms; 1 wave/SIMD with 64 keys/wave 9 ms
+//   dQ     : 32-key tiles (152 VGPRs, 3 waves/SIMD) 3.07 ms vs 64-key tiles (196 VGPRs) 3.22 ms; forcing 3 waves/SIMD on the
+//            64-key version spills into the loop: 10.97 ms
+//   forward: already 3 waves/SIMD at 158 VGPRs
+#ifndef MU_DKV_OCC
+#define MU_DKV_OCC 3
+#endif
+#ifndef MU_DQ_OCC
+#define MU_DQ_OCC 3
+#endif
+#ifndef MU_FWD_OCC
+#define MU_FWD_OCC 2
+#endif
+#ifndef MU_DQ_KT
+#define MU_DQ_KT 32
+#endif
 
 typedef __fp16 fp16x4v __attribute__((__vector_size__(4 * sizeof(__fp16))));
 #define LDS_TR16(ptr) __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) fp16x4v*)(ptr))
@@ -378,7 +395,7 @@ template <int D> struct AccLd<float, D> {
 };
 
 template <typename T, int D, int KT, int NW, int OCC = 0, int NQ = 2>
-__global__ __launch_bounds__(NW * 64, OCC ? OCC : ((NW == 4 && D <= 64 && sizeof(T) == 2) ? 2 : 1)) void attn_fwd2_kernel(const T* __restrict__ qkv, const T* __restrict__ x, const int* __restrict__ kidx,
+__global__ __launch_bounds__(NW * 64, OCC ? OCC : ((NW == 4 && D <= 64 && sizeof(T) == 2) ? MU_FWD_OCC : 1)) void attn_fwd2_kernel(const T* __restrict__ qkv, const T* __restrict__ x, const int* __restrict__ kidx,
                                                         const int* __restrict__ kcnt, const float* __restrict__ gamma,
                                                         const float* __restrict__ beta, T* __restrict__ out, T* __restrict__ oattn,
                                                         float* __restrict__ lse2, float* __restrict__ ln_mean, float* __restrict__ ln_rstd,
@@ -868,7 +885,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const T* __restrict__
 // backward v2 kernels: LDS-DMA double-buffered tiles, swizzled images (see attn_fwd2_kernel)
 // ------------------------------------------------------------------------------------------
 template <typename T, int D, int KT, int NW>
-__global__ __launch_bounds__(NW * 64, (NW == 4 && D <= 64 && sizeof(T) == 2) ? 2 : 1) void attn_bwd_dq2_kernel(const T* __restrict__ qkv, const T* __restrict__ dY, const int* __restrict__ kidx,
+__global__ __launch_bounds__(NW * 64, (NW == 4 && D <= 64 && sizeof(T) == 2) ? MU_DQ_OCC : 1) void attn_bwd_dq2_kernel(const T* __restrict__ qkv, const T* __restrict__ dY, const int* __restrict__ kidx,
                                                            const int* __restrict__ kcnt, const float* __restrict__ lse2,
                                                            const float* __restrict__ delta, T* __restrict__ dqkv, int N, int nkmax,
                                                            float scale, float scale_log2) {
@@ -1155,7 +1172,7 @@ __global__ __launch_bounds__(256, (D <= 64 && sizeof(T) == 2) ? 2 : 1) void attn
 // ring), so the counted waits are exact: each wave issues exactly 3 DMA instructions per tile.
 // ------------------------------------------------------------------------------------------
 template <typename T, int D, int NKT>
-__global__ __launch_bounds__(256, (D <= 64 && sizeof(T) == 2) ? 2 : 1) void attn_bwd_dkv3_kernel(
+__global__ __launch_bounds__(256, (D <= 64 && sizeof(T) == 2 && NKT <= 2) ? MU_DKV_OCC : 1) void attn_bwd_dkv3_kernel(
     const T* __restrict__ qkv, const T* __restrict__ dY, const int* __restrict__ kidx, const int* __restrict__ kcnt,
     const float* __restrict__ rowc, T* __restrict__ dqkv, int N, int nkmax, float scale, float scale_log2) {
     using A = AT<T>;
@@ -1181,24 +1198,34 @@ __global__ __launch_bounds__(256, (D <= 64 && sizeof(T) == 2) ? 2 : 1) void attn
     const int ntile = (N + QT - 1) / QT;
     const float* rowc_b = rowc + (long)b * ntile * 64;
 
-    // exactly 2*NPW + 1 DMA instructions per wave per tile
-    auto issue = [&](int tile) {
-        const int slot = tile % DKV_RING;
-        T* Qt = lds + slot * STG;
-        T* Ot = Qt + QT * D;
+    // exactly 2*NPW + 1 DMA instructions per wave per tile.  Per-lane source offsets are loop-invariant (precomputed); a tile
+    // only moves the scalar base.  (The generic index arithmetic made the three DMAs cost ~250 issue cycles per tile.)
+    int qlane[NPW], olane[NPW], rowl[NPW];
+    {
         const int lrow = lane / Z::CPR, lch = lane % Z::CPR;
 #pragma unroll
         for (int n = 0; n < NPW; ++n) {
             const int i = wave + 4 * n;
             const int ii = i < NI ? i : 0;                   // (NI >= 4 for every instantiation: never clamps)
             const int row = ii * Z::RPW + lrow;
-            const int q = tile * QT + row;
             const int sc = lch ^ (row & Z::SW);
-            const void *qs = mu_attn_zero_page, *os = mu_attn_zero_page;
-            if (q < N) {
-                qs = qkv_b + (long)q * 3 * D + sc * Z::VN;
-                os = dY_b + (long)q * D + sc * Z::VN;
-            }
+            rowl[n] = row;
+            qlane[n] = row * 3 * D + sc * Z::VN;
+            olane[n] = row * D + sc * Z::VN;
+        }
+    }
+    auto issue = [&](int tile) {
+        const int slot = tile % DKV_RING;
+        T* Qt = lds + slot * STG;
+        T* Ot = Qt + QT * D;
+        const T* qb = qkv_b + (long)tile * QT * 3 * D;       // wave-uniform bases
+        const T* ob = dY_b + (long)tile * QT * D;
+        const bool full = tile * QT + QT <= N;               // wave-uniform: only the last tile can be partial
+#pragma unroll
+        for (int n = 0; n < NPW; ++n) {
+            const int ii = (wave + 4 * n) < NI ? (wave + 4 * n) : 0;
+            const void *qs = qb + qlane[n], *os = ob + olane[n];
+            if (!full && tile * QT + rowl[n] >= N) { qs = mu_attn_zero_page; os = mu_attn_zero_page; }
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)qs,
                                              (__attribute__((address_space(3))) void*)(Qt + ii * Z::RPW * D), 16, 0, 0);
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)os,
@@ -1252,7 +1279,6 @@ __global__ __launch_bounds__(256, (D <= 64 && sizeof(T) == 2) ? 2 : 1) void attn
         else if (DKV_RING == 4 && newer == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(OPS) : "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();                        // everyone's share of tile tl landed; tile tl-1 fully consumed
-        if (tl + DKV_RING - 1 < ntile) issue(tl + DKV_RING - 1);   // into the slot tile tl-1 just vacated
         const T* Qt = lds + SLOT * STG;
         const T* Ot = Qt + QT * D;
         const float* rc = rcs + SLOT * 256;
@@ -1306,6 +1332,9 @@ __global__ __launch_bounds__(256, (D <= 64 && sizeof(T) == 2) ? 2 : 1) void attn
                 A::mma_acc(qa, dp[0][kt], dp[1][kt], dk[dt][kt]);
             }
         }
+        // Refill the slot tile tl-1 vacated -- issued LAST in the tile: LDS reads queue behind an in-flight LDS-DMA issue
+        // (in-kernel s_memtime stamps: the row-constant reads right after the DMA cost ~980 cycles/tile, ~80 without it)
+        if (tl + DKV_RING - 1 < ntile) issue(tl + DKV_RING - 1);
     };
     for (int tl = 0; tl < ntile; tl += DKV_RING) {
         tile(std::integral_constant<int, 0>{}, tl);
@@ -1406,11 +1435,16 @@ static int attn_bwd_t(const T* qkv, const T* x, const T* oattn, const T* gout, c
         attn_ln_bwd_final_kernel<<<mu_cdiv(DD, 4), 256, 0, st>>>((const double*)ws, nblk, DD, dgamma, dbeta);                   \
     }                                                                                                                           \
     if (phases & 2) attn_bwd_dq2_kernel<T, DD, KTQ, 4><<<gq, 256, 0, st>>>(qkv, dY, kidx, kcnt, lse2, delta, dqkv, N, nkmax, scale, sl2); \
-    if (phases & 4) attn_bwd_dkv3_kernel<T, DD, NKT><<<dim3(mu_cdiv(nkmax, 64 * NKT), B), 256, 0, st>>>(qkv, dY, kidx, kcnt, rowc, dqkv, N, nkmax, scale, sl2)
+    if (phases & 4) {                                                                                                           \
+        if (DD == 64 && sizeof(T) == 2 && getenv("MU_DKV_NKT4"))                                                                \
+            attn_bwd_dkv3_kernel<T, DD, 4><<<dim3(mu_cdiv(nkmax, 256), B), 256, 0, st>>>(qkv, dY, kidx, kcnt, rowc, dqkv, N, nkmax, scale, sl2); \
+        else                                                                                                                    \
+            attn_bwd_dkv3_kernel<T, DD, NKT><<<dim3(mu_cdiv(nkmax, 64 * NKT), B), 256, 0, st>>>(qkv, dY, kidx, kcnt, rowc, dqkv, N, nkmax, scale, sl2); \
+    }
     if (N % 4) return MU_ERR_SHAPE;
     switch (C) {
         case 32: { constexpr int KTQ = 64; LAUNCH_BWD(32, 2); } break;
-        case 64: { constexpr int KTQ = 64; LAUNCH_BWD(64, 2); } break;
+        case 64: { constexpr int KTQ = MU_DQ_KT; LAUNCH_BWD(64, 2); } break;
         case 128: { constexpr int KTQ = 32; LAUNCH_BWD(128, 2); } break;
         case 256: { constexpr int KTQ = 32; LAUNCH_BWD(256, 1); } break;
         default: return MU_ERR_SHAPE;

@@ -1,0 +1,59 @@
+#!/usr/bin/env python3
+"""In-process interleaved A/B timing of library variants (cdna guide rule 24): python tests/ab_bench.py attn|conv A B [C ...]
+Variants are gpurun_variants/libmu_<NAME>.so built by tests/build_variant.sh.  Debug aid."""
+import ctypes, os, statistics, sys
+import torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from maskunet_amd import _lib
+
+
+def load(name):
+    lib = ctypes.CDLL(os.path.join(ROOT, "gpurun_variants", f"libmu_{name}.so"))
+    for n, (res, args) in _lib.SIGNATURES.items():
+        f = getattr(lib, n); f.restype = res; f.argtypes = args
+    return lib
+
+
+def timeit(fn, reps=3):
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps): fn()
+    e1.record(); torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / reps
+
+
+def main():
+    what, names = sys.argv[1], sys.argv[2:]
+    libs = {n: load(n) for n in names}
+    dev = "cuda"; dt = torch.float16; st = torch.cuda.current_stream().cuda_stream
+    if what == "attn":
+        B, N, C = 64, 16384, 64
+        qkv = torch.randn(B, N, 3 * C, device=dev, dtype=dt); x = torch.randn(B, N, C, device=dev, dtype=dt)
+        keep = torch.randint(0, 2, (B, N), device=dev, dtype=torch.uint8)
+        kidx = torch.argsort(keep, dim=1, descending=True, stable=True).to(torch.int32).contiguous(); kcnt = keep.sum(1, dtype=torch.int32).contiguous()
+        g = torch.ones(C, device=dev); b_ = torch.zeros(C, device=dev)
+        out = torch.empty_like(x); oattn = torch.empty_like(x); lse = torch.empty(B, N, device=dev); mean = torch.empty_like(lse); rstd = torch.empty_like(lse)
+        dY = torch.empty_like(x); dqkv = torch.empty_like(qkv); delta = torch.empty_like(lse); dg = torch.empty(C, device=dev); db = torch.empty(C, device=dev)
+        gout = torch.randn_like(x)
+        ws = torch.empty(_lib.load().mu_attn_bwd_workspace_bytes(B, N, C), dtype=torch.uint8, device=dev)
+        def mk(lib, phase):
+            if phase == 0:
+                return lambda: lib.mu_attn_fwd(qkv.data_ptr(), x.data_ptr(), kidx.data_ptr(), kcnt.data_ptr(), g.data_ptr(), b_.data_ptr(), out.data_ptr(), oattn.data_ptr(), lse.data_ptr(), mean.data_ptr(), rstd.data_ptr(), B, N, C, N, 1e-5, 1, st)
+            return lambda: lib.mu_attn_bwd_phases(qkv.data_ptr(), x.data_ptr(), oattn.data_ptr(), gout.data_ptr(), kidx.data_ptr(), kcnt.data_ptr(), lse.data_ptr(), mean.data_ptr(), rstd.data_ptr(), g.data_ptr(), dY.data_ptr(), delta.data_ptr(), dqkv.data_ptr(), dg.data_ptr(), db.data_ptr(), B, N, C, N, ws.data_ptr(), ws.numel(), 1, phase, st)
+        cases = [("fwd", 0), ("dq", 2), ("dkv", 4)]
+        first = libs[names[0]]; mk(first, 0)(); mk(first, 1)()
+    else:
+        B, H, Cin, Cout = 64, 128, 128, 128
+        x = torch.randn(B, H, H, Cin, device=dev, dtype=dt); w = (torch.randn(9, Cout, Cin, device=dev) * 0.05).to(dt); y = torch.empty(B, H, H, Cout, device=dev, dtype=dt)
+        def mk(lib, phase):
+            return lambda: lib.mu_conv_fwd(x.data_ptr(), w.data_ptr(), None, y.data_ptr(), B, H, H, Cin, Cout, 9, Cin, Cout, 1, st)
+        cases = [("conv128", 0)]
+    for cname, phase in cases:
+        res = {n: [] for n in names}
+        for n in names: timeit(mk(libs[n], phase), 2)
+        for rnd in range(7):
+            for n in names: res[n].append(timeit(mk(libs[n], phase)))
+        print(cname, {n: f"med {statistics.median(v):.3f} min {min(v):.3f} ms" for n, v in res.items()})
+
+main()

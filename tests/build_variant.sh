@@ -1,0 +1,16 @@
+#!/bin/bash
+# Build a variant of the HIP library for in-process A/B timing: tests/build_variant.sh NAME "-DMU_FLAG=1 ..."
+# -> gpurun_variants/libmu_NAME.so (used by tests/ab_bench.py).  Debug aid, not part of the product build.
+set -e
+NAME=$1; shift
+EXTRA="$*"
+ROOT=$(cd "$(dirname "$0")/.." && pwd)
+OUT=$ROOT/gpurun_variants
+mkdir -p $OUT/obj_$NAME
+for f in elementwise norm conv attn loss version; do
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -fPIC -std=c++17 -Wno-unused-value -Wno-pass-failed $EXTRA -c $ROOT/maskunet_amd/csrc/$f.hip -o $OUT/obj_$NAME/$f.o &
+done
+wait
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC $OUT/obj_$NAME/*.o -o $OUT/libmu_$NAME.so
+rm -rf $OUT/obj_$NAME
+echo built $OUT/libmu_$NAME.so
