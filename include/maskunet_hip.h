@@ -46,10 +46,15 @@ const char* mu_version_host(void);
  * NCHW<->NHWC conversions at the module boundary. */
 int mu_transpose(const void* src, int src_dtype, long src_ld, void* dst, int dst_dtype, long dst_ld, int batch, int R, int C,
                  void* stream);
+/* as mu_transpose, and additionally dst[b][c][r] = 0 for R <= r < R_pad <= dst_ld (the zero channel padding of the NHWC
+ * layout). */
+int mu_transpose_pad(const void* src, int src_dtype, long src_ld, void* dst, int dst_dtype, long dst_ld, int batch, int R, int C,
+                     int R_pad, void* stream);
 /* elementwise dtype conversion of n elements */
 int mu_cast(const void* src, int src_dtype, void* dst, int dst_dtype, long n, void* stream);
 /* OIHW fp32 parameter -> tap-major compute layout [taps][rows_pad][cols_pad].
- * mode 0: forward weights (rows=O, cols=I); mode 1: data-gradient weights (taps flipped, rows=I, cols=O). */
+ * mode 0: forward weights (rows=O, cols=I); mode 1: data-gradient weights (taps flipped, rows=I, cols=O);
+ * mode 2: both in one launch, dst = the mode-0 block followed by the mode-1 block [taps][cols_pad][rows_pad]. */
 int mu_prep_weight(const float* w_oihw, void* dst, int dtype, int O, int I, int taps, int rows_pad, int cols_pad, int mode,
                    void* stream);
 

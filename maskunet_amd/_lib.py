@@ -24,6 +24,7 @@ P, I, L, F = c_void_p, c_int, c_long, c_float
 SIGNATURES = {
     "mu_version_host": (c_char_p, []),
     "mu_transpose": (I, [P, I, L, P, I, L, I, I, I, P]),
+    "mu_transpose_pad": (I, [P, I, L, P, I, L, I, I, I, I, P]),
     "mu_cast": (I, [P, I, P, I, L, P]),
     "mu_prep_weight": (I, [P, P, I, I, I, I, I, I, I, P]),
     "mu_conv_fwd": (I, [P, P, P, P, I, I, I, I, I, I, L, L, I, P]),

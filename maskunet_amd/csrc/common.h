@@ -55,6 +55,39 @@ __device__ __forceinline__ float mu_act_grad(float x, int act) {
     return act == MU_ACT_GELU ? mu_gelu_grad(x) : (act == MU_ACT_RELU ? (x > 0.f ? 1.f : 0.f) : 1.f);
 }
 
+// Exact-GELU pieces for fp16 storage: Phi(x) = 0.5 erfc(-x/sqrt2) from the Abramowitz-Stegun 7.1.26 rational form
+// erfc(z) = t (a1 + t (a2 + ...)) exp(-z^2), t = 1/(1 + p z), |abs error| <= 1.5e-7 * exp(-z^2) -- three decimal orders
+// below the fp16 rounding of the result -- with one v_rcp and one v_exp instead of the ~40-instruction erff.  The
+// negative side is evaluated as erfc directly (no 1 - erf cancellation).  *pdf = exp(-x^2/2), shared with the gradient.
+__device__ __forceinline__ float mu_phi_fast(float x, float* e_out) {
+    const float z = fabsf(x) * 0.70710678118654752440f;
+    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z, 1.0f));
+    float p = fmaf(t, 1.061405429f, -1.453152027f);
+    p = fmaf(t, p, 1.421413741f);
+    p = fmaf(t, p, -0.284496736f);
+    p = fmaf(t, p, 0.254829592f);
+    const float e = __builtin_amdgcn_exp2f(x * x * -0.72134752044448170368f);      // exp(-x^2/2)
+    const float q = 0.5f * t * p * e;
+    *e_out = e;
+    return x < 0.f ? q : 1.0f - q;
+}
+template <bool FAST>
+__device__ __forceinline__ float mu_act_t(float x, int act) {
+    if (act == MU_ACT_GELU) {
+        if (FAST) { float e; return x * mu_phi_fast(x, &e); }
+        return mu_gelu(x);
+    }
+    return act == MU_ACT_RELU ? fmaxf(x, 0.f) : x;
+}
+template <bool FAST>
+__device__ __forceinline__ float mu_act_grad_t(float x, int act) {
+    if (act == MU_ACT_GELU) {
+        if (FAST) { float e; const float phi = mu_phi_fast(x, &e); return fmaf(x * 0.39894228040143267794f, e, phi); }
+        return mu_gelu_grad(x);
+    }
+    return act == MU_ACT_RELU ? (x > 0.f ? 1.f : 0.f) : 1.f;
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);

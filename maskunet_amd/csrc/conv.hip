@@ -628,6 +628,194 @@ __global__ __launch_bounds__(256, 2) void conv_nt3p_kernel(const T* __restrict__
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// v4 for 3x3, fp16, Cout % 128 == 0: the halo-tile kernel re-scheduled as a ping-pong pipeline (cdna guide, "256^2 8-phase
+// template": one block per CU, LDS-DMA prefetch that stays in flight across raw s_barriers, counted vmcnt, two wave groups
+// staggered by one barrier so that one group's MFMA section overlaps the other group's LDS-read/DMA-issue section).
+//   block : 512 threads = 8 waves, tile 128 output channels x (16 x 16) pixels of one image; wave = 64 co x (4 rows x 16) px
+//   LDS   : halo 18 x 18 x 128 B double-buffered (2 x 41 KB) + ring of FOUR 16 KB weight tiles (tap x 64 ci) + 1 KB dump
+//   phase : half a tap (32 of the 64 ci): 8 ds_read_b128 -> s_barrier -> 16 MFMA -> s_barrier; 4 barriers per tap
+//   DMA   : issued in the second phase of tap s: one halo piece of the next 64-channel chunk (taps 0..6; a dummy afterwards,
+//           so that every wave issues exactly 3 DMAs per tap and vmcnt counts stay uniform) + the 2 instructions of this
+//           wave's share of W(s+3) into ring slot (s+3)&3 == (s-1)&3, whose last readers passed a barrier a full phase ago
+//   wait  : s_waitcnt vmcnt(3) in the first phase's MFMA section of tap s retires W(s+1) (issued in tap s-2) and leaves
+//           tap s-1's three DMAs in flight; two barriers separate that wait from the first read of W(s+1) -- one more
+//           than the unstaggered rule needs, because group B trails group A by one barrier.
+// Versus v3 the weight tile is shared by 256 instead of 128 pixels (half the L2->LDS bytes per flop) and the DMA
+// lookahead grows from one tap (~0.25 us, less than an L2 hit under load) to three phases.
+// ------------------------------------------------------------------------------------------
+#ifndef MU_CONV_NT4
+#define MU_CONV_NT4 1
+#endif
+__global__ __launch_bounds__(512, 1) void conv_nt4_kernel(const h16* __restrict__ x, const h16* __restrict__ w, const float* __restrict__ bias,
+                                                          h16* __restrict__ y, int B, int H, int W, int Cin, int Cout, long x_ld, long y_ld) {
+    using M_ = Mma<h16>;
+    using Frag = M_::Frag;
+    constexpr int VN = 8, KC = 64, TM = 4, TN = 4, WC = 4, NWV = 8, BCO = 128;
+    constexpr int TH = 16, TW = 16, HW_ = TW + 2, HROWS = (TH + 2) * HW_;       // 324 halo rows of 128 B
+    constexpr int HINST = (HROWS + 7) / 8;                                       // 41 wave-DMA instructions (8 rows each)
+    constexpr int HPW = 7;                                                       // halo pieces per wave: taps 0..6
+    static_assert(HPW * NWV >= HINST, "halo does not fit the 7 tap steps");
+    constexpr int HBYTES = HINST * 1024, WBYTES = BCO * 128, NWB = 4;
+
+    __shared__ __attribute__((aligned(16))) char lds[2 * HBYTES + NWB * WBYTES + 1024];
+    char* Hs = lds;
+    char* Ws = lds + 2 * HBYTES;
+    char* dump = lds + 2 * HBYTES + NWB * WBYTES;
+
+    const int tiles_w = W / TW, tiles_h = H / TH;
+    const int ntile = B * tiles_h * tiles_w, ncb = Cout / BCO;
+    const int L = xcd_remap(blockIdx.x, ntile * ncb);
+    const int cb = L % ncb, tl = L / ncb;
+    const int co0 = cb * BCO;
+    const int tw_ = tl % tiles_w, th_ = (tl / tiles_w) % tiles_h, bimg = tl / (tiles_w * tiles_h);
+    const int h0 = th_ * TH, w0 = tw_ * TW;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform: scalar branches
+    const int wr = wave >> 2, wc = wave & 3;                 // wr doubles as the ping-pong group (waves 0-3 / 4-7: one of each per SIMD)
+    const int r16 = lane & 15, g = lane >> 4;
+    const int srow = lane >> 3, sch = lane & 7;
+
+    const int kchunks = Cin / KC;
+    const int nsteps = 9 * kchunks;
+
+    int wl[2];                                               // this wave's two weight-DMA instructions: rows (i*8+wave)*8 + srow
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int row = (i * NWV + wave) * 8 + srow;
+        wl[i] = (co0 + row) * Cin + (sch ^ (row & 7)) * VN;
+    }
+    int hl[HPW];                                             // halo pieces k*8+wave: element offset, -1 = zero ring
+#pragma unroll
+    for (int k = 0; k < HPW; ++k) {
+        const int hr = (k * NWV + wave) * 8 + srow;
+        const int hy = hr / HW_, hx = hr - hy * HW_;
+        const int hh = h0 - 1 + hy, ww = w0 - 1 + hx;
+        const bool ok = hr < HROWS && hh >= 0 && hh < H && ww >= 0 && ww < W;
+        hl[k] = ok ? (int)(((long)hh * W + ww) * x_ld) + (sch ^ (hx & 7)) * VN : -1;
+    }
+    const h16* xb = x + (long)bimg * H * W * x_ld;
+
+    auto stage_w = [&](int s) {                              // W(s) -> ring slot s & 3 (dummy beyond the last step)
+        if (s < nsteps) {
+            const int tap = s % 9, ci0 = (s / 9) * KC;
+            const h16* wb = w + (long)tap * Cout * Cin + ci0;
+            char* Wb = Ws + (s & 3) * WBYTES;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) glds16(wb + wl[i], Wb + (i * NWV + wave) * 1024);
+        } else {
+            glds16(mu_zero_page, dump);
+            glds16(mu_zero_page, dump);
+        }
+    };
+    auto stage_h = [&](int k, int c) {                       // piece k of chunk c's halo -> buffer c & 1 (dummy if none)
+        const int off = hl[k];
+        if (c < kchunks && k * NWV + wave < HINST) {        // wave-uniform
+#ifdef MU_NT4_ABL_NOHALO
+            const void* src = (const void*)mu_zero_page;
+#else
+            const void* src = off >= 0 ? (const void*)(xb + off + c * KC) : (const void*)mu_zero_page;
+#endif
+            glds16(src, Hs + (c & 1) * HBYTES + (k * NWV + wave) * 1024);
+        } else {
+            glds16(mu_zero_page, dump);
+        }
+    };
+
+    f32x4 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    int aoff[2], boff[3][2];
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+        aoff[kk] = (wr * TM * 16 + r16) * 128 + (((kk * 4 + g) ^ (r16 & 7)) << 4);
+#pragma unroll
+        for (int dw = 0; dw < 3; ++dw) boff[dw][kk] = (wc * TN * HW_ + r16 + dw) * 128 + (((kk * 4 + g) ^ ((r16 + dw) & 7)) << 4);
+    }
+
+    // prologue: halo of chunk 0 and W(0..2), drained; then group B falls one barrier behind
+#pragma unroll
+    for (int k = 0; k < HPW; ++k) stage_h(k, 0);
+    stage_w(0);
+    stage_w(1);
+    stage_w(2);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (wr == 1) __builtin_amdgcn_s_barrier();
+
+    int s = 0;
+    for (int c = 0; c < kchunks; ++c) {
+        const int hbuf = (c & 1) * HBYTES;
+#pragma unroll
+        for (int t = 0; t < 9; ++t, ++s) {
+            const int dh = t / 3, dw = t % 3;
+            const char* Wb = Ws + (s & 3) * WBYTES;
+            const char* Hb = Hs + hbuf + dh * (HW_ * 128);
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+                Frag a[TM], b[TN];
+                const char* wa = Wb + aoff[kk];
+                const char* hb = Hb + boff[dw][kk];
+#pragma unroll
+                for (int i = 0; i < TM; ++i) a[i] = *reinterpret_cast<const Frag*>(wa + i * 2048);
+#pragma unroll
+                for (int j = 0; j < TN; ++j) b[j] = *reinterpret_cast<const Frag*>(hb + j * (HW_ * 128));
+                if (kk == 1) {                               // exactly three DMAs per wave per tap
+                    if (t < HPW) stage_h(t, c + 1); else glds16(mu_zero_page, dump);
+                    stage_w(s + 3);
+                }
+                __builtin_amdgcn_s_barrier();
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_sched_barrier(0);
+                __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) M_::mma(a[i], b[j], acc[i][j]);
+                __builtin_amdgcn_s_setprio(0);
+                if (kk == 0) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+                __builtin_amdgcn_sched_barrier(0);
+                __builtin_amdgcn_s_barrier();
+            }
+        }
+    }
+    if (wr == 0) __builtin_amdgcn_s_barrier();
+
+    // Epilogue through LDS (the halo buffers are free now): the accumulator layout gives each lane 4 channels of one pixel
+    // (8-byte pieces, 32 contiguous bytes per 4 lanes); staged as out[pixel][128 co] and re-read as 16-byte pieces, every
+    // wave store covers four whole 256-byte pixel rows.  8-byte slot of row p is XORed with (p & 15) << 1 on the write,
+    // i.e. 16-byte slot ^ (p & 15) on the read: both sides are bank-conflict free.
+    char* Os = lds;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int p = (wc * TN + j) * 16 + r16;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const int co = (wr * TM + i) * 16 + 4 * g;
+            float v[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = acc[i][j][r] + (bias ? bias[co0 + co + r] : 0.f);
+            h16x4 o = {(h16)v[0], (h16)v[1], (h16)v[2], (h16)v[3]};
+            *reinterpret_cast<h16x4*>(Os + p * 256 + (((co >> 2) ^ (r16 << 1)) << 3)) = o;
+        }
+    }
+    __syncthreads();
+    const int q = tid & 15;
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+        const int p = it * 32 + (tid >> 4);
+        const h16x8 o = *reinterpret_cast<const h16x8*>(Os + p * 256 + ((q ^ (p & 15)) << 4));
+        const long gp = ((long)bimg * H + h0 + (p >> 4)) * W + w0 + (p & 15);
+#ifdef MU_NT4_ABL_NOSTORE
+        if (B < 0)
+#endif
+        *reinterpret_cast<h16x8*>(y + gp * y_ld + co0 + q * 8) = o;
+    }
+}
+
 template <typename T, int TAPS>
 static int conv_fwd_launch(const T* x, const T* w, const float* bias, T* y, int B, int H, int W, int Cin, int Cout, long x_ld,
                            long y_ld, hipStream_t st) {
@@ -639,6 +827,12 @@ static int conv_fwd_launch(const T* x, const T* w, const float* bias, T* y, int 
             // L2->LDS bytes per flop) yet the step time is unchanged (45.39 vs 45.29 ms): v3 is no longer L2->LDS bound
             conv_nt3_kernel<T, 4, 4, 2, 8><<<B * (H / 16) * (W / 16) * (Cout / 128), 512, 0, st>>>(x, w, bias, y, B, H, W, Cin, Cout, x_ld, y_ld);
             return MU_OK;
+        }
+        if constexpr (sizeof(T) == 2 && MU_CONV_NT4) {
+            if (Cout % 128 == 0 && H % 16 == 0 && Cin % 64 == 0 && !getenv("MU_CONV_NO_NT4")) {
+                conv_nt4_kernel<<<B * (H / 16) * (W / 16) * (Cout / 128), 512, 0, st>>>(x, w, bias, y, B, H, W, Cin, Cout, x_ld, y_ld);
+                return MU_OK;
+            }
         }
         if (Cout % 128 == 0 && H % 8 == 0) {
             const int ntile = B * (H / 8) * (W / 16), ncb = Cout / 128;
@@ -973,17 +1167,45 @@ __global__ __launch_bounds__(NWV * 64, 1) void conv_wgrad3_kernel(const h16* __r
 }
 
 // dst_oihw[o][i][t] = sum_split part[split][t][o][i]   (valid region only)
-__global__ void wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ dst, int nsplit, int taps, int Cout, int Cin,
-                                    int O, int I) {
+// KL k-lanes per output element: each lane sums every KL-th slab with 4 independent accumulators (16 loads in flight per
+// element instead of one dependent chain); lanes are combined through LDS in a fixed order, so the result is deterministic.
+template <int KL>
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ dst, int nsplit, int taps,
+                                                           int Cout, int Cin, int O, int I) {
+    constexpr int EPB = 256 / KL;                     // elements per block
+    __shared__ float red[KL][EPB];
     const long n = (long)O * I * taps;
-    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < n; idx += (long)gridDim.x * blockDim.x) {
+    const int e = threadIdx.x % EPB, kl = threadIdx.x / EPB;
+    const long slab = (long)taps * Cout * Cin;
+    for (long base = (long)blockIdx.x * EPB; base < n; base += (long)gridDim.x * EPB) {
+        const long idx = base + e;
         // iterate in slab order (t, o, i) for coalesced reads
         const int i = idx % I;
         const int o = (idx / I) % O;
         const int t = idx / ((long)I * O);
-        float s = 0.f;
-        for (int k = 0; k < nsplit; ++k) s += part[(((long)k * taps + t) * Cout + o) * Cin + i];
-        dst[((long)o * I + i) * taps + t] = s;
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+        if (idx < n) {
+            const float* p = part + ((long)t * Cout + o) * Cin + i;
+            int k = kl;
+            for (; k + 3 * KL < nsplit; k += 4 * KL) {
+                s0 += p[(long)k * slab];
+                s1 += p[(long)(k + KL) * slab];
+                s2 += p[(long)(k + 2 * KL) * slab];
+                s3 += p[(long)(k + 3 * KL) * slab];
+            }
+            for (; k < nsplit; k += KL) s0 += p[(long)k * slab];
+        }
+        float s = (s0 + s1) + (s2 + s3);
+        if (KL > 1) {
+            red[kl][e] = s;
+            __syncthreads();
+            if (kl == 0) {
+#pragma unroll
+                for (int j = 1; j < KL; ++j) s += red[j][e];
+            }
+        }
+        if (kl == 0 && idx < n) dst[((long)o * I + i) * taps + t] = s;
+        if (KL > 1) __syncthreads();
     }
 }
 
@@ -1081,8 +1303,13 @@ extern "C" int mu_conv_wgrad(const void* x, const void* dy, float* dw_oihw, int 
         else wgrad_launch<float, 1>((const float*)x, (const float*)dy, part, B, H, W, Cin, Cout, x_ld, dy_ld, bco, nsplit, pps, st);
     } else return MU_ERR_ARG;
     const long n = (long)cout_valid * cin_valid * taps;
-    const int grid = (int)((n + 255) / 256 > 2048 ? 2048 : (n + 255) / 256);
-    wgrad_reduce_kernel<<<grid, 256, 0, st>>>(part, dw_oihw, nsplit, taps, Cout, Cin, cout_valid, cin_valid);
+    if (nsplit >= 16) {
+        const long nb = (n + 63) / 64;
+        wgrad_reduce_kernel<4><<<(int)(nb > 4096 ? 4096 : nb), 256, 0, st>>>(part, dw_oihw, nsplit, taps, Cout, Cin, cout_valid, cin_valid);
+    } else {
+        const long nb = (n + 255) / 256;
+        wgrad_reduce_kernel<1><<<(int)(nb > 2048 ? 2048 : nb), 256, 0, st>>>(part, dw_oihw, nsplit, taps, Cout, Cin, cout_valid, cin_valid);
+    }
     MU_CHECK_LAUNCH();
     return MU_OK;
 }

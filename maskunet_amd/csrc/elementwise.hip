@@ -10,7 +10,7 @@
 // ------------------------------------------------------------------------------------------
 template <typename TS, typename TD>
 __global__ __launch_bounds__(256) void transpose_kernel(const TS* __restrict__ src, long src_ld, TD* __restrict__ dst,
-                                                        long dst_ld, int R, int C) {
+                                                        long dst_ld, int R, int C, int R_pad) {
     __shared__ float tile[64][65];
     const int b = blockIdx.z;
     const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
@@ -26,45 +26,121 @@ __global__ __launch_bounds__(256) void transpose_kernel(const TS* __restrict__ s
 #pragma unroll 4
     for (int i = ty; i < 64; i += 4) {
         int c = c0 + i, r = r0 + tx;
-        if (c < C && r < R) d[(long)c * dst_ld + r] = (TD)tile[tx][i];
+        if (c < C && r < R_pad) d[(long)c * dst_ld + r] = (TD)tile[tx][i];      // rows >= R hold zeros
     }
 }
 
-extern "C" int mu_transpose(const void* src, int src_dtype, long src_ld, void* dst, int dst_dtype, long dst_ld,
-                            int batch, int R, int C, void* stream) {
-    if (!src || !dst || batch <= 0 || R <= 0 || C <= 0 || src_ld < C || dst_ld < R) return MU_ERR_ARG;
-    dim3 grid(mu_cdiv(C, 64), mu_cdiv(R, 64), batch), block(256);
+// Vector variant: 4-element (8/16-byte) global accesses on both sides, rows r in [R, R_pad) of the destination are written
+// as zeros (channel padding of the NHWC layout, so the caller does not need a separate memset).
+// Requires 4-element alignment of both base pointers and leading dimensions; edges fall back to guarded scalars.
+template <typename T> struct V4 { T v[4]; };
+template <typename TS, typename TD>
+__global__ __launch_bounds__(256) void transpose_vec_kernel(const TS* __restrict__ src, long src_ld, TD* __restrict__ dst,
+                                                            long dst_ld, int R, int C, int R_pad) {
+    __shared__ float tile[64][65];
+    const int b = blockIdx.z;
+    const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
+    const TS* s = src + (long)b * R * src_ld;
+    TD* d = dst + (long)b * C * dst_ld;
+    const int tv = (threadIdx.x & 15) * 4, ty = threadIdx.x >> 4;
+#pragma unroll
+    for (int i = ty; i < 64; i += 16) {
+        const int r = r0 + i, c = c0 + tv;
+        float v[4] = {0.f, 0.f, 0.f, 0.f};
+        if (r < R) {
+            if (c + 3 < C) {
+                V4<TS> q = *reinterpret_cast<const V4<TS>*>(s + (long)r * src_ld + c);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) v[k] = (float)q.v[k];
+            } else {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) if (c + k < C) v[k] = (float)s[(long)r * src_ld + c + k];
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) tile[i][tv + k] = v[k];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = ty; i < 64; i += 16) {
+        const int c = c0 + i, r = r0 + tv;
+        if (c >= C || r >= R_pad) continue;
+        V4<TD> q;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) q.v[k] = (TD)tile[tv + k][i];     // rows >= R hold zeros
+        if (r + 3 < R_pad) {
+            *reinterpret_cast<V4<TD>*>(d + (long)c * dst_ld + r) = q;
+        } else {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) if (r + k < R_pad) d[(long)c * dst_ld + r + k] = q.v[k];
+        }
+    }
+}
+
+extern "C" int mu_transpose_pad(const void* src, int src_dtype, long src_ld, void* dst, int dst_dtype, long dst_ld,
+                                int batch, int R, int C, int R_pad, void* stream) {
+    if (!src || !dst || batch <= 0 || R <= 0 || C <= 0 || src_ld < C || R_pad < R || dst_ld < R_pad) return MU_ERR_ARG;
     hipStream_t st = (hipStream_t)stream;
+    const size_t es = src_dtype == MU_F32 ? 4 : 2, ed = dst_dtype == MU_F32 ? 4 : 2;
+    const bool vec = ((size_t)src % (4 * es) == 0) && ((size_t)dst % (4 * ed) == 0) && src_ld % 4 == 0 && dst_ld % 4 == 0 &&
+                     ((long)R * src_ld) % 4 == 0 && ((long)C * dst_ld) % 4 == 0;
+    if (vec) {
+        dim3 grid(mu_cdiv(C, 64), mu_cdiv(R_pad, 64), batch), block(256);
+        if (src_dtype == MU_F32 && dst_dtype == MU_F32)
+            transpose_vec_kernel<float, float><<<grid, block, 0, st>>>((const float*)src, src_ld, (float*)dst, dst_ld, R, C, R_pad);
+        else if (src_dtype == MU_F32 && dst_dtype == MU_F16)
+            transpose_vec_kernel<float, h16><<<grid, block, 0, st>>>((const float*)src, src_ld, (h16*)dst, dst_ld, R, C, R_pad);
+        else if (src_dtype == MU_F16 && dst_dtype == MU_F32)
+            transpose_vec_kernel<h16, float><<<grid, block, 0, st>>>((const h16*)src, src_ld, (float*)dst, dst_ld, R, C, R_pad);
+        else if (src_dtype == MU_F16 && dst_dtype == MU_F16)
+            transpose_vec_kernel<h16, h16><<<grid, block, 0, st>>>((const h16*)src, src_ld, (h16*)dst, dst_ld, R, C, R_pad);
+        else
+            return MU_ERR_ARG;
+        MU_CHECK_LAUNCH();
+        return MU_OK;
+    }
+    dim3 grid(mu_cdiv(C, 64), mu_cdiv(R_pad, 64), batch), block(256);
     if (src_dtype == MU_F32 && dst_dtype == MU_F32)
-        transpose_kernel<float, float><<<grid, block, 0, st>>>((const float*)src, src_ld, (float*)dst, dst_ld, R, C);
+        transpose_kernel<float, float><<<grid, block, 0, st>>>((const float*)src, src_ld, (float*)dst, dst_ld, R, C, R_pad);
     else if (src_dtype == MU_F32 && dst_dtype == MU_F16)
-        transpose_kernel<float, h16><<<grid, block, 0, st>>>((const float*)src, src_ld, (h16*)dst, dst_ld, R, C);
+        transpose_kernel<float, h16><<<grid, block, 0, st>>>((const float*)src, src_ld, (h16*)dst, dst_ld, R, C, R_pad);
     else if (src_dtype == MU_F16 && dst_dtype == MU_F32)
-        transpose_kernel<h16, float><<<grid, block, 0, st>>>((const h16*)src, src_ld, (float*)dst, dst_ld, R, C);
+        transpose_kernel<h16, float><<<grid, block, 0, st>>>((const h16*)src, src_ld, (float*)dst, dst_ld, R, C, R_pad);
     else if (src_dtype == MU_F16 && dst_dtype == MU_F16)
-        transpose_kernel<h16, h16><<<grid, block, 0, st>>>((const h16*)src, src_ld, (h16*)dst, dst_ld, R, C);
+        transpose_kernel<h16, h16><<<grid, block, 0, st>>>((const h16*)src, src_ld, (h16*)dst, dst_ld, R, C, R_pad);
     else
         return MU_ERR_ARG;
     MU_CHECK_LAUNCH();
     return MU_OK;
 }
 
+extern "C" int mu_transpose(const void* src, int src_dtype, long src_ld, void* dst, int dst_dtype, long dst_ld,
+                            int batch, int R, int C, void* stream) {
+    return mu_transpose_pad(src, src_dtype, src_ld, dst, dst_dtype, dst_ld, batch, R, C, R, stream);
+}
+
 // ------------------------------------------------------------------------------------------
 // weight re-layout: OIHW fp32 -> [tap][rows_pad][cols_pad] T
 //   mode 0 (forward):   dst[t][o][i]      = w[o][i][t]
 //   mode 1 (data-grad): dst[T-1-t][i][o]  = w[o][i][t]   (taps flipped, in/out swapped)
+//   mode 2 (both, one launch): the mode-0 block [taps][rows_pad][cols_pad] followed by the mode-1 block [taps][cols_pad][rows_pad]
 // rows/cols beyond the valid extent are zero.
 // ------------------------------------------------------------------------------------------
 template <typename T>
 __global__ void prep_weight_kernel(const float* __restrict__ w, T* __restrict__ dst, int O, int I, int taps,
                                    int rows_pad, int cols_pad, int mode) {
-    long n = (long)taps * rows_pad * cols_pad;
-    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < n; idx += (long)gridDim.x * blockDim.x) {
-        int c = idx % cols_pad;
-        int r = (idx / cols_pad) % rows_pad;
-        int t = idx / ((long)cols_pad * rows_pad);
+    const long n = (long)taps * rows_pad * cols_pad;
+    const long total = mode == 2 ? 2 * n : n;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        const bool second = idx >= n;
+        const int m = mode == 2 ? (second ? 1 : 0) : mode;
+        const long j = second ? idx - n : idx;
+        const int rp = second ? cols_pad : rows_pad, cp = second ? rows_pad : cols_pad;
+        int c = j % cp;
+        int r = (j / cp) % rp;
+        int t = j / ((long)cp * rp);
         float v = 0.f;
-        if (mode == 0) {
+        if (m == 0) {
             if (r < O && c < I) v = w[((long)r * I + c) * taps + t];
         } else {
             if (r < I && c < O) v = w[((long)c * I + r) * taps + (taps - 1 - t)];
@@ -76,8 +152,9 @@ __global__ void prep_weight_kernel(const float* __restrict__ w, T* __restrict__ 
 extern "C" int mu_prep_weight(const float* w_oihw, void* dst, int dtype, int O, int I, int taps, int rows_pad,
                               int cols_pad, int mode, void* stream) {
     if (!w_oihw || !dst || O <= 0 || I <= 0 || (taps != 1 && taps != 9)) return MU_ERR_ARG;
-    if (mode == 0 ? (rows_pad < O || cols_pad < I) : (rows_pad < I || cols_pad < O)) return MU_ERR_ARG;
-    long n = (long)taps * rows_pad * cols_pad;
+    if (mode < 0 || mode > 2) return MU_ERR_ARG;
+    if (mode != 1 ? (rows_pad < O || cols_pad < I) : (rows_pad < I || cols_pad < O)) return MU_ERR_ARG;
+    long n = (long)taps * rows_pad * cols_pad * (mode == 2 ? 2 : 1);
     int grid = (int)((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048);
     hipStream_t st = (hipStream_t)stream;
     if (dtype == MU_F32)

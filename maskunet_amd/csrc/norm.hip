@@ -14,6 +14,10 @@
 // MODE 0: (sum x, sum x^2)                                  -> BN forward statistics
 // MODE 1: dz = g * act'(pre), writes dz to dzbuf, sums (dz, dz*xhat) -> BN backward
 // layout of thread work: tc = channel vector chunk, tr = row lane; LDS [tr][C][2] reduce.
+// Each thread keeps U independent 16-byte loads per operand in flight (the sweep is latency-bound otherwise: one load
+// per wave covers 1 KB and a CU needs ~64 KB outstanding to saturate HBM), sums the U rows in fp32 and folds that
+// short sum into the fp64 accumulators -- U-fold fewer fp64 instructions, same final precision (fp32 sum of <= 8 terms).
+// FAST = the fp16-storage GELU (common.h mu_phi_fast); fp32 storage keeps erff.
 // ------------------------------------------------------------------------------------------
 template <typename T, int MODE>
 __global__ __launch_bounds__(256) void bn_partial_kernel(const T* __restrict__ x, const T* __restrict__ g, const T* __restrict__ res,
@@ -22,6 +26,8 @@ __global__ __launch_bounds__(256) void bn_partial_kernel(const T* __restrict__ x
                                                          const float* __restrict__ gamma, const float* __restrict__ beta, int act,
                                                          double* __restrict__ part) {
     constexpr int N = Vec16<T>::N;
+    constexpr int U = MODE == 0 ? 8 : 4;
+    constexpr bool FAST = sizeof(T) == 2;
     extern __shared__ __attribute__((aligned(16))) double sh[];   // [rpi][C][2]
     const int cv = C / N;
     const int rpi = 256 / cv;
@@ -38,32 +44,51 @@ __global__ __launch_bounds__(256) void bn_partial_kernel(const T* __restrict__ x
 #pragma unroll
             for (int i = 0; i < N; ++i) { mu[i] = mean[c + i]; rs[i] = rstd[c + i]; ga[i] = gamma[c + i]; be[i] = beta[c + i]; }
         }
-        for (long r = r0 + tr; r < r1; r += rpi) {
-            Vec16<T> xv;
-            xv.load(x + r * ld + c);
-            if (MODE == 0) {
+        for (long r = r0 + tr; r < r1; r += (long)U * rpi) {
+            Vec16<T> xv[U], gv[U], rv[U];
 #pragma unroll
-                for (int i = 0; i < N; ++i) {
-                    double v = (double)xv.get(i);
-                    s0[i] += v;
-                    s1[i] += v * v;
+            for (int u = 0; u < U; ++u) {
+                const long rr = r + (long)u * rpi;
+                if (rr < r1) {
+                    xv[u].load(x + rr * ld + c);
+                    if (MODE == 1) {
+                        gv[u].load(g + rr * ld + c);
+                        if (res) rv[u].load(res + rr * ld + c);
+                    }
+                } else {
+                    xv[u].zero();
+                    if (MODE == 1) { gv[u].zero(); rv[u].zero(); }      // g = 0 -> dz = 0: no contribution
                 }
-            } else {
-                Vec16<T> gv, rv, dz;
-                gv.load(g + r * ld + c);
-                if (res) rv.load(res + r * ld + c);
-#pragma unroll
-                for (int i = 0; i < N; ++i) {
-                    float xh = (xv.get(i) - mu[i]) * rs[i];
-                    float pre = xh * ga[i] + be[i] + (res ? rv.get(i) : 0.f);
-                    float d = gv.get(i) * mu_act_grad(pre, act);
-                    dz.set(i, d);
-                    d = dz.get(i);       // the value the apply pass will re-read (rounded to T)
-                    s0[i] += (double)d;
-                    s1[i] += (double)d * (double)xh;
-                }
-                dz.store(dzbuf + r * ld + c);
             }
+            float f0[N], f1[N];
+#pragma unroll
+            for (int i = 0; i < N; ++i) { f0[i] = 0.f; f1[i] = 0.f; }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                if (MODE == 0) {
+#pragma unroll
+                    for (int i = 0; i < N; ++i) {
+                        const float v = xv[u].get(i);
+                        f0[i] += v;
+                        f1[i] = fmaf(v, v, f1[i]);
+                    }
+                } else {
+                    const long rr = r + (long)u * rpi;
+                    Vec16<T> dz;
+#pragma unroll
+                    for (int i = 0; i < N; ++i) {
+                        const float xh = (xv[u].get(i) - mu[i]) * rs[i];
+                        const float pre = fmaf(xh, ga[i], be[i]) + (res ? rv[u].get(i) : 0.f);
+                        dz.set(i, gv[u].get(i) * mu_act_grad_t<FAST>(pre, act));
+                        const float d = dz.get(i);       // the value the apply pass will re-read (rounded to T)
+                        f0[i] += d;
+                        f1[i] = fmaf(d, xh, f1[i]);
+                    }
+                    if (rr < r1) dz.store(dzbuf + rr * ld + c);
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < N; ++i) { s0[i] += (double)f0[i]; s1[i] += (double)f1[i]; }
         }
 #pragma unroll
         for (int i = 0; i < N; ++i) {
@@ -127,36 +152,49 @@ __global__ void bn_bwd_final_kernel(const double* __restrict__ part, int nblk, i
     s2[c] = training ? (float)(b / (double)M) : 0.f;
 }
 
+// Elementwise passes: grid-stride over 16-byte vectors with a stride that is a multiple of the vectors per row (ew_grid),
+// so a thread's channel chunk -- and its per-channel constants -- never change; U vectors per operand in flight.
 template <typename T>
 __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const T* __restrict__ x, const T* __restrict__ res, T* __restrict__ y, long M,
                                                          int C, long ld, const float* __restrict__ mean, const float* __restrict__ rstd,
                                                          const float* __restrict__ gamma, const float* __restrict__ beta, int act) {
     constexpr int N = Vec16<T>::N;
+    constexpr int U = 4;
+    constexpr bool FAST = sizeof(T) == 2;
     const int cv = C / N;
     const long total = M * cv;
-    int last_tc = -1;
+    const long stride = (long)gridDim.x * 256;
+    const long first = (long)blockIdx.x * 256 + threadIdx.x;
+    const int c = (int)(first % cv) * N;
+    const long rstep = stride / cv;
     float a[N], b[N];
-    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
-        const int tc = idx % cv;
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        a[i] = rstd[c + i] * gamma[c + i];
+        b[i] = beta[c + i] - mean[c + i] * a[i];
+    }
+    for (long idx = first; idx < total; idx += U * stride) {
         const long r = idx / cv;
-        const int c = tc * N;
-        if (tc != last_tc) {
+        Vec16<T> xv[U], rv[U];
 #pragma unroll
-            for (int i = 0; i < N; ++i) {
-                a[i] = rstd[c + i] * gamma[c + i];
-                b[i] = beta[c + i] - mean[c + i] * a[i];
+        for (int u = 0; u < U; ++u) {
+            if (idx + u * stride < total) {
+                xv[u].load(x + (r + u * rstep) * ld + c);
+                if (res) rv[u].load(res + (r + u * rstep) * ld + c);
             }
-            last_tc = tc;
         }
-        Vec16<T> xv, rv, o;
-        xv.load(x + r * ld + c);
-        if (res) rv.load(res + r * ld + c);
 #pragma unroll
-        for (int i = 0; i < N; ++i) {
-            float pre = xv.get(i) * a[i] + b[i] + (res ? rv.get(i) : 0.f);
-            o.set(i, mu_act(pre, act));
+        for (int u = 0; u < U; ++u) {
+            if (idx + u * stride < total) {
+                Vec16<T> o;
+#pragma unroll
+                for (int i = 0; i < N; ++i) {
+                    const float pre = fmaf(xv[u].get(i), a[i], b[i]) + (res ? rv[u].get(i) : 0.f);
+                    o.set(i, mu_act_t<FAST>(pre, act));
+                }
+                o.store(y + (r + u * rstep) * ld + c);
+            }
         }
-        o.store(y + r * ld + c);
     }
 }
 
@@ -167,30 +205,41 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
                                                            const float* __restrict__ gamma, const float* __restrict__ s1,
                                                            const float* __restrict__ s2) {
     constexpr int N = Vec16<T>::N;
+    constexpr int U = 4;
     const int cv = C / N;
     const long total = M * cv;
-    int last_tc = -1;
-    float mu[N], rs[N], gr[N], a1[N], a2[N];
-    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
-        const int tc = idx % cv;
+    const long stride = (long)gridDim.x * 256;
+    const long first = (long)blockIdx.x * 256 + threadIdx.x;
+    const int c = (int)(first % cv) * N;
+    const long rstep = stride / cv;
+    // dx = k0 + k1 * x + gr * dz with xhat = (x - mu) rs:  k1 = -gr rs s2,  k0 = -gr s1 - k1 mu
+    float gr[N], k0[N], k1[N];
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        const float rs = rstd[c + i];
+        gr[i] = gamma[c + i] * rs;
+        k1[i] = -gr[i] * rs * s2[c + i];
+        k0[i] = -gr[i] * s1[c + i] - k1[i] * mean[c + i];
+    }
+    for (long idx = first; idx < total; idx += U * stride) {
         const long r = idx / cv;
-        const int c = tc * N;
-        if (tc != last_tc) {
+        Vec16<T> xv[U], dz[U];
 #pragma unroll
-            for (int i = 0; i < N; ++i) {
-                mu[i] = mean[c + i]; rs[i] = rstd[c + i]; gr[i] = gamma[c + i] * rs[i]; a1[i] = s1[c + i]; a2[i] = s2[c + i];
+        for (int u = 0; u < U; ++u) {
+            if (idx + u * stride < total) {
+                xv[u].load(x + (r + u * rstep) * ld + c);
+                dz[u].load(dzbuf + (r + u * rstep) * ld + c);
             }
-            last_tc = tc;
         }
-        Vec16<T> xv, dz, o;
-        xv.load(x + r * ld + c);
-        dz.load(dzbuf + r * ld + c);
 #pragma unroll
-        for (int i = 0; i < N; ++i) {
-            float xh = (xv.get(i) - mu[i]) * rs[i];
-            o.set(i, gr[i] * (dz.get(i) - a1[i] - xh * a2[i]));
+        for (int u = 0; u < U; ++u) {
+            if (idx + u * stride < total) {
+                Vec16<T> o;
+#pragma unroll
+                for (int i = 0; i < N; ++i) o.set(i, fmaf(gr[i], dz[u].get(i), fmaf(k1[i], xv[u].get(i), k0[i])));
+                o.store(dx + (r + u * rstep) * ld + c);
+            }
         }
-        o.store(dx + r * ld + c);
     }
 }
 
@@ -198,10 +247,13 @@ static inline int stat_blocks(long M) {
     long b = M / 32;
     return (int)(b < 1 ? 1 : (b > MU_STAT_MAXBLK ? MU_STAT_MAXBLK : b));
 }
-static inline int ew_grid(long total) {
-    long g = (total + 255) / 256;
-    // multiple of 5 keeps the channel chunk loop-invariant for C=160 (20/40 chunks per row)
-    g = g < 1 ? 1 : (g > 10240 ? 10240 : g);
+static inline long mu_gcd(long a, long b) { while (b) { long t = a % b; a = b; b = t; } return a; }
+// blocks of 256 threads, ~4 vectors per thread, and 256*grid a multiple of cv (vectors per row): the kernels rely on it
+static inline int ew_grid(long total, int cv) {
+    const long m = cv / mu_gcd(cv, 256);
+    long g = (total + 1023) / 1024;
+    g = g < 1 ? 1 : (g > 8192 ? 8192 : g);
+    g = (g + m - 1) / m * m;
     return (int)g;
 }
 
@@ -280,9 +332,9 @@ extern "C" int mu_bn_act_fwd(const void* x, const void* res, void* y, long M, in
     if (!x || !y || !mean || !rstd || !gamma || !beta || M <= 0 || C <= 0 || C % 8 || ld < C) return MU_ERR_ARG;
     hipStream_t st = (hipStream_t)stream;
     if (dtype == MU_F32)
-        bn_act_fwd_kernel<float><<<ew_grid(M * (C / 4)), 256, 0, st>>>((const float*)x, (const float*)res, (float*)y, M, C, ld, mean, rstd, gamma, beta, act);
+        bn_act_fwd_kernel<float><<<ew_grid(M * (C / 4), C / 4), 256, 0, st>>>((const float*)x, (const float*)res, (float*)y, M, C, ld, mean, rstd, gamma, beta, act);
     else if (dtype == MU_F16)
-        bn_act_fwd_kernel<h16><<<ew_grid(M * (C / 8)), 256, 0, st>>>((const h16*)x, (const h16*)res, (h16*)y, M, C, ld, mean, rstd, gamma, beta, act);
+        bn_act_fwd_kernel<h16><<<ew_grid(M * (C / 8), C / 8), 256, 0, st>>>((const h16*)x, (const h16*)res, (h16*)y, M, C, ld, mean, rstd, gamma, beta, act);
     else return MU_ERR_ARG;
     MU_CHECK_LAUNCH();
     return MU_OK;
@@ -304,7 +356,7 @@ static int bn_act_bwd_t(const T* x, const T* res, const T* g, T* dx, T* dres, lo
     T* dzbuf = res ? dres : dx;     // d(residual) == dz exactly, so it doubles as the dz buffer
     bn_partial_kernel<T, 1><<<nblk, 256, lds, st>>>(x, g, res, dzbuf, M, C, ld, mean, rstd, gamma, beta, act, part);
     bn_bwd_final_kernel<<<mu_cdiv(C, 4), 256, 0, st>>>(part, nblk, C, M, training, dgamma, dbeta, s1, s2);
-    bn_bwd_apply_kernel<T><<<ew_grid(M * cv), 256, 0, st>>>(x, dzbuf, dx, M, C, ld, mean, rstd, gamma, s1, s2);
+    bn_bwd_apply_kernel<T><<<ew_grid(M * cv, cv), 256, 0, st>>>(x, dzbuf, dx, M, C, ld, mean, rstd, gamma, s1, s2);
     return MU_OK;
 }
 

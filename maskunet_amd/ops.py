@@ -38,9 +38,8 @@ class _ToNHWC(torch.autograd.Function):
         B, C, H, W = x.shape
         x = x.contiguous()
         Cp = pad32(C)
-        alloc = torch.zeros if Cp != C else torch.empty
-        y = alloc((B, H, W, Cp), dtype=dtype, device=x.device)
-        call("mu_transpose", ptr(x), dt(x), H * W, ptr(y), dt(y), Cp, B, C, H * W, stream())
+        y = torch.empty((B, H, W, Cp), dtype=dtype, device=x.device)
+        call("mu_transpose_pad", ptr(x), dt(x), H * W, ptr(y), dt(y), Cp, B, C, H * W, Cp, stream())
         ctx.C, ctx.in_dtype = C, x.dtype
         return y
 
@@ -71,9 +70,8 @@ class _ToNCHW(torch.autograd.Function):
     def backward(ctx, g):
         g = g.contiguous()
         B, C, H, W = g.shape
-        alloc = torch.zeros if ctx.Cp != C else torch.empty
-        gx = alloc((B, H, W, ctx.Cp), dtype=ctx.in_dtype, device=g.device)
-        call("mu_transpose", ptr(g), dt(g), H * W, ptr(gx), dt(gx), ctx.Cp, B, C, H * W, stream())
+        gx = torch.empty((B, H, W, ctx.Cp), dtype=ctx.in_dtype, device=g.device)
+        call("mu_transpose_pad", ptr(g), dt(g), H * W, ptr(gx), dt(gx), ctx.Cp, B, C, H * W, ctx.Cp, stream())
         return gx, None, None
 
 
@@ -103,12 +101,16 @@ def to_nchw(x, C, out_dtype=torch.float32):
 # convolution / linear
 # ------------------------------------------------------------------------------------------------
 def _prep_weight(w, dtype, rows_pad, cols_pad, mode):
+    """mode 0: forward layout; 1: data-gradient layout; 2: both from one launch -> (fwd, dgrad) views of one buffer."""
     O, I = w.shape[0], w.shape[1]
     taps = w.shape[2] * w.shape[3] if w.dim() == 4 else 1
-    dst = torch.empty((taps, rows_pad, cols_pad), dtype=dtype, device=w.device)
+    n = taps * rows_pad * cols_pad
+    dst = torch.empty((2 * n if mode == 2 else n,), dtype=dtype, device=w.device)
     wf = w.detach().float().contiguous()
     call("mu_prep_weight", ptr(wf), ptr(dst), dt(dtype), O, I, taps, rows_pad, cols_pad, mode, stream())
-    return dst
+    if mode == 2:
+        return dst[:n].view(taps, rows_pad, cols_pad), dst[n:].view(taps, cols_pad, rows_pad)
+    return dst.view(taps, rows_pad, cols_pad)
 
 
 def _conv_raw(x, wprep, bias_p, Cout_p, taps):
@@ -150,7 +152,12 @@ class _Conv(torch.autograd.Function):
         Cin_p, Cout_p = x.shape[-1], pad32(O)
         if pad32(I) != Cin_p:
             raise RuntimeError(f"conv: input has {Cin_p} (padded) channels, weight expects {I}")
-        wprep = _prep_weight(weight, x.dtype, Cout_p, Cin_p, 0)
+        # the data-gradient layout is produced by the same launch when the backward will need it
+        ctx.wd = None
+        if ctx.needs_input_grad[0]:
+            wprep, ctx.wd = _prep_weight(weight, x.dtype, Cout_p, Cin_p, 2)
+        else:
+            wprep = _prep_weight(weight, x.dtype, Cout_p, Cin_p, 0)
         bias_p = _pad_vec(bias, Cout_p, 0.0) if bias is not None else None
         y = _conv_raw(x, wprep, bias_p, Cout_p, taps)
         ctx.save_for_backward(x, weight)
@@ -165,7 +172,8 @@ class _Conv(torch.autograd.Function):
         O, I = weight.shape[0], weight.shape[1]
         gx = gw = gb = None
         if ctx.needs_input_grad[0]:
-            wd = _prep_weight(weight, gy.dtype, x.shape[-1], gy.shape[-1], 1)
+            wd = ctx.wd if ctx.wd is not None else _prep_weight(weight, gy.dtype, x.shape[-1], gy.shape[-1], 1)
+            ctx.wd = None
             gx = _conv_raw(gy, wd, None, x.shape[-1], ctx.taps)
         if ctx.needs_input_grad[1]:
             gw = _wgrad_raw(x, gy, tuple(weight.shape), ctx.taps)
@@ -396,7 +404,11 @@ class _MaskAttention(torch.autograd.Function):
         N = H * W
         wqkv = torch.cat([wq.detach(), wk.detach(), wv.detach()], 0).float().view(3 * C, C, 1, 1)
         bqkv = torch.cat([bq.detach(), bk.detach(), bv.detach()], 0).float().contiguous()
-        wprep = _prep_weight(wqkv, x.dtype, 3 * C, C, 0)
+        ctx.wd = None
+        if ctx.needs_input_grad[0]:
+            wprep, ctx.wd = _prep_weight(wqkv, x.dtype, 3 * C, C, 2)
+        else:
+            wprep = _prep_weight(wqkv, x.dtype, 3 * C, C, 0)
         qkv = _conv_raw(x, wprep, bqkv, 3 * C, 1)                      # [B,H,W,3C] == [B,N,3C]
         out = torch.empty((B, N, C), dtype=x.dtype, device=x.device)
         oattn = torch.empty_like(out)
@@ -433,7 +445,8 @@ class _MaskAttention(torch.autograd.Function):
         dqkv4 = dqkv.view(B, H, W, 3 * C)
         gx = None
         if ctx.needs_input_grad[0]:
-            wd = _prep_weight(wqkv, x.dtype, C, 3 * C, 1)
+            wd = ctx.wd if ctx.wd is not None else _prep_weight(wqkv, x.dtype, C, 3 * C, 1)
+            ctx.wd = None
             gx = _conv_raw(dqkv4, wd, None, C, 1)
             call("mu_add", ptr(gx), ptr(dY), ptr(gx), gx.numel(), dt(gx), stream())
         gw = _wgrad_raw(x, dqkv4, (3 * C, C, 1, 1), 1).view(3 * C, C)

@@ -65,6 +65,18 @@ def check_transpose(dtype):
         ref = torch.zeros(B, C, dld)
         ref[:, :, :R] = s.float().cpu()[:, :, :C].transpose(1, 2)
         out.append((f"transpose{(B, R, C)}", _err(d, ref), 1e-6))
+    # zero padding of destination rows [R, R_pad) over a garbage-filled destination: aligned (vector) and unaligned paths
+    for (B, R, C, sld, dld, Rp) in [(2, 3, 200, 200, 32, 32), (2, 150, 96, 96, 160, 160), (1, 19, 45, 45, 35, 33), (2, 70, 130, 132, 96, 90)]:
+        src = torch.zeros(B, R, sld)
+        src[:, :, :C] = _rnd(gen, B, R, C)
+        s = src.to(DEV, dtype)
+        for ddt in (torch.float32, dtype):
+            d = torch.full((B, C, dld), 7.0, dtype=ddt, device=DEV)
+            _lib.call("mu_transpose_pad", _lib.ptr(s), _lib.dt(s), sld, _lib.ptr(d), _lib.dt(d), dld, B, R, C, Rp, _lib.stream())
+            ref = torch.full((B, C, dld), 7.0)
+            ref[:, :, :Rp] = 0
+            ref[:, :, :R] = s.float().cpu()[:, :, :C].transpose(1, 2)
+            out.append((f"transpose_pad{(B, R, C, Rp)}->{str(ddt)[6:]}", _err(d.float(), ref), 1e-6))
     return out
 
 
@@ -90,7 +102,9 @@ def check_conv(dtype, cases=None):
                       (1, 8, 8, 64, 150, 1), (2, 9, 7, 256, 256, 3), (1, 16, 16, 3, 64, 3), (2, 8, 8, 32, 1, 1),
                       (1, 6, 6, 512, 256, 3),
                       # W % 32 == 0: exercises the 3-taps-per-block weight-gradient kernel (fp16) incl. row/image borders
-                      (2, 32, 32, 64, 64, 3), (1, 64, 32, 128, 128, 3), (2, 16, 64, 64, 128, 3), (1, 32, 32, 256, 128, 3)]
+                      (2, 32, 32, 64, 64, 3), (1, 64, 32, 128, 128, 3), (2, 16, 64, 64, 128, 3), (1, 32, 32, 256, 128, 3),
+                      # 16x16-tile ping-pong kernel: odd number of 64-channel chunks, non-square image, two channel blocks
+                      (2, 32, 48, 192, 256, 3), (3, 16, 16, 128, 128, 3)]
     for (B, H, W, Cin, Cout, k) in cases:
         x = _rnd(gen, B, Cin, H, W)
         w = _rnd(gen, Cout, Cin, k, k, scale=1.0 / math.sqrt(Cin * k * k))

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""In-process interleaved A/B timing of library variants (cdna guide rule 24): python tests/ab_bench.py attn|conv A B [C ...]
+"""In-process interleaved A/B timing of library variants (cdna guide rule 24): python tests/ab_bench.py attn|bn|conv|wgrad A B [C ...]
 Variants are gpurun_variants/libmu_<NAME>.so built by tests/build_variant.sh.  Debug aid."""
 import ctypes, os, statistics, sys
 import torch
@@ -11,7 +11,9 @@ from maskunet_amd import _lib
 def load(name):
     lib = ctypes.CDLL(os.path.join(ROOT, "gpurun_variants", f"libmu_{name}.so"))
     for n, (res, args) in _lib.SIGNATURES.items():
-        f = getattr(lib, n); f.restype = res; f.argtypes = args
+        f = getattr(lib, n, None)
+        if f is None: continue          # older variant without this entry point
+        f.restype = res; f.argtypes = args
     return lib
 
 
@@ -43,12 +45,33 @@ def main():
             return lambda: lib.mu_attn_bwd_phases(qkv.data_ptr(), x.data_ptr(), oattn.data_ptr(), gout.data_ptr(), kidx.data_ptr(), kcnt.data_ptr(), lse.data_ptr(), mean.data_ptr(), rstd.data_ptr(), g.data_ptr(), dY.data_ptr(), delta.data_ptr(), dqkv.data_ptr(), dg.data_ptr(), db.data_ptr(), B, N, C, N, ws.data_ptr(), ws.numel(), 1, phase, st)
         cases = [("fwd", 0), ("dq", 2), ("dkv", 4)]
         first = libs[names[0]]; mk(first, 0)(); mk(first, 1)()
-    else:
-        B, H, Cin, Cout = 64, 128, 128, 128
-        x = torch.randn(B, H, H, Cin, device=dev, dtype=dt); w = (torch.randn(9, Cout, Cin, device=dev) * 0.05).to(dt); y = torch.empty(B, H, H, Cout, device=dev, dtype=dt)
+    elif what == "bn":
+        M, C = 64 * 128 * 128, 128
+        x = torch.randn(M, C, device=dev, dtype=dt); y = torch.empty_like(x); gy = torch.randn_like(x); dx = torch.empty_like(x)
+        mean = torch.zeros(C, device=dev); rstd = torch.ones(C, device=dev); gam = torch.ones(C, device=dev); bet = torch.zeros(C, device=dev)
+        dgam = torch.empty(C, device=dev); dbet = torch.empty(C, device=dev)
+        ws = torch.empty(_lib.load().mu_bn_workspace_bytes(C), dtype=torch.uint8, device=dev)
         def mk(lib, phase):
-            return lambda: lib.mu_conv_fwd(x.data_ptr(), w.data_ptr(), None, y.data_ptr(), B, H, H, Cin, Cout, 9, Cin, Cout, 1, st)
-        cases = [("conv128", 0)]
+            if phase == 0:
+                return lambda: lib.mu_bn_train_stats(x.data_ptr(), M, C, C, mean.data_ptr(), rstd.data_ptr(), None, None, C, 0.1, 1e-5, ws.data_ptr(), ws.numel(), 1, st)
+            if phase == 1:
+                return lambda: lib.mu_bn_act_fwd(x.data_ptr(), None, y.data_ptr(), M, C, C, mean.data_ptr(), rstd.data_ptr(), gam.data_ptr(), bet.data_ptr(), 1, 1, st)
+            return lambda: lib.mu_bn_act_bwd(x.data_ptr(), None, gy.data_ptr(), dx.data_ptr(), None, M, C, C, mean.data_ptr(), rstd.data_ptr(), gam.data_ptr(), bet.data_ptr(), 1, 1, dgam.data_ptr(), dbet.data_ptr(), ws.data_ptr(), ws.numel(), 1, st)
+        cases = [("bn_stats 268MB", 0), ("bn_act_fwd", 1), ("bn_act_bwd", 2)]
+    else:
+        shapes = [(64, 128, 128, 128), (64, 64, 256, 256), (64, 32, 512, 512), (64, 16, 512, 512), (64, 128, 64, 128)]
+        bufs = []
+        for (B, H, Cin, Cout) in shapes:
+            bufs.append((torch.randn(B, H, H, Cin, device=dev, dtype=dt), (torch.randn(9, Cout, Cin, device=dev) * 0.05).to(dt), torch.empty(B, H, H, Cout, device=dev, dtype=dt),
+                         torch.randn(B, H, H, Cout, device=dev, dtype=dt), torch.empty(Cout, Cin, 3, 3, device=dev),
+                         torch.empty(_lib.load().mu_conv_wgrad_workspace_bytes(B, H, H, Cin, Cout, 9), dtype=torch.uint8, device=dev)))
+        def mk(lib, phase):
+            (B, H, Cin, Cout), (x, w, y, dy, gw, ws) = shapes[phase // 2], bufs[phase // 2]
+            if phase % 2 == 0:
+                return lambda: lib.mu_conv_fwd(x.data_ptr(), w.data_ptr(), None, y.data_ptr(), B, H, H, Cin, Cout, 9, Cin, Cout, 1, st)
+            return lambda: lib.mu_conv_wgrad(x.data_ptr(), dy.data_ptr(), gw.data_ptr(), B, H, H, Cin, Cout, 9, Cin, Cout, Cin, Cout, ws.data_ptr(), ws.numel(), 1, st)
+        sel = (0, 2, 4, 6, 8) if what == "conv" else (1, 3, 5, 7, 9)
+        cases = [(f"{'fwd' if p % 2 == 0 else 'wgrad'} {shapes[p // 2]} {2e-9 * 9 * shapes[p // 2][0] * shapes[p // 2][1] ** 2 * shapes[p // 2][2] * shapes[p // 2][3]:.0f} GF", p) for p in sel]
     for cname, phase in cases:
         res = {n: [] for n in names}
         for n in names: timeit(mk(libs[n], phase), 2)

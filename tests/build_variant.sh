@@ -5,10 +5,11 @@ set -e
 NAME=$1; shift
 EXTRA="$*"
 ROOT=$(cd "$(dirname "$0")/.." && pwd)
+SRC=${MU_SRC:-$ROOT/maskunet_amd/csrc}      # MU_SRC=<dir> builds another checkout's sources (e.g. a git worktree of HEAD)
 OUT=$ROOT/gpurun_variants
 mkdir -p $OUT/obj_$NAME
 for f in elementwise norm conv attn loss version; do
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -fPIC -std=c++17 -Wno-unused-value -Wno-pass-failed $EXTRA -c $ROOT/maskunet_amd/csrc/$f.hip -o $OUT/obj_$NAME/$f.o &
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -fPIC -std=c++17 -Wno-unused-value -Wno-pass-failed $EXTRA -c $SRC/$f.hip -o $OUT/obj_$NAME/$f.o &
 done
 wait
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC $OUT/obj_$NAME/*.o -o $OUT/libmu_$NAME.so
