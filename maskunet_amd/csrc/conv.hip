@@ -194,6 +194,17 @@ __device__ __forceinline__ void glds16(const void* gsrc, void* lds_wave_base) {
                                      (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
 }
 
+// The same LDS-DMA issued through inline asm, for the ring-buffered kernels that order their DMAs with explicit counted
+// s_waitcnt vmcnt(N) + s_barrier.  hipcc's waitcnt pass treats ds_read_b64_tr_b16 (no memory operand) as aliasing every
+// pending LDS-DMA it knows of and puts s_waitcnt vmcnt(0) in front of the first transposed read of each stage, which
+// drains the whole ring (measured: ring depth 2..8 made no difference until the DMA was hidden from the pass).  Hidden
+// DMAs are NOT covered by __syncthreads(): every consumer must sit behind an explicit vmcnt wait and a barrier.
+// M0 carries the wave-uniform LDS destination; nothing else in these kernels uses M0.
+__device__ __forceinline__ void glds16a(const void* gsrc, void* lds_wave_base) {
+    const uint32_t l = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)lds_wave_base);
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(l), "v"(gsrc) : "memory");
+}
+
 template <typename T, int TM, int TN, int WR, int TAPS>
 __global__ __launch_bounds__(256) void conv_nt2_kernel(const T* __restrict__ x, const T* __restrict__ w, const float* __restrict__ bias,
                                                        T* __restrict__ y, int B, int H, int W, int Cin, int Cout, long x_ld, long y_ld) {
@@ -1053,6 +1064,17 @@ template <int BCH> __device__ __forceinline__ int wg_hash(int row) {
     return (BCH >= 128) ? ((row & 3) | (((row >> 3) & 1) << 2)) : (row & 3);
 }
 
+template <int N> __device__ __forceinline__ void wait_vmcnt_c() {
+    static_assert(N >= 0 && N < 64, "vmcnt is a 6-bit counter");
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+// The pixel stream comes straight from HBM (every block sweeps its own pixel range once), so the stage ring is NS deep with
+// NS-1 stages in flight: counted s_waitcnt vmcnt + ONE raw s_barrier per 32-pixel stage (the former double buffer prefetched
+// a single stage, ~0.2 us of MFMA work, far less than an HBM round trip).
+#ifndef MU_WG_NS
+#define MU_WG_NS 6
+#endif
 template <int TM, int TN, int WR, int NWV = 4>
 __global__ __launch_bounds__(NWV * 64, 1) void conv_wgrad3_kernel(const h16* __restrict__ x, const h16* __restrict__ dy, float* __restrict__ part,
                                                              int B, int H, int W, int Cin, int Cout, long x_ld, long dy_ld, int nsplit,
@@ -1065,46 +1087,85 @@ __global__ __launch_bounds__(NWV * 64, 1) void conv_wgrad3_kernel(const h16* __r
     constexpr int NIA = KP / RPW, NIB = XR / RPW;          // DMA wave-instructions per tile
     constexpr int STAGE = (KP + XR) * BCO;                 // elements per stage
 
-    __shared__ __attribute__((aligned(16))) h16 lds[2 * STAGE];
+    constexpr int NS = MU_WG_NS;
+    __shared__ __attribute__((aligned(16))) h16 lds[NS * STAGE];
 
     const long Mtot = (long)B * H * W;
     const int nco = Cout / BCO, nci = Cin / BCI;
-    int bid = blockIdx.x;
-    const int split = bid % nsplit; bid /= nsplit;
+    // The 3*nco*nci blocks that sweep the SAME pixel range (one per kernel row and channel-tile pair) get consecutive
+    // logical ids inside one XCD, so they run side by side on that XCD and all but the first find the x / dy rows in its
+    // L2: without this every block streams its operands from HBM (3.4-3.8 TB/s measured on every layer shape = the bound).
+    int bid = xcd_remap(blockIdx.x, gridDim.x);
+#ifdef MU_WG_NO_XCD
+    bid = blockIdx.x;
+#endif
     const int cib = bid % nci; bid /= nci;
     const int cob = bid % nco; bid /= nco;
-    const int dh = bid - 1;                                 // kernel row: taps 3*(dh+1) + {0,1,2}
+    const int dh = bid % 3 - 1; bid /= 3;                   // kernel row: taps 3*(dh+1) + {0,1,2}
+    const int split = bid;
     const int co0 = cob * BCO, ci0 = cib * BCI;
     const long p_begin = (long)split * pix_per_split;
     const long p_end = p_begin + pix_per_split < Mtot ? p_begin + pix_per_split : Mtot;
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wave / WC, wc = wave % WC;
     const int r16 = lane & 15, g = lane >> 4;
     const int lrow = lane / CPR, c16 = lane % CPR;
+    // DMA instructions this wave issues per stage (dy tile: i = wave, wave+NWV, ..; x window likewise)
+    constexpr int NAW = (NIA + NWV - 1) / NWV, NBW = (NIB + NWV - 1) / NWV;
+    const int n_w = (NIA - wave + NWV - 1) / NWV + (NIB - wave + NWV - 1) / NWV;
 
-    auto stage = [&](long pbase, int buf) {
+    // Per-lane source offsets are loop-invariant; the stage position (pixel, column, image row) is carried as scalars and
+    // advanced by 32 pixels per stage -- the 64-bit div/mod of the flat pixel index used to cost more SALU time per stage
+    // than the stage's MFMAs.
+    int aoff[NAW], boff[NBW], bkind[NBW];      // bkind: 0 plain row, 1 window row 0 (needs w0 > 0), 2 row KP+1 (needs w0+KP < W), 3 unused
+#pragma unroll
+    for (int k = 0; k < NAW; ++k) {
+        const int row = (wave + k * NWV) * RPW + lrow;
+        const int sc = (((c16 >> 1) ^ wg_hash<BCO>(row)) << 1) | (c16 & 1);
+        aoff[k] = row * (int)dy_ld + co0 + sc * 8;
+    }
+#pragma unroll
+    for (int k = 0; k < NBW; ++k) {
+        const int row = (wave + k * NWV) * RPW + lrow;      // window row: flat pixel pbase + dh*W - 1 + row
+        const int sc = (((c16 >> 1) ^ wg_hash<BCO>(row)) << 1) | (c16 & 1);
+        boff[k] = (row - 1) * (int)x_ld + ci0 + sc * 8;
+        bkind[k] = row == 0 ? 1 : (row == KP + 1 ? 2 : (row > KP + 1 ? 3 : 0));
+    }
+    long pis = p_begin;                                     // next stage to issue
+    int wi = (int)(p_begin % W), hi = (int)((p_begin / W) % H);
+    const h16* dyp = dy + p_begin * dy_ld;
+    const h16* xp = x + (p_begin + (long)dh * W) * x_ld;
+
+    auto stage = [&](int buf) {                  // past p_end: an all-zero stage (keeps the per-wave DMA count uniform)
         h16* At = lds + buf * STAGE;
         h16* Bt = At + KP * BCO;
+        const bool live = pis < p_end;
 #pragma unroll
-        for (int i = wave; i < NIA; i += NWV) {
-            const int row = i * RPW + lrow;
-            const long pp = pbase + row;
-            const int sc = (((c16 >> 1) ^ wg_hash<BCO>(row)) << 1) | (c16 & 1);
-            const void* src = pp < p_end ? (const void*)(dy + pp * dy_ld + co0 + sc * 8) : (const void*)mu_zero_page;
-            glds16(src, At + i * RPW * BCO);
+        for (int k = 0; k < NAW; ++k) {
+            const int i = wave + k * NWV;
+            if (i < NIA) {
+                const void* src = live ? (const void*)(dyp + aoff[k]) : (const void*)mu_zero_page;
+                glds16a(src, At + i * RPW * BCO);
+            }
         }
-        const int w0 = (int)(pbase % W);
-        const int hh = (int)((pbase / W) % H) + dh;
-        const bool rowok = hh >= 0 && hh < H;
+        const int hh = hi + dh;
+        const bool rowok = live && hh >= 0 && hh < H;
+        const bool lok = wi > 0, rok = wi + KP < W;
 #pragma unroll
-        for (int i = wave; i < NIB; i += NWV) {
-            const int row = i * RPW + lrow;                 // window row: flat pixel pbase + dh*W - 1 + row
-            const bool ok = rowok && row <= KP + 1 && (row >= 1 || w0 > 0) && (row <= KP || w0 + KP < W);
-            const int sc = (((c16 >> 1) ^ wg_hash<BCO>(row)) << 1) | (c16 & 1);
-            const void* src = ok ? (const void*)(x + (pbase + (long)dh * W - 1 + row) * x_ld + ci0 + sc * 8) : (const void*)mu_zero_page;
-            glds16(src, Bt + i * RPW * BCO);
+        for (int k = 0; k < NBW; ++k) {
+            const int i = wave + k * NWV;
+            if (i < NIB) {
+                const bool ok = rowok && (bkind[k] == 0 || (bkind[k] == 1 && lok) || (bkind[k] == 2 && rok));
+                const void* src = ok ? (const void*)(xp + boff[k]) : (const void*)mu_zero_page;
+                glds16a(src, Bt + i * RPW * BCO);
+            }
         }
+        pis += KP;
+        dyp += KP * dy_ld;
+        xp += KP * x_ld;
+        wi += KP;
+        if (wi >= W) { wi = 0; hi = hi + 1 == H ? 0 : hi + 1; }
     };
 
     f32x4 acc[3][TM][TN];
@@ -1116,22 +1177,21 @@ __global__ __launch_bounds__(NWV * 64, 1) void conv_wgrad3_kernel(const h16* __r
             for (int j = 0; j < TN; ++j) acc[t][i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
     const int nsteps = (int)((p_end - p_begin + KP - 1) / KP);
-    if (nsteps > 0) stage(p_begin, 0);
-    __syncthreads();
     const int q = r16 >> 2, pc = r16 & 3;
-    for (int s = 0; s < nsteps; ++s) {
-        const int buf = s & 1;
-        if (s + 1 < nsteps) stage(p_begin + (long)(s + 1) * KP, buf ^ 1);
+
+    // Register double-buffered fragments: the transposed LDS reads of stage s+1 are issued before the MFMAs of stage s, so
+    // the LDS latency (8 + 12 dependent-free ds_read_tr per 24 MFMAs) no longer sits between the MFMA groups.
+    struct Frags { h16x8 a[TM]; h16x8 b[3][TN]; };
+    auto load_frags = [&](int buf, Frags& f) {
         const h16* At = lds + buf * STAGE;
         const h16* Bt = At + KP * BCO;
-        h16x8 a[TM];
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
             const int col = (wr * TM + i) * 16 + 4 * pc;    // 4 halfs inside 32-byte chunk (col >> 4)
             const int r0 = 8 * g + q, r1 = r0 + 4;
             auto lo = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) fp16x4v*)(At + r0 * BCO + ((((col >> 4) ^ wg_hash<BCO>(r0)) << 4) | (col & 15))));
             auto hi = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) fp16x4v*)(At + r1 * BCO + ((((col >> 4) ^ wg_hash<BCO>(r1)) << 4) | (col & 15))));
-            a[i] = (h16x8){(h16)lo[0], (h16)lo[1], (h16)lo[2], (h16)lo[3], (h16)hi[0], (h16)hi[1], (h16)hi[2], (h16)hi[3]};
+            f.a[i] = (h16x8){(h16)lo[0], (h16)lo[1], (h16)lo[2], (h16)lo[3], (h16)hi[0], (h16)hi[1], (h16)hi[2], (h16)hi[3]};
         }
 #pragma unroll
         for (int t = 0; t < 3; ++t) {
@@ -1141,12 +1201,47 @@ __global__ __launch_bounds__(NWV * 64, 1) void conv_wgrad3_kernel(const h16* __r
                 const int r0 = 8 * g + q + t, r1 = r0 + 4;
                 auto lo = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) fp16x4v*)(Bt + r0 * BCO + ((((col >> 4) ^ wg_hash<BCO>(r0)) << 4) | (col & 15))));
                 auto hi = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) fp16x4v*)(Bt + r1 * BCO + ((((col >> 4) ^ wg_hash<BCO>(r1)) << 4) | (col & 15))));
-                h16x8 bf = (h16x8){(h16)lo[0], (h16)lo[1], (h16)lo[2], (h16)lo[3], (h16)hi[0], (h16)hi[1], (h16)hi[2], (h16)hi[3]};
-#pragma unroll
-                for (int i = 0; i < TM; ++i) acc[t][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[i], bf, acc[t][i][j], 0, 0, 0);
+                f.b[t][j] = (h16x8){(h16)lo[0], (h16)lo[1], (h16)lo[2], (h16)lo[3], (h16)hi[0], (h16)hi[1], (h16)hi[2], (h16)hi[3]};
             }
         }
-        __syncthreads();
+    };
+    auto compute = [&](const Frags& f) {
+#pragma unroll
+        for (int t = 0; t < 3; ++t)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int i = 0; i < TM; ++i) acc[t][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(f.a[i], f.b[t][j], acc[t][i][j], 0, 0, 0);
+    };
+
+    // Ring protocol (one raw barrier per stage):
+    //   top of step s : this wave's DMAs of stage s+1 have landed (vmcnt <= (NS-3) n_w); barrier -> everybody's have, and
+    //                   everybody's reads of stage s-1 (issued in step s-2, consumed by the MFMAs of step s-1) are complete
+    //   then          : DMA of stage s+NS-1 into the slot of stage s-1; fragment reads of stage s+1; MFMAs of stage s
+#pragma unroll 1
+    for (int k = 0; k < NS - 1; ++k) stage(k);
+    auto wait_ring = [&]() {                                 // all but the newest NS-3 stages of this wave have landed
+        constexpr int FULL = NAW + NBW;
+        if (n_w == FULL) wait_vmcnt_c<(NS - 3) * FULL>();
+        else if (n_w == FULL - 1) wait_vmcnt_c<(NS - 3) * (FULL - 1)>();
+        else wait_vmcnt_c<(NS - 3) * (FULL > 2 ? FULL - 2 : 0)>();
+    };
+    wait_ring();
+    __builtin_amdgcn_s_barrier();
+    Frags f0, f1;
+    load_frags(0, f0);
+    int buf = 0;                                            // slot of stage s
+    auto step = [&](int s, Frags& cur, Frags& nxt) {
+        wait_ring();
+        __builtin_amdgcn_s_barrier();
+        stage(buf == 0 ? NS - 1 : buf - 1);
+        buf = buf + 1 == NS ? 0 : buf + 1;
+        if (s + 1 < nsteps) load_frags(buf, nxt);
+        compute(cur);
+    };
+    for (int s = 0; s < nsteps; s += 2) {
+        step(s, f0, f1);
+        if (s + 1 < nsteps) step(s + 1, f1, f0);
     }
 
 #pragma unroll
@@ -1287,10 +1382,8 @@ extern "C" int mu_conv_wgrad(const void* x, const void* dy, float* dw_oihw, int 
         wgrad3_plan((long)B * H * W, Cin, Cout, bco, &nsplit, &pps);
         if (ws_bytes < (long)nsplit * taps * Cout * Cin * (long)sizeof(float)) return MU_ERR_WORKSPACE;
         const int grid = 3 * (Cout / bco) * (Cin / bco) * nsplit;
-        if (bco == 128 && !getenv("MU_WG_NW4"))     // 8 waves, 64x32 tile x 3 taps per wave (96 accumulators): 2 waves/SIMD
+        if (bco == 128)     // 8 waves, 64x32 tile x 3 taps per wave (96 accumulators): 2 waves/SIMD
             conv_wgrad3_kernel<4, 2, 2, 8><<<grid, 512, 0, st>>>((const h16*)x, (const h16*)dy, part, B, H, W, Cin, Cout, x_ld, dy_ld, nsplit, pps);
-        else if (bco == 128)
-            conv_wgrad3_kernel<4, 4, 2><<<grid, 256, 0, st>>>((const h16*)x, (const h16*)dy, part, B, H, W, Cin, Cout, x_ld, dy_ld, nsplit, pps);
         else
             conv_wgrad3_kernel<2, 2, 2><<<grid, 256, 0, st>>>((const h16*)x, (const h16*)dy, part, B, H, W, Cin, Cout, x_ld, dy_ld, nsplit, pps);
     } else if (ws_bytes < (long)nsplit * taps * Cout * Cin * (long)sizeof(float)) {
