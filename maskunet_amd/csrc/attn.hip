@@ -35,6 +35,30 @@
 #endif
 
 typedef __fp16 fp16x4v __attribute__((__vector_size__(4 * sizeof(__fp16))));
+// LDS-DMA through inline asm (see conv.hip glds16a): hipcc's waitcnt pass puts s_waitcnt vmcnt(0) in front of every
+// ds_read_b64_tr_b16 (and of reads of a second __shared__ object) while an LDS-DMA it knows of is pending, which turned
+// every "tile j+1 in flight while tile j is processed" scheme here into synchronous staging.  Hidden DMAs are ordered by
+// hand: MU_SYNC_DMA() (vmcnt(0) + workgroup barrier) where the code used to rely on __syncthreads(), counted waits in
+// the ring kernels.  M0 carries the wave-uniform LDS destination; nothing else in these kernels uses M0.
+__device__ __forceinline__ void glds16a(const void* gsrc, void* lds_wave_base) {
+    const uint32_t l = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)lds_wave_base);
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(l), "v"(gsrc) : "memory");
+}
+// scalar-base form: source = sbase (wave-uniform, SGPR pair) + voff (per-lane unsigned byte offset): no 64-bit per-lane
+// pointer arithmetic and no pointer pairs held in VGPRs across the loop
+__device__ __forceinline__ void glds16s(const void* sbase, uint32_t voff, void* lds_wave_base) {
+    const uint32_t l = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)lds_wave_base);
+    const uint64_t b = (uint64_t)(uintptr_t)sbase;
+    const uint64_t sb = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(b >> 32)) << 32) |
+                        (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)b);      // (the builtin returns a SIGNED int)
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(l), "v"(voff), "s"(sb) : "memory");
+}
+#define MU_SYNC_DMA()                                        \
+    do {                                                     \
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     \
+        __syncthreads();                                     \
+    } while (0)
+
 #define LDS_TR16(ptr) __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) fp16x4v*)(ptr))
 
 template <typename T> struct AT;
@@ -168,7 +192,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const T* __restrict__ qkv
     __shared__ __attribute__((aligned(16))) T Ks[ATT_KT * S];
     __shared__ __attribute__((aligned(16))) T Vs[ATT_KT * S];
 
-    const int b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r16 = lane & 15, g = lane >> 4;
     const int q0 = blockIdx.x * 128 + wave * 32;
     const T* qkv_b = qkv + (long)b * N * 3 * D;
@@ -191,9 +215,9 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const T* __restrict__ qkv
     float m[2] = {-INFINITY, -INFINITY}, l[2] = {0.f, 0.f};
 
     for (int j0 = 0; j0 < Nk; j0 += ATT_KT) {
-        __syncthreads();
+        MU_SYNC_DMA();
         stage_rows<T, D>(Ks, Vs, qkv_b + D, qkv_b + 2 * D, 3 * D, 3 * D, kidx_b, j0, Nk, tid);
-        __syncthreads();
+        MU_SYNC_DMA();
         f32x4 s[2][2];
 #pragma unroll
         for (int kt = 0; kt < 2; ++kt)
@@ -328,31 +352,41 @@ template <typename T, int D, int KT, int NW> struct KvStage {
     static constexpr int NPW = (NI + NW - 1) / NW;         // per wave
     int idx[NPW];
 
+    // Unconditional, clamped loads (rows past the end re-read the last kept key: finite data, masked through the score):
+    // a conditional load needs a "-1" default, and overwriting a register with a possibly pending load costs a
+    // s_waitcnt vmcnt(0) -- right behind the DMA issue, i.e. it would serialise the staging.
     __device__ __forceinline__ void load_idx(const int* kidx_b, int j0, int Nk, int wave, int lane) {
         const int lrow = lane / Z::CPR;
 #pragma unroll
         for (int n = 0; n < NPW; ++n) {
             const int i = wave + NW * n;
-            const int j = j0 + i * Z::RPW + lrow;
-            idx[n] = (i < NI && j < Nk) ? kidx_b[j] : -1;
+            int j = j0 + i * Z::RPW + lrow;
+            j = j < Nk ? j : Nk - 1;
+            idx[n] = kidx_b[j < 0 ? 0 : j];
         }
     }
+    // Rows past the end re-read a valid key row instead of a zero page: every consumer masks those keys through the score
+    // (s = -inf -> p = 0 -> ds = 0), so they only need FINITE data, and a common scalar base keeps the DMA in its
+    // SGPR-base + 32-bit-offset form.
     template <bool DOK = true, bool DOV = true>
     __device__ __forceinline__ void issue(T* Kt, T* Vt, const T* qkv_b, int wave, int lane) const {
         const int lrow = lane / Z::CPR, lch = lane % Z::CPR;
+        // all offsets first: each consumes an index load, and the wait for the LAST index load is a vmcnt(0) as far as the
+        // compiler can tell -- it must not come after the first (hidden) DMA or that DMA is drained on the spot
+        uint32_t off[NPW];
+#pragma unroll
+        for (int n = 0; n < NPW; ++n) {
+            const int row = (wave + NW * n) * Z::RPW + lrow;
+            const int sc = lch ^ (row & Z::SW);
+            off[n] = (uint32_t)((idx[n] * 3 * D + sc * Z::VN) * (int)sizeof(T));
+            asm volatile("" ::"v"(off[n]));
+        }
 #pragma unroll
         for (int n = 0; n < NPW; ++n) {
             const int i = wave + NW * n;
-            if (i >= NI) break;                            // wave-uniform
-            const int row = i * Z::RPW + lrow;
-            const int sc = lch ^ (row & Z::SW);
-            const T* base = qkv_b + (long)(idx[n] < 0 ? 0 : idx[n]) * 3 * D + sc * Z::VN;
-            const void* ks = idx[n] < 0 ? (const void*)mu_attn_zero_page : (const void*)(base + D);
-            const void* vs = idx[n] < 0 ? (const void*)mu_attn_zero_page : (const void*)(base + 2 * D);
-            if (DOK) __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)ks,
-                                                      (__attribute__((address_space(3))) void*)(Kt + i * Z::RPW * D), 16, 0, 0);
-            if (DOV) __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)vs,
-                                                      (__attribute__((address_space(3))) void*)(Vt + i * Z::RPW * D), 16, 0, 0);
+            if constexpr (NI % NW != 0) { if (i >= NI) break; }     // wave-uniform; no branch at all when every wave has NPW rows
+            if (DOK) glds16s(qkv_b + D, off[n], Kt + i * Z::RPW * D);
+            if (DOV) glds16s(qkv_b + 2 * D, off[n], Vt + i * Z::RPW * D);
         }
     }
 };
@@ -406,7 +440,7 @@ __global__ __launch_bounds__(NW * 64, OCC ? OCC : ((NW == 4 && D <= 64 && sizeof
     constexpr int VN = A::VN, KR = A::KR, NKS = D / KR, NDT = D / 16, NKT = KT / 16, NH = KT / 32;
     __shared__ __attribute__((aligned(16))) T lds[2 * 2 * KT * D];      // [buf][K|V][KT][D]
 
-    const int b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r16 = lane & 15, g = lane >> 4;
     const int q0 = blockIdx.x * (NW * NQ * 16) + wave * (NQ * 16);     // NQ 16-query tiles per wave
     const T* qkv_b = qkv + (long)b * N * 3 * D;
@@ -443,7 +477,7 @@ __global__ __launch_bounds__(NW * 64, OCC ? OCC : ((NW == 4 && D <= 64 && sizeof
         for (int dt = 0; dt < NDT; ++dt) o[dt][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
     }
     const typename A::AccA ones = AccLd<T, D>::ones();
-    __syncthreads();
+    MU_SYNC_DMA();
 
     // one KT-key tile out of LDS buffer BUF.  S' = K (c Q)^T - m comes straight out of the matrix core (C operand =
     // -m broadcast), so the common case is p = exp2(S') with no per-element subtract; only when some row's maximum
@@ -523,7 +557,7 @@ __global__ __launch_bounds__(NW * 64, OCC ? OCC : ((NW == 4 && D <= 64 && sizeof
                 for (int t = 0; t < NQ; ++t) A::mma_acc(va, s[2 * h][t], s[2 * h + 1][t], o[dt][t]);
             }
         }
-        __syncthreads();        // tile j+1 landed (vmcnt(0)) and everyone is done reading tile j
+        MU_SYNC_DMA();        // tile j+1 landed (vmcnt(0)) and everyone is done reading tile j
     };
     for (int j0 = 0; j0 < Nk; j0 += 2 * KT) {
         tile(std::integral_constant<int, 0>{}, j0);
@@ -648,7 +682,7 @@ __global__ __launch_bounds__(256) void attn_ln_bwd_kernel(const T* __restrict__ 
     __shared__ float sh[256 * 2 * 8];
 #pragma unroll
     for (int i = 0; i < VN; ++i) { sh[(tid * VN + i) * 2] = dga[i]; sh[(tid * VN + i) * 2 + 1] = dbe[i]; }
-    __syncthreads();
+    MU_SYNC_DMA();
     for (int cc = tid; cc < D; cc += 256) {
         double sa = 0.0, sb = 0.0;
         const int lcc = cc / VN, ii = cc % VN;
@@ -688,7 +722,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const T* __restrict__ 
     __shared__ __attribute__((aligned(16))) T Ks[ATT_KT * S];
     __shared__ __attribute__((aligned(16))) T Vs[ATT_KT * S];
 
-    const int b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r16 = lane & 15, g = lane >> 4;
     const int q0 = blockIdx.x * 128 + wave * 32;
     const T* qkv_b = qkv + (long)b * N * 3 * D;
@@ -717,9 +751,9 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const T* __restrict__ 
         for (int t = 0; t < 2; ++t) dq[dt][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
     for (int j0 = 0; j0 < Nk; j0 += ATT_KT) {
-        __syncthreads();
+        MU_SYNC_DMA();
         stage_rows<T, D>(Ks, Vs, qkv_b + D, qkv_b + 2 * D, 3 * D, 3 * D, kidx_b, j0, Nk, tid);
-        __syncthreads();
+        MU_SYNC_DMA();
         f32x4 s[2][2], dp[2][2];
 #pragma unroll
         for (int kt = 0; kt < 2; ++kt)
@@ -785,7 +819,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const T* __restrict__
     __shared__ __attribute__((aligned(16))) T Os[ATT_KT * S];
     __shared__ float lse_s[ATT_KT], del_s[ATT_KT];
 
-    const int b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r16 = lane & 15, g = lane >> 4;
     const int Nk = kcnt[b];
     const int kb0 = blockIdx.x * (4 * NKT * 16);
@@ -817,14 +851,14 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const T* __restrict__
         for (int kt = 0; kt < NKT; ++kt) { dk[dt][kt] = (f32x4){0.f, 0.f, 0.f, 0.f}; dv[dt][kt] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
 
     for (int q0 = 0; q0 < N; q0 += ATT_KT) {
-        __syncthreads();
+        MU_SYNC_DMA();
         stage_rows<T, D>(Qs, Os, qkv_b, dY + (long)b * N * D, 3 * D, D, nullptr, q0, N, tid);
         if (tid < ATT_KT) {
             const int q = q0 + tid;
             lse_s[tid] = q < N ? lse2[(long)b * N + q] : INFINITY;     // exp2(-inf) = 0 for padded queries
             del_s[tid] = q < N ? delta[(long)b * N + q] : 0.f;
         }
-        __syncthreads();
+        MU_SYNC_DMA();
         f32x4 s[2][NKT], dp[2][NKT];
 #pragma unroll
         for (int qt = 0; qt < 2; ++qt)
@@ -895,7 +929,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 && D <= 64 && sizeof(T) == 2) ? M
     constexpr int VN = A::VN, KR = A::KR, NKS = D / KR, NDT = D / 16, NKT = KT / 16, NH = KT / 32;
     __shared__ __attribute__((aligned(16))) T lds[2 * 2 * KT * D];
 
-    const int b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r16 = lane & 15, g = lane >> 4;
     const int q0 = blockIdx.x * (NW * 32) + wave * 32;
     const T* qkv_b = qkv + (long)b * N * 3 * D;
@@ -934,7 +968,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 && D <= 64 && sizeof(T) == 2) ? M
     for (int dt = 0; dt < NDT; ++dt)
 #pragma unroll
         for (int t = 0; t < 2; ++t) dq[dt][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    __syncthreads();
+    MU_SYNC_DMA();
 
     auto tile = [&](auto BUFC, int j0) {
         constexpr int BUF = decltype(BUFC)::value;
@@ -982,7 +1016,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 && D <= 64 && sizeof(T) == 2) ? M
 #pragma unroll
                 for (int t = 0; t < 2; ++t) A::mma_acc(ka, s[2 * h][t], s[2 * h + 1][t], dq[dt][t]);
             }
-        __syncthreads();
+        MU_SYNC_DMA();
     };
     for (int j0 = 0; j0 < Nk; j0 += 2 * KT) {
         tile(std::integral_constant<int, 0>{}, j0);
@@ -1017,10 +1051,8 @@ __device__ __forceinline__ void stage_qo_dma(T* Qt, T* Ot, const T* qkv_b, const
             qs = qkv_b + (long)q * 3 * D + sc * Z::VN;
             os = dY_b + (long)q * D + sc * Z::VN;
         }
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)qs,
-                                         (__attribute__((address_space(3))) void*)(Qt + i * Z::RPW * D), 16, 0, 0);
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)os,
-                                         (__attribute__((address_space(3))) void*)(Ot + i * Z::RPW * D), 16, 0, 0);
+        glds16a(qs, Qt + i * Z::RPW * D);
+        glds16a(os, Ot + i * Z::RPW * D);
     }
 }
 
@@ -1035,7 +1067,7 @@ __global__ __launch_bounds__(256, (D <= 64 && sizeof(T) == 2) ? 2 : 1) void attn
     constexpr int VN = A::VN, KR = A::KR, NKS = D / KR, NDT = D / 16, QT = 32;
     __shared__ __attribute__((aligned(16))) T lds[2 * 2 * QT * D];
 
-    const int b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r16 = lane & 15, g = lane >> 4;
     const int Nk = kcnt[b];
     const int kb0 = blockIdx.x * (4 * NKT * 16);
@@ -1089,7 +1121,7 @@ __global__ __launch_bounds__(256, (D <= 64 && sizeof(T) == 2) ? 2 : 1) void attn
     };
     f32x4 ls_c[2], de_c[2], ls_n[2], de_n[2];
     load_rows(0, ls_c, de_c);
-    __syncthreads();
+    MU_SYNC_DMA();
 
     auto tile = [&](auto BUFC, int q0) {
         constexpr int BUF = decltype(BUFC)::value;
@@ -1143,7 +1175,7 @@ __global__ __launch_bounds__(256, (D <= 64 && sizeof(T) == 2) ? 2 : 1) void attn
 #pragma unroll
             for (int qt = 0; qt < 2; ++qt) { ls_c[qt] = ls_n[qt]; de_c[qt] = de_n[qt]; }
         }
-        __syncthreads();
+        MU_SYNC_DMA();
     };
     for (int q0 = 0; q0 < N; q0 += 2 * QT) {
         tile(std::integral_constant<int, 0>{}, q0);
@@ -1187,7 +1219,7 @@ __global__ __launch_bounds__(256, (D <= 64 && sizeof(T) == 2 && NKT <= 2) ? MU_D
     __shared__ __attribute__((aligned(16))) T lds[DKV_RING * STG];
     __shared__ __attribute__((aligned(16))) float rcs[DKV_RING * 256 + 256];   // 1 KB per slot: [{-lse2},{-delta*scale}][32] in its first 256 B; + 1 KB dump
 
-    const int b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r16 = lane & 15, g = lane >> 4;
     const int Nk = kcnt[b];
     const int kb0 = blockIdx.x * (4 * NKT * 16);
@@ -1224,18 +1256,19 @@ __global__ __launch_bounds__(256, (D <= 64 && sizeof(T) == 2 && NKT <= 2) ? MU_D
 #pragma unroll
         for (int n = 0; n < NPW; ++n) {
             const int ii = (wave + 4 * n) < NI ? (wave + 4 * n) : 0;
-            const void *qs = qb + qlane[n], *os = ob + olane[n];
-            if (!full && tile * QT + rowl[n] >= N) { qs = mu_attn_zero_page; os = mu_attn_zero_page; }
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)qs,
-                                             (__attribute__((address_space(3))) void*)(Qt + ii * Z::RPW * D), 16, 0, 0);
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)os,
-                                             (__attribute__((address_space(3))) void*)(Ot + ii * Z::RPW * D), 16, 0, 0);
+            int qo = qlane[n], oo = olane[n];
+            if (!full && tile * QT + rowl[n] >= N) {          // rows past N: re-read row N-1 (finite); their row constants
+                const int back = tile * QT + rowl[n] - (N - 1);      // (-inf, 0) zero the probabilities
+                qo -= back * 3 * D;
+                oo -= back * D;
+            }
+            glds16s(qb, (uint32_t)(qo * (int)sizeof(T)), Qt + ii * Z::RPW * D);
+            glds16s(ob, (uint32_t)(oo * (int)sizeof(T)), Ot + ii * Z::RPW * D);
         }
         // row constants: 16 lanes x 16 B = the tile's 64 floats.  Every wave issues one DMA so that all waves count the same
-        // number of vector-memory ops: wave 0's lanes >= 16 pad the rest of the slot, waves 1-3 write zeros to a dump area
-        const void* rs = (wave == 0 && lane < 16) ? (const void*)(rowc_b + (long)tile * 64 + lane * 4) : (const void*)mu_attn_zero_page;
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)rs,
-                                         (__attribute__((address_space(3))) void*)(rcs + (wave == 0 ? slot * 256 : DKV_RING * 256)), 16, 0, 0);
+        // number of vector-memory ops: wave 0's lanes >= 16 repeat the constants into the unused rest of the slot, waves 1-3
+        // write theirs to a dump area
+        glds16s(rowc_b + (long)tile * 64, (uint32_t)((lane & 15) * 16), rcs + (wave == 0 ? slot * 256 : DKV_RING * 256));
     };
     constexpr int OPS = 2 * NPW + 1;
 
