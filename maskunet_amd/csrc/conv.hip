@@ -1075,7 +1075,7 @@ template <int N> __device__ __forceinline__ void wait_vmcnt_c() {
 #ifndef MU_WG_NS
 #define MU_WG_NS 6
 #endif
-template <int TM, int TN, int WR, int NWV = 4>
+template <int TM, int TN, int WR, int NWV = 4, bool W16 = false>
 __global__ __launch_bounds__(NWV * 64, 1) void conv_wgrad3_kernel(const h16* __restrict__ x, const h16* __restrict__ dy, float* __restrict__ part,
                                                              int B, int H, int W, int Cin, int Cout, long x_ld, long dy_ld, int nsplit,
                                                              long pix_per_split) {
@@ -1125,12 +1125,21 @@ __global__ __launch_bounds__(NWV * 64, 1) void conv_wgrad3_kernel(const h16* __r
         const int sc = (((c16 >> 1) ^ wg_hash<BCO>(row)) << 1) | (c16 & 1);
         aoff[k] = row * (int)dy_ld + co0 + sc * 8;
     }
+    // W == 16: a 32-pixel stage is two whole image rows; the window is two 18-row halves (columns -1 .. 16 of each image
+    // row, the outer two always zero) instead of one 34-row run of the flat pixel index
+    constexpr bool w16 = W16;
 #pragma unroll
     for (int k = 0; k < NBW; ++k) {
         const int row = (wave + k * NWV) * RPW + lrow;      // window row: flat pixel pbase + dh*W - 1 + row
         const int sc = (((c16 >> 1) ^ wg_hash<BCO>(row)) << 1) | (c16 & 1);
-        boff[k] = (row - 1) * (int)x_ld + ci0 + sc * 8;
-        bkind[k] = row == 0 ? 1 : (row == KP + 1 ? 2 : (row > KP + 1 ? 3 : 0));
+        if (w16) {
+            const int half = row >= 18, kk = row - half * 18;
+            boff[k] = (half * 16 + kk - 1) * (int)x_ld + ci0 + sc * 8;
+            bkind[k] = (kk == 0 || kk == 17 || row >= 36) ? 3 : (half ? 5 : 4);     // 4 / 5: plain row of the first / second image row
+        } else {
+            boff[k] = (row - 1) * (int)x_ld + ci0 + sc * 8;
+            bkind[k] = row == 0 ? 1 : (row == KP + 1 ? 2 : (row > KP + 1 ? 3 : 0));
+        }
     }
     long pis = p_begin;                                     // next stage to issue
     int wi = (int)(p_begin % W), hi = (int)((p_begin / W) % H);
@@ -1150,13 +1159,14 @@ __global__ __launch_bounds__(NWV * 64, 1) void conv_wgrad3_kernel(const h16* __r
             }
         }
         const int hh = hi + dh;
-        const bool rowok = live && hh >= 0 && hh < H;
+        const bool rowok = live && hh >= 0 && hh < H, rowok1 = live && hh + 1 >= 0 && hh + 1 < H;
         const bool lok = wi > 0, rok = wi + KP < W;
 #pragma unroll
         for (int k = 0; k < NBW; ++k) {
             const int i = wave + k * NWV;
             if (i < NIB) {
-                const bool ok = rowok && (bkind[k] == 0 || (bkind[k] == 1 && lok) || (bkind[k] == 2 && rok));
+                const bool ok = W16 ? ((rowok && bkind[k] == 4) || (rowok1 && bkind[k] == 5))
+                                    : (rowok && (bkind[k] == 0 || (bkind[k] == 1 && lok) || (bkind[k] == 2 && rok)));
                 const void* src = ok ? (const void*)(xp + boff[k]) : (const void*)mu_zero_page;
                 glds16a(src, Bt + i * RPW * BCO);
             }
@@ -1164,8 +1174,13 @@ __global__ __launch_bounds__(NWV * 64, 1) void conv_wgrad3_kernel(const h16* __r
         pis += KP;
         dyp += KP * dy_ld;
         xp += KP * x_ld;
-        wi += KP;
-        if (wi >= W) { wi = 0; hi = hi + 1 == H ? 0 : hi + 1; }
+        if (w16) {
+            hi += 2;
+            if (hi >= H) hi -= H;
+        } else {
+            wi += KP;
+            if (wi >= W) { wi = 0; hi = hi + 1 == H ? 0 : hi + 1; }
+        }
     };
 
     f32x4 acc[3][TM][TN];
@@ -1182,6 +1197,7 @@ __global__ __launch_bounds__(NWV * 64, 1) void conv_wgrad3_kernel(const h16* __r
     // Register double-buffered fragments: the transposed LDS reads of stage s+1 are issued before the MFMAs of stage s, so
     // the LDS latency (8 + 12 dependent-free ds_read_tr per 24 MFMAs) no longer sits between the MFMA groups.
     struct Frags { h16x8 a[TM]; h16x8 b[3][TN]; };
+    const int wsh = (W16 && g >= 2) ? 2 : 0;                 // second image row's window starts 18 rows in
     auto load_frags = [&](int buf, Frags& f) {
         const h16* At = lds + buf * STAGE;
         const h16* Bt = At + KP * BCO;
@@ -1198,7 +1214,7 @@ __global__ __launch_bounds__(NWV * 64, 1) void conv_wgrad3_kernel(const h16* __r
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
                 const int col = (wc * TN + j) * 16 + 4 * pc;
-                const int r0 = 8 * g + q + t, r1 = r0 + 4;
+                const int r0 = 8 * g + q + t + wsh, r1 = r0 + 4;
                 auto lo = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) fp16x4v*)(Bt + r0 * BCO + ((((col >> 4) ^ wg_hash<BCO>(r0)) << 4) | (col & 15))));
                 auto hi = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) fp16x4v*)(Bt + r1 * BCO + ((((col >> 4) ^ wg_hash<BCO>(r1)) << 4) | (col & 15))));
                 f.b[t][j] = (h16x8){(h16)lo[0], (h16)lo[1], (h16)lo[2], (h16)lo[3], (h16)hi[0], (h16)hi[1], (h16)hi[2], (h16)hi[3]};
@@ -1326,7 +1342,9 @@ static inline void wgrad_tile(int Cin, int Cout, int* bco, int* bci) {
 }
 
 // v2 (3 taps per block) applies to fp16 3x3 layers with W % 32 == 0 and 64/128-wide channel tiles
-static inline bool wgrad3_ok(int W, int taps, int bt, int dtype) { return dtype == MU_F16 && taps == 9 && W % 32 == 0 && (bt == 128 || bt == 64); }
+static inline bool wgrad3_ok(int H, int W, int taps, int bt, int dtype) {
+    return dtype == MU_F16 && taps == 9 && (W % 32 == 0 || (W == 16 && H % 2 == 0)) && (bt == 128 || bt == 64);
+}
 static inline void wgrad3_plan(long M, int Cin, int Cout, int bt, int* nsplit, long* pps) {
     long tiles = 3L * (Cout / bt) * (Cin / bt);
     // 128-wide tiles: one block per CU (192 accumulator registers) -> ~2 rounds of blocks; fewer, longer splits also halve
@@ -1342,15 +1360,116 @@ static inline void wgrad3_plan(long M, int Cin, int Cout, int bt, int* nsplit, l
     *nsplit = (int)((M + p - 1) / p);
 }
 
+// ------------------------------------------------------------------------------------------
+// weight gradient of the first layer (<= 4 valid input channels, 3x3): 64 x 3 x 9 outputs, each a dot product over every
+// pixel -- 3.6 GFLOP but 200 MB of dy/x.  The MFMA tile kernels spend nine 32-channel-padded tap passes on it (0.5 ms);
+// this one streams dy once with plain FMAs: a block walks image rows, keeps the three input rows around the current one
+// in LDS as float4 (zero ring), lane = (pixel sub-index, 4 output channels), 27 x 4 accumulators per lane.
+// Partial slab layout [block][tap][Cout][4] feeds the same deterministic reduce as the other kernels.
+// ------------------------------------------------------------------------------------------
+#define MU_RGB_MAXW 256
+template <typename T>
+__global__ __launch_bounds__(256) void wgrad_rgb_kernel(const T* __restrict__ x, const T* __restrict__ dy, float* __restrict__ part,
+                                                        int B, int H, int W, int Cout, int cin_valid, long x_ld, long dy_ld) {
+    __shared__ float4 xs[3][MU_RGB_MAXW + 2];
+    __shared__ float red[4][27][64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int pi = lane >> 4, cg = lane & 15;                 // pixel sub-index (4 per wave step), 4-channel group
+    const int co0 = blockIdx.y * 64;
+    float acc[27][4];
+#pragma unroll
+    for (int t = 0; t < 27; ++t)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) acc[t][c] = 0.f;
+
+    const int rows = B * H;
+    for (int r = blockIdx.x; r < rows; r += gridDim.x) {
+        const int b = r / H, h = r - b * H;
+        __syncthreads();                                       // previous row's readers are done
+        for (int i = tid; i < 3 * (W + 2); i += 256) {
+            const int dh = i / (W + 2), wc = i - dh * (W + 2);
+            const int hh = h + dh - 1, ww = wc - 1;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (hh >= 0 && hh < H && ww >= 0 && ww < W) {
+                const T* px = x + (((long)b * H + hh) * W + ww) * x_ld;
+                v.x = (float)px[0];
+                if (cin_valid > 1) v.y = (float)px[1];
+                if (cin_valid > 2) v.z = (float)px[2];
+                if (cin_valid > 3) v.w = (float)px[3];
+            }
+            xs[dh][wc] = v;
+        }
+        __syncthreads();
+        const T* dyr = dy + ((long)r * W) * dy_ld + co0 + cg * 4;
+        for (int p0 = wave * 4; p0 < W; p0 += 16) {
+            const int p = p0 + pi;
+            float d[4] = {0.f, 0.f, 0.f, 0.f};
+            if (p < W) {
+                if constexpr (sizeof(T) == 2) {
+                    const h16x4 v = *reinterpret_cast<const h16x4*>(dyr + (long)p * dy_ld);
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) d[c] = (float)v[c];
+                } else {
+                    const float4 v = *reinterpret_cast<const float4*>(dyr + (long)p * dy_ld);
+                    d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+                }
+            }
+            const int pc = p < W ? p : 0;
+#pragma unroll
+            for (int dh = 0; dh < 3; ++dh)
+#pragma unroll
+                for (int dw = 0; dw < 3; ++dw) {
+                    const float4 xv = xs[dh][pc + dw];
+                    const int t = (dh * 3 + dw) * 3;
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        acc[t + 0][c] = fmaf(d[c], xv.x, acc[t + 0][c]);
+                        acc[t + 1][c] = fmaf(d[c], xv.y, acc[t + 1][c]);
+                        acc[t + 2][c] = fmaf(d[c], xv.z, acc[t + 2][c]);
+                    }
+                }
+        }
+    }
+    // (tap, ci) x 4 co per lane: fold the four pixel sub-indices (lanes 16 apart), then the four waves, in a fixed order
+#pragma unroll
+    for (int t = 0; t < 27; ++t)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            float v = acc[t][c];
+            v += __shfl_xor(v, 16);
+            v += __shfl_xor(v, 32);
+            acc[t][c] = v;
+        }
+    if (pi == 0) {
+#pragma unroll
+        for (int t = 0; t < 27; ++t)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) red[wave][t][cg * 4 + c] = acc[t][c];
+    }
+    __syncthreads();
+    // part[blk][tap][Cout][4]: ci in the last index (entries >= cin_valid are never read by the reduce)
+    for (int i = tid; i < 27 * 64; i += 256) {
+        const int t = i / 64, co = i - t * 64;
+        const float v = (red[0][t][co] + red[1][t][co]) + (red[2][t][co] + red[3][t][co]);
+        const int tap = t / 3, ci = t - tap * 3;
+        part[(((long)blockIdx.x * 9 + tap) * Cout + co0 + co) * 4 + ci] = v;
+    }
+}
+#define MU_RGB_MAXBLK 1024
+
 extern "C" long mu_conv_wgrad_workspace_bytes(int B, int H, int W, int Cin, int Cout, int taps) {
     int bco, bci, nsplit; long pps;
     wgrad_tile(Cin, Cout, &bco, &bci);
     wgrad_plan((long)B * H * W, Cin, Cout, taps, bco, bci, &nsplit, &pps);
     long a = (long)nsplit * taps * Cout * Cin * sizeof(float);
-    if (taps == 9 && W % 32 == 0 && (bco == 128 || bco == 64)) {
+    if (taps == 9 && (W % 32 == 0 || W == 16) && (bco == 128 || bco == 64)) {
         wgrad3_plan((long)B * H * W, Cin, Cout, bco, &nsplit, &pps);
         long b = (long)nsplit * taps * Cout * Cin * sizeof(float);
         if (b > a) a = b;
+    }
+    if (taps == 9 && Cin == 32) {                       // first-layer kernel (<= 4 valid input channels): [blocks][9][Cout][4]
+        long c = (long)MU_RGB_MAXBLK * 9 * Cout * 4 * sizeof(float);
+        if (c > a) a = c;
     }
     return a;
 }
@@ -1378,14 +1497,33 @@ extern "C" int mu_conv_wgrad(const void* x, const void* dy, float* dw_oihw, int 
     wgrad_plan((long)B * H * W, Cin, Cout, taps, bco, bci, &nsplit, &pps);
     hipStream_t st = (hipStream_t)stream;
     float* part = (float*)workspace;
-    if (wgrad3_ok(W, taps, bco, dtype)) {
+    if (taps == 9 && cin_valid <= 3 && Cout % 64 == 0 && W <= MU_RGB_MAXW && (dtype == MU_F16 || dtype == MU_F32)) {
+        long nb = ws_bytes / ((long)9 * Cout * 4 * (long)sizeof(float));
+        if (nb > MU_RGB_MAXBLK) nb = MU_RGB_MAXBLK;
+        if (nb > (long)B * H) nb = (long)B * H;
+        if (nb < 1) return MU_ERR_WORKSPACE;
+        dim3 grid((int)nb, Cout / 64);
+        if (dtype == MU_F16) wgrad_rgb_kernel<h16><<<grid, 256, 0, st>>>((const h16*)x, (const h16*)dy, part, B, H, W, Cout, cin_valid, x_ld, dy_ld);
+        else wgrad_rgb_kernel<float><<<grid, 256, 0, st>>>((const float*)x, (const float*)dy, part, B, H, W, Cout, cin_valid, x_ld, dy_ld);
+        const long n = (long)cout_valid * cin_valid * 9;
+        const long nblk = (n + 63) / 64;
+        wgrad_reduce_kernel<4><<<(int)(nblk > 4096 ? 4096 : nblk), 256, 0, st>>>(part, dw_oihw, (int)nb, 9, Cout, 4, cout_valid, cin_valid);
+        MU_CHECK_LAUNCH();
+        return MU_OK;
+    }
+    if (wgrad3_ok(H, W, taps, bco, dtype)) {
         wgrad3_plan((long)B * H * W, Cin, Cout, bco, &nsplit, &pps);
         if (ws_bytes < (long)nsplit * taps * Cout * Cin * (long)sizeof(float)) return MU_ERR_WORKSPACE;
         const int grid = 3 * (Cout / bco) * (Cin / bco) * nsplit;
-        if (bco == 128)     // 8 waves, 64x32 tile x 3 taps per wave (96 accumulators): 2 waves/SIMD
-            conv_wgrad3_kernel<4, 2, 2, 8><<<grid, 512, 0, st>>>((const h16*)x, (const h16*)dy, part, B, H, W, Cin, Cout, x_ld, dy_ld, nsplit, pps);
+        const h16 *xh = (const h16*)x, *dyh = (const h16*)dy;
+        if (bco == 128 && W == 16)      // 8 waves, 64x32 tile x 3 taps per wave (96 accumulators): 2 waves/SIMD
+            conv_wgrad3_kernel<4, 2, 2, 8, true><<<grid, 512, 0, st>>>(xh, dyh, part, B, H, W, Cin, Cout, x_ld, dy_ld, nsplit, pps);
+        else if (bco == 128)
+            conv_wgrad3_kernel<4, 2, 2, 8><<<grid, 512, 0, st>>>(xh, dyh, part, B, H, W, Cin, Cout, x_ld, dy_ld, nsplit, pps);
+        else if (W == 16)
+            conv_wgrad3_kernel<2, 2, 2, 4, true><<<grid, 256, 0, st>>>(xh, dyh, part, B, H, W, Cin, Cout, x_ld, dy_ld, nsplit, pps);
         else
-            conv_wgrad3_kernel<2, 2, 2><<<grid, 256, 0, st>>>((const h16*)x, (const h16*)dy, part, B, H, W, Cin, Cout, x_ld, dy_ld, nsplit, pps);
+            conv_wgrad3_kernel<2, 2, 2><<<grid, 256, 0, st>>>(xh, dyh, part, B, H, W, Cin, Cout, x_ld, dy_ld, nsplit, pps);
     } else if (ws_bytes < (long)nsplit * taps * Cout * Cin * (long)sizeof(float)) {
         return MU_ERR_WORKSPACE;
     } else if (dtype == MU_F16) {

@@ -104,7 +104,11 @@ def check_conv(dtype, cases=None):
                       # W % 32 == 0: exercises the 3-taps-per-block weight-gradient kernel (fp16) incl. row/image borders
                       (2, 32, 32, 64, 64, 3), (1, 64, 32, 128, 128, 3), (2, 16, 64, 64, 128, 3), (1, 32, 32, 256, 128, 3),
                       # 16x16-tile ping-pong kernel: odd number of 64-channel chunks, non-square image, two channel blocks
-                      (2, 32, 48, 192, 256, 3), (3, 16, 16, 128, 128, 3)]
+                      (2, 32, 48, 192, 256, 3), (3, 16, 16, 128, 128, 3),
+                      # first-layer weight-gradient kernel (<= 3 valid input channels): ragged width, two channel blocks, 1 channel
+                      (2, 20, 24, 3, 128, 3), (1, 8, 8, 1, 64, 3),
+                      # 16-pixel-wide images through the 3-tap weight-gradient kernel (two image rows per stage)
+                      (2, 8, 16, 256, 128, 3), (5, 16, 16, 64, 64, 3)]
     for (B, H, W, Cin, Cout, k) in cases:
         x = _rnd(gen, B, Cin, H, W)
         w = _rnd(gen, Cout, Cin, k, k, scale=1.0 / math.sqrt(Cin * k * k))
