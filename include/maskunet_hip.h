@@ -76,10 +76,11 @@ int mu_colsum(const void* x, long M, int C, long ld, float* out, void* workspace
 /* ---- BatchNorm2d (+activation, +residual) --------------------------------------------------- */
 /* nn.BatchNorm2d training statistics (ade_semantic.py:200,204,219,240,285): biased batch variance ->
  * mean/rstd; running stats updated with the unbiased variance and `momentum` for c < c_valid
- * (running_* may be NULL). */
+ * (running_* may be NULL); *num_batches_tracked (int64 on the device, may be NULL) is incremented. */
 long mu_bn_workspace_bytes(int C);
 int mu_bn_train_stats(const void* x, long M, int C, long ld, float* mean, float* rstd, float* running_mean, float* running_var,
-                      int c_valid, float momentum, float eps, void* workspace, long ws_bytes, int dtype, void* stream);
+                      long* num_batches_tracked, int c_valid, float momentum, float eps, void* workspace, long ws_bytes, int dtype,
+                      void* stream);
 /* eval mode: mean/rstd from the running statistics */
 int mu_bn_eval_stats(const float* running_mean, const float* running_var, float eps, float* mean, float* rstd, int C, int c_valid,
                      void* stream);

@@ -33,7 +33,7 @@ SIGNATURES = {
     "mu_colsum_workspace_bytes": (L, [I]),
     "mu_colsum": (I, [P, L, I, L, P, P, L, I, P]),
     "mu_bn_workspace_bytes": (L, [I]),
-    "mu_bn_train_stats": (I, [P, L, I, L, P, P, P, P, I, F, F, P, L, I, P]),
+    "mu_bn_train_stats": (I, [P, L, I, L, P, P, P, P, P, I, F, F, P, L, I, P]),
     "mu_bn_eval_stats": (I, [P, P, F, P, P, I, I, P]),
     "mu_bn_act_fwd": (I, [P, P, P, L, I, L, P, P, P, P, I, I, P]),
     "mu_bn_act_bwd": (I, [P, P, P, P, P, L, I, L, P, P, P, P, I, I, P, P, P, L, I, P]),

@@ -84,7 +84,7 @@ __global__ __launch_bounds__(256) void bn_partial_kernel(const T* __restrict__ x
                         f0[i] += d;
                         f1[i] = fmaf(d, xh, f1[i]);
                     }
-                    if (rr < r1) dz.store(dzbuf + rr * ld + c);
+                    if (dzbuf && rr < r1) dz.store(dzbuf + rr * ld + c);
                 }
             }
 #pragma unroll
@@ -108,7 +108,8 @@ __global__ __launch_bounds__(256) void bn_partial_kernel(const T* __restrict__ x
 // BN forward finalize: mean, rstd (biased var) + running-stat update (unbiased var, momentum)
 __global__ void bn_fwd_final_kernel(const double* __restrict__ part, int nblk, int C, long M, float eps, float momentum,
                                     float* __restrict__ mean, float* __restrict__ rstd, float* __restrict__ running_mean,
-                                    float* __restrict__ running_var, int c_valid) {
+                                    float* __restrict__ running_var, int c_valid, long* __restrict__ num_batches_tracked) {
+    if (num_batches_tracked && blockIdx.x == 0 && threadIdx.x == 0) *num_batches_tracked += 1;   // nn.BatchNorm2d's step counter
     // one wave per channel: lanes stride over the partial blocks, then a wave reduction
     const int c = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (c >= C) return;
@@ -198,14 +199,17 @@ __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const T* __restrict__ x
     }
 }
 
-// dx = gamma*rstd*(dz - s1 - xhat*s2)   (dz read from dzbuf; may alias dx)
-template <typename T>
+// dx = gamma*rstd*(dz - s1 - xhat*s2).  RECOMP = false: dz is read from dzbuf (may alias dx) -- the residual form, whose
+// d(residual) IS dz and has to be written anyway.  RECOMP = true (no residual): dz = g * act'(pre) is recomputed from x and
+// the incoming gradient, so the statistics sweep writes nothing: 5 tensor passes per BatchNorm backward instead of 6.
+template <typename T, bool RECOMP>
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__ x, const T* dzbuf, T* dx, long M, int C, long ld,
                                                            const float* __restrict__ mean, const float* __restrict__ rstd,
-                                                           const float* __restrict__ gamma, const float* __restrict__ s1,
-                                                           const float* __restrict__ s2) {
+                                                           const float* __restrict__ gamma, const float* __restrict__ beta, int act,
+                                                           const float* __restrict__ s1, const float* __restrict__ s2) {
     constexpr int N = Vec16<T>::N;
     constexpr int U = 4;
+    constexpr bool FAST = sizeof(T) == 2;
     const int cv = C / N;
     const long total = M * cv;
     const long stride = (long)gridDim.x * 256;
@@ -213,13 +217,15 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
     const int c = (int)(first % cv) * N;
     const long rstep = stride / cv;
     // dx = k0 + k1 * x + gr * dz with xhat = (x - mu) rs:  k1 = -gr rs s2,  k0 = -gr s1 - k1 mu
-    float gr[N], k0[N], k1[N];
+    // RECOMP: pre = xhat * gamma + beta, evaluated exactly as in the statistics sweep so both see the same rounded dz
+    float gr[N], k0[N], k1[N], mu[N], rsv[N], ga[N], be[N];
 #pragma unroll
     for (int i = 0; i < N; ++i) {
         const float rs = rstd[c + i];
         gr[i] = gamma[c + i] * rs;
         k1[i] = -gr[i] * rs * s2[c + i];
         k0[i] = -gr[i] * s1[c + i] - k1[i] * mean[c + i];
+        mu[i] = mean[c + i]; rsv[i] = rs; ga[i] = gamma[c + i]; be[i] = RECOMP ? beta[c + i] : 0.f;
     }
     for (long idx = first; idx < total; idx += U * stride) {
         const long r = idx / cv;
@@ -236,7 +242,16 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
             if (idx + u * stride < total) {
                 Vec16<T> o;
 #pragma unroll
-                for (int i = 0; i < N; ++i) o.set(i, fmaf(gr[i], dz[u].get(i), fmaf(k1[i], xv[u].get(i), k0[i])));
+                for (int i = 0; i < N; ++i) {
+                    float d = dz[u].get(i);
+                    if (RECOMP) {
+                        Vec16<T> t;                         // round dz to T exactly like the statistics sweep did
+                        const float xh = (xv[u].get(i) - mu[i]) * rsv[i];
+                        t.set(i, d * mu_act_grad_t<FAST>(fmaf(xh, ga[i], be[i]), act));
+                        d = t.get(i);
+                    }
+                    o.set(i, fmaf(gr[i], d, fmaf(k1[i], xv[u].get(i), k0[i])));
+                }
                 o.store(dx + (r + u * rstep) * ld + c);
             }
         }
@@ -291,8 +306,8 @@ extern "C" int mu_colsum(const void* x, long M, int C, long ld, float* out, void
 extern "C" long mu_bn_workspace_bytes(int C) { return (long)MU_STAT_MAXBLK * C * 2 * sizeof(double) + 2L * C * sizeof(float); }
 
 template <typename T>
-static int bn_train_stats_t(const T* x, long M, int C, long ld, float* mean, float* rstd, float* rmean, float* rvar, int c_valid,
-                            float momentum, float eps, void* ws, hipStream_t st) {
+static int bn_train_stats_t(const T* x, long M, int C, long ld, float* mean, float* rstd, float* rmean, float* rvar, long* nbt,
+                            int c_valid, float momentum, float eps, void* ws, hipStream_t st) {
     constexpr int N = Vec16<T>::N;
     int cv = C / N;
     if (cv > 256) return MU_ERR_SHAPE;
@@ -300,19 +315,19 @@ static int bn_train_stats_t(const T* x, long M, int C, long ld, float* mean, flo
     int nblk = stat_blocks(M);
     size_t lds = (size_t)rpi * C * 2 * sizeof(double);
     bn_partial_kernel<T, 0><<<nblk, 256, lds, st>>>(x, nullptr, nullptr, nullptr, M, C, ld, nullptr, nullptr, nullptr, nullptr, 0, (double*)ws);
-    bn_fwd_final_kernel<<<mu_cdiv(C, 4), 256, 0, st>>>((const double*)ws, nblk, C, M, eps, momentum, mean, rstd, rmean, rvar, c_valid);
+    bn_fwd_final_kernel<<<mu_cdiv(C, 4), 256, 0, st>>>((const double*)ws, nblk, C, M, eps, momentum, mean, rstd, rmean, rvar, c_valid, nbt);
     return MU_OK;
 }
 
 extern "C" int mu_bn_train_stats(const void* x, long M, int C, long ld, float* mean, float* rstd, float* running_mean,
-                                 float* running_var, int c_valid, float momentum, float eps, void* workspace, long ws_bytes,
-                                 int dtype, void* stream) {
+                                 float* running_var, long* num_batches_tracked, int c_valid, float momentum, float eps,
+                                 void* workspace, long ws_bytes, int dtype, void* stream) {
     if (!x || !mean || !rstd || !workspace || M <= 0 || C <= 0 || C % 8 || ld < C) return MU_ERR_ARG;
     if (ws_bytes < mu_bn_workspace_bytes(C)) return MU_ERR_WORKSPACE;
     hipStream_t st = (hipStream_t)stream;
     int rc;
-    if (dtype == MU_F32) rc = bn_train_stats_t<float>((const float*)x, M, C, ld, mean, rstd, running_mean, running_var, c_valid, momentum, eps, workspace, st);
-    else if (dtype == MU_F16) rc = bn_train_stats_t<h16>((const h16*)x, M, C, ld, mean, rstd, running_mean, running_var, c_valid, momentum, eps, workspace, st);
+    if (dtype == MU_F32) rc = bn_train_stats_t<float>((const float*)x, M, C, ld, mean, rstd, running_mean, running_var, num_batches_tracked, c_valid, momentum, eps, workspace, st);
+    else if (dtype == MU_F16) rc = bn_train_stats_t<h16>((const h16*)x, M, C, ld, mean, rstd, running_mean, running_var, num_batches_tracked, c_valid, momentum, eps, workspace, st);
     else return MU_ERR_ARG;
     if (rc) return rc;
     MU_CHECK_LAUNCH();
@@ -353,10 +368,15 @@ static int bn_act_bwd_t(const T* x, const T* res, const T* g, T* dx, T* dres, lo
     double* part = (double*)ws;
     float* s1 = (float*)((char*)ws + (size_t)MU_STAT_MAXBLK * C * 2 * sizeof(double));
     float* s2 = s1 + C;
-    T* dzbuf = res ? dres : dx;     // d(residual) == dz exactly, so it doubles as the dz buffer
-    bn_partial_kernel<T, 1><<<nblk, 256, lds, st>>>(x, g, res, dzbuf, M, C, ld, mean, rstd, gamma, beta, act, part);
-    bn_bwd_final_kernel<<<mu_cdiv(C, 4), 256, 0, st>>>(part, nblk, C, M, training, dgamma, dbeta, s1, s2);
-    bn_bwd_apply_kernel<T><<<ew_grid(M * cv, cv), 256, 0, st>>>(x, dzbuf, dx, M, C, ld, mean, rstd, gamma, s1, s2);
+    if (res) {                      // d(residual) == dz exactly, so it doubles as the dz buffer
+        bn_partial_kernel<T, 1><<<nblk, 256, lds, st>>>(x, g, res, dres, M, C, ld, mean, rstd, gamma, beta, act, part);
+        bn_bwd_final_kernel<<<mu_cdiv(C, 4), 256, 0, st>>>(part, nblk, C, M, training, dgamma, dbeta, s1, s2);
+        bn_bwd_apply_kernel<T, false><<<ew_grid(M * cv, cv), 256, 0, st>>>(x, dres, dx, M, C, ld, mean, rstd, gamma, beta, act, s1, s2);
+    } else {                        // no residual: nothing is written by the statistics sweep, dz is recomputed in the apply pass
+        bn_partial_kernel<T, 1><<<nblk, 256, lds, st>>>(x, g, nullptr, nullptr, M, C, ld, mean, rstd, gamma, beta, act, part);
+        bn_bwd_final_kernel<<<mu_cdiv(C, 4), 256, 0, st>>>(part, nblk, C, M, training, dgamma, dbeta, s1, s2);
+        bn_bwd_apply_kernel<T, true><<<ew_grid(M * cv, cv), 256, 0, st>>>(x, g, dx, M, C, ld, mean, rstd, gamma, beta, act, s1, s2);
+    }
     return MU_OK;
 }
 

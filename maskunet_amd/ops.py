@@ -194,7 +194,7 @@ class _BNAct(torch.autograd.Function):
     :285-286 (BN, ReLU).  Training uses batch statistics and updates the running buffers in place."""
 
     @staticmethod
-    def forward(ctx, x, res, gamma, beta, running_mean, running_var, training, momentum, eps, act):
+    def forward(ctx, x, res, gamma, beta, running_mean, running_var, training, momentum, eps, act, nbt=None):
         x = x.contiguous()
         C = x.shape[-1]
         M = x.numel() // C
@@ -206,7 +206,7 @@ class _BNAct(torch.autograd.Function):
         if training:
             rm = running_mean if running_mean is not None else None
             rv = running_var if running_var is not None else None
-            call("mu_bn_train_stats", ptr(x), M, C, C, ptr(mean), ptr(rstd), ptr(rm), ptr(rv), cv, float(momentum), float(eps),
+            call("mu_bn_train_stats", ptr(x), M, C, C, ptr(mean), ptr(rstd), ptr(rm), ptr(rv), ptr(nbt), cv, float(momentum), float(eps),
                  ptr(ws), ws.numel(), dt(x), stream())
         else:
             call("mu_bn_eval_stats", ptr(running_mean), ptr(running_var), float(eps), ptr(mean), ptr(rstd), C, cv, stream())
@@ -232,17 +232,20 @@ class _BNAct(torch.autograd.Function):
         ws = workspace(_lib.load().mu_bn_workspace_bytes(C), x.device)
         call("mu_bn_act_bwd", ptr(x), ptr(res), ptr(gy), ptr(dx), ptr(dres), M, C, C, ptr(mean), ptr(rstd), ptr(g_p), ptr(b_p),
              ctx.act, int(ctx.training), ptr(dgamma), ptr(dbeta), ptr(ws), ws.numel(), dt(x), stream())
-        return dx, dres, dgamma[:ctx.cv], dbeta[:ctx.cv], None, None, None, None, None, None
+        return dx, dres, dgamma[:ctx.cv], dbeta[:ctx.cv], None, None, None, None, None, None, None
 
 
 def bn_act(x, bn, act=ACT_NONE, res=None):
     """Apply the BatchNorm2d parameter container `bn` (an nn.BatchNorm2d used only for its
     parameters/buffers/flags) followed by `act`, optionally adding `res` before the activation."""
     training = bn.training or bn.running_mean is None
-    if bn.training and bn.num_batches_tracked is not None:
-        bn.num_batches_tracked.add_(1)
+    # the step counter is bumped by the statistics kernel (one tiny torch kernel per BatchNorm otherwise: 39 per step)
+    nbt = bn.num_batches_tracked if (bn.training and bn.num_batches_tracked is not None) else None
+    if nbt is not None and (nbt.device != x.device or nbt.dtype != torch.int64):
+        nbt.add_(1)
+        nbt = None
     momentum = 0.1 if bn.momentum is None else bn.momentum
-    return _BNAct.apply(x, res, bn.weight, bn.bias, bn.running_mean, bn.running_var, training, momentum, bn.eps, act)
+    return _BNAct.apply(x, res, bn.weight, bn.bias, bn.running_mean, bn.running_var, training, momentum, bn.eps, act, nbt)
 
 
 # ------------------------------------------------------------------------------------------------

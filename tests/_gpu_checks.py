@@ -172,7 +172,8 @@ def check_bn_act(dtype):
                 (tag + " dgamma", _rel_err(bn_dev.weight.grad, bn_ref.weight.grad), tol),
                 (tag + " dbeta", _rel_err(bn_dev.bias.grad, bn_ref.bias.grad), tol),
                 (tag + " rmean", _err(bn_dev.running_mean, bn_ref.running_mean), tol),
-                (tag + " rvar", _err(bn_dev.running_var, bn_ref.running_var), tol)]
+                (tag + " rvar", _err(bn_dev.running_var, bn_ref.running_var), tol),
+                (tag + " num_batches_tracked", abs(int(bn_dev.num_batches_tracked) - int(bn_ref.num_batches_tracked)), 0.0)]
         if use_res:
             out.append((tag + " dres", _rel_err(rd.grad, rr.grad), tol))
     return out

@@ -53,13 +53,13 @@ def main():
         ws = torch.empty(_lib.load().mu_bn_workspace_bytes(C), dtype=torch.uint8, device=dev)
         def mk(lib, phase):
             if phase == 0:
-                return lambda: lib.mu_bn_train_stats(x.data_ptr(), M, C, C, mean.data_ptr(), rstd.data_ptr(), None, None, C, 0.1, 1e-5, ws.data_ptr(), ws.numel(), 1, st)
+                return lambda: lib.mu_bn_train_stats(x.data_ptr(), M, C, C, mean.data_ptr(), rstd.data_ptr(), None, None, None, C, 0.1, 1e-5, ws.data_ptr(), ws.numel(), 1, st)
             if phase == 1:
                 return lambda: lib.mu_bn_act_fwd(x.data_ptr(), None, y.data_ptr(), M, C, C, mean.data_ptr(), rstd.data_ptr(), gam.data_ptr(), bet.data_ptr(), 1, 1, st)
             return lambda: lib.mu_bn_act_bwd(x.data_ptr(), None, gy.data_ptr(), dx.data_ptr(), None, M, C, C, mean.data_ptr(), rstd.data_ptr(), gam.data_ptr(), bet.data_ptr(), 1, 1, dgam.data_ptr(), dbet.data_ptr(), ws.data_ptr(), ws.numel(), 1, st)
         cases = [("bn_stats 268MB", 0), ("bn_act_fwd", 1), ("bn_act_bwd", 2)]
     else:
-        shapes = [(64, 128, 128, 128), (64, 64, 256, 256), (64, 32, 512, 512), (64, 16, 512, 512), (64, 128, 64, 128)]
+        shapes = [(64, 128, 128, 128), (64, 64, 256, 256), (64, 32, 512, 512), (64, 16, 512, 512), (64, 128, 64, 128), (64, 16, 256, 256), (64, 16, 256, 512), (64, 32, 256, 256), (64, 64, 128, 128)]
         bufs = []
         for (B, H, Cin, Cout) in shapes:
             bufs.append((torch.randn(B, H, H, Cin, device=dev, dtype=dt), (torch.randn(9, Cout, Cin, device=dev) * 0.05).to(dt), torch.empty(B, H, H, Cout, device=dev, dtype=dt),
@@ -70,7 +70,7 @@ def main():
             if phase % 2 == 0:
                 return lambda: lib.mu_conv_fwd(x.data_ptr(), w.data_ptr(), None, y.data_ptr(), B, H, H, Cin, Cout, 9, Cin, Cout, 1, st)
             return lambda: lib.mu_conv_wgrad(x.data_ptr(), dy.data_ptr(), gw.data_ptr(), B, H, H, Cin, Cout, 9, Cin, Cout, Cin, Cout, ws.data_ptr(), ws.numel(), 1, st)
-        sel = (0, 2, 4, 6, 8) if what == "conv" else (1, 3, 5, 7, 9)
+        sel = tuple(range(0, 2 * len(shapes), 2)) if what == "conv" else tuple(range(1, 2 * len(shapes), 2))
         cases = [(f"{'fwd' if p % 2 == 0 else 'wgrad'} {shapes[p // 2]} {2e-9 * 9 * shapes[p // 2][0] * shapes[p // 2][1] ** 2 * shapes[p // 2][2] * shapes[p // 2][3]:.0f} GF", p) for p in sel]
     for cname, phase in cases:
         res = {n: [] for n in names}
