@@ -28,7 +28,11 @@ class FusedAdamW(torch.optim.Optimizer):
                 bt += [i] * n
                 bc += list(range(n))
             dev = params[0].device
-            plan = (torch.tensor(bt, dtype=torch.int32, device=dev), torch.tensor(bc, dtype=torch.int32, device=dev), len(bt))
+            # pointer-table staging: a small ring of pinned host buffers (+ the event of their last upload) and one device
+            # table per slot, allocated once -- pinning memory per step costs milliseconds of host time
+            ring = [(torch.empty((len(params), 6), dtype=torch.int64).pin_memory(),
+                     torch.empty((len(params), 6), dtype=torch.int64, device=dev), torch.cuda.Event()) for _ in range(4)]
+            plan = (torch.tensor(bt, dtype=torch.int32, device=dev), torch.tensor(bc, dtype=torch.int32, device=dev), len(bt), ring, [0])
             self._plans = {key: plan}
         return plan
 
@@ -62,10 +66,13 @@ class FusedAdamW(torch.optim.Optimizer):
                 rows.append((p.data_ptr(), g.data_ptr() if g is not None else 0, st["exp_avg"].data_ptr(),
                              st["exp_avg_sq"].data_ptr(), p.numel(), bc))
             # pointer table: {p, g, m, v, n, (bc1, bc2_sqrt)} = 6 x 8 bytes per tensor, uploaded asynchronously (pinned staging)
-            host = torch.tensor(rows, dtype=torch.int64).pin_memory()
-            table = host.to(params[0].device, non_blocking=True)
-            bt, bc, nblocks = self._plan(gi, params)
+            bt, bc, nblocks, ring, cursor = self._plan(gi, params)
+            host, table, ev = ring[cursor[0] % len(ring)]
+            cursor[0] += 1
+            ev.synchronize()                 # the upload that last used this slot (4 steps ago) is long done
+            host.copy_(torch.tensor(rows, dtype=torch.int64))
+            table.copy_(host, non_blocking=True)
+            ev.record()
             call("mu_adamw_multi", ptr(table), ptr(bt), ptr(bc), nblocks, float(group["lr"]), float(b1), float(b2), float(group["eps"]),
                  float(group["weight_decay"]), 1.0 / float(grad_scale), stream())
-            self._keep = (host, table)       # alive until the kernel has run
         return loss
