@@ -658,6 +658,9 @@ __global__ __launch_bounds__(256, 2) void conv_nt3p_kernel(const T* __restrict__
 #ifndef MU_CONV_NT4
 #define MU_CONV_NT4 1
 #endif
+#ifndef MU_CONV_NT4P
+#define MU_CONV_NT4P 1
+#endif
 __global__ __launch_bounds__(512, 1) void conv_nt4_kernel(const h16* __restrict__ x, const h16* __restrict__ w, const float* __restrict__ bias,
                                                           h16* __restrict__ y, int B, int H, int W, int Cin, int Cout, long x_ld, long y_ld) {
     using M_ = Mma<h16>;
@@ -781,13 +784,19 @@ __global__ __launch_bounds__(512, 1) void conv_nt4_kernel(const h16* __restrict_
                 __builtin_amdgcn_s_barrier();
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 __builtin_amdgcn_sched_barrier(0);
+#ifndef MU_NT4_ABL_NOPRIO
                 __builtin_amdgcn_s_setprio(1);
+#endif
 #pragma unroll
                 for (int i = 0; i < TM; ++i)
 #pragma unroll
                     for (int j = 0; j < TN; ++j) M_::mma(a[i], b[j], acc[i][j]);
+#ifndef MU_NT4_ABL_NOPRIO
                 __builtin_amdgcn_s_setprio(0);
+#endif
+#ifndef MU_NT4_ABL_NOWAIT
                 if (kk == 0) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+#endif
                 __builtin_amdgcn_sched_barrier(0);
                 __builtin_amdgcn_s_barrier();
             }
@@ -795,35 +804,237 @@ __global__ __launch_bounds__(512, 1) void conv_nt4_kernel(const h16* __restrict_
     }
     if (wr == 0) __builtin_amdgcn_s_barrier();
 
-    // Epilogue through LDS (the halo buffers are free now): the accumulator layout gives each lane 4 channels of one pixel
-    // (8-byte pieces, 32 contiguous bytes per 4 lanes); staged as out[pixel][128 co] and re-read as 16-byte pieces, every
-    // wave store covers four whole 256-byte pixel rows.  8-byte slot of row p is XORed with (p & 15) << 1 on the write,
-    // i.e. 16-byte slot ^ (p & 15) on the read: both sides are bank-conflict free.
-    char* Os = lds;
+    // Epilogue, wave-private and barrier-free (all LDS is free now): every wave stages its own 64 co x 64 px tile (8 KB as
+    // [pixel][64 co], 128-byte rows) and reads it back as 16-byte pieces, so each wave store writes eight whole 128-byte rows
+    // instead of 32-byte fragments.  8-byte slot XORed with ((p >> 1) & 7) << 1 on the write == 16-byte slot ^ ((p >> 1) & 7)
+    // on the read: both sides bank-conflict free.
+    char* Os = lds + wave * 8192;
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
-        const int p = (wc * TN + j) * 16 + r16;
+        const int p = j * 16 + r16;
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
-            const int co = (wr * TM + i) * 16 + 4 * g;
+            const int co = i * 16 + 4 * g;
             float v[4];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) v[r] = acc[i][j][r] + (bias ? bias[co0 + co + r] : 0.f);
+            for (int r = 0; r < 4; ++r) v[r] = acc[i][j][r] + (bias ? bias[co0 + wr * 64 + co + r] : 0.f);
             h16x4 o = {(h16)v[0], (h16)v[1], (h16)v[2], (h16)v[3]};
-            *reinterpret_cast<h16x4*>(Os + p * 256 + (((co >> 2) ^ (r16 << 1)) << 3)) = o;
+            *reinterpret_cast<h16x4*>(Os + p * 128 + (((co >> 2) ^ (((p >> 1) & 7) << 1)) << 3)) = o;
         }
     }
-    __syncthreads();
-    const int q = tid & 15;
+    const int q = lane & 7;
 #pragma unroll
     for (int it = 0; it < 8; ++it) {
-        const int p = it * 32 + (tid >> 4);
-        const h16x8 o = *reinterpret_cast<const h16x8*>(Os + p * 256 + ((q ^ (p & 15)) << 4));
-        const long gp = ((long)bimg * H + h0 + (p >> 4)) * W + w0 + (p & 15);
+        const int p = it * 8 + (lane >> 3);                 // pixel inside the wave tile: image row wc*4 + (p >> 4), column p & 15
+        const h16x8 o = *reinterpret_cast<const h16x8*>(Os + p * 128 + ((q ^ ((p >> 1) & 7)) << 4));
+        const long gp = ((long)bimg * H + h0 + wc * TN + (p >> 4)) * W + w0 + (p & 15);
 #ifdef MU_NT4_ABL_NOSTORE
         if (B < 0)
 #endif
-        *reinterpret_cast<h16x8*>(y + gp * y_ld + co0 + q * 8) = o;
+        *reinterpret_cast<h16x8*>(y + gp * y_ld + co0 + wr * 64 + q * 8) = o;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// v4p: the ping-pong kernel as a PERSISTENT tile loop -- one block per CU walks the 16x16 tiles of its output-channel block.
+// Measured on v4 (in-process, 128->128 @128^2): every tile pays ~4.8 us of launch / index / prologue (halo + three weight
+// tiles behind a vmcnt(0)) / epilogue around 18 taps x 0.87 us.  Here the DMA stream simply runs on across the tile
+// boundary: the last chunk of a tile prefetches the NEXT tile's first halo (pieces at taps 0..6) and its first three weight
+// tiles, so only the first tile of a block has a prologue.  The epilogue stages the output through the just-freed halo
+// buffer in two 32 KB halves (the other buffer already holds the next tile's halo).  Its 8 global stores per thread count
+// in vmcnt like the DMAs: the first two taps of a tile wait with vmcnt(11) = 3 DMAs + 8 younger stores, afterwards vmcnt(3).
+// LDS-DMA through inline asm (glds16a): the epilogue's LDS writes would otherwise be fenced with vmcnt(0) by the compiler.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(512, 1) void conv_nt4p_kernel(const h16* __restrict__ x, const h16* __restrict__ w, const float* __restrict__ bias,
+                                                           h16* __restrict__ y, int B, int H, int W, int Cin, int Cout, long x_ld, long y_ld) {
+    using M_ = Mma<h16>;
+    using Frag = M_::Frag;
+    constexpr int VN = 8, KC = 64, TM = 4, TN = 4, NWV = 8, BCO = 128;
+    constexpr int TH = 16, TW = 16, HW_ = TW + 2, HROWS = (TH + 2) * HW_;
+    constexpr int HINST = (HROWS + 7) / 8;
+    constexpr int HPW = 7;
+    constexpr int HBYTES = HINST * 1024, WBYTES = BCO * 128, NWB = 4;
+
+    __shared__ __attribute__((aligned(16))) char lds[2 * HBYTES + NWB * WBYTES + 1024 + 8192];
+    char* Hs = lds;
+    char* Ws = lds + 2 * HBYTES;
+    char* dump = lds + 2 * HBYTES + NWB * WBYTES;
+    char* spare = dump + 1024;                               // 8 KB: wave 7's output stage
+
+    const int tiles_w = W / TW, tiles_h = H / TH;
+    const int ntile = B * tiles_h * tiles_w, ncb = Cout / BCO;
+    const int nblk = gridDim.x / ncb;                        // blocks per output-channel block
+    const int L = xcd_remap(blockIdx.x, gridDim.x);          // the ncb blocks sweeping the same tiles sit on one XCD
+    const int cb = L % ncb, bx = L / ncb;
+    const int co0 = cb * BCO;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 2, wc = wave & 3;
+    const int r16 = lane & 15, g = lane >> 4;
+    const int srow = lane >> 3, sch = lane & 7;
+    const int kchunks = Cin / KC;
+
+    int wl[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int row = (i * NWV + wave) * 8 + srow;
+        wl[i] = (co0 + row) * Cin + (sch ^ (row & 7)) * VN;
+    }
+    // per-lane halo source offsets of tile tl (element offsets inside its image, -1 = zero ring) and that image's base.
+    // Recomputed at every chunk start for the chunk's prefetch target (~80 VALU against 9 taps of MFMA work) rather than
+    // kept for two tiles: the kernel sits at the register limit.
+    int hl[HPW];
+    const h16* xb;
+    auto halo_offsets = [&](int tl) {
+        const int tw_ = tl % tiles_w, th_ = (tl / tiles_w) % tiles_h, bi = tl / (tiles_w * tiles_h);
+        const int hh0 = th_ * TH - 1, ww0 = tw_ * TW - 1;
+        xb = x + (long)bi * H * W * x_ld;
+#pragma unroll
+        for (int k = 0; k < HPW; ++k) {
+            const int hr = (k * NWV + wave) * 8 + srow;
+            const int hy = hr / HW_, hx = hr - hy * HW_;
+            const int hh = hh0 + hy, ww = ww0 + hx;
+            const bool ok = hr < HROWS && hh >= 0 && hh < H && ww >= 0 && ww < W;
+            hl[k] = ok ? (int)(((long)hh * W + ww) * x_ld) + (sch ^ (hx & 7)) * VN : -1;
+        }
+    };
+    auto stage_w = [&](int slot, int tap, int chunk, bool real) {     // one (tap, 64-channel chunk) weight tile -> ring slot
+        if (real) {
+            const h16* wb = w + (long)tap * Cout * Cin + chunk * KC;
+            char* Wb = Ws + slot * WBYTES;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) glds16a(wb + wl[i], Wb + (i * NWV + wave) * 1024);
+        } else {
+            glds16a(mu_zero_page, dump);
+            glds16a(mu_zero_page, dump);
+        }
+    };
+    auto stage_h = [&](int k, int chunk, int buf, bool real) {
+        if (real && k * NWV + wave < HINST) {
+            const int off = hl[k];
+            const void* src = off >= 0 ? (const void*)(xb + off + chunk * KC) : (const void*)mu_zero_page;
+            glds16a(src, Hs + buf * HBYTES + (k * NWV + wave) * 1024);
+        } else {
+            glds16a(mu_zero_page, dump);
+        }
+    };
+
+    int aoff[2], boff[3][2];
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+        aoff[kk] = (wr * TM * 16 + r16) * 128 + (((kk * 4 + g) ^ (r16 & 7)) << 4);
+#pragma unroll
+        for (int dw = 0; dw < 3; ++dw) boff[dw][kk] = (wc * TN * HW_ + r16 + dw) * 128 + (((kk * 4 + g) ^ ((r16 + dw) & 7)) << 4);
+    }
+
+    int tl = bx;
+    if (tl >= ntile) return;                                 // (whole block: no barrier has been executed yet)
+    halo_offsets(tl);
+
+    // prologue of the block's first tile: halo of chunk 0 and W(0..2), drained; then group B falls one barrier behind
+#pragma unroll
+    for (int k = 0; k < HPW; ++k) stage_h(k, 0, 0, true);
+#pragma unroll
+    for (int q = 0; q < 3; ++q) stage_w(q, q % 9, q / 9, q < 9 * kchunks);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (wr == 1) __builtin_amdgcn_s_barrier();
+
+    int sg = 0, G = 0;                                       // running tap step (weight ring slot) and chunk (halo buffer) counters
+    for (; tl < ntile; tl += nblk) {
+        const bool has_next = tl + nblk < ntile;
+        f32x4 acc[TM][TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+        for (int c = 0; c < kchunks; ++c, ++G) {
+            const int hbuf = (G & 1) * HBYTES;
+            const bool last_chunk = c + 1 == kchunks;
+            // this chunk prefetches the halo of the tile's next chunk, or of the next tile's first chunk
+            if (last_chunk) { if (has_next) halo_offsets(tl + nblk); }
+            else if (c == 0) halo_offsets(tl);
+            const bool pf_real = !last_chunk || has_next;
+            const int pf_chunk = last_chunk ? 0 : c + 1;
+#pragma unroll
+            for (int t = 0; t < 9; ++t, ++sg) {
+                const int dh = t / 3, dw = t % 3;
+                const char* Wb = Ws + (sg & 3) * WBYTES;
+                const char* Hb = Hs + hbuf + dh * (HW_ * 128);
+#pragma unroll
+                for (int kk = 0; kk < 2; ++kk) {
+                    Frag a[TM], b[TN];
+                    const char* wa = Wb + aoff[kk];
+                    const char* hb = Hb + boff[dw][kk];
+#pragma unroll
+                    for (int i = 0; i < TM; ++i) a[i] = *reinterpret_cast<const Frag*>(wa + i * 2048);
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) b[j] = *reinterpret_cast<const Frag*>(hb + j * (HW_ * 128));
+                    if (kk == 1) {                           // exactly three DMAs per wave per tap
+                        if (t < HPW) stage_h(t, pf_chunk, (G + 1) & 1, pf_real);
+                        else glds16a(mu_zero_page, dump);
+                        const int t3 = (t + 3) % 9, c3 = c + (t + 3) / 9;       // the tap three steps ahead (may be the next tile's)
+                        if (c3 < kchunks) stage_w((sg + 3) & 3, t3, c3, true);
+                        else stage_w((sg + 3) & 3, t3, 0, has_next);
+                    }
+                    __builtin_amdgcn_s_barrier();
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    __builtin_amdgcn_sched_barrier(0);
+                    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+                    for (int i = 0; i < TM; ++i)
+#pragma unroll
+                        for (int j = 0; j < TN; ++j) M_::mma(a[i], b[j], acc[i][j]);
+                    __builtin_amdgcn_s_setprio(0);
+                    if (kk == 0) {
+                        // taps 0 and 1 of a tile: the previous tile's 8 output stores are younger than the awaited weight tile
+                        if (t < 2) { if (c == 0) asm volatile("s_waitcnt vmcnt(11)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); }
+                        else asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                    __builtin_amdgcn_s_barrier();
+                }
+            }
+        }
+        if (wr == 0) __builtin_amdgcn_s_barrier();          // group A waits for B: both are done with this tile's LDS
+
+        // Epilogue, wave-private and barrier-free: every wave stages its own 64 co x 64 px tile (8 KB as [pixel][64 co], 128-byte
+        // rows) in LDS that is free at this point -- waves 0-4 in the halo buffer of the chunk just finished, waves 5-6 in the
+        // one weight slot that holds no prefetched tile, wave 7 in a spare 8 KB -- and reads it back as 16-byte pieces, so each
+        // wave store writes eight whole 128-byte rows.  8-byte slot XORed with ((p >> 1) & 7) << 1 on the write, i.e. 16-byte
+        // slot ^ ((p >> 1) & 7) on the read.  The next DMA into these regions is issued behind two more block barriers.
+        char* Os = wave < 5 ? Hs + ((G - 1) & 1) * HBYTES + wave * 8192
+                            : (wave < 7 ? Ws + ((sg + 3) & 3) * WBYTES + (wave - 5) * 8192 : spare);
+        const int tw_ = tl % tiles_w, th_ = (tl / tiles_w) % tiles_h, bimg = tl / (tiles_w * tiles_h);
+        const int h0 = th_ * TH, w0 = tw_ * TW;
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int p = j * 16 + r16;
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                const int co = i * 16 + 4 * g;
+                float v[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = acc[i][j][r] + (bias ? bias[co0 + wr * 64 + co + r] : 0.f);
+                h16x4 o = {(h16)v[0], (h16)v[1], (h16)v[2], (h16)v[3]};
+                *reinterpret_cast<h16x4*>(Os + p * 128 + (((co >> 2) ^ (((p >> 1) & 7) << 1)) << 3)) = o;
+            }
+        }
+        {
+            const int q = lane & 7;
+#pragma unroll
+            for (int it = 0; it < 8; ++it) {
+                const int p = it * 8 + (lane >> 3);             // pixel inside the wave tile: image row wc*4 + (p >> 4), column p & 15
+                const h16x8 o = *reinterpret_cast<const h16x8*>(Os + p * 128 + ((q ^ ((p >> 1) & 7)) << 4));
+                const long gp = ((long)bimg * H + h0 + wc * TN + (p >> 4)) * W + w0 + (p & 15);
+#ifdef MU_NT4_ABL_NOSTORE
+                if (B < 0)
+#endif
+                *reinterpret_cast<h16x8*>(y + gp * y_ld + co0 + wr * 64 + q * 8) = o;
+            }
+        }
+        if (has_next && wr == 1) __builtin_amdgcn_s_barrier();      // re-stagger
     }
 }
 
@@ -841,6 +1052,15 @@ static int conv_fwd_launch(const T* x, const T* w, const float* bias, T* y, int 
         }
         if constexpr (sizeof(T) == 2 && MU_CONV_NT4) {
             if (Cout % 128 == 0 && H % 16 == 0 && Cin % 64 == 0 && !getenv("MU_CONV_NO_NT4")) {
+#if MU_CONV_NT4P
+                const int ntile4 = B * (H / 16) * (W / 16), ncb4 = Cout / 128;
+                // measured (in-process A/B): 128->128 @128^2 322 -> 307 us, 64->128 @128^2 205 -> 176 us, 256->256 @64^2 equal,
+                // 512->512 @32^2 and two-tile blocks 1-3 % slower -> persistent only for >= 4 tiles per block and short K loops
+                if (ntile4 * ncb4 >= 1024 && Cin <= 256 && 256 % ncb4 == 0) {
+                    conv_nt4p_kernel<<<256, 512, 0, st>>>(x, w, bias, y, B, H, W, Cin, Cout, x_ld, y_ld);
+                    return MU_OK;
+                }
+#endif
                 conv_nt4_kernel<<<B * (H / 16) * (W / 16) * (Cout / 128), 512, 0, st>>>(x, w, bias, y, B, H, W, Cin, Cout, x_ld, y_ld);
                 return MU_OK;
             }
