@@ -1295,7 +1295,17 @@ template <int N> __device__ __forceinline__ void wait_vmcnt_c() {
 #ifndef MU_WG_NS
 #define MU_WG_NS 6
 #endif
-template <int TM, int TN, int WR, int NWV = 4, bool W16 = false>
+#ifndef MU_WG_SPS2
+#define MU_WG_SPS2 1
+#endif
+#ifndef MU_WG_SPS2_64
+#define MU_WG_SPS2_64 1
+#endif
+// SPS = 32-pixel k-steps per DMA stage.  SPS = 2 (W % 64 == 0): one barrier / DMA batch / ring step per 64 pixels -- the two
+// waves of a SIMD run in lockstep behind the per-stage barrier, so the ~500 cycles of scalar + address work per ring step sit
+// in front of both waves' MFMA bursts (PMC: SQ_ACTIVE_INST_SCA 18 % of wave cycles, MFMA pipe 44 % busy at SPS = 1).
+// W16 = two-image-rows-per-stage mode: W == 16 with SPS = 1 (two 18-row windows) or W == 32 with SPS = 2 (two 34-row windows).
+template <int TM, int TN, int WR, int NWV = 4, bool W16 = false, int SPS = 1>
 __global__ __launch_bounds__(NWV * 64, 1) void conv_wgrad3_kernel(const h16* __restrict__ x, const h16* __restrict__ dy, float* __restrict__ part,
                                                              int B, int H, int W, int Cin, int Cout, long x_ld, long dy_ld, int nsplit,
                                                              long pix_per_split) {
@@ -1303,11 +1313,13 @@ __global__ __launch_bounds__(NWV * 64, 1) void conv_wgrad3_kernel(const h16* __r
     constexpr int BCO = WR * TM * 16, BCI = WC * TN * 16;
     static_assert(BCO == BCI, "square channel tiles");
     constexpr int ROWB = BCO * 2, CPR = ROWB / 16, RPW = 1024 / ROWB;
-    constexpr int KP = 32, XR = (KP + 2 + RPW - 1) / RPW * RPW;   // pixels per stage; x-window rows allocated (34 used)
-    constexpr int NIA = KP / RPW, NIB = XR / RPW;          // DMA wave-instructions per tile
-    constexpr int STAGE = (KP + XR) * BCO;                 // elements per stage
+    constexpr int KP = 32, SP = SPS * KP;                   // pixels per k-step (one MFMA K) and per DMA stage
+    constexpr int RW = SP / 2;                              // two-row mode: image width
+    constexpr int XR = ((W16 ? SP + 4 : SP + 2) + RPW - 1) / RPW * RPW;      // x-window rows allocated (SP + 2, or 2 x (RW + 2))
+    constexpr int NIA = SP / RPW, NIB = XR / RPW;          // DMA wave-instructions per tile
+    constexpr int STAGE = (SP + XR) * BCO;                 // elements per stage
 
-    constexpr int NS = MU_WG_NS;
+    constexpr int NS = SPS == 1 ? MU_WG_NS : 4;
     __shared__ __attribute__((aligned(16))) h16 lds[NS * STAGE];
 
     const long Mtot = (long)B * H * W;
@@ -1353,12 +1365,12 @@ __global__ __launch_bounds__(NWV * 64, 1) void conv_wgrad3_kernel(const h16* __r
         const int row = (wave + k * NWV) * RPW + lrow;      // window row: flat pixel pbase + dh*W - 1 + row
         const int sc = (((c16 >> 1) ^ wg_hash<BCO>(row)) << 1) | (c16 & 1);
         if (w16) {
-            const int half = row >= 18, kk = row - half * 18;
-            boff[k] = (half * 16 + kk - 1) * (int)x_ld + ci0 + sc * 8;
-            bkind[k] = (kk == 0 || kk == 17 || row >= 36) ? 3 : (half ? 5 : 4);     // 4 / 5: plain row of the first / second image row
+            const int half = row >= RW + 2, kk = row - half * (RW + 2);
+            boff[k] = (half * RW + kk - 1) * (int)x_ld + ci0 + sc * 8;
+            bkind[k] = (kk == 0 || kk == RW + 1 || row >= 2 * (RW + 2)) ? 3 : (half ? 5 : 4);     // 4 / 5: plain row of the first / second image row
         } else {
             boff[k] = (row - 1) * (int)x_ld + ci0 + sc * 8;
-            bkind[k] = row == 0 ? 1 : (row == KP + 1 ? 2 : (row > KP + 1 ? 3 : 0));
+            bkind[k] = row == 0 ? 1 : (row == SP + 1 ? 2 : (row > SP + 1 ? 3 : 0));
         }
     }
     long pis = p_begin;                                     // next stage to issue
@@ -1368,7 +1380,7 @@ __global__ __launch_bounds__(NWV * 64, 1) void conv_wgrad3_kernel(const h16* __r
 
     auto stage = [&](int buf) {                  // past p_end: an all-zero stage (keeps the per-wave DMA count uniform)
         h16* At = lds + buf * STAGE;
-        h16* Bt = At + KP * BCO;
+        h16* Bt = At + SP * BCO;
         const bool live = pis < p_end;
 #pragma unroll
         for (int k = 0; k < NAW; ++k) {
@@ -1380,7 +1392,7 @@ __global__ __launch_bounds__(NWV * 64, 1) void conv_wgrad3_kernel(const h16* __r
         }
         const int hh = hi + dh;
         const bool rowok = live && hh >= 0 && hh < H, rowok1 = live && hh + 1 >= 0 && hh + 1 < H;
-        const bool lok = wi > 0, rok = wi + KP < W;
+        const bool lok = wi > 0, rok = wi + SP < W;
 #pragma unroll
         for (int k = 0; k < NBW; ++k) {
             const int i = wave + k * NWV;
@@ -1391,14 +1403,14 @@ __global__ __launch_bounds__(NWV * 64, 1) void conv_wgrad3_kernel(const h16* __r
                 glds16a(src, Bt + i * RPW * BCO);
             }
         }
-        pis += KP;
-        dyp += KP * dy_ld;
-        xp += KP * x_ld;
+        pis += SP;
+        dyp += SP * dy_ld;
+        xp += SP * x_ld;
         if (w16) {
             hi += 2;
             if (hi >= H) hi -= H;
         } else {
-            wi += KP;
+            wi += SP;
             if (wi >= W) { wi = 0; hi = hi + 1 == H ? 0 : hi + 1; }
         }
     };
@@ -1411,20 +1423,23 @@ __global__ __launch_bounds__(NWV * 64, 1) void conv_wgrad3_kernel(const h16* __r
 #pragma unroll
             for (int j = 0; j < TN; ++j) acc[t][i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    const int nsteps = (int)((p_end - p_begin + KP - 1) / KP);
+    const int nsteps = (int)((p_end - p_begin + KP - 1) / KP);      // k-steps (32 pixels each)
     const int q = r16 >> 2, pc = r16 & 3;
 
     // Register double-buffered fragments: the transposed LDS reads of stage s+1 are issued before the MFMAs of stage s, so
     // the LDS latency (8 + 12 dependent-free ds_read_tr per 24 MFMAs) no longer sits between the MFMA groups.
     struct Frags { h16x8 a[TM]; h16x8 b[3][TN]; };
-    const int wsh = (W16 && g >= 2) ? 2 : 0;                 // second image row's window starts 18 rows in
-    auto load_frags = [&](int buf, Frags& f) {
+    const int wsh = (W16 && SPS == 1 && g >= 2) ? 2 : 0;     // W = 16: the second image row's window starts 18 rows in
+    auto load_frags = [&](int buf, int half, Frags& f) {     // k-step `half` of the stage in slot `buf`
         const h16* At = lds + buf * STAGE;
-        const h16* Bt = At + KP * BCO;
+        const h16* Bt = At + SP * BCO;
+        // absolute tile rows (the swizzle hash is a function of the row the DMA wrote): k-step `half` starts at dy row half*32
+        // and at window row half*32 (flat) or half*34 (W = 32: one window per image row)
+        const int ra = half * KP, rb = half * (W16 ? KP + 2 : KP);
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
             const int col = (wr * TM + i) * 16 + 4 * pc;    // 4 halfs inside 32-byte chunk (col >> 4)
-            const int r0 = 8 * g + q, r1 = r0 + 4;
+            const int r0 = ra + 8 * g + q, r1 = r0 + 4;
             auto lo = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) fp16x4v*)(At + r0 * BCO + ((((col >> 4) ^ wg_hash<BCO>(r0)) << 4) | (col & 15))));
             auto hi = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) fp16x4v*)(At + r1 * BCO + ((((col >> 4) ^ wg_hash<BCO>(r1)) << 4) | (col & 15))));
             f.a[i] = (h16x8){(h16)lo[0], (h16)lo[1], (h16)lo[2], (h16)lo[3], (h16)hi[0], (h16)hi[1], (h16)hi[2], (h16)hi[3]};
@@ -1434,7 +1449,7 @@ __global__ __launch_bounds__(NWV * 64, 1) void conv_wgrad3_kernel(const h16* __r
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
                 const int col = (wc * TN + j) * 16 + 4 * pc;
-                const int r0 = 8 * g + q + t + wsh, r1 = r0 + 4;
+                const int r0 = rb + 8 * g + q + t + wsh, r1 = r0 + 4;
                 auto lo = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) fp16x4v*)(Bt + r0 * BCO + ((((col >> 4) ^ wg_hash<BCO>(r0)) << 4) | (col & 15))));
                 auto hi = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) fp16x4v*)(Bt + r1 * BCO + ((((col >> 4) ^ wg_hash<BCO>(r1)) << 4) | (col & 15))));
                 f.b[t][j] = (h16x8){(h16)lo[0], (h16)lo[1], (h16)lo[2], (h16)lo[3], (h16)hi[0], (h16)hi[1], (h16)hi[2], (h16)hi[3]};
@@ -1465,19 +1480,33 @@ __global__ __launch_bounds__(NWV * 64, 1) void conv_wgrad3_kernel(const h16* __r
     wait_ring();
     __builtin_amdgcn_s_barrier();
     Frags f0, f1;
-    load_frags(0, f0);
-    int buf = 0;                                            // slot of stage s
-    auto step = [&](int s, Frags& cur, Frags& nxt) {
-        wait_ring();
-        __builtin_amdgcn_s_barrier();
-        stage(buf == 0 ? NS - 1 : buf - 1);
-        buf = buf + 1 == NS ? 0 : buf + 1;
-        if (s + 1 < nsteps) load_frags(buf, nxt);
+    load_frags(0, 0, f0);
+    int buf = 0;                                            // slot of the stage being multiplied
+    // one k-step: (ring step if it opens a stage) -> MFMAs of `cur` -> fragment reads of the next k-step into `nxt`.
+    // MFMAs first (in-process A/B: 2-3 % faster than reads first; hiding the reads from the compiler with inline asm and a
+    // manual lgkmcnt(0) per step -- no waits between the MFMAs at all -- was 6 % SLOWER)
+    auto kstep = [&](int s, auto HALFC, Frags& cur, Frags& nxt) {
+        constexpr int HALF = decltype(HALFC)::value;
+        if (HALF == 0) {
+            wait_ring();
+            __builtin_amdgcn_s_barrier();
+            stage(buf == 0 ? NS - 1 : buf - 1);
+        }
         compute(cur);
+        if (s + 1 < nsteps) {
+            if (HALF + 1 < SPS) {
+                load_frags(buf, HALF + 1, nxt);
+            } else {
+                buf = buf + 1 == NS ? 0 : buf + 1;
+                load_frags(buf, 0, nxt);
+            }
+        } else if (HALF + 1 == SPS) {
+            buf = buf + 1 == NS ? 0 : buf + 1;
+        }
     };
     for (int s = 0; s < nsteps; s += 2) {
-        step(s, f0, f1);
-        if (s + 1 < nsteps) step(s + 1, f1, f0);
+        kstep(s, std::integral_constant<int, 0>{}, f0, f1);
+        if (s + 1 < nsteps) kstep(s + 1, std::integral_constant<int, (SPS == 2 ? 1 : 0)>{}, f1, f0);
     }
 
 #pragma unroll
@@ -1575,7 +1604,7 @@ static inline void wgrad3_plan(long M, int Cin, int Cout, int bt, int* nsplit, l
     if (want > max_split) want = max_split;
     if (want > 256) want = 256;
     long p = (M + want - 1) / want;
-    p = (p + 31) / 32 * 32;
+    p = (p + 63) / 64 * 64;                     // whole 64-pixel stages (the two-k-step kernel); M is a multiple of 32
     *pps = p;
     *nsplit = (int)((M + p - 1) / p);
 }
@@ -1738,10 +1767,20 @@ extern "C" int mu_conv_wgrad(const void* x, const void* dy, float* dw_oihw, int 
         const h16 *xh = (const h16*)x, *dyh = (const h16*)dy;
         if (bco == 128 && W == 16)      // 8 waves, 64x32 tile x 3 taps per wave (96 accumulators): 2 waves/SIMD
             conv_wgrad3_kernel<4, 2, 2, 8, true><<<grid, 512, 0, st>>>(xh, dyh, part, B, H, W, Cin, Cout, x_ld, dy_ld, nsplit, pps);
+        else if (bco == 128 && W == 32 && H % 2 == 0 && MU_WG_SPS2)
+            conv_wgrad3_kernel<4, 2, 2, 8, true, 2><<<grid, 512, 0, st>>>(xh, dyh, part, B, H, W, Cin, Cout, x_ld, dy_ld, nsplit, pps);
+        else if (bco == 128 && W % 64 == 0 && MU_WG_SPS2)
+            conv_wgrad3_kernel<4, 2, 2, 8, false, 2><<<grid, 512, 0, st>>>(xh, dyh, part, B, H, W, Cin, Cout, x_ld, dy_ld, nsplit, pps);
         else if (bco == 128)
             conv_wgrad3_kernel<4, 2, 2, 8><<<grid, 512, 0, st>>>(xh, dyh, part, B, H, W, Cin, Cout, x_ld, dy_ld, nsplit, pps);
         else if (W == 16)
             conv_wgrad3_kernel<2, 2, 2, 4, true><<<grid, 256, 0, st>>>(xh, dyh, part, B, H, W, Cin, Cout, x_ld, dy_ld, nsplit, pps);
+#if MU_WG_SPS2_64
+        else if (W == 32 && H % 2 == 0)
+            conv_wgrad3_kernel<2, 2, 2, 4, true, 2><<<grid, 256, 0, st>>>(xh, dyh, part, B, H, W, Cin, Cout, x_ld, dy_ld, nsplit, pps);
+        else if (W % 64 == 0)
+            conv_wgrad3_kernel<2, 2, 2, 4, false, 2><<<grid, 256, 0, st>>>(xh, dyh, part, B, H, W, Cin, Cout, x_ld, dy_ld, nsplit, pps);
+#endif
         else
             conv_wgrad3_kernel<2, 2, 2><<<grid, 256, 0, st>>>(xh, dyh, part, B, H, W, Cin, Cout, x_ld, dy_ld, nsplit, pps);
     } else if (ws_bytes < (long)nsplit * taps * Cout * Cin * (long)sizeof(float)) {
