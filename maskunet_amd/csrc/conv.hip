@@ -1301,11 +1301,19 @@ template <int N> __device__ __forceinline__ void wait_vmcnt_c() {
 #ifndef MU_WG_SPS2_64
 #define MU_WG_SPS2_64 1
 #endif
+// ping-pong schedule of the weight-grad kernel: parity-clean but neutral (in-process A/B: 128->128 @128^2 369 vs 371 us,
+// 256->256 @64^2 339 vs 348, 128->128 @64^2 106 vs 102) -- kept opt-in as the starting point for a finer-grained interleave
+#ifndef MU_WG_PP
+#define MU_WG_PP 0
+#endif
 // SPS = 32-pixel k-steps per DMA stage.  SPS = 2 (W % 64 == 0): one barrier / DMA batch / ring step per 64 pixels -- the two
 // waves of a SIMD run in lockstep behind the per-stage barrier, so the ~500 cycles of scalar + address work per ring step sit
 // in front of both waves' MFMA bursts (PMC: SQ_ACTIVE_INST_SCA 18 % of wave cycles, MFMA pipe 44 % busy at SPS = 1).
 // W16 = two-image-rows-per-stage mode: W == 16 with SPS = 1 (two 18-row windows) or W == 32 with SPS = 2 (two 34-row windows).
-template <int TM, int TN, int WR, int NWV = 4, bool W16 = false, int SPS = 1>
+// PP = ping-pong schedule (8 waves, SPS = 2): the two wave groups (wr = 0 / 1, one wave of each per SIMD) run one section apart,
+// a section being either a k-step's 24 MFMAs or its DMA issue + 20 transposed reads, so one group's matrix burst covers the
+// other group's scalar / address / LDS work instead of both doing each in lockstep.
+template <int TM, int TN, int WR, int NWV = 4, bool W16 = false, int SPS = 1, bool PP = false>
 __global__ __launch_bounds__(NWV * 64, 1) void conv_wgrad3_kernel(const h16* __restrict__ x, const h16* __restrict__ dy, float* __restrict__ part,
                                                              int B, int H, int W, int Cin, int Cout, long x_ld, long dy_ld, int nsplit,
                                                              long pix_per_split) {
@@ -1319,6 +1327,7 @@ __global__ __launch_bounds__(NWV * 64, 1) void conv_wgrad3_kernel(const h16* __r
     constexpr int NIA = SP / RPW, NIB = XR / RPW;          // DMA wave-instructions per tile
     constexpr int STAGE = (SP + XR) * BCO;                 // elements per stage
 
+    static_assert(!PP || (SPS == 2 && NWV == 8 && WR == 2), "ping-pong needs two 4-wave groups and two k-steps per stage");
     constexpr int NS = SPS == 1 ? MU_WG_NS : 4;
     __shared__ __attribute__((aligned(16))) h16 lds[NS * STAGE];
 
@@ -1469,6 +1478,45 @@ __global__ __launch_bounds__(NWV * 64, 1) void conv_wgrad3_kernel(const h16* __r
     //   top of step s : this wave's DMAs of stage s+1 have landed (vmcnt <= (NS-3) n_w); barrier -> everybody's have, and
     //                   everybody's reads of stage s-1 (issued in step s-2, consumed by the MFMAs of step s-1) are complete
     //   then          : DMA of stage s+NS-1 into the slot of stage s-1; fragment reads of stage s+1; MFMAs of stage s
+    if constexpr (PP) {
+        // Epochs: group A runs X(k) [DMA issue of stage S+2 when k opens stage S, then the k-step's fragment reads] at epoch 2k and
+        // M(k) [its MFMAs, and when k opens a stage the wait for stage S+1] at 2k+1; group B one epoch later; one raw barrier per
+        // epoch.  RAW: stage S+1 is first read in X(2S+2) (A: epoch 4S+4); both groups' waits sit in M(2S) (B: epoch 4S+2) and a
+        // barrier follows.  WAR: stage S+2 overwrites the slot of stage S-2, last read in X(2S-3) (B: epoch 4S-5) -- four slots.
+        stage(0);
+        stage(1);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (wr == 1) __builtin_amdgcn_s_barrier();
+        Frags f;
+        int buf = 0;
+        auto kstep = [&](auto HALFC) {
+            constexpr int HALF = decltype(HALFC)::value;
+            if (HALF == 0) stage(buf >= 2 ? buf - 2 : buf + 2);          // stage S+2 -> slot (S+2) & 3
+            load_frags(buf, HALF, f);
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_setprio(1);
+            compute(f);
+            __builtin_amdgcn_s_setprio(0);
+            if (HALF == 0) {                                             // stage S+1 landed, stage S+2 may stay in flight
+                constexpr int FULL = NAW + NBW;
+                if (n_w == FULL) wait_vmcnt_c<FULL>();
+                else if (n_w == FULL - 1) wait_vmcnt_c<FULL - 1>();
+                else wait_vmcnt_c<(FULL > 2 ? FULL - 2 : 0)>();
+            } else {
+                buf = (buf + 1) & 3;
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();
+        };
+        const int nstage = (nsteps + 1) / 2;
+        for (int S = 0; S < nstage; ++S) {
+            kstep(std::integral_constant<int, 0>{});
+            kstep(std::integral_constant<int, 1>{});            // (an odd tail k-step multiplies an all-zero half stage)
+        }
+        if (wr == 0) __builtin_amdgcn_s_barrier();
+    } else {
 #pragma unroll 1
     for (int k = 0; k < NS - 1; ++k) stage(k);
     auto wait_ring = [&]() {                                 // all but the newest NS-3 stages of this wave have landed
@@ -1507,6 +1555,8 @@ __global__ __launch_bounds__(NWV * 64, 1) void conv_wgrad3_kernel(const h16* __r
     for (int s = 0; s < nsteps; s += 2) {
         kstep(s, std::integral_constant<int, 0>{}, f0, f1);
         if (s + 1 < nsteps) kstep(s + 1, std::integral_constant<int, (SPS == 2 ? 1 : 0)>{}, f1, f0);
+    }
+
     }
 
 #pragma unroll
@@ -1769,6 +1819,8 @@ extern "C" int mu_conv_wgrad(const void* x, const void* dy, float* dw_oihw, int 
             conv_wgrad3_kernel<4, 2, 2, 8, true><<<grid, 512, 0, st>>>(xh, dyh, part, B, H, W, Cin, Cout, x_ld, dy_ld, nsplit, pps);
         else if (bco == 128 && W == 32 && H % 2 == 0 && MU_WG_SPS2)
             conv_wgrad3_kernel<4, 2, 2, 8, true, 2><<<grid, 512, 0, st>>>(xh, dyh, part, B, H, W, Cin, Cout, x_ld, dy_ld, nsplit, pps);
+        else if (bco == 128 && W % 64 == 0 && MU_WG_SPS2 && MU_WG_PP)
+            conv_wgrad3_kernel<4, 2, 2, 8, false, 2, true><<<grid, 512, 0, st>>>(xh, dyh, part, B, H, W, Cin, Cout, x_ld, dy_ld, nsplit, pps);
         else if (bco == 128 && W % 64 == 0 && MU_WG_SPS2)
             conv_wgrad3_kernel<4, 2, 2, 8, false, 2><<<grid, 512, 0, st>>>(xh, dyh, part, B, H, W, Cin, Cout, x_ld, dy_ld, nsplit, pps);
         else if (bco == 128)
