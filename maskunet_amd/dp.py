@@ -104,6 +104,10 @@ class DataParallel(nn.Module):
             if self._comm_stream is None:
                 self._comm_stream = torch.cuda.Stream(device=dev)
             self._comm_stream.wait_stream(torch.cuda.current_stream(dev))
+            from . import ops
+            side = ops.wgrad_stream(dev)          # conv weight gradients are produced on their own stream (ops._wgrad_side)
+            if side is not None:
+                self._comm_stream.wait_stream(side)
             with torch.cuda.stream(self._comm_stream):
                 b.flat = torch.cat([g.reshape(-1).float() for g in grads])
                 b.work = dist.all_reduce(b.flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
