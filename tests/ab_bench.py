@@ -46,7 +46,7 @@ def main():
         cases = [("fwd", 0), ("dq", 2), ("dkv", 4)]
         first = libs[names[0]]; mk(first, 0)(); mk(first, 1)()
     elif what == "bn":
-        M, C = 64 * 128 * 128, 128
+        M, C = (int(v) for v in os.environ.get("MU_BN_SHAPE", "1048576,128").split(","))
         x = torch.randn(M, C, device=dev, dtype=dt); y = torch.empty_like(x); gy = torch.randn_like(x); dx = torch.empty_like(x)
         mean = torch.zeros(C, device=dev); rstd = torch.ones(C, device=dev); gam = torch.ones(C, device=dev); bet = torch.zeros(C, device=dev)
         dgam = torch.empty(C, device=dev); dbet = torch.empty(C, device=dev)
@@ -57,7 +57,7 @@ def main():
             if phase == 1:
                 return lambda: lib.mu_bn_act_fwd(x.data_ptr(), None, y.data_ptr(), M, C, C, mean.data_ptr(), rstd.data_ptr(), gam.data_ptr(), bet.data_ptr(), 1, 1, st)
             return lambda: lib.mu_bn_act_bwd(x.data_ptr(), None, gy.data_ptr(), dx.data_ptr(), None, M, C, C, mean.data_ptr(), rstd.data_ptr(), gam.data_ptr(), bet.data_ptr(), 1, 1, dgam.data_ptr(), dbet.data_ptr(), ws.data_ptr(), ws.numel(), 1, st)
-        cases = [("bn_stats 268MB", 0), ("bn_act_fwd", 1), ("bn_act_bwd", 2)]
+        cases = [(f"bn_stats {M * C * 2 >> 20} MiB", 0), ("bn_act_fwd", 1), ("bn_act_bwd", 2)]
     else:
         shapes = [(64, 128, 128, 128), (64, 64, 256, 256), (64, 32, 512, 512), (64, 16, 512, 512), (64, 128, 64, 128), (64, 16, 256, 256), (64, 16, 256, 512), (64, 32, 256, 256), (64, 64, 128, 128)]
         bufs = []
