@@ -30,6 +30,25 @@
 #ifndef MU_FWD_OCC
 #define MU_FWD_OCC 2
 #endif
+// C = 128 blocks (N = 4096): without a bound the compiler takes ~320 registers (VGPR + AGPR) and runs ONE wave per SIMD.
+// In-process A/B (B=64, N=4096, C=128): forward 0.624 -> 0.341 ms with a 2-waves/SIMD bound and 32-key tiles (168 VGPRs),
+// dQ 0.520 -> 0.374 ms with the bound alone (226 VGPRs, no spills), dK/dV 1.174 -> 0.959 ms with 16 keys per wave (NKT = 1,
+// 150 VGPRs; the 32-key version spills under the bound).  3 waves/SIMD: no further gain.
+#ifndef MU_FWD_OCC128
+#define MU_FWD_OCC128 2
+#endif
+#ifndef MU_DQ_OCC128
+#define MU_DQ_OCC128 2
+#endif
+#ifndef MU_DKV_OCC128
+#define MU_DKV_OCC128 2
+#endif
+#ifndef MU_FWD_KT128
+#define MU_FWD_KT128 32
+#endif
+#ifndef MU_DKV_NKT128
+#define MU_DKV_NKT128 1
+#endif
 #ifndef MU_DQ_KT
 #define MU_DQ_KT 32
 #endif
@@ -429,7 +448,7 @@ template <int D> struct AccLd<float, D> {
 };
 
 template <typename T, int D, int KT, int NW, int OCC = 0, int NQ = 2>
-__global__ __launch_bounds__(NW * 64, OCC ? OCC : ((NW == 4 && D <= 64 && sizeof(T) == 2) ? MU_FWD_OCC : 1)) void attn_fwd2_kernel(const T* __restrict__ qkv, const T* __restrict__ x, const int* __restrict__ kidx,
+__global__ __launch_bounds__(NW * 64, OCC ? OCC : ((NW == 4 && D <= 64 && sizeof(T) == 2) ? MU_FWD_OCC : ((NW == 4 && D == 128 && sizeof(T) == 2) ? MU_FWD_OCC128 : 1))) void attn_fwd2_kernel(const T* __restrict__ qkv, const T* __restrict__ x, const int* __restrict__ kidx,
                                                         const int* __restrict__ kcnt, const float* __restrict__ gamma,
                                                         const float* __restrict__ beta, T* __restrict__ out, T* __restrict__ oattn,
                                                         float* __restrict__ lse2, float* __restrict__ ln_mean, float* __restrict__ ln_rstd,
@@ -919,7 +938,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const T* __restrict__
 // backward v2 kernels: LDS-DMA double-buffered tiles, swizzled images (see attn_fwd2_kernel)
 // ------------------------------------------------------------------------------------------
 template <typename T, int D, int KT, int NW>
-__global__ __launch_bounds__(NW * 64, (NW == 4 && D <= 64 && sizeof(T) == 2) ? MU_DQ_OCC : 1) void attn_bwd_dq2_kernel(const T* __restrict__ qkv, const T* __restrict__ dY, const int* __restrict__ kidx,
+__global__ __launch_bounds__(NW * 64, (NW == 4 && D <= 64 && sizeof(T) == 2) ? MU_DQ_OCC : ((NW == 4 && D == 128 && sizeof(T) == 2) ? MU_DQ_OCC128 : 1)) void attn_bwd_dq2_kernel(const T* __restrict__ qkv, const T* __restrict__ dY, const int* __restrict__ kidx,
                                                            const int* __restrict__ kcnt, const float* __restrict__ lse2,
                                                            const float* __restrict__ delta, T* __restrict__ dqkv, int N, int nkmax,
                                                            float scale, float scale_log2) {
@@ -1204,7 +1223,7 @@ __global__ __launch_bounds__(256, (D <= 64 && sizeof(T) == 2) ? 2 : 1) void attn
 // ring), so the counted waits are exact: each wave issues exactly 3 DMA instructions per tile.
 // ------------------------------------------------------------------------------------------
 template <typename T, int D, int NKT>
-__global__ __launch_bounds__(256, (D <= 64 && sizeof(T) == 2 && NKT <= 2) ? MU_DKV_OCC : 1) void attn_bwd_dkv3_kernel(
+__global__ __launch_bounds__(256, (D <= 64 && sizeof(T) == 2 && NKT <= 2) ? MU_DKV_OCC : ((D == 128 && sizeof(T) == 2 && NKT <= 2) ? MU_DKV_OCC128 : 1)) void attn_bwd_dkv3_kernel(
     const T* __restrict__ qkv, const T* __restrict__ dY, const int* __restrict__ kidx, const int* __restrict__ kcnt,
     const float* __restrict__ rowc, T* __restrict__ dqkv, int N, int nkmax, float scale, float scale_log2) {
     using A = AT<T>;
@@ -1422,7 +1441,7 @@ static int attn_fwd_t(const T* qkv, const T* x, const int* kidx, const int* kcnt
     switch (C) {
         case 32: LAUNCH_FWD(32, 64); break;
         case 64: LAUNCH_FWD(64, 64); break;
-        case 128: LAUNCH_FWD(128, 64); break;
+        case 128: LAUNCH_FWD(128, MU_FWD_KT128); break;
         case 256: LAUNCH_FWD(256, 32); break;
         default: return MU_ERR_SHAPE;
     }
@@ -1478,7 +1497,7 @@ static int attn_bwd_t(const T* qkv, const T* x, const T* oattn, const T* gout, c
     switch (C) {
         case 32: { constexpr int KTQ = 64; LAUNCH_BWD(32, 2); } break;
         case 64: { constexpr int KTQ = MU_DQ_KT; LAUNCH_BWD(64, 2); } break;
-        case 128: { constexpr int KTQ = 32; LAUNCH_BWD(128, 2); } break;
+        case 128: { constexpr int KTQ = 32; LAUNCH_BWD(128, MU_DKV_NKT128); } break;
         case 256: { constexpr int KTQ = 32; LAUNCH_BWD(256, 1); } break;
         default: return MU_ERR_SHAPE;
     }

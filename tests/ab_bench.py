@@ -30,7 +30,7 @@ def main():
     libs = {n: load(n) for n in names}
     dev = "cuda"; dt = torch.float16; st = torch.cuda.current_stream().cuda_stream
     if what == "attn":
-        B, N, C = 64, 16384, 64
+        B, N, C = (int(v) for v in os.environ.get("MU_ATTN_SHAPE", "64,16384,64").split(","))
         qkv = torch.randn(B, N, 3 * C, device=dev, dtype=dt); x = torch.randn(B, N, C, device=dev, dtype=dt)
         keep = torch.randint(0, 2, (B, N), device=dev, dtype=torch.uint8)
         kidx = torch.argsort(keep, dim=1, descending=True, stable=True).to(torch.int32).contiguous(); kcnt = keep.sum(1, dtype=torch.int32).contiguous()
