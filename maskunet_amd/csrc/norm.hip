@@ -8,6 +8,18 @@
 #include "../../include/maskunet_hip.h"
 
 #define MU_STAT_MAXBLK 1024
+#ifndef MU_BN_U1
+#define MU_BN_U1 2
+#endif
+#ifndef MU_BN_UF
+#define MU_BN_UF 2
+#endif
+#ifndef MU_BN_UA
+#define MU_BN_UA 2
+#endif
+#ifndef MU_BN_OCC1
+#define MU_BN_OCC1 1
+#endif
 
 // ------------------------------------------------------------------------------------------
 // per-channel partial sums over a block of rows.
@@ -20,13 +32,13 @@
 // FAST = the fp16-storage GELU (common.h mu_phi_fast); fp32 storage keeps erff.
 // ------------------------------------------------------------------------------------------
 template <typename T, int MODE>
-__global__ __launch_bounds__(256) void bn_partial_kernel(const T* __restrict__ x, const T* __restrict__ g, const T* __restrict__ res,
+__global__ __launch_bounds__(256, MODE == 1 ? MU_BN_OCC1 : 1) void bn_partial_kernel(const T* __restrict__ x, const T* __restrict__ g, const T* __restrict__ res,
                                                          T* __restrict__ dzbuf, long M, int C, long ld,
                                                          const float* __restrict__ mean, const float* __restrict__ rstd,
                                                          const float* __restrict__ gamma, const float* __restrict__ beta, int act,
                                                          double* __restrict__ part) {
     constexpr int N = Vec16<T>::N;
-    constexpr int U = MODE == 0 ? 8 : 4;
+    constexpr int U = MODE == 0 ? 8 : MU_BN_U1;
     constexpr bool FAST = sizeof(T) == 2;
     extern __shared__ __attribute__((aligned(16))) double sh[];   // [rpi][C][2]
     const int cv = C / N;
@@ -160,7 +172,7 @@ __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const T* __restrict__ x
                                                          int C, long ld, const float* __restrict__ mean, const float* __restrict__ rstd,
                                                          const float* __restrict__ gamma, const float* __restrict__ beta, int act) {
     constexpr int N = Vec16<T>::N;
-    constexpr int U = 4;
+    constexpr int U = MU_BN_UF;
     constexpr bool FAST = sizeof(T) == 2;
     const int cv = C / N;
     const long total = M * cv;
@@ -208,7 +220,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
                                                            const float* __restrict__ gamma, const float* __restrict__ beta, int act,
                                                            const float* __restrict__ s1, const float* __restrict__ s2) {
     constexpr int N = Vec16<T>::N;
-    constexpr int U = 4;
+    constexpr int U = MU_BN_UA;
     constexpr bool FAST = sizeof(T) == 2;
     const int cv = C / N;
     const long total = M * cv;
