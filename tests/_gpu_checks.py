@@ -80,6 +80,34 @@ def check_transpose(dtype):
     return out
 
 
+def check_prep_weight(dtype):
+    """OIHW fp32 -> tap-major compute layouts: forward, flipped/transposed data-gradient, and both from one launch."""
+    from maskunet_amd import _lib
+    gen = np.random.default_rng(11)
+    out = []
+    for (O, I, k) in [(19, 3, 3), (64, 32, 3), (150, 64, 1), (96, 160, 3)]:
+        taps = k * k
+        w = _rnd(gen, O, I, k, k)
+        wd = w.to(DEV)
+        Op, Ip = (O + 31) // 32 * 32, (I + 31) // 32 * 32
+        ref0 = torch.zeros(taps, Op, Ip)
+        ref0[:, :O, :I] = w.reshape(O, I, taps).permute(2, 0, 1)
+        ref1 = torch.zeros(taps, Ip, Op)
+        ref1[:, :I, :O] = w.reshape(O, I, taps).flip(2).permute(2, 1, 0)
+        ref0, ref1 = ref0.to(dtype).float(), ref1.to(dtype).float()
+        d0 = torch.full((taps, Op, Ip), 7.0, dtype=dtype, device=DEV)
+        d1 = torch.full((taps, Ip, Op), 7.0, dtype=dtype, device=DEV)
+        d2 = torch.full((2 * taps * Op * Ip,), 7.0, dtype=dtype, device=DEV)
+        _lib.call("mu_prep_weight", _lib.ptr(wd), _lib.ptr(d0), _lib.dt(d0), O, I, taps, Op, Ip, 0, _lib.stream())
+        _lib.call("mu_prep_weight", _lib.ptr(wd), _lib.ptr(d1), _lib.dt(d1), O, I, taps, Ip, Op, 1, _lib.stream())
+        _lib.call("mu_prep_weight", _lib.ptr(wd), _lib.ptr(d2), _lib.dt(d2), O, I, taps, Op, Ip, 2, _lib.stream())
+        n = taps * Op * Ip
+        out += [(f"prep{(O, I, k)} fwd", _err(d0.float(), ref0), 0.0), (f"prep{(O, I, k)} dgrad", _err(d1.float(), ref1), 0.0),
+                (f"prep{(O, I, k)} both/fwd", _err(d2[:n].view(taps, Op, Ip).float(), ref0), 0.0),
+                (f"prep{(O, I, k)} both/dgrad", _err(d2[n:].view(taps, Ip, Op).float(), ref1), 0.0)]
+    return out
+
+
 def check_layout_roundtrip(dtype):
     from maskunet_amd import ops
     gen = np.random.default_rng(2)

@@ -24,7 +24,7 @@ def test_library_loaded_is_in_tree():
 @pytest.mark.parametrize("dtype", DTYPES)
 def test_transpose(dtype):
     from tests import _gpu_checks as G
-    _assert_all(G.check_transpose(dtype) + G.check_layout_roundtrip(dtype))
+    _assert_all(G.check_transpose(dtype) + G.check_layout_roundtrip(dtype) + G.check_prep_weight(dtype))
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
