@@ -65,6 +65,13 @@ int mu_prep_weight(const float* w_oihw, void* dst, int dtype, int O, int I, int 
  * data-gradient of the same layer. */
 int mu_conv_fwd(const void* x, const void* w, const float* bias, void* y, int B, int H, int W, int Cin, int Cout, int taps, long x_ld,
                 long y_ld, int dtype, void* stream);
+/* mu_conv_fwd that also leaves per-tile BatchNorm statistics of its (rounded) output: stat_part[rows][Cout][2] floats =
+ * (sum, sum of squares) per output channel, rows = mu_conv_stats_rows(...) (0 = this shape has no statistics epilogue;
+ * stat_part must then be NULL).  Feeds mu_bn_train_stats_rows and saves the separate statistics sweep of
+ * conv -> BatchNorm2d (ade_semantic.py:199-200, 202-204). */
+int mu_conv_stats_rows(int B, int H, int W, int Cin, int Cout, int taps, int dtype);
+int mu_conv_fwd_stats(const void* x, const void* w, const float* bias, void* y, int B, int H, int W, int Cin, int Cout, int taps,
+                      long x_ld, long y_ld, int dtype, float* stat_part, void* stream);
 /* dw_oihw[o][i][tap] = sum_p dy[p][o] * x[p+shift(tap)][i] for o < cout_valid, i < cin_valid (fp32, OIHW). */
 long mu_conv_wgrad_workspace_bytes(int B, int H, int W, int Cin, int Cout, int taps);
 int mu_conv_wgrad(const void* x, const void* dy, float* dw_oihw, int B, int H, int W, int Cin, int Cout, int taps, int cin_valid,
@@ -81,6 +88,10 @@ long mu_bn_workspace_bytes(int C);
 int mu_bn_train_stats(const void* x, long M, int C, long ld, float* mean, float* rstd, float* running_mean, float* running_var,
                       long* num_batches_tracked, int c_valid, float momentum, float eps, void* workspace, long ws_bytes, int dtype,
                       void* stream);
+/* the same from the rows written by mu_conv_fwd_stats (M = pixels per channel behind those rows) */
+int mu_bn_train_stats_rows(const float* stat_part, int rows, long M, int C, float* mean, float* rstd, float* running_mean,
+                           float* running_var, long* num_batches_tracked, int c_valid, float momentum, float eps, void* workspace,
+                           long ws_bytes, void* stream);
 /* eval mode: mean/rstd from the running statistics */
 int mu_bn_eval_stats(const float* running_mean, const float* running_var, float eps, float* mean, float* rstd, int C, int c_valid,
                      void* stream);

@@ -28,12 +28,15 @@ SIGNATURES = {
     "mu_cast": (I, [P, I, P, I, L, P]),
     "mu_prep_weight": (I, [P, P, I, I, I, I, I, I, I, P]),
     "mu_conv_fwd": (I, [P, P, P, P, I, I, I, I, I, I, L, L, I, P]),
+    "mu_conv_stats_rows": (I, [I, I, I, I, I, I, I]),
+    "mu_conv_fwd_stats": (I, [P, P, P, P, I, I, I, I, I, I, L, L, I, P, P]),
     "mu_conv_wgrad_workspace_bytes": (L, [I, I, I, I, I, I]),
     "mu_conv_wgrad": (I, [P, P, P, I, I, I, I, I, I, I, I, L, L, P, L, I, P]),
     "mu_colsum_workspace_bytes": (L, [I]),
     "mu_colsum": (I, [P, L, I, L, P, P, L, I, P]),
     "mu_bn_workspace_bytes": (L, [I]),
     "mu_bn_train_stats": (I, [P, L, I, L, P, P, P, P, P, I, F, F, P, L, I, P]),
+    "mu_bn_train_stats_rows": (I, [P, I, L, I, P, P, P, P, P, I, F, F, P, L, P]),
     "mu_bn_eval_stats": (I, [P, P, F, P, P, I, I, P]),
     "mu_bn_act_fwd": (I, [P, P, P, L, I, L, P, P, P, P, I, I, P]),
     "mu_bn_act_bwd": (I, [P, P, P, P, P, L, I, L, P, P, P, P, I, I, P, P, P, L, I, P]),

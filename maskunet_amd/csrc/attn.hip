@@ -1035,7 +1035,11 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 && D <= 64 && sizeof(T) == 2) ? M
 #pragma unroll
                 for (int t = 0; t < 2; ++t) A::mma_acc(ka, s[2 * h][t], s[2 * h + 1][t], dq[dt][t]);
             }
+#ifdef MU_DQ_ABL_NOBAR
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#else
         MU_SYNC_DMA();
+#endif
     };
     for (int j0 = 0; j0 < Nk; j0 += 2 * KT) {
         tile(std::integral_constant<int, 0>{}, j0);
@@ -1330,7 +1334,12 @@ __global__ __launch_bounds__(256, (D <= 64 && sizeof(T) == 2 && NKT <= 2) ? MU_D
         if (DKV_RING == 4 && newer >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * OPS) : "memory");
         else if (DKV_RING == 4 && newer == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(OPS) : "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#ifndef MU_DKV_ABL_NOBAR
         __builtin_amdgcn_s_barrier();                        // everyone's share of tile tl landed; tile tl-1 fully consumed
+#endif
+#ifdef MU_DKV_ISSUE_FIRST
+        if (tl + DKV_RING - 1 < ntile) issue(tl + DKV_RING - 1);
+#endif
         const T* Qt = lds + SLOT * STG;
         const T* Ot = Qt + QT * D;
         const float* rc = rcs + SLOT * 256;
@@ -1386,7 +1395,9 @@ __global__ __launch_bounds__(256, (D <= 64 && sizeof(T) == 2 && NKT <= 2) ? MU_D
         }
         // Refill the slot tile tl-1 vacated -- issued LAST in the tile: LDS reads queue behind an in-flight LDS-DMA issue
         // (in-kernel s_memtime stamps: the row-constant reads right after the DMA cost ~980 cycles/tile, ~80 without it)
+#ifndef MU_DKV_ISSUE_FIRST
         if (tl + DKV_RING - 1 < ntile) issue(tl + DKV_RING - 1);
+#endif
     };
     for (int tl = 0; tl < ntile; tl += DKV_RING) {
         tile(std::integral_constant<int, 0>{}, tl);

@@ -639,6 +639,34 @@ __global__ __launch_bounds__(256, 2) void conv_nt3p_kernel(const T* __restrict__
     }
 }
 
+// Per-channel (sum, sum of squares) of a wave's staged 64-pixel x 64-channel output tile, taken from the SAME fp16-rounded
+// values that were just stored (what BatchNorm will read): lane = (pixel sub-index lane>>3, 8-channel group q), 8 pixels per lane,
+// then the eight lanes of a channel group are folded with xor-shuffles and lanes 0-7 write 8 channels x {sum, sumsq} each.
+// part row layout [Cout][2] floats; rows = one per (tile, 4-image-row group).  Saves BatchNorm's separate statistics sweep.
+__device__ __forceinline__ void tile_stats_accum(const h16x8& o, float (&ssum)[8], float (&ssq)[8]) {
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+        const float v = (float)o[c];
+        ssum[c] += v;
+        ssq[c] = fmaf(v, v, ssq[c]);
+    }
+}
+__device__ __forceinline__ void tile_stats_store(float (&ssum)[8], float (&ssq)[8], float* __restrict__ row, int co, int lane) {
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+#pragma unroll
+        for (int m = 8; m < 64; m <<= 1) {
+            ssum[c] += __shfl_xor(ssum[c], m);
+            ssq[c] += __shfl_xor(ssq[c], m);
+        }
+    }
+    if (lane < 8) {
+#pragma unroll
+        for (int c = 0; c < 8; c += 2)
+            *reinterpret_cast<float4*>(row + (co + c) * 2) = make_float4(ssum[c], ssq[c], ssum[c + 1], ssq[c + 1]);
+    }
+}
+
 // ------------------------------------------------------------------------------------------
 // v4 for 3x3, fp16, Cout % 128 == 0: the halo-tile kernel re-scheduled as a ping-pong pipeline (cdna guide, "256^2 8-phase
 // template": one block per CU, LDS-DMA prefetch that stays in flight across raw s_barriers, counted vmcnt, two wave groups
@@ -662,7 +690,8 @@ __global__ __launch_bounds__(256, 2) void conv_nt3p_kernel(const T* __restrict__
 #define MU_CONV_NT4P 1
 #endif
 __global__ __launch_bounds__(512, 1) void conv_nt4_kernel(const h16* __restrict__ x, const h16* __restrict__ w, const float* __restrict__ bias,
-                                                          h16* __restrict__ y, int B, int H, int W, int Cin, int Cout, long x_ld, long y_ld) {
+                                                          h16* __restrict__ y, int B, int H, int W, int Cin, int Cout, long x_ld, long y_ld,
+                                                          float* __restrict__ stat_part) {
     using M_ = Mma<h16>;
     using Frag = M_::Frag;
     constexpr int VN = 8, KC = 64, TM = 4, TN = 4, WC = 4, NWV = 8, BCO = 128;
@@ -823,6 +852,7 @@ __global__ __launch_bounds__(512, 1) void conv_nt4_kernel(const h16* __restrict_
         }
     }
     const int q = lane & 7;
+    float ssum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, ssq[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int it = 0; it < 8; ++it) {
         const int p = it * 8 + (lane >> 3);                 // pixel inside the wave tile: image row wc*4 + (p >> 4), column p & 15
@@ -832,7 +862,9 @@ __global__ __launch_bounds__(512, 1) void conv_nt4_kernel(const h16* __restrict_
         if (B < 0)
 #endif
         *reinterpret_cast<h16x8*>(y + gp * y_ld + co0 + wr * 64 + q * 8) = o;
+        if (stat_part) tile_stats_accum(o, ssum, ssq);
     }
+    if (stat_part) tile_stats_store(ssum, ssq, stat_part + ((long)tl * 4 + wc) * Cout * 2, co0 + wr * 64 + q * 8, lane);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -846,7 +878,8 @@ __global__ __launch_bounds__(512, 1) void conv_nt4_kernel(const h16* __restrict_
 // LDS-DMA through inline asm (glds16a): the epilogue's LDS writes would otherwise be fenced with vmcnt(0) by the compiler.
 // ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(512, 1) void conv_nt4p_kernel(const h16* __restrict__ x, const h16* __restrict__ w, const float* __restrict__ bias,
-                                                           h16* __restrict__ y, int B, int H, int W, int Cin, int Cout, long x_ld, long y_ld) {
+                                                           h16* __restrict__ y, int B, int H, int W, int Cin, int Cout, long x_ld, long y_ld,
+                                                           float* __restrict__ stat_part) {
     using M_ = Mma<h16>;
     using Frag = M_::Frag;
     constexpr int VN = 8, KC = 64, TM = 4, TN = 4, NWV = 8, BCO = 128;
@@ -1023,6 +1056,7 @@ __global__ __launch_bounds__(512, 1) void conv_nt4p_kernel(const h16* __restrict
         }
         {
             const int q = lane & 7;
+            float ssum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, ssq[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int it = 0; it < 8; ++it) {
                 const int p = it * 8 + (lane >> 3);             // pixel inside the wave tile: image row wc*4 + (p >> 4), column p & 15
@@ -1032,7 +1066,9 @@ __global__ __launch_bounds__(512, 1) void conv_nt4p_kernel(const h16* __restrict
                 if (B < 0)
 #endif
                 *reinterpret_cast<h16x8*>(y + gp * y_ld + co0 + wr * 64 + q * 8) = o;
+                if (stat_part) tile_stats_accum(o, ssum, ssq);
             }
+            if (stat_part) tile_stats_store(ssum, ssq, stat_part + ((long)tl * 4 + wc) * Cout * 2, co0 + wr * 64 + q * 8, lane);
         }
         if (has_next && wr == 1) __builtin_amdgcn_s_barrier();      // re-stagger
     }
@@ -1040,7 +1076,7 @@ __global__ __launch_bounds__(512, 1) void conv_nt4p_kernel(const h16* __restrict
 
 template <typename T, int TAPS>
 static int conv_fwd_launch(const T* x, const T* w, const float* bias, T* y, int B, int H, int W, int Cin, int Cout, long x_ld,
-                           long y_ld, hipStream_t st) {
+                           long y_ld, hipStream_t st, float* stat_part = nullptr) {
     const long M = (long)B * H * W;
     const int npb = (int)((M + 127) / 128);
     if (TAPS == 9 && (Cin * (int)sizeof(T)) % 128 == 0 && W % 16 == 0) {     // halo-tile version
@@ -1057,11 +1093,11 @@ static int conv_fwd_launch(const T* x, const T* w, const float* bias, T* y, int 
                 // measured (in-process A/B): 128->128 @128^2 322 -> 307 us, 64->128 @128^2 205 -> 176 us, 256->256 @64^2 equal,
                 // 512->512 @32^2 and two-tile blocks 1-3 % slower -> persistent only for >= 4 tiles per block and short K loops
                 if (ntile4 * ncb4 >= 1024 && Cin <= 256 && 256 % ncb4 == 0) {
-                    conv_nt4p_kernel<<<256, 512, 0, st>>>(x, w, bias, y, B, H, W, Cin, Cout, x_ld, y_ld);
+                    conv_nt4p_kernel<<<256, 512, 0, st>>>(x, w, bias, y, B, H, W, Cin, Cout, x_ld, y_ld, stat_part);
                     return MU_OK;
                 }
 #endif
-                conv_nt4_kernel<<<B * (H / 16) * (W / 16) * (Cout / 128), 512, 0, st>>>(x, w, bias, y, B, H, W, Cin, Cout, x_ld, y_ld);
+                conv_nt4_kernel<<<B * (H / 16) * (W / 16) * (Cout / 128), 512, 0, st>>>(x, w, bias, y, B, H, W, Cin, Cout, x_ld, y_ld, stat_part);
                 return MU_OK;
             }
         }
@@ -1097,6 +1133,25 @@ static int conv_fwd_launch(const T* x, const T* w, const float* bias, T* y, int 
     } else {
         conv_nt_kernel<T, 2, 2, 1, TAPS><<<npb * (Cout / 32), 256, 0, st>>>(x, w, bias, y, B, H, W, Cin, Cout, x_ld, y_ld);
     }
+    return MU_OK;
+}
+
+// Rows of per-tile BatchNorm statistics mu_conv_fwd_stats writes for this layer shape (0: the kernel that serves it has no
+// statistics epilogue -- run mu_bn_train_stats on the output instead).  One row per 16x16 output tile and 4-image-row group.
+extern "C" int mu_conv_stats_rows(int B, int H, int W, int Cin, int Cout, int taps, int dtype) {
+    if (dtype != MU_F16 || taps != 9 || !MU_CONV_NT4 || getenv("MU_CONV_NO_NT4")) return 0;
+    if (Cin % 64 || Cout % 128 || H % 16 || W % 16 || B <= 0) return 0;
+    return B * (H / 16) * (W / 16) * 4;
+}
+
+extern "C" int mu_conv_fwd_stats(const void* x, const void* w, const float* bias, void* y, int B, int H, int W, int Cin, int Cout,
+                                 int taps, long x_ld, long y_ld, int dtype, float* stat_part, void* stream) {
+    if (!x || !w || !y || B <= 0 || H <= 0 || W <= 0) return MU_ERR_ARG;
+    if (Cin <= 0 || Cout <= 0 || Cin % 32 || Cout % 32 || x_ld < Cin || y_ld < Cout || x_ld % 8 || y_ld % 8) return MU_ERR_SHAPE;
+    if (stat_part && mu_conv_stats_rows(B, H, W, Cin, Cout, taps, dtype) == 0) return MU_ERR_SHAPE;
+    if (!stat_part) return mu_conv_fwd(x, w, bias, y, B, H, W, Cin, Cout, taps, x_ld, y_ld, dtype, stream);
+    conv_fwd_launch<h16, 9>((const h16*)x, (const h16*)w, bias, (h16*)y, B, H, W, Cin, Cout, x_ld, y_ld, (hipStream_t)stream, stat_part);
+    MU_CHECK_LAUNCH();
     return MU_OK;
 }
 

@@ -346,6 +346,40 @@ extern "C" int mu_bn_train_stats(const void* x, long M, int C, long ld, float* m
     return MU_OK;
 }
 
+// Statistics from the conv epilogue's per-tile rows: part[rows][C][2] floats (sum, sum of squares of the fp16 outputs).
+// Stage 1 folds 16+ rows per block into the fp64 partial layout of the in-kernel path (coalesced: consecutive threads read
+// consecutive floats of a row), stage 2 is the regular finalize.
+__global__ __launch_bounds__(256) void bn_fold_rows_kernel(const float* __restrict__ part, int rows, int rpb, int C2, double* __restrict__ out) {
+    const int r0 = blockIdx.x * rpb, r1 = r0 + rpb < rows ? r0 + rpb : rows;
+    for (int c = threadIdx.x; c < C2; c += 256) {
+        double a[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+        int r = r0;
+        for (; r + 7 < r1; r += 8) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) a[u] += (double)part[(long)(r + u) * C2 + c];
+        }
+        for (; r < r1; ++r) a[0] += (double)part[(long)r * C2 + c];
+        out[(long)blockIdx.x * C2 + c] = ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
+    }
+}
+
+extern "C" int mu_bn_train_stats_rows(const float* stat_part, int rows, long M, int C, float* mean, float* rstd, float* running_mean,
+                                      float* running_var, long* num_batches_tracked, int c_valid, float momentum, float eps,
+                                      void* workspace, long ws_bytes, void* stream) {
+    if (!stat_part || !mean || !rstd || !workspace || rows <= 0 || M <= 0 || C <= 0) return MU_ERR_ARG;
+    // many short blocks (the fold is latency-bound): 16 rows each, more only when that would exceed the partial-slab capacity
+    int rpb = 16;
+    if ((rows + rpb - 1) / rpb > MU_STAT_MAXBLK) rpb = ((rows + MU_STAT_MAXBLK - 1) / MU_STAT_MAXBLK + 7) / 8 * 8;
+    const int nblk = (rows + rpb - 1) / rpb;
+    if (ws_bytes < mu_bn_workspace_bytes(C)) return MU_ERR_WORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    bn_fold_rows_kernel<<<nblk, 256, 0, st>>>(stat_part, rows, rpb, 2 * C, (double*)workspace);
+    bn_fwd_final_kernel<<<mu_cdiv(C, 4), 256, 0, st>>>((const double*)workspace, nblk, C, M, eps, momentum, mean, rstd, running_mean,
+                                                        running_var, c_valid, num_batches_tracked);
+    MU_CHECK_LAUNCH();
+    return MU_OK;
+}
+
 extern "C" int mu_bn_eval_stats(const float* running_mean, const float* running_var, float eps, float* mean, float* rstd, int C,
                                 int c_valid, void* stream) {
     if (!running_mean || !running_var || !mean || !rstd || C <= 0) return MU_ERR_ARG;

@@ -158,12 +158,12 @@ class ConvBlock(_HipModule):
 
     def forward_nhwc(self, x):
         cb = self.conv_block
-        y = ops.conv(x, cb[0].weight)
-        y = ops.bn_act(y, cb[1], ACT_GELU)
-        y = ops.conv(y, cb[3].weight)
+        y, st = ops.conv_stats(x, cb[0].weight, want=cb[1].training)   # BatchNorm statistics from the conv epilogue where it has one
+        y = ops.bn_act(y, cb[1], ACT_GELU, stats=st)
+        y, st = ops.conv_stats(y, cb[3].weight, want=cb[4].training)
         if self.residual:
-            return ops.bn_act(y, cb[4], ACT_GELU, res=x)      # gelu(x + BN(conv(...)))  (:208)
-        return ops.bn_act(y, cb[4], ACT_NONE)
+            return ops.bn_act(y, cb[4], ACT_GELU, res=x, stats=st)      # gelu(x + BN(conv(...)))  (:208)
+        return ops.bn_act(y, cb[4], ACT_NONE, stats=st)
 
     def forward(self, x):
         self._check_device(x)

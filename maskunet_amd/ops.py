@@ -115,9 +115,20 @@ def _prep_weight(w, dtype, rows_pad, cols_pad, mode):
     return dst.view(taps, rows_pad, cols_pad)
 
 
-def _conv_raw(x, wprep, bias_p, Cout_p, taps):
+def _conv_raw(x, wprep, bias_p, Cout_p, taps, want_stats=False):
+    """y = conv(x); with want_stats also the per-tile BatchNorm statistics rows of y ([rows, Cout_p, 2] floats) when the kernel
+    serving this shape has a statistics epilogue (else None)."""
     B, H, W, Cin_p = x.shape
     y = torch.empty((B, H, W, Cout_p), dtype=x.dtype, device=x.device)
+    if want_stats:
+        rows = _lib.load().mu_conv_stats_rows(B, H, W, Cin_p, Cout_p, taps, dt(x))
+        if rows > 0:
+            part = torch.empty((rows, Cout_p, 2), dtype=torch.float32, device=x.device)
+            call("mu_conv_fwd_stats", ptr(x), ptr(wprep), ptr(bias_p), ptr(y), B, H, W, Cin_p, Cout_p, taps, Cin_p, Cout_p, dt(x),
+                 ptr(part), stream())
+            return y, part
+        call("mu_conv_fwd", ptr(x), ptr(wprep), ptr(bias_p), ptr(y), B, H, W, Cin_p, Cout_p, taps, Cin_p, Cout_p, dt(x), stream())
+        return y, None
     call("mu_conv_fwd", ptr(x), ptr(wprep), ptr(bias_p), ptr(y), B, H, W, Cin_p, Cout_p, taps, Cin_p, Cout_p, dt(x), stream())
     return y
 
@@ -199,7 +210,7 @@ class _Conv(torch.autograd.Function):
     """nn.Conv2d k=3/pad=1 or k=1, NHWC (ade_semantic.py:199,202,284; city_instance.py:243-249)."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias):
+    def forward(ctx, x, weight, bias, want_stats=False):
         x = x.contiguous()
         O, I = weight.shape[0], weight.shape[1]
         taps = weight.shape[2] * weight.shape[3]
@@ -213,15 +224,24 @@ class _Conv(torch.autograd.Function):
         else:
             wprep = _prep_weight(weight, x.dtype, Cout_p, Cin_p, 0)
         bias_p = _pad_vec(bias, Cout_p, 0.0) if bias is not None else None
-        y = _conv_raw(x, wprep, bias_p, Cout_p, taps)
+        part = None
+        if want_stats:
+            y, part = _conv_raw(x, wprep, bias_p, Cout_p, taps, True)
+        else:
+            y = _conv_raw(x, wprep, bias_p, Cout_p, taps)
         ctx.save_for_backward(x, weight)
         ctx.wparam = weight                      # the Parameter itself: backward looks at its .grad
         ctx.has_bias, ctx.taps = bias is not None, taps
-        return y
+        if not want_stats:
+            return y
+        if part is None:
+            part = torch.empty(0, dtype=torch.float32, device=x.device)
+        ctx.mark_non_differentiable(part)
+        return y, part
 
     @staticmethod
     @once_differentiable
-    def backward(ctx, gy):
+    def backward(ctx, gy, gpart=None):
         x, weight = ctx.saved_tensors
         gy = gy.contiguous()
         O, I = weight.shape[0], weight.shape[1]
@@ -239,11 +259,22 @@ class _Conv(torch.autograd.Function):
             gw = _wgrad_raw(x, gy, tuple(weight.shape), ctx.taps)
         if ctx.has_bias and ctx.needs_input_grad[2]:
             gb = _colsum(gy, O)
-        return gx, gw, gb
+        return gx, gw, gb, None
 
 
 def conv(x, weight, bias=None):
     return _Conv.apply(x, weight, bias)
+
+
+CONV_STATS = os.environ.get("MU_CONV_STATS", "1") != "0"      # debug switch: 0 = always the separate statistics sweep
+
+
+def conv_stats(x, weight, bias=None, want=True):
+    """conv() that also returns the BatchNorm statistics rows of its output (an empty tensor when the kernel has none) --
+    pass them to bn_act(..., stats=rows) to skip the separate statistics sweep."""
+    if not want or not CONV_STATS:
+        return _Conv.apply(x, weight, bias), None
+    return _Conv.apply(x, weight, bias, True)
 
 
 # ------------------------------------------------------------------------------------------------
@@ -254,7 +285,7 @@ class _BNAct(torch.autograd.Function):
     :285-286 (BN, ReLU).  Training uses batch statistics and updates the running buffers in place."""
 
     @staticmethod
-    def forward(ctx, x, res, gamma, beta, running_mean, running_var, training, momentum, eps, act, nbt=None):
+    def forward(ctx, x, res, gamma, beta, running_mean, running_var, training, momentum, eps, act, nbt=None, stats=None):
         x = x.contiguous()
         C = x.shape[-1]
         M = x.numel() // C
@@ -266,8 +297,12 @@ class _BNAct(torch.autograd.Function):
         if training:
             rm = running_mean if running_mean is not None else None
             rv = running_var if running_var is not None else None
-            call("mu_bn_train_stats", ptr(x), M, C, C, ptr(mean), ptr(rstd), ptr(rm), ptr(rv), ptr(nbt), cv, float(momentum), float(eps),
-                 ptr(ws), ws.numel(), dt(x), stream())
+            if stats is not None and stats.numel() > 0:          # rows left by the producing conv's epilogue
+                call("mu_bn_train_stats_rows", ptr(stats), stats.shape[0], M, C, ptr(mean), ptr(rstd), ptr(rm), ptr(rv), ptr(nbt), cv,
+                     float(momentum), float(eps), ptr(ws), ws.numel(), stream())
+            else:
+                call("mu_bn_train_stats", ptr(x), M, C, C, ptr(mean), ptr(rstd), ptr(rm), ptr(rv), ptr(nbt), cv, float(momentum), float(eps),
+                     ptr(ws), ws.numel(), dt(x), stream())
         else:
             call("mu_bn_eval_stats", ptr(running_mean), ptr(running_var), float(eps), ptr(mean), ptr(rstd), C, cv, stream())
         y = torch.empty_like(x)
@@ -292,12 +327,13 @@ class _BNAct(torch.autograd.Function):
         ws = workspace(_lib.load().mu_bn_workspace_bytes(C), x.device)
         call("mu_bn_act_bwd", ptr(x), ptr(res), ptr(gy), ptr(dx), ptr(dres), M, C, C, ptr(mean), ptr(rstd), ptr(g_p), ptr(b_p),
              ctx.act, int(ctx.training), ptr(dgamma), ptr(dbeta), ptr(ws), ws.numel(), dt(x), stream())
-        return dx, dres, dgamma[:ctx.cv], dbeta[:ctx.cv], None, None, None, None, None, None, None
+        return dx, dres, dgamma[:ctx.cv], dbeta[:ctx.cv], None, None, None, None, None, None, None, None
 
 
-def bn_act(x, bn, act=ACT_NONE, res=None):
+def bn_act(x, bn, act=ACT_NONE, res=None, stats=None):
     """Apply the BatchNorm2d parameter container `bn` (an nn.BatchNorm2d used only for its
-    parameters/buffers/flags) followed by `act`, optionally adding `res` before the activation."""
+    parameters/buffers/flags) followed by `act`, optionally adding `res` before the activation.
+    `stats`: statistics rows of x from conv_stats() (training mode only; ignored otherwise)."""
     training = bn.training or bn.running_mean is None
     # the step counter is bumped by the statistics kernel (one tiny torch kernel per BatchNorm otherwise: 39 per step)
     nbt = bn.num_batches_tracked if (bn.training and bn.num_batches_tracked is not None) else None
@@ -305,7 +341,8 @@ def bn_act(x, bn, act=ACT_NONE, res=None):
         nbt.add_(1)
         nbt = None
     momentum = 0.1 if bn.momentum is None else bn.momentum
-    return _BNAct.apply(x, res, bn.weight, bn.bias, bn.running_mean, bn.running_var, training, momentum, bn.eps, act, nbt)
+    return _BNAct.apply(x, res, bn.weight, bn.bias, bn.running_mean, bn.running_var, training, momentum, bn.eps, act, nbt,
+                        stats if training else None)
 
 
 # ------------------------------------------------------------------------------------------------

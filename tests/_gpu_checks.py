@@ -162,6 +162,25 @@ def check_conv(dtype, cases=None):
     return out
 
 
+def check_conv_stats(dtype):
+    """BatchNorm statistics rows left by the conv epilogue == column sums / sums of squares of the conv output it wrote."""
+    from maskunet_amd import ops
+    gen = np.random.default_rng(12)
+    out = []
+    if dtype != torch.float16:
+        return [("conv_stats (fp16 only)", 0.0, 0.0)]
+    for (B, H, W, Cin, Cout) in [(2, 16, 32, 64, 128), (3, 32, 32, 128, 256), (8, 64, 64, 64, 128)]:     # the last runs the persistent kernel
+        x = ops.to_nhwc(_rnd(gen, B, Cin, H, W).to(DEV), dtype)
+        w = _rnd(gen, Cout, Cin, 3, 3, scale=1.0 / math.sqrt(Cin * 9)).to(DEV)
+        y, part = ops.conv_stats(x, w)
+        assert part.numel() > 0 and part.shape[0] == B * (H // 16) * (W // 16) * 4
+        yf = y.float().reshape(-1, Cout)
+        ssum, ssq = part[:, :, 0].double().sum(0), part[:, :, 1].double().sum(0)
+        out += [(f"conv_stats{(B, H, W, Cin, Cout)} sum", float((ssum - yf.double().sum(0)).abs().max() / yf.abs().sum(0).max()), 1e-5),
+                (f"conv_stats{(B, H, W, Cin, Cout)} sumsq", float((ssq - (yf.double() ** 2).sum(0)).abs().max() / (yf.double() ** 2).sum(0).max()), 1e-5)]
+    return out
+
+
 def check_bn_act(dtype):
     from maskunet_amd import ops, _lib
     import torch.nn as nn

@@ -33,6 +33,7 @@ if __name__ == "__main__":
             run(f"transpose {tag}", G.check_transpose, dt)
             run(f"layout {tag}", G.check_layout_roundtrip, dt)
             run(f"prep_weight {tag}", G.check_prep_weight, dt)
+            run(f"conv_stats {tag}", G.check_conv_stats, dt)
             run(f"conv {tag}", G.check_conv, dt)
             run(f"bn_act {tag}", G.check_bn_act, dt)
             run(f"pool/up {tag}", G.check_pool_up, dt)
