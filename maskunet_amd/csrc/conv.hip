@@ -689,6 +689,9 @@ __device__ __forceinline__ void tile_stats_store(float (&ssum)[8], float (&ssq)[
 #ifndef MU_CONV_NT4P
 #define MU_CONV_NT4P 1
 #endif
+#ifndef MU_CONV_WIDE1X1
+#define MU_CONV_WIDE1X1 1
+#endif
 __global__ __launch_bounds__(512, 1) void conv_nt4_kernel(const h16* __restrict__ x, const h16* __restrict__ w, const float* __restrict__ bias,
                                                           h16* __restrict__ y, int B, int H, int W, int Cin, int Cout, long x_ld, long y_ld,
                                                           float* __restrict__ stat_part) {
@@ -1116,6 +1119,18 @@ static int conv_fwd_launch(const T* x, const T* w, const float* bias, T* y, int 
         }
         if (Cout % 64 == 0 && H % 8 == 0) {
             conv_nt3_kernel<T, 4, 2, 1><<<B * (H / 8) * (W / 16) * (Cout / 64), 256, 0, st>>>(x, w, bias, y, B, H, W, Cin, Cout, x_ld, y_ld);
+            return MU_OK;
+        }
+    }
+    if constexpr (TAPS == 1 && sizeof(T) == 2 && MU_CONV_WIDE1X1) {
+        // 1x1 layers are HBM-bound streams (q/k/v projection of the N = 16384 block: 134 MB in, 402 MB out): a tile that spans all
+        // output channels reads the activations once instead of once per 64-channel tile
+        if ((Cin * 2) % 128 == 0 && Cout % 192 == 0) {
+            conv_nt2_kernel<T, 6, 4, 2, 1><<<npb * (Cout / 192), 256, 0, st>>>(x, w, bias, y, B, H, W, Cin, Cout, x_ld, y_ld);
+            return MU_OK;
+        }
+        if ((Cin * 2) % 128 == 0 && Cout == 160) {
+            conv_nt2_kernel<T, 5, 4, 2, 1><<<npb, 256, 0, st>>>(x, w, bias, y, B, H, W, Cin, Cout, x_ld, y_ld);
             return MU_OK;
         }
     }
