@@ -88,6 +88,11 @@ template <> struct AT<h16> {
     static __device__ __forceinline__ void mma_row(const Frag& a, const Frag& b, f32x4& c) {
         c = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
     }
+    // first k-step of a product whose accumulator starts from a row constant: C operand = the constant, D = the accumulator
+    // (written as "acc = c0; mma_row(a, b, acc)" the compiler materialises one 4-register copy per accumulator)
+    static __device__ __forceinline__ f32x4 mma_row_from(const Frag& a, const Frag& b, const f32x4& c0) {
+        return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c0, 0, 0, 0);
+    }
     // A operand [m = tile column col0+r16][k-slot j <-> tile row 4g+j, 16+4g+j]
     static __device__ __forceinline__ AccA ld_acc_a(const h16* tile, int stride, int col0, int g, int r16) {
         const int q = r16 >> 2, pc = r16 & 3;
@@ -109,6 +114,12 @@ template <> struct AT<float> {
     static __device__ __forceinline__ void mma_row(const Frag& a, const Frag& b, f32x4& c) {
 #pragma unroll
         for (int s = 0; s < 4; ++s) c = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s], b[s], c, 0, 0, 0);
+    }
+    static __device__ __forceinline__ f32x4 mma_row_from(const Frag& a, const Frag& b, const f32x4& c0) {
+        f32x4 c = __builtin_amdgcn_mfma_f32_16x16x4f32(a[0], b[0], c0, 0, 0, 0);
+#pragma unroll
+        for (int s = 1; s < 4; ++s) c = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s], b[s], c, 0, 0, 0);
+        return c;
     }
     static __device__ __forceinline__ AccA ld_acc_a(const float* tile, int stride, int col0, int g, int r16) {
         AccA a;
@@ -518,8 +529,8 @@ __global__ __launch_bounds__(NW * 64, OCC ? OCC : ((NW == 4 && D <= 64 && sizeof
                 Frag a = ld16<T>(Kt + Z::off(kt * 16 + r16, ks * KR + g * VN));
 #pragma unroll
                 for (int t = 0; t < NQ; ++t) {
-                    if (ks == 0) s[kt][t] = negm[t];
-                    A::mma_row(a, qf[t][ks], s[kt][t]);
+                    if (ks == 0) s[kt][t] = A::mma_row_from(a, qf[t][0], negm[t]);     // -m rides in as the C operand
+                    else A::mma_row(a, qf[t][ks], s[kt][t]);
                 }
             }
         const bool partial = j0 + KT > Nk;          // wave-uniform
@@ -1007,9 +1018,13 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 && D <= 64 && sizeof(T) == 2) ? M
                 Frag va = ld16<T>(Vt + Z::off(kt * 16 + r16, ks * KR + g * VN));
 #pragma unroll
                 for (int t = 0; t < 2; ++t) {
-                    if (ks == 0) { s[kt][t] = nlse[t]; dp[kt][t] = ndel[t]; }
-                    A::mma_row(ka, qf[t][ks], s[kt][t]);
-                    A::mma_row(va, dof[t][ks], dp[kt][t]);
+                    if (ks == 0) {                            // row constants as the C operand of the first k-step (no copies)
+                        s[kt][t] = A::mma_row_from(ka, qf[t][0], nlse[t]);
+                        dp[kt][t] = A::mma_row_from(va, dof[t][0], ndel[t]);
+                    } else {
+                        A::mma_row(ka, qf[t][ks], s[kt][t]);
+                        A::mma_row(va, dof[t][ks], dp[kt][t]);
+                    }
                 }
             }
         if (j0 + KT > Nk) {                          // wave-uniform: only the last, partial tile pays for key-range masking
@@ -1344,12 +1359,11 @@ __global__ __launch_bounds__(256, (D <= 64 && sizeof(T) == 2 && NKT <= 2) ? MU_D
         const T* Ot = Qt + QT * D;
         const float* rc = rcs + SLOT * 256;
         f32x4 s[2][NKT], dp[2][NKT];
+        f32x4 nl[2], nd[2];
 #pragma unroll
         for (int qt = 0; qt < 2; ++qt) {
-            const f32x4 nl = *reinterpret_cast<const f32x4*>(rc + qt * 16 + 4 * g);
-            const f32x4 nd = *reinterpret_cast<const f32x4*>(rc + 32 + qt * 16 + 4 * g);
-#pragma unroll
-            for (int kt = 0; kt < NKT; ++kt) { s[qt][kt] = nl; dp[qt][kt] = nd; }
+            nl[qt] = *reinterpret_cast<const f32x4*>(rc + qt * 16 + 4 * g);
+            nd[qt] = *reinterpret_cast<const f32x4*>(rc + 32 + qt * 16 + 4 * g);
         }
 #pragma unroll
         for (int ks = 0; ks < NKS; ++ks)
@@ -1359,8 +1373,13 @@ __global__ __launch_bounds__(256, (D <= 64 && sizeof(T) == 2 && NKT <= 2) ? MU_D
                 Frag oa = ld16<T>(Ot + Z::off(qt * 16 + r16, ks * KR + g * VN));
 #pragma unroll
                 for (int kt = 0; kt < NKT; ++kt) {
-                    A::mma_row(qa, kf[kt][ks], s[qt][kt]);
-                    A::mma_row(oa, vf[kt][ks], dp[qt][kt]);
+                    if (ks == 0) {                           // the row constants enter as the C operand of the first k-step
+                        s[qt][kt] = A::mma_row_from(qa, kf[kt][0], nl[qt]);
+                        dp[qt][kt] = A::mma_row_from(oa, vf[kt][0], nd[qt]);
+                    } else {
+                        A::mma_row(qa, kf[kt][ks], s[qt][kt]);
+                        A::mma_row(oa, vf[kt][ks], dp[qt][kt]);
+                    }
                 }
             }
         if (tl * QT + QT > N) {                              // last, partial tile: padded queries contribute nothing

@@ -136,7 +136,11 @@ def check_conv(dtype, cases=None):
                       # first-layer weight-gradient kernel (<= 3 valid input channels): ragged width, two channel blocks, 1 channel
                       (2, 20, 24, 3, 128, 3), (1, 8, 8, 1, 64, 3),
                       # 16-pixel-wide images through the 3-tap weight-gradient kernel (two image rows per stage)
-                      (2, 8, 16, 256, 128, 3), (5, 16, 16, 64, 64, 3)]
+                      (2, 8, 16, 256, 128, 3), (5, 16, 16, 64, 64, 3),
+                      # shapes around the kernel-selection edges: 80-wide (16x16 conv tiles, one-tap weight-grad), 192-wide (64-pixel
+                      # weight-grad stages), 32-wide with even / odd height (two-row stages / flat stages), persistent conv with a tail
+                      (2, 48, 80, 64, 128, 3), (1, 32, 192, 128, 128, 3), (2, 6, 32, 128, 128, 3), (1, 5, 32, 128, 128, 3),
+                      (5, 64, 64, 64, 128, 3)]
     for (B, H, W, Cin, Cout, k) in cases:
         x = _rnd(gen, B, Cin, H, W)
         w = _rnd(gen, Cout, Cin, k, k, scale=1.0 / math.sqrt(Cin * k * k))
