@@ -1389,13 +1389,14 @@ __global__ __launch_bounds__(NWV * 64, 1) void conv_wgrad3_kernel(const h16* __r
                                                              long pix_per_split) {
     constexpr int WC = NWV / WR;
     constexpr int BCO = WR * TM * 16, BCI = WC * TN * 16;
-    static_assert(BCO == BCI, "square channel tiles");
-    constexpr int ROWB = BCO * 2, CPR = ROWB / 16, RPW = 1024 / ROWB;
+    // the dy tile (BCO wide) and the x window (BCI wide) may differ in width (128 x 64 tiles for the 64-channel layers): each has
+    // its own row size, DMA lane mapping and swizzle hash
+    constexpr int CPRA = BCO / 8, RPWA = 1024 / (BCO * 2), CPRB = BCI / 8, RPWB = 1024 / (BCI * 2);
     constexpr int KP = 32, SP = SPS * KP;                   // pixels per k-step (one MFMA K) and per DMA stage
     constexpr int RW = SP / 2;                              // two-row mode: image width
-    constexpr int XR = ((W16 ? SP + 4 : SP + 2) + RPW - 1) / RPW * RPW;      // x-window rows allocated (SP + 2, or 2 x (RW + 2))
-    constexpr int NIA = SP / RPW, NIB = XR / RPW;          // DMA wave-instructions per tile
-    constexpr int STAGE = (SP + XR) * BCO;                 // elements per stage
+    constexpr int XR = ((W16 ? SP + 4 : SP + 2) + RPWB - 1) / RPWB * RPWB;   // x-window rows allocated (SP + 2, or 2 x (RW + 2))
+    constexpr int NIA = SP / RPWA, NIB = XR / RPWB;        // DMA wave-instructions per tile
+    constexpr int STAGE = SP * BCO + XR * BCI;             // elements per stage
 
     static_assert(!PP || (SPS == 2 && NWV == 8 && WR == 2), "ping-pong needs two 4-wave groups and two k-steps per stage");
     constexpr int NS = SPS == 1 ? MU_WG_NS : 4;
@@ -1421,7 +1422,7 @@ __global__ __launch_bounds__(NWV * 64, 1) void conv_wgrad3_kernel(const h16* __r
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wave / WC, wc = wave % WC;
     const int r16 = lane & 15, g = lane >> 4;
-    const int lrow = lane / CPR, c16 = lane % CPR;
+    const int lrowA = lane / CPRA, c16A = lane % CPRA, lrowB = lane / CPRB, c16B = lane % CPRB;
     // DMA instructions this wave issues per stage (dy tile: i = wave, wave+NWV, ..; x window likewise)
     constexpr int NAW = (NIA + NWV - 1) / NWV, NBW = (NIB + NWV - 1) / NWV;
     const int n_w = (NIA - wave + NWV - 1) / NWV + (NIB - wave + NWV - 1) / NWV;
@@ -1432,8 +1433,8 @@ __global__ __launch_bounds__(NWV * 64, 1) void conv_wgrad3_kernel(const h16* __r
     int aoff[NAW], boff[NBW], bkind[NBW];      // bkind: 0 plain row, 1 window row 0 (needs w0 > 0), 2 row KP+1 (needs w0+KP < W), 3 unused
 #pragma unroll
     for (int k = 0; k < NAW; ++k) {
-        const int row = (wave + k * NWV) * RPW + lrow;
-        const int sc = (((c16 >> 1) ^ wg_hash<BCO>(row)) << 1) | (c16 & 1);
+        const int row = (wave + k * NWV) * RPWA + lrowA;
+        const int sc = (((c16A >> 1) ^ wg_hash<BCO>(row)) << 1) | (c16A & 1);
         aoff[k] = row * (int)dy_ld + co0 + sc * 8;
     }
     // W == 16: a 32-pixel stage is two whole image rows; the window is two 18-row halves (columns -1 .. 16 of each image
@@ -1441,8 +1442,8 @@ __global__ __launch_bounds__(NWV * 64, 1) void conv_wgrad3_kernel(const h16* __r
     constexpr bool w16 = W16;
 #pragma unroll
     for (int k = 0; k < NBW; ++k) {
-        const int row = (wave + k * NWV) * RPW + lrow;      // window row: flat pixel pbase + dh*W - 1 + row
-        const int sc = (((c16 >> 1) ^ wg_hash<BCO>(row)) << 1) | (c16 & 1);
+        const int row = (wave + k * NWV) * RPWB + lrowB;    // window row: flat pixel pbase + dh*W - 1 + row
+        const int sc = (((c16B >> 1) ^ wg_hash<BCI>(row)) << 1) | (c16B & 1);
         if (w16) {
             const int half = row >= RW + 2, kk = row - half * (RW + 2);
             boff[k] = (half * RW + kk - 1) * (int)x_ld + ci0 + sc * 8;
@@ -1466,7 +1467,7 @@ __global__ __launch_bounds__(NWV * 64, 1) void conv_wgrad3_kernel(const h16* __r
             const int i = wave + k * NWV;
             if (i < NIA) {
                 const void* src = live ? (const void*)(dyp + aoff[k]) : (const void*)mu_zero_page;
-                glds16a(src, At + i * RPW * BCO);
+                glds16a(src, At + i * RPWA * BCO);
             }
         }
         const int hh = hi + dh;
@@ -1479,7 +1480,7 @@ __global__ __launch_bounds__(NWV * 64, 1) void conv_wgrad3_kernel(const h16* __r
                 const bool ok = W16 ? ((rowok && bkind[k] == 4) || (rowok1 && bkind[k] == 5))
                                     : (rowok && (bkind[k] == 0 || (bkind[k] == 1 && lok) || (bkind[k] == 2 && rok)));
                 const void* src = ok ? (const void*)(xp + boff[k]) : (const void*)mu_zero_page;
-                glds16a(src, Bt + i * RPW * BCO);
+                glds16a(src, Bt + i * RPWB * BCI);
             }
         }
         pis += SP;
@@ -1529,8 +1530,8 @@ __global__ __launch_bounds__(NWV * 64, 1) void conv_wgrad3_kernel(const h16* __r
             for (int j = 0; j < TN; ++j) {
                 const int col = (wc * TN + j) * 16 + 4 * pc;
                 const int r0 = rb + 8 * g + q + t + wsh, r1 = r0 + 4;
-                auto lo = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) fp16x4v*)(Bt + r0 * BCO + ((((col >> 4) ^ wg_hash<BCO>(r0)) << 4) | (col & 15))));
-                auto hi = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) fp16x4v*)(Bt + r1 * BCO + ((((col >> 4) ^ wg_hash<BCO>(r1)) << 4) | (col & 15))));
+                auto lo = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) fp16x4v*)(Bt + r0 * BCI + ((((col >> 4) ^ wg_hash<BCI>(r0)) << 4) | (col & 15))));
+                auto hi = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) fp16x4v*)(Bt + r1 * BCI + ((((col >> 4) ^ wg_hash<BCI>(r1)) << 4) | (col & 15))));
                 f.b[t][j] = (h16x8){(h16)lo[0], (h16)lo[1], (h16)lo[2], (h16)lo[3], (h16)hi[0], (h16)hi[1], (h16)hi[2], (h16)hi[3]};
             }
         }
@@ -1710,15 +1711,26 @@ static inline void wgrad_tile(int Cin, int Cout, int* bco, int* bci) {
     *bco = m; *bci = m;
 }
 
-// v2 (3 taps per block) applies to fp16 3x3 layers with W % 32 == 0 and 64/128-wide channel tiles
-static inline bool wgrad3_ok(int H, int W, int taps, int bt, int dtype) {
-    return dtype == MU_F16 && taps == 9 && (W % 32 == 0 || (W == 16 && H % 2 == 0)) && (bt == 128 || bt == 64);
+// v2 (3 taps per block) applies to fp16 3x3 layers with W % 32 == 0 (or W == 16) and 64/128-wide channel tiles.
+// Tile choice: 128x128 (8 waves) or 64x64 (4 waves).  The kernel also runs 128x64 / 64x128 tiles (MU_WG_MIXED=1: layers with one
+// 64-channel side, dy or x tile twice as wide), parity-clean but measured SLOWER in-process (64->128 @128^2: 333 vs 252 us,
+// 128->64: 356 vs 250 us): at 4 waves they need ~256 VGPRs and only the 32-pixel stages fit twice into the LDS.
+#ifndef MU_WG_MIXED
+#define MU_WG_MIXED 0
+#endif
+static inline bool wgrad3_choose(int H, int W, int Cin, int Cout, int taps, int dtype, int* tco, int* tci) {
+    if (dtype != MU_F16 || taps != 9 || !(W % 32 == 0 || (W == 16 && H % 2 == 0))) return false;
+    const int a = Cout % 128 == 0 ? 128 : (Cout % 64 == 0 ? 64 : 0), b = Cin % 128 == 0 ? 128 : (Cin % 64 == 0 ? 64 : 0);
+    if (!a || !b) return false;
+    if (a == b || MU_WG_MIXED) { *tco = a; *tci = b; }
+    else { *tco = 64; *tci = 64; }
+    return true;
 }
-static inline void wgrad3_plan(long M, int Cin, int Cout, int bt, int* nsplit, long* pps) {
-    long tiles = 3L * (Cout / bt) * (Cin / bt);
-    // 128-wide tiles: one block per CU (192 accumulator registers) -> ~2 rounds of blocks; fewer, longer splits also halve
-    // the fp32 slab traffic of the reduce.  64-wide tiles run 5 waves/SIMD and want more blocks in flight.
-    long want = (bt == 128 ? 512 : 1536) / tiles;
+static inline void wgrad3_plan(long M, int Cin, int Cout, int tco, int tci, int* nsplit, long* pps) {
+    long tiles = 3L * (Cout / tco) * (Cin / tci);
+    // 128x128 tiles: one block per CU (192 accumulator registers) -> ~2 rounds of blocks; fewer, longer splits also halve
+    // the fp32 slab traffic of the reduce.  The 4-wave tiles run two blocks per CU and want more blocks in flight.
+    long want = ((tco == 128 && tci == 128) ? 512 : 1536) / tiles;
     if (want < 1) want = 1;
     long max_split = (M + 511) / 512;
     if (want > max_split) want = max_split;
@@ -1831,8 +1843,9 @@ extern "C" long mu_conv_wgrad_workspace_bytes(int B, int H, int W, int Cin, int 
     wgrad_tile(Cin, Cout, &bco, &bci);
     wgrad_plan((long)B * H * W, Cin, Cout, taps, bco, bci, &nsplit, &pps);
     long a = (long)nsplit * taps * Cout * Cin * sizeof(float);
-    if (taps == 9 && (W % 32 == 0 || W == 16) && (bco == 128 || bco == 64)) {
-        wgrad3_plan((long)B * H * W, Cin, Cout, bco, &nsplit, &pps);
+    int tco, tci;
+    if (wgrad3_choose(H, W, Cin, Cout, taps, MU_F16, &tco, &tci)) {
+        wgrad3_plan((long)B * H * W, Cin, Cout, tco, tci, &nsplit, &pps);
         long b = (long)nsplit * taps * Cout * Cin * sizeof(float);
         if (b > a) a = b;
     }
@@ -1880,31 +1893,33 @@ extern "C" int mu_conv_wgrad(const void* x, const void* dy, float* dw_oihw, int 
         MU_CHECK_LAUNCH();
         return MU_OK;
     }
-    if (wgrad3_ok(H, W, taps, bco, dtype)) {
-        wgrad3_plan((long)B * H * W, Cin, Cout, bco, &nsplit, &pps);
+    int tco, tci;
+    if (wgrad3_choose(H, W, Cin, Cout, taps, dtype, &tco, &tci)) {
+        wgrad3_plan((long)B * H * W, Cin, Cout, tco, tci, &nsplit, &pps);
         if (ws_bytes < (long)nsplit * taps * Cout * Cin * (long)sizeof(float)) return MU_ERR_WORKSPACE;
-        const int grid = 3 * (Cout / bco) * (Cin / bco) * nsplit;
+        const int grid = 3 * (Cout / tco) * (Cin / tci) * nsplit;
         const h16 *xh = (const h16*)x, *dyh = (const h16*)dy;
-        if (bco == 128 && W == 16)      // 8 waves, 64x32 tile x 3 taps per wave (96 accumulators): 2 waves/SIMD
-            conv_wgrad3_kernel<4, 2, 2, 8, true><<<grid, 512, 0, st>>>(xh, dyh, part, B, H, W, Cin, Cout, x_ld, dy_ld, nsplit, pps);
-        else if (bco == 128 && W == 32 && H % 2 == 0 && MU_WG_SPS2)
-            conv_wgrad3_kernel<4, 2, 2, 8, true, 2><<<grid, 512, 0, st>>>(xh, dyh, part, B, H, W, Cin, Cout, x_ld, dy_ld, nsplit, pps);
-        else if (bco == 128 && W % 64 == 0 && MU_WG_SPS2 && MU_WG_PP)
-            conv_wgrad3_kernel<4, 2, 2, 8, false, 2, true><<<grid, 512, 0, st>>>(xh, dyh, part, B, H, W, Cin, Cout, x_ld, dy_ld, nsplit, pps);
-        else if (bco == 128 && W % 64 == 0 && MU_WG_SPS2)
-            conv_wgrad3_kernel<4, 2, 2, 8, false, 2><<<grid, 512, 0, st>>>(xh, dyh, part, B, H, W, Cin, Cout, x_ld, dy_ld, nsplit, pps);
-        else if (bco == 128)
-            conv_wgrad3_kernel<4, 2, 2, 8><<<grid, 512, 0, st>>>(xh, dyh, part, B, H, W, Cin, Cout, x_ld, dy_ld, nsplit, pps);
-        else if (W == 16)
-            conv_wgrad3_kernel<2, 2, 2, 4, true><<<grid, 256, 0, st>>>(xh, dyh, part, B, H, W, Cin, Cout, x_ld, dy_ld, nsplit, pps);
-#if MU_WG_SPS2_64
-        else if (W == 32 && H % 2 == 0)
-            conv_wgrad3_kernel<2, 2, 2, 4, true, 2><<<grid, 256, 0, st>>>(xh, dyh, part, B, H, W, Cin, Cout, x_ld, dy_ld, nsplit, pps);
-        else if (W % 64 == 0)
-            conv_wgrad3_kernel<2, 2, 2, 4, false, 2><<<grid, 256, 0, st>>>(xh, dyh, part, B, H, W, Cin, Cout, x_ld, dy_ld, nsplit, pps);
-#endif
-        else
-            conv_wgrad3_kernel<2, 2, 2><<<grid, 256, 0, st>>>(xh, dyh, part, B, H, W, Cin, Cout, x_ld, dy_ld, nsplit, pps);
+#define WG3(...) conv_wgrad3_kernel<__VA_ARGS__><<<grid, (tco == 128 && tci == 128) ? 512 : 256, 0, st>>>(xh, dyh, part, B, H, W, Cin, Cout, x_ld, dy_ld, nsplit, pps)
+        const bool two_row32 = W == 32 && H % 2 == 0, flat64 = W % 64 == 0;
+        if (tco == 128 && tci == 128) {   // 8 waves, 64x32 tile x 3 taps per wave (96 accumulators): 2 waves/SIMD
+            if (W == 16) WG3(4, 2, 2, 8, true);
+            else if (two_row32 && MU_WG_SPS2) WG3(4, 2, 2, 8, true, 2);
+            else if (flat64 && MU_WG_SPS2 && MU_WG_PP) WG3(4, 2, 2, 8, false, 2, true);
+            else if (flat64 && MU_WG_SPS2) WG3(4, 2, 2, 8, false, 2);
+            else WG3(4, 2, 2, 8);
+        } else if (tco == 128) {          // 128 x 64: 4 waves, 64x32 per wave
+            if (W == 16) WG3(4, 2, 2, 4, true);
+            else WG3(4, 2, 2, 4);
+        } else if (tci == 128) {          // 64 x 128: 4 waves, 32x64 per wave
+            if (W == 16) WG3(2, 4, 2, 4, true);
+            else WG3(2, 4, 2, 4);
+        } else {
+            if (W == 16) WG3(2, 2, 2, 4, true);
+            else if (two_row32 && MU_WG_SPS2_64) WG3(2, 2, 2, 4, true, 2);
+            else if (flat64 && MU_WG_SPS2_64) WG3(2, 2, 2, 4, false, 2);
+            else WG3(2, 2, 2);
+        }
+#undef WG3
     } else if (ws_bytes < (long)nsplit * taps * Cout * Cin * (long)sizeof(float)) {
         return MU_ERR_WORKSPACE;
     } else if (dtype == MU_F16) {

@@ -59,7 +59,7 @@ def main():
             return lambda: lib.mu_bn_act_bwd(x.data_ptr(), None, gy.data_ptr(), dx.data_ptr(), None, M, C, C, mean.data_ptr(), rstd.data_ptr(), gam.data_ptr(), bet.data_ptr(), 1, 1, dgam.data_ptr(), dbet.data_ptr(), ws.data_ptr(), ws.numel(), 1, st)
         cases = [(f"bn_stats {M * C * 2 >> 20} MiB", 0), ("bn_act_fwd", 1), ("bn_act_bwd", 2)]
     else:
-        shapes = [(64, 128, 128, 128), (64, 64, 256, 256), (64, 32, 512, 512), (64, 16, 512, 512), (64, 128, 64, 128), (64, 16, 256, 256), (64, 16, 256, 512), (64, 32, 256, 256), (64, 64, 128, 128)]
+        shapes = [(64, 128, 128, 128), (64, 64, 256, 256), (64, 32, 512, 512), (64, 16, 512, 512), (64, 128, 64, 128), (64, 16, 256, 256), (64, 16, 256, 512), (64, 32, 256, 256), (64, 64, 128, 128), (64, 128, 128, 64), (64, 128, 64, 64), (64, 64, 64, 64)]
         bufs = []
         for (B, H, Cin, Cout) in shapes:
             bufs.append((torch.randn(B, H, H, Cin, device=dev, dtype=dt), (torch.randn(9, Cout, Cin, device=dev) * 0.05).to(dt), torch.empty(B, H, H, Cout, device=dev, dtype=dt),
