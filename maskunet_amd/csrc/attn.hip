@@ -181,176 +181,9 @@ template <> __device__ __forceinline__ void load4<float>(const float* p, float v
     v[0] = o.x; v[1] = o.y; v[2] = o.z; v[3] = o.w;
 }
 
-#define ATT_KT 32      // keys (or queries) staged per LDS tile
-template <typename T, int D> struct TileGeom {
-    static constexpr int PAD = 16 / sizeof(T);    // one 16-byte chunk of padding per row
-    static constexpr int S = D + PAD;
-};
-
-// stage ATT_KT gathered rows of two row-major sources into LDS (zero rows past `nvalid`)
-template <typename T, int D>
-__device__ __forceinline__ void stage_rows(T* dstA, T* dstB, const T* srcA, const T* srcB, long ldA, long ldB, const int* idx,
-                                           int j0, int nvalid, int tid) {
-    constexpr int VN = AT<T>::VN, CPR = D / VN, S = TileGeom<T, D>::S;
-    for (int i = tid; i < ATT_KT * CPR; i += 256) {
-        const int row = i / CPR, c = (i % CPR) * VN;
-        const int j = j0 + row;
-        typename AT<T>::Frag a = zero_frag<T>(), b = zero_frag<T>();
-        if (j < nvalid) {
-            const long r = idx ? idx[j] : j;
-            a = ld16<T>(srcA + r * ldA + c);
-            b = ld16<T>(srcB + r * ldB + c);
-        }
-        *reinterpret_cast<typename AT<T>::Frag*>(dstA + row * S + c) = a;
-        *reinterpret_cast<typename AT<T>::Frag*>(dstB + row * S + c) = b;
-    }
-}
-
 // ------------------------------------------------------------------------------------------
-// forward: block = 128 queries of one image (4 waves x 32 queries), loop over kept-key tiles.
-// epilogue fuses 1/l, the residual add and LayerNorm([C]) and stores token-major.
-// ------------------------------------------------------------------------------------------
-template <typename T, int D>
-__global__ __launch_bounds__(256) void attn_fwd_kernel(const T* __restrict__ qkv, const T* __restrict__ x, const int* __restrict__ kidx,
-                                                       const int* __restrict__ kcnt, const float* __restrict__ gamma,
-                                                       const float* __restrict__ beta, T* __restrict__ out, T* __restrict__ oattn,
-                                                       float* __restrict__ lse2, float* __restrict__ ln_mean, float* __restrict__ ln_rstd,
-                                                       int N, int nkmax, float scale_log2, float eps) {
-    using A = AT<T>;
-    using Frag = typename A::Frag;
-    constexpr int VN = A::VN, KR = A::KR, NKS = D / KR, NDT = D / 16, S = TileGeom<T, D>::S;
-    __shared__ __attribute__((aligned(16))) T Ks[ATT_KT * S];
-    __shared__ __attribute__((aligned(16))) T Vs[ATT_KT * S];
-
-    const int b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int r16 = lane & 15, g = lane >> 4;
-    const int q0 = blockIdx.x * 128 + wave * 32;
-    const T* qkv_b = qkv + (long)b * N * 3 * D;
-    const int Nk = kcnt[b];
-    const int* kidx_b = kidx + (long)b * nkmax;
-
-    Frag qf[2][NKS];
-#pragma unroll
-    for (int t = 0; t < 2; ++t) {
-        int qrow = q0 + t * 16 + r16;
-        if (qrow > N - 1) qrow = N - 1;
-#pragma unroll
-        for (int ks = 0; ks < NKS; ++ks) qf[t][ks] = ld16<T>(qkv_b + (long)qrow * 3 * D + ks * KR + g * VN);
-    }
-    f32x4 o[NDT][2];
-#pragma unroll
-    for (int dt = 0; dt < NDT; ++dt)
-#pragma unroll
-        for (int t = 0; t < 2; ++t) o[dt][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    float m[2] = {-INFINITY, -INFINITY}, l[2] = {0.f, 0.f};
-
-    for (int j0 = 0; j0 < Nk; j0 += ATT_KT) {
-        MU_SYNC_DMA();
-        stage_rows<T, D>(Ks, Vs, qkv_b + D, qkv_b + 2 * D, 3 * D, 3 * D, kidx_b, j0, Nk, tid);
-        MU_SYNC_DMA();
-        f32x4 s[2][2];
-#pragma unroll
-        for (int kt = 0; kt < 2; ++kt)
-#pragma unroll
-            for (int t = 0; t < 2; ++t) s[kt][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int ks = 0; ks < NKS; ++ks)
-#pragma unroll
-            for (int kt = 0; kt < 2; ++kt) {
-                Frag a = ld16<T>(Ks + (kt * 16 + r16) * S + ks * KR + g * VN);
-#pragma unroll
-                for (int t = 0; t < 2; ++t) A::mma_row(a, qf[t][ks], s[kt][t]);
-            }
-#pragma unroll
-        for (int t = 0; t < 2; ++t) {
-            float mx = -INFINITY;
-#pragma unroll
-            for (int kt = 0; kt < 2; ++kt)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const bool ok = j0 + kt * 16 + 4 * g + r < Nk;
-                    const float v = ok ? s[kt][t][r] * scale_log2 : -INFINITY;
-                    s[kt][t][r] = v;
-                    mx = fmaxf(mx, v);
-                }
-            mx = grp_max(mx);
-            const float m_new = fmaxf(m[t], mx);
-            const float alpha = exp2f(m[t] - m_new);
-            m[t] = m_new;
-            float psum = 0.f;
-#pragma unroll
-            for (int kt = 0; kt < 2; ++kt)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const float p = exp2f(s[kt][t][r] - m_new);
-                    s[kt][t][r] = p;
-                    psum += p;
-                }
-            l[t] = l[t] * alpha + psum;
-#pragma unroll
-            for (int dt = 0; dt < NDT; ++dt) o[dt][t] *= alpha;
-        }
-#pragma unroll
-        for (int dt = 0; dt < NDT; ++dt) {
-            typename A::AccA va = A::ld_acc_a(Vs, S, dt * 16, g, r16);
-#pragma unroll
-            for (int t = 0; t < 2; ++t) A::mma_acc(va, s[0][t], s[1][t], o[dt][t]);
-        }
-    }
-
-    // epilogue: lane holds channels dt*16 + 4g + r of query (t, r16)
-#pragma unroll
-    for (int t = 0; t < 2; ++t) {
-        const float ltot = grp_sum(l[t]);
-        const float inv = 1.0f / ltot;
-        const int qrow = q0 + t * 16 + r16;
-        const bool valid = qrow < N;
-        const long tok = (long)b * N + (valid ? qrow : 0);
-        float y[NDT][4];
-        float sum = 0.f;
-#pragma unroll
-        for (int dt = 0; dt < NDT; ++dt) {
-            float xr[4] = {0.f, 0.f, 0.f, 0.f};
-            if (valid) load4<T>(x + tok * D + dt * 16 + 4 * g, xr);
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                o[dt][t][r] *= inv;
-                y[dt][r] = o[dt][t][r] + xr[r];
-                sum += y[dt][r];
-            }
-        }
-        const float mean = grp_sum(sum) * (1.0f / D);
-        float sq = 0.f;
-#pragma unroll
-        for (int dt = 0; dt < NDT; ++dt)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) { const float d = y[dt][r] - mean; sq += d * d; }
-        const float rstd = rsqrtf(grp_sum(sq) * (1.0f / D) + eps);
-        if (valid) {
-#pragma unroll
-            for (int dt = 0; dt < NDT; ++dt) {
-                const int c = dt * 16 + 4 * g;
-                float ov[4], av[4];
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    ov[r] = (y[dt][r] - mean) * rstd * gamma[c + r] + beta[c + r];
-                    av[r] = o[dt][t][r];
-                }
-                store4<T>(out + tok * D + c, ov);
-                store4<T>(oattn + tok * D + c, av);
-            }
-            if (g == 0) {
-                lse2[tok] = m[t] + log2f(ltot);
-                ln_mean[tok] = mean;
-                ln_rstd[tok] = rstd;
-            }
-        }
-    }
-}
-
-
-// ------------------------------------------------------------------------------------------
-// forward v2: same math as attn_fwd_kernel, restructured for throughput
+// forward: flash-style masked attention over the kept keys (the first, register-staged version of this kernel and of the
+// backward sweeps was removed once these LDS-DMA versions had replaced it everywhere)
 //  * K/V tiles (KT kept keys) arrive by LDS-DMA (global_load_lds_dwordx4 with per-lane gathered
 //    source rows; padded rows read a zero page), double-buffered: tile j+1 is in flight while tile j
 //    is processed; the XOR chunk swizzle sits on the source chunk and on every read, which makes
@@ -360,7 +193,6 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const T* __restrict__ qkv
 //  * the O/l rescale runs only when some row's running max actually moved (wave-uniform branch);
 //  * key-range masking only in the final, partial tile.
 // ------------------------------------------------------------------------------------------
-__device__ __attribute__((aligned(16))) char mu_attn_zero_page[16];
 
 template <typename T, int D> struct SwzTile {
     static constexpr int VN = AT<T>::VN;
@@ -737,212 +569,6 @@ __global__ void attn_ln_bwd_final_kernel(const double* __restrict__ part, int nb
     dbeta[c] = (float)b;
 }
 
-// ------------------------------------------------------------------------------------------
-// backward dQ: same sweep as the forward.  S^T = K Q^T, dP^T = V dO^T, dS^T = P^T o (dP^T - delta) * scale,
-// dQ^T += K^T dS^T.
-// ------------------------------------------------------------------------------------------
-template <typename T, int D>
-__global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const T* __restrict__ qkv, const T* __restrict__ dY, const int* __restrict__ kidx,
-                                                          const int* __restrict__ kcnt, const float* __restrict__ lse2,
-                                                          const float* __restrict__ delta, T* __restrict__ dqkv, int N, int nkmax,
-                                                          float scale, float scale_log2) {
-    using A = AT<T>;
-    using Frag = typename A::Frag;
-    constexpr int VN = A::VN, KR = A::KR, NKS = D / KR, NDT = D / 16, S = TileGeom<T, D>::S;
-    __shared__ __attribute__((aligned(16))) T Ks[ATT_KT * S];
-    __shared__ __attribute__((aligned(16))) T Vs[ATT_KT * S];
-
-    const int b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int r16 = lane & 15, g = lane >> 4;
-    const int q0 = blockIdx.x * 128 + wave * 32;
-    const T* qkv_b = qkv + (long)b * N * 3 * D;
-    const int Nk = kcnt[b];
-    const int* kidx_b = kidx + (long)b * nkmax;
-
-    Frag qf[2][NKS], dof[2][NKS];
-    float lse_q[2], del_q[2];
-#pragma unroll
-    for (int t = 0; t < 2; ++t) {
-        int qrow = q0 + t * 16 + r16;
-        if (qrow > N - 1) qrow = N - 1;
-        const long tok = (long)b * N + qrow;
-#pragma unroll
-        for (int ks = 0; ks < NKS; ++ks) {
-            qf[t][ks] = ld16<T>(qkv_b + (long)qrow * 3 * D + ks * KR + g * VN);
-            dof[t][ks] = ld16<T>(dY + tok * D + ks * KR + g * VN);
-        }
-        lse_q[t] = lse2[tok];
-        del_q[t] = delta[tok];
-    }
-    f32x4 dq[NDT][2];
-#pragma unroll
-    for (int dt = 0; dt < NDT; ++dt)
-#pragma unroll
-        for (int t = 0; t < 2; ++t) dq[dt][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
-
-    for (int j0 = 0; j0 < Nk; j0 += ATT_KT) {
-        MU_SYNC_DMA();
-        stage_rows<T, D>(Ks, Vs, qkv_b + D, qkv_b + 2 * D, 3 * D, 3 * D, kidx_b, j0, Nk, tid);
-        MU_SYNC_DMA();
-        f32x4 s[2][2], dp[2][2];
-#pragma unroll
-        for (int kt = 0; kt < 2; ++kt)
-#pragma unroll
-            for (int t = 0; t < 2; ++t) { s[kt][t] = (f32x4){0.f, 0.f, 0.f, 0.f}; dp[kt][t] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
-#pragma unroll
-        for (int ks = 0; ks < NKS; ++ks)
-#pragma unroll
-            for (int kt = 0; kt < 2; ++kt) {
-                Frag ka = ld16<T>(Ks + (kt * 16 + r16) * S + ks * KR + g * VN);
-                Frag va = ld16<T>(Vs + (kt * 16 + r16) * S + ks * KR + g * VN);
-#pragma unroll
-                for (int t = 0; t < 2; ++t) {
-                    A::mma_row(ka, qf[t][ks], s[kt][t]);
-                    A::mma_row(va, dof[t][ks], dp[kt][t]);
-                }
-            }
-#pragma unroll
-        for (int t = 0; t < 2; ++t)
-#pragma unroll
-            for (int kt = 0; kt < 2; ++kt)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const bool ok = j0 + kt * 16 + 4 * g + r < Nk;
-                    const float p = ok ? exp2f(s[kt][t][r] * scale_log2 - lse_q[t]) : 0.f;
-                    s[kt][t][r] = p * (dp[kt][t][r] - del_q[t]) * scale;
-                }
-#pragma unroll
-        for (int dt = 0; dt < NDT; ++dt) {
-            typename A::AccA ka = A::ld_acc_a(Ks, S, dt * 16, g, r16);
-#pragma unroll
-            for (int t = 0; t < 2; ++t) A::mma_acc(ka, s[0][t], s[1][t], dq[dt][t]);
-        }
-    }
-#pragma unroll
-    for (int t = 0; t < 2; ++t) {
-        const int qrow = q0 + t * 16 + r16;
-        if (qrow >= N) continue;
-        T* dst = dqkv + ((long)b * N + qrow) * 3 * D;
-#pragma unroll
-        for (int dt = 0; dt < NDT; ++dt) {
-            float v[4] = {dq[dt][t][0], dq[dt][t][1], dq[dt][t][2], dq[dt][t][3]};
-            store4<T>(dst + dt * 16 + 4 * g, v);
-        }
-    }
-}
-
-// ------------------------------------------------------------------------------------------
-// backward dK/dV: a wave owns NKT*16 kept keys (K,V fragments in registers, dK^T/dV^T accumulators),
-// the block sweeps all queries in LDS tiles of 32.
-//   S = Q K^T, dP = dO V^T (rows = queries), P = exp2(S*c - lse2), dS = P o (dP - delta) * scale,
-//   dV^T += dO^T P, dK^T += Q^T dS.
-// ------------------------------------------------------------------------------------------
-template <typename T, int D, int NKT>
-__global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const T* __restrict__ qkv, const T* __restrict__ dY, const int* __restrict__ kidx,
-                                                           const int* __restrict__ kcnt, const float* __restrict__ lse2,
-                                                           const float* __restrict__ delta, T* __restrict__ dqkv, int N, int nkmax,
-                                                           float scale, float scale_log2) {
-    using A = AT<T>;
-    using Frag = typename A::Frag;
-    constexpr int VN = A::VN, KR = A::KR, NKS = D / KR, NDT = D / 16, S = TileGeom<T, D>::S;
-    __shared__ __attribute__((aligned(16))) T Qs[ATT_KT * S];
-    __shared__ __attribute__((aligned(16))) T Os[ATT_KT * S];
-    __shared__ float lse_s[ATT_KT], del_s[ATT_KT];
-
-    const int b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int r16 = lane & 15, g = lane >> 4;
-    const int Nk = kcnt[b];
-    const int kb0 = blockIdx.x * (4 * NKT * 16);
-    if (kb0 >= Nk) return;                       // uniform per block
-    const int* kidx_b = kidx + (long)b * nkmax;
-    const T* qkv_b = qkv + (long)b * N * 3 * D;
-
-    Frag kf[NKT][NKS], vf[NKT][NKS];
-    int keyrow[NKT];
-#pragma unroll
-    for (int kt = 0; kt < NKT; ++kt) {
-        const int j = kb0 + (wave * NKT + kt) * 16 + r16;
-        keyrow[kt] = j < Nk ? kidx_b[j] : -1;
-#pragma unroll
-        for (int ks = 0; ks < NKS; ++ks) {
-            if (keyrow[kt] >= 0) {
-                kf[kt][ks] = ld16<T>(qkv_b + (long)keyrow[kt] * 3 * D + D + ks * KR + g * VN);
-                vf[kt][ks] = ld16<T>(qkv_b + (long)keyrow[kt] * 3 * D + 2 * D + ks * KR + g * VN);
-            } else {
-                kf[kt][ks] = zero_frag<T>();
-                vf[kt][ks] = zero_frag<T>();
-            }
-        }
-    }
-    f32x4 dk[NDT][NKT], dv[NDT][NKT];
-#pragma unroll
-    for (int dt = 0; dt < NDT; ++dt)
-#pragma unroll
-        for (int kt = 0; kt < NKT; ++kt) { dk[dt][kt] = (f32x4){0.f, 0.f, 0.f, 0.f}; dv[dt][kt] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
-
-    for (int q0 = 0; q0 < N; q0 += ATT_KT) {
-        MU_SYNC_DMA();
-        stage_rows<T, D>(Qs, Os, qkv_b, dY + (long)b * N * D, 3 * D, D, nullptr, q0, N, tid);
-        if (tid < ATT_KT) {
-            const int q = q0 + tid;
-            lse_s[tid] = q < N ? lse2[(long)b * N + q] : INFINITY;     // exp2(-inf) = 0 for padded queries
-            del_s[tid] = q < N ? delta[(long)b * N + q] : 0.f;
-        }
-        MU_SYNC_DMA();
-        f32x4 s[2][NKT], dp[2][NKT];
-#pragma unroll
-        for (int qt = 0; qt < 2; ++qt)
-#pragma unroll
-            for (int kt = 0; kt < NKT; ++kt) { s[qt][kt] = (f32x4){0.f, 0.f, 0.f, 0.f}; dp[qt][kt] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
-#pragma unroll
-        for (int ks = 0; ks < NKS; ++ks)
-#pragma unroll
-            for (int qt = 0; qt < 2; ++qt) {
-                Frag qa = ld16<T>(Qs + (qt * 16 + r16) * S + ks * KR + g * VN);
-                Frag oa = ld16<T>(Os + (qt * 16 + r16) * S + ks * KR + g * VN);
-#pragma unroll
-                for (int kt = 0; kt < NKT; ++kt) {
-                    A::mma_row(qa, kf[kt][ks], s[qt][kt]);
-                    A::mma_row(oa, vf[kt][ks], dp[qt][kt]);
-                }
-            }
-        // rows = queries qt*16 + 4g + r, column = this lane's key
-#pragma unroll
-        for (int qt = 0; qt < 2; ++qt)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const float ls = lse_s[qt * 16 + 4 * g + r], de = del_s[qt * 16 + 4 * g + r];
-#pragma unroll
-                for (int kt = 0; kt < NKT; ++kt) {
-                    const float p = exp2f(s[qt][kt][r] * scale_log2 - ls);
-                    s[qt][kt][r] = p;
-                    dp[qt][kt][r] = p * (dp[qt][kt][r] - de) * scale;
-                }
-            }
-#pragma unroll
-        for (int dt = 0; dt < NDT; ++dt) {
-            typename A::AccA oa = A::ld_acc_a(Os, S, dt * 16, g, r16);
-            typename A::AccA qa = A::ld_acc_a(Qs, S, dt * 16, g, r16);
-#pragma unroll
-            for (int kt = 0; kt < NKT; ++kt) {
-                A::mma_acc(oa, s[0][kt], s[1][kt], dv[dt][kt]);
-                A::mma_acc(qa, dp[0][kt], dp[1][kt], dk[dt][kt]);
-            }
-        }
-    }
-#pragma unroll
-    for (int kt = 0; kt < NKT; ++kt) {
-        if (keyrow[kt] < 0) continue;
-        T* dst = dqkv + ((long)b * N + keyrow[kt]) * 3 * D;
-#pragma unroll
-        for (int dt = 0; dt < NDT; ++dt) {
-            float kv[4] = {dk[dt][kt][0], dk[dt][kt][1], dk[dt][kt][2], dk[dt][kt][3]};
-            float vv[4] = {dv[dt][kt][0], dv[dt][kt][1], dv[dt][kt][2], dv[dt][kt][3]};
-            store4<T>(dst + D + dt * 16 + 4 * g, kv);
-            store4<T>(dst + 2 * D + dt * 16 + 4 * g, vv);
-        }
-    }
-}
 
 
 // ------------------------------------------------------------------------------------------
@@ -1073,165 +699,6 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 && D <= 64 && sizeof(T) == 2) ? M
     }
 }
 
-// stage QT query rows of Q (from qkv, row stride 3D) and dO (from dY, row stride D), swizzled, by LDS-DMA
-template <typename T, int D, int QT>
-__device__ __forceinline__ void stage_qo_dma(T* Qt, T* Ot, const T* qkv_b, const T* dY_b, int q0, int N, int wave, int lane) {
-    using Z = SwzTile<T, D>;
-    constexpr int NI = QT / Z::RPW;
-    const int lrow = lane / Z::CPR, lch = lane % Z::CPR;
-#pragma unroll
-    for (int i = wave; i < NI; i += 4) {
-        const int row = i * Z::RPW + lrow;
-        const int q = q0 + row;
-        const int sc = lch ^ (row & Z::SW);
-        const void *qs = mu_attn_zero_page, *os = mu_attn_zero_page;
-        if (q < N) {
-            qs = qkv_b + (long)q * 3 * D + sc * Z::VN;
-            os = dY_b + (long)q * D + sc * Z::VN;
-        }
-        glds16a(qs, Qt + i * Z::RPW * D);
-        glds16a(os, Ot + i * Z::RPW * D);
-    }
-}
-
-template <typename T, int D, int NKT>
-__global__ __launch_bounds__(256, (D <= 64 && sizeof(T) == 2) ? 2 : 1) void attn_bwd_dkv2_kernel(const T* __restrict__ qkv, const T* __restrict__ dY, const int* __restrict__ kidx,
-                                                            const int* __restrict__ kcnt, const float* __restrict__ lse2,
-                                                            const float* __restrict__ delta, T* __restrict__ dqkv, int N, int nkmax,
-                                                            float scale, float scale_log2) {
-    using A = AT<T>;
-    using Frag = typename A::Frag;
-    using Z = SwzTile<T, D>;
-    constexpr int VN = A::VN, KR = A::KR, NKS = D / KR, NDT = D / 16, QT = 32;
-    __shared__ __attribute__((aligned(16))) T lds[2 * 2 * QT * D];
-
-    const int b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int r16 = lane & 15, g = lane >> 4;
-    const int Nk = kcnt[b];
-    const int kb0 = blockIdx.x * (4 * NKT * 16);
-    if (kb0 >= Nk) return;
-    const int* kidx_b = kidx + (long)b * nkmax;
-    const T* qkv_b = qkv + (long)b * N * 3 * D;
-    const T* dY_b = dY + (long)b * N * D;
-    const float* lse_b = lse2 + (long)b * N;
-    const float* del_b = delta + (long)b * N;
-
-    stage_qo_dma<T, D, QT>(lds, lds + QT * D, qkv_b, dY_b, 0, N, wave, lane);
-
-    // this wave's keys live in registers: K pre-scaled by log2(e)/sqrt(C) (S comes out as the exponent of P once
-    // -lse2 is the C operand) and V by 1/sqrt(C) (dP comes out as (dP - delta)/sqrt(C) with -delta/sqrt(C) as C)
-    Frag kf[NKT][NKS], vf[NKT][NKS];
-    int keyrow[NKT];
-#pragma unroll
-    for (int kt = 0; kt < NKT; ++kt) {
-        const int j = kb0 + (wave * NKT + kt) * 16 + r16;
-        keyrow[kt] = j < Nk ? kidx_b[j] : -1;
-#pragma unroll
-        for (int ks = 0; ks < NKS; ++ks) {
-            Frag fk = zero_frag<T>(), fv = zero_frag<T>();
-            if (keyrow[kt] >= 0) {
-                fk = ld16<T>(qkv_b + (long)keyrow[kt] * 3 * D + D + ks * KR + g * VN);
-                fv = ld16<T>(qkv_b + (long)keyrow[kt] * 3 * D + 2 * D + ks * KR + g * VN);
-#pragma unroll
-                for (int e = 0; e < VN; ++e) { fk[e] = (T)((float)fk[e] * scale_log2); fv[e] = (T)((float)fv[e] * scale); }
-            }
-            kf[kt][ks] = fk;
-            vf[kt][ks] = fv;
-        }
-    }
-    f32x4 dk[NDT][NKT], dv[NDT][NKT];
-#pragma unroll
-    for (int dt = 0; dt < NDT; ++dt)
-#pragma unroll
-        for (int kt = 0; kt < NKT; ++kt) { dk[dt][kt] = (f32x4){0.f, 0.f, 0.f, 0.f}; dv[dt][kt] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
-
-    // per-lane row constants of a tile: queries qt*16 + 4g + r  (N % 4 == 0)
-    auto load_rows = [&](int q0, f32x4 (&ls)[2], f32x4 (&de)[2]) {
-#pragma unroll
-        for (int qt = 0; qt < 2; ++qt) {
-            int q = q0 + qt * 16 + 4 * g;
-            if (q > N - 4) q = N - 4;
-            const float4 a = *reinterpret_cast<const float4*>(lse_b + q);
-            const float4 d = *reinterpret_cast<const float4*>(del_b + q);
-            ls[qt] = (f32x4){-a.x, -a.y, -a.z, -a.w};
-            de[qt] = (f32x4){-d.x * scale, -d.y * scale, -d.z * scale, -d.w * scale};
-        }
-    };
-    f32x4 ls_c[2], de_c[2], ls_n[2], de_n[2];
-    load_rows(0, ls_c, de_c);
-    MU_SYNC_DMA();
-
-    auto tile = [&](auto BUFC, int q0) {
-        constexpr int BUF = decltype(BUFC)::value;
-        const T* Qt = lds + BUF * 2 * QT * D;
-        const T* Ot = Qt + QT * D;
-        const bool more = q0 + QT < N;
-        if (more) {
-            load_rows(q0 + QT, ls_n, de_n);           // issued BEFORE the DMA so their wait does not drain it
-            T* Qn = lds + (BUF ^ 1) * 2 * QT * D;
-            stage_qo_dma<T, D, QT>(Qn, Qn + QT * D, qkv_b, dY_b, q0 + QT, N, wave, lane);
-        }
-        f32x4 s[2][NKT], dp[2][NKT];
-#pragma unroll
-        for (int ks = 0; ks < NKS; ++ks)
-#pragma unroll
-            for (int qt = 0; qt < 2; ++qt) {
-                Frag qa = ld16<T>(Qt + Z::off(qt * 16 + r16, ks * KR + g * VN));
-                Frag oa = ld16<T>(Ot + Z::off(qt * 16 + r16, ks * KR + g * VN));
-#pragma unroll
-                for (int kt = 0; kt < NKT; ++kt) {
-                    if (ks == 0) { s[qt][kt] = ls_c[qt]; dp[qt][kt] = de_c[qt]; }
-                    A::mma_row(qa, kf[kt][ks], s[qt][kt]);
-                    A::mma_row(oa, vf[kt][ks], dp[qt][kt]);
-                }
-            }
-        const bool partial = q0 + QT > N;
-#pragma unroll
-        for (int qt = 0; qt < 2; ++qt)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const bool dead = partial && (q0 + qt * 16 + 4 * g + r >= N);
-#pragma unroll
-                for (int kt = 0; kt < NKT; ++kt) {
-                    float p = __builtin_amdgcn_exp2f(s[qt][kt][r]);
-                    if (dead) p = 0.f;
-                    s[qt][kt][r] = p;
-                    dp[qt][kt][r] *= p;
-                }
-            }
-#pragma unroll
-        for (int dt = 0; dt < NDT; ++dt) {
-            typename A::AccA oa = AccLd<T, D>::ld(Ot, 0, dt * 16, g, r16);
-            typename A::AccA qa = AccLd<T, D>::ld(Qt, 0, dt * 16, g, r16);
-#pragma unroll
-            for (int kt = 0; kt < NKT; ++kt) {
-                A::mma_acc(oa, s[0][kt], s[1][kt], dv[dt][kt]);
-                A::mma_acc(qa, dp[0][kt], dp[1][kt], dk[dt][kt]);
-            }
-        }
-        if (more) {
-#pragma unroll
-            for (int qt = 0; qt < 2; ++qt) { ls_c[qt] = ls_n[qt]; de_c[qt] = de_n[qt]; }
-        }
-        MU_SYNC_DMA();
-    };
-    for (int q0 = 0; q0 < N; q0 += 2 * QT) {
-        tile(std::integral_constant<int, 0>{}, q0);
-        if (q0 + QT < N) tile(std::integral_constant<int, 1>{}, q0 + QT);
-    }
-#pragma unroll
-    for (int kt = 0; kt < NKT; ++kt) {
-        if (keyrow[kt] < 0) continue;
-        T* dst = dqkv + ((long)b * N + keyrow[kt]) * 3 * D;
-#pragma unroll
-        for (int dt = 0; dt < NDT; ++dt) {
-            float kv[4] = {dk[dt][kt][0], dk[dt][kt][1], dk[dt][kt][2], dk[dt][kt][3]};
-            float vv[4] = {dv[dt][kt][0], dv[dt][kt][1], dv[dt][kt][2], dv[dt][kt][3]};
-            store4<T>(dst + D + dt * 16 + 4 * g, kv);
-            store4<T>(dst + 2 * D + dt * 16 + 4 * g, vv);
-        }
-    }
-}
 
 
 // ------------------------------------------------------------------------------------------
