@@ -245,6 +245,44 @@ def mean_iou(y_pred, y_true, num_classes, smooth=1e-6):
     return torch.mean(torch.stack(ious))
 
 
+def instance_contrastive_loss(features, instance_mask, u, margin: float = 1.0, ignore_index=None):
+    """InstanceContrastiveLoss (ade_panoptic.py:390-418; with `ignore_index=255` city_instance.py:279-307 and
+    coco_panoptic.py:482-521): for every instance id != 0 with at least two pixels, a triplet margin loss between the feature
+    columns addressed by the FIRST two pixels of the instance and by one random pixel outside it, averaged over instances.
+
+    Faithful to the reference's indexing: `nonzero(as_tuple=True)` of the [B,H,W] mask yields (batch, row, col) index
+    vectors and the reference uses entries [0] and [1] -- i.e. (batch, row) of a pixel -- as (h, w) into
+    features[:, :, h, w], so each "pixel feature" is the [B*C] column features[:, :, b_pix, row_pix].
+    The reference draws the negative with torch.randint(0, n_neg); here the k-th instance that reaches the draw takes
+    index floor(u[k] * n_neg) (the golden generator patches torch.randint the same way)."""
+    if ignore_index is None:
+        ids = torch.unique(instance_mask)
+    else:
+        ids = torch.unique(instance_mask[instance_mask != ignore_index])
+    loss = features.new_zeros(())
+    count = 0
+    k = 0
+    for inst in ids.tolist():
+        if inst == 0:
+            continue
+        pb, ph, _ = (instance_mask == inst).nonzero(as_tuple=True)
+        if pb.numel() < 2:
+            continue
+        nb, nh, _ = (instance_mask != inst).nonzero(as_tuple=True)
+        if nb.numel() == 0:
+            continue
+        j = min(int(float(u[k]) * nb.numel()), nb.numel() - 1)
+        k += 1
+        anchor = features[:, :, pb[0], ph[0]].reshape(1, -1)
+        positive = features[:, :, pb[1], ph[1]].reshape(1, -1)
+        negative = features[:, :, nb[j], nh[j]].reshape(1, -1)
+        d_ap = F.pairwise_distance(anchor, positive, p=2.0, eps=1e-6)
+        d_an = F.pairwise_distance(anchor, negative, p=2.0, eps=1e-6)
+        loss = loss + torch.clamp(d_ap - d_an + margin, min=0.0).mean()
+        count += 1
+    return loss / count if count > 0 else features.new_zeros(())
+
+
 # --------------------------------------------------------------------------------------
 # deterministic parameter / input recipe shared by the golden generator and the tests
 # --------------------------------------------------------------------------------------

@@ -12,7 +12,7 @@ DTYPES = [torch.float32, torch.float16]
 _G = os.path.join(os.path.dirname(__file__), "golden")
 # cases whose channel counts the stand-alone modules accept (UpSample needs multiples of 32 to concatenate)
 MODULE_CASES = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(_G, "*.npz"))
-                      if not os.path.basename(p).startswith(("unet", "up_32_16")))
+                      if not os.path.basename(p).startswith(("unet", "up_32_16", "instloss")))
 
 
 def _assert_all(results):

@@ -37,7 +37,7 @@ def _check(a, b, tol=TOL, what=""):
 
 
 MODULE_CASES = sorted(os.path.basename(p)[:-4] for p in glob.glob(
-    os.path.join(os.path.dirname(__file__), "golden", "*.npz")) if not os.path.basename(p).startswith("unet"))
+    os.path.join(os.path.dirname(__file__), "golden", "*.npz")) if not os.path.basename(p).startswith(("unet", "instloss")))
 
 
 def test_have_module_cases():
@@ -149,3 +149,18 @@ def test_unet1_train(golden_dir):
 
 def test_unet3_train(golden_dir):
     _unet_case(golden_dir, "unet3_c19_b2_train", True)
+
+
+@pytest.mark.parametrize("name", ["instloss_ade_small", "instloss_ade_sparse", "instloss_city_ignore", "instloss_none"])
+def test_oracle_instance_contrastive_loss(golden_dir, name):
+    """oracle.instance_contrastive_loss == the reference's InstanceContrastiveLoss (loss and feature gradient) on the fixtures
+    written by tests/golden/make_golden_losses.py."""
+    g = np.load(os.path.join(golden_dir, name + ".npz"))
+    feat = torch.from_numpy(g["feat"]).requires_grad_(True)
+    ign = int(g["ignore"])
+    loss = O.instance_contrastive_loss(feat, torch.from_numpy(g["mask"]), torch.from_numpy(g["u"]), 1.0, None if ign < 0 else ign)
+    if loss.requires_grad:
+        loss.backward()
+    grad = feat.grad if feat.grad is not None else torch.zeros_like(feat)
+    assert abs(float(loss) - float(g["loss"])) <= 1e-6
+    assert float((grad - torch.from_numpy(g["dfeat"])).abs().max()) <= 1e-6
