@@ -162,6 +162,16 @@ int mu_ce_bwd(const void* logits, const long* labels, const float* lse, const fl
  * logits[(r / inner) * outer_stride + c * c_stride + (r % inner) * p_stride]; counts is scratch [3*C] uint32; out[0] = mean IoU. */
 int mu_mean_iou(const void* logits, const long* labels, long M, int C, long inner, long outer_stride, long c_stride, long p_stride,
                 float smooth, unsigned int* counts, float* out, int dtype, void* stream);
+/* f1b: InstanceContrastiveLoss (ade_panoptic.py:390-418, city_instance.py:279-307) on the device, no host round trips.
+ * feat: fp32 NCHW [B,C,H,W]; mask: int64 [B,H,W] instance ids in [0, id_cap) (others ignored); ignore_label < 0: none;
+ * u[k] in [0,1): the k-th instance (ids ascending) that reaches the reference's torch.randint draw takes negative pixel
+ * floor(u[k] * n_neg); at most max_inst instances.  loss[0] = mean triplet margin loss (0 without instances).  The backward
+ * re-uses the workspace of the forward and writes d loss / d feat * grad_out[0] (dfeat is zero-filled first). */
+long mu_inst_triplet_workspace_bytes(int id_cap, int max_inst);
+int mu_inst_triplet_fwd(const float* feat, const long* mask, int B, int C, int H, int W, int ignore_label, float margin,
+                        const float* u, int id_cap, int max_inst, void* workspace, long ws_bytes, float* loss, void* stream);
+int mu_inst_triplet_bwd(const float* feat, int B, int C, int H, int W, const void* workspace, int id_cap, int max_inst,
+                        const float* grad_out, float* dfeat, void* stream);
 /* f2: optim.AdamW step (ade_semantic.py:379,401) for every parameter in one launch.  table: device array of
  * {float* p; const float* g; float* m; float* v; long n; float bc1; float bc2_sqrt;} (48 bytes; g may be NULL; bc1 = 1-beta1^t,
  * bc2_sqrt = sqrt(1-beta2^t) for that tensor's own step count t); block_tensor/block_chunk: per-block (tensor index, chunk

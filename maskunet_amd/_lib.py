@@ -56,6 +56,9 @@ SIGNATURES = {
     "mu_ce_fwd": (I, [P, P, L, I, I, L, P, P, P, P, L, I, P]),
     "mu_ce_bwd": (I, [P, P, P, P, P, F, L, I, I, L, P, I, P]),
     "mu_mean_iou": (I, [P, P, L, I, L, L, L, L, F, P, P, I, P]),
+    "mu_inst_triplet_workspace_bytes": (L, [I, I]),
+    "mu_inst_triplet_fwd": (I, [P, P, I, I, I, I, I, F, P, I, I, P, L, P, P]),
+    "mu_inst_triplet_bwd": (I, [P, I, I, I, I, P, I, I, P, P, P]),
     "mu_u8_to_nhwc": (I, [P, P, L, I, I, I, P]),
     "mu_adamw_chunk": (I, []),
     "mu_adamw_multi": (I, [P, P, P, I, F, F, F, F, F, F, P]),

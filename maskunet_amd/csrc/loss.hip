@@ -231,3 +231,192 @@ extern "C" int mu_adamw_multi(const void* table, const int* block_tensor, const 
     MU_CHECK_LAUNCH();
     return MU_OK;
 }
+
+// ------------------------------------------------------------------------------------------
+// f1 (second half): InstanceContrastiveLoss (ade_panoptic.py:390-418; city_instance.py:279-307; coco_panoptic.py:482-521) without
+// torch.unique / nonzero host round trips.  Per instance id != 0 (and != ignore) with >= 2 pixels: triplet margin loss between the
+// feature columns addressed by the first two pixels of the instance and by the floor(u[k] n_neg)-th pixel outside it; mean over the
+// instances.  "Feature column of pixel (b,h,w)" is features[:, :, b, h] ([B*C] values) -- the reference indexes dims 2,3 with the
+// batch and row index vectors of nonzero(as_tuple=True); restated as is (needs B <= H and H <= W).
+// Workspace (ints unless noted): count[id_cap] first[id_cap] second[id_cap] ids[max_inst] K neg[max_inst] | floats li[max_inst]
+// dap[max_inst] dan[max_inst].  Instance ids must lie in [0, id_cap); others are ignored (flag in ws).
+// ------------------------------------------------------------------------------------------
+struct InstWs {
+    int *count, *first, *second, *ids, *K, *neg, *flag;
+    float *li, *dap, *dan;
+};
+static inline long inst_ws_bytes(int id_cap, int max_inst) { return (3L * id_cap + 2L * max_inst + 8) * sizeof(int) + 3L * max_inst * sizeof(float); }
+__host__ __device__ static inline InstWs inst_ws(void* ws, int id_cap, int max_inst) {
+    InstWs w;
+    int* p = (int*)ws;
+    w.count = p; p += id_cap;
+    w.first = p; p += id_cap;
+    w.second = p; p += id_cap;
+    w.ids = p; p += max_inst;
+    w.neg = p; p += max_inst;
+    w.K = p; w.flag = p + 1; p += 8;
+    w.li = (float*)p; w.dap = w.li + max_inst; w.dan = w.dap + max_inst;
+    return w;
+}
+__global__ void inst_init_kernel(InstWs w, int id_cap) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < id_cap) { w.count[i] = 0; w.first[i] = 0x7fffffff; w.second[i] = 0x7fffffff; }
+    if (i == 0) { *w.K = 0; *w.flag = 0; }
+}
+template <int PASS>
+__global__ __launch_bounds__(256) void inst_scan_kernel(const long* __restrict__ mask, int npix, int id_cap, InstWs w) {
+    for (int p = blockIdx.x * 256 + threadIdx.x; p < npix; p += gridDim.x * 256) {
+        const long id = mask[p];
+        if (id < 0 || id >= id_cap) { if (PASS == 0) *w.flag = 1; continue; }
+        if (PASS == 0) {
+            atomicAdd(&w.count[id], 1);
+            atomicMin(&w.first[id], p);
+        } else if (p > w.first[id]) {
+            atomicMin(&w.second[id], p);
+        }
+    }
+}
+// sorted list of the instance ids that reach the draw (one block; ids in increasing order = torch.unique's order)
+__global__ __launch_bounds__(1024) void inst_list_kernel(InstWs w, int id_cap, int npix, int ignore, int max_inst) {
+    __shared__ int psum[1024];
+    const int per = (id_cap + 1023) / 1024, lo = threadIdx.x * per, hi = lo + per < id_cap ? lo + per : id_cap;
+    int n = 0;
+    for (int id = lo; id < hi; ++id) n += (id != 0 && id != ignore && w.count[id] >= 2 && npix - w.count[id] > 0);
+    psum[threadIdx.x] = n;
+    __syncthreads();
+    for (int o = 1; o < 1024; o <<= 1) {                         // inclusive scan
+        const int v = threadIdx.x >= o ? psum[threadIdx.x - o] : 0;
+        __syncthreads();
+        psum[threadIdx.x] += v;
+        __syncthreads();
+    }
+    int k = psum[threadIdx.x] - n;
+    for (int id = lo; id < hi; ++id)
+        if (id != 0 && id != ignore && w.count[id] >= 2 && npix - w.count[id] > 0) {
+            if (k < max_inst) w.ids[k] = id;
+            ++k;
+        }
+    if (threadIdx.x == 1023) *w.K = psum[1023] < max_inst ? psum[1023] : max_inst;
+}
+// block k: the floor(u[k] * n_neg)-th pixel (row-major) whose label differs from instance k's id
+__global__ __launch_bounds__(256) void inst_neg_kernel(const long* __restrict__ mask, int npix, const float* __restrict__ u, InstWs w) {
+    const int k = blockIdx.x;
+    if (k >= *w.K) return;
+    const long id = w.ids[k];
+    const int nneg = npix - w.count[id];
+    int r = (int)(u[k] * (float)nneg);
+    r = r < nneg - 1 ? r : nneg - 1;
+    __shared__ int wsum[4];
+    __shared__ int base_s;
+    if (threadIdx.x == 0) base_s = 0;
+    __syncthreads();
+    for (int p0 = 0; p0 < npix; p0 += 256) {
+        const int p = p0 + threadIdx.x;
+        const int isneg = (p < npix && mask[p] != id) ? 1 : 0;
+        const unsigned long long b = __ballot(isneg);
+        const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+        if (lane == 0) wsum[wv] = __popcll(b);
+        __syncthreads();
+        int before = base_s;
+        for (int i = 0; i < wv; ++i) before += wsum[i];
+        const int mine = before + __popcll(b & ((1ull << lane) - 1));
+        if (isneg && mine == r) w.neg[k] = p;
+        const int tot = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+        __syncthreads();
+        if (threadIdx.x == 0) base_s += tot;
+        __syncthreads();
+        if (base_s > r) break;
+    }
+}
+__device__ __forceinline__ long inst_col(int p, int H, int W) {       // pixel p = (b, h, w) -> offset of features[0, 0, b, h]
+    const int b = p / (H * W), h = (p / W) % H;
+    return (long)b * W + h;
+}
+// block k: d(a,p), d(a,n) over the B*C feature column entries, li = max(d_ap - d_an + margin, 0)
+__global__ __launch_bounds__(256) void inst_dist_kernel(const float* __restrict__ feat, int BC, int H, int W, float margin, InstWs w) {
+    const int k = blockIdx.x;
+    if (k >= *w.K) return;
+    const int id = w.ids[k];
+    const long ca = inst_col(w.first[id], H, W), cp = inst_col(w.second[id], H, W), cn = inst_col(w.neg[k], H, W);
+    const long hw = (long)H * W;
+    float sp = 0.f, sn = 0.f;
+    for (int e = threadIdx.x; e < BC; e += 256) {
+        const float a = feat[e * hw + ca];
+        const float dp = a - feat[e * hw + cp] + 1e-6f, dn = a - feat[e * hw + cn] + 1e-6f;
+        sp = fmaf(dp, dp, sp);
+        sn = fmaf(dn, dn, sn);
+    }
+    __shared__ float rp[256], rn[256];
+    rp[threadIdx.x] = sp; rn[threadIdx.x] = sn;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (threadIdx.x < o) { rp[threadIdx.x] += rp[threadIdx.x + o]; rn[threadIdx.x] += rn[threadIdx.x + o]; }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        const float dap = sqrtf(rp[0]), dan = sqrtf(rn[0]);
+        w.dap[k] = dap; w.dan[k] = dan;
+        w.li[k] = fmaxf(dap - dan + margin, 0.f);
+    }
+}
+__global__ void inst_final_kernel(InstWs w, float* __restrict__ loss) {
+    const int K = *w.K;
+    float s = 0.f;
+    for (int k = 0; k < K; ++k) s += w.li[k];
+    loss[0] = K > 0 ? s / (float)K : 0.f;
+}
+// one block walks the instances in order (their feature columns may coincide), threads over the B*C entries: deterministic
+__global__ __launch_bounds__(1024) void inst_bwd_kernel(const float* __restrict__ feat, int BC, int H, int W, InstWs w,
+                                                        const float* __restrict__ grad_out, float* __restrict__ dfeat) {
+    const int K = *w.K;
+    const long hw = (long)H * W;
+    const float g = K > 0 ? grad_out[0] / (float)K : 0.f;
+    for (int k = 0; k < K; ++k) {
+        if (w.li[k] > 0.f) {
+            const int id = w.ids[k];
+            const long ca = inst_col(w.first[id], H, W), cp = inst_col(w.second[id], H, W), cn = inst_col(w.neg[k], H, W);
+            const float ip = g / w.dap[k], in_ = g / w.dan[k];
+            for (int e = threadIdx.x; e < BC; e += 1024) {
+                const float a = feat[e * hw + ca];
+                const float up = (a - feat[e * hw + cp] + 1e-6f) * ip, un = (a - feat[e * hw + cn] + 1e-6f) * in_;
+                dfeat[e * hw + ca] += up - un;          // same thread, in order: columns may coincide (a == p when the first two
+                dfeat[e * hw + cp] -= up;               // pixels share an image row)
+                dfeat[e * hw + cn] += un;
+            }
+        }
+        __syncthreads();
+    }
+}
+
+extern "C" long mu_inst_triplet_workspace_bytes(int id_cap, int max_inst) { return inst_ws_bytes(id_cap, max_inst); }
+
+extern "C" int mu_inst_triplet_fwd(const float* feat, const long* mask, int B, int C, int H, int W, int ignore_label, float margin,
+                                   const float* u, int id_cap, int max_inst, void* workspace, long ws_bytes, float* loss, void* stream) {
+    if (!feat || !mask || !u || !workspace || !loss || B <= 0 || C <= 0 || H <= 0 || W <= 0 || id_cap <= 1 || max_inst <= 0) return MU_ERR_ARG;
+    if (B > H || H > W) return MU_ERR_SHAPE;             // the (batch, row) -> (h, w) indexing of the reference would run off the tensor
+    if ((long)B * H * W > 0x7fffffffL) return MU_ERR_SHAPE;
+    if (ws_bytes < inst_ws_bytes(id_cap, max_inst)) return MU_ERR_WORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    const InstWs w = inst_ws(workspace, id_cap, max_inst);
+    const int npix = B * H * W;
+    const int nb = (npix + 255) / 256 < 2048 ? (npix + 255) / 256 : 2048;
+    inst_init_kernel<<<(id_cap + 255) / 256, 256, 0, st>>>(w, id_cap);
+    inst_scan_kernel<0><<<nb, 256, 0, st>>>(mask, npix, id_cap, w);
+    inst_scan_kernel<1><<<nb, 256, 0, st>>>(mask, npix, id_cap, w);
+    inst_list_kernel<<<1, 1024, 0, st>>>(w, id_cap, npix, ignore_label, max_inst);
+    inst_neg_kernel<<<max_inst, 256, 0, st>>>(mask, npix, u, w);
+    inst_dist_kernel<<<max_inst, 256, 0, st>>>(feat, B * C, H, W, margin, w);
+    inst_final_kernel<<<1, 1, 0, st>>>(w, loss);
+    MU_CHECK_LAUNCH();
+    return MU_OK;
+}
+
+extern "C" int mu_inst_triplet_bwd(const float* feat, int B, int C, int H, int W, const void* workspace, int id_cap, int max_inst,
+                                   const float* grad_out, float* dfeat, void* stream) {
+    if (!feat || !workspace || !grad_out || !dfeat || B <= 0 || C <= 0 || H <= 0 || W <= 0) return MU_ERR_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    if (hipMemsetAsync(dfeat, 0, (size_t)B * C * H * W * sizeof(float), st) != hipSuccess) return MU_ERR_LAUNCH;
+    inst_bwd_kernel<<<1, 1024, 0, st>>>(feat, B * C, H, W, inst_ws(const_cast<void*>(workspace), id_cap, max_inst), grad_out, dfeat);
+    MU_CHECK_LAUNCH();
+    return MU_OK;
+}

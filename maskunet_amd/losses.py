@@ -69,3 +69,53 @@ def mean_iou(y_pred, y_true, num_classes, smooth=1e-6):
     call("mu_mean_iou", ptr(y_pred), ptr(labels), M, num_classes, inner, outer, cs, ps, float(smooth), ptr(counts), ptr(out),
          dt(y_pred), stream())
     return out.view(())
+
+
+class _InstanceTriplet(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, features, mask, u, margin, ignore_index, id_cap, max_inst):
+        features = features.contiguous()
+        mask = mask.contiguous()
+        if features.dtype != torch.float32 or features.dim() != 4 or not features.is_cuda:
+            raise RuntimeError("InstanceContrastiveLoss expects fp32 CUDA features [B,C,H,W] (the model's NCHW output)")
+        B, C, H, W = features.shape
+        if mask.dtype != torch.int64 or tuple(mask.shape) != (B, H, W):
+            raise RuntimeError("InstanceContrastiveLoss: instance_mask must be int64 [B,H,W]")
+        ws = torch.empty(_lib.load().mu_inst_triplet_workspace_bytes(id_cap, max_inst), dtype=torch.uint8, device=features.device)
+        loss = torch.empty(1, dtype=torch.float32, device=features.device)
+        call("mu_inst_triplet_fwd", ptr(features), ptr(mask), B, C, H, W, -1 if ignore_index is None else int(ignore_index), float(margin),
+             ptr(u), id_cap, max_inst, ptr(ws), ws.numel(), ptr(loss), stream())
+        ctx.save_for_backward(features, ws)
+        ctx.meta = (id_cap, max_inst)
+        return loss.view(())
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g):
+        features, ws = ctx.saved_tensors
+        id_cap, max_inst = ctx.meta
+        B, C, H, W = features.shape
+        g = g.contiguous().float().view(1)
+        df = torch.empty_like(features)
+        call("mu_inst_triplet_bwd", ptr(features), B, C, H, W, ptr(ws), id_cap, max_inst, ptr(g), ptr(df), stream())
+        return df, None, None, None, None, None, None
+
+
+class InstanceContrastiveLoss(torch.nn.Module):
+    """Device-side InstanceContrastiveLoss (ade_panoptic.py:390-418; `ignore_index=255`: city_instance.py:279-307): same
+    constructor and call signature as the reference class, no torch.unique / nonzero host round trips.
+
+    The negative pixel of the k-th instance is floor(u[k] * n_neg) with u ~ U[0,1) drawn on the device per call (pass `u` to fix it);
+    the reference draws torch.randint on the host.  Instance ids must lie in [0, id_cap)."""
+
+    def __init__(self, margin=1.0, ignore_index=None, id_cap=65536, max_instances=1024):
+        super().__init__()
+        self.margin, self.ignore_index, self.id_cap, self.max_instances = margin, ignore_index, id_cap, max_instances
+
+    def forward(self, features, instance_mask, u=None):
+        if u is None:
+            u = torch.rand(self.max_instances, dtype=torch.float32, device=features.device)
+        elif u.numel() < self.max_instances:
+            u = torch.cat([u.float().to(features.device), torch.zeros(self.max_instances - u.numel(), device=features.device)])
+        return _InstanceTriplet.apply(features, instance_mask, u.contiguous(), self.margin, self.ignore_index, self.id_cap,
+                                      self.max_instances)

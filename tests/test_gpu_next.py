@@ -126,3 +126,47 @@ def test_u8_input_pipeline_matches_totensor():
     a = m.forward_u8(img)
     b = m(ref.permute(0, 3, 1, 2).contiguous())
     assert torch.allclose(a, b, atol=1e-5)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["instloss_ade_small", "instloss_ade_sparse", "instloss_city_ignore", "instloss_none"])
+def test_instance_contrastive_loss_matches_reference_goldens(name):
+    """Device InstanceContrastiveLoss vs the fixtures generated from the reference class (tests/golden/make_golden_losses.py)."""
+    import os
+    import numpy as np
+    import maskunet_amd
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", name + ".npz"))
+    ign = int(g["ignore"])
+    feat = torch.from_numpy(g["feat"]).cuda().requires_grad_(True)
+    crit = maskunet_amd.InstanceContrastiveLoss(margin=1.0, ignore_index=None if ign < 0 else ign, id_cap=32768, max_instances=64)
+    loss = crit(feat, torch.from_numpy(g["mask"]).cuda(), torch.from_numpy(g["u"]).cuda())
+    (loss * 3.0).backward()
+    assert abs(float(loss) - float(g["loss"])) <= 1e-5
+    assert float((feat.grad.cpu() / 3.0 - torch.from_numpy(g["dfeat"])).abs().max()) <= 1e-5
+
+
+@pytest.mark.gpu
+def test_instance_contrastive_loss_matches_oracle_at_model_shape():
+    """B=4, 19 classes, 128x128, Cityscapes-style ids with an ignore label: device loss/gradient vs the oracle restatement."""
+    import numpy as np
+    import maskunet_amd
+    from oracle import maskunet_oracle as O
+    rng = np.random.default_rng(77)
+    B, C, H, W = 4, 19, 128, 128
+    feat = torch.from_numpy(rng.standard_normal((B, C, H, W)).astype(np.float32))
+    mask = torch.zeros((B, H, W), dtype=torch.int64)
+    ids = [24000, 24001, 26000, 26001, 26002, 33000]
+    for i, v in enumerate(ids):                              # rectangles of instance ids, some overlapping, plus an ignore band
+        b = i % B
+        mask[b, 10 * i:10 * i + 30, 5 * i:5 * i + 40] = v
+    mask[:, 120:, :] = 255
+    mask[1, 3, 3] = 31000                                    # a one-pixel instance is skipped
+    u = torch.from_numpy(rng.random(64).astype(np.float32))
+    fr = feat.clone().requires_grad_(True)
+    lr = O.instance_contrastive_loss(fr, mask, u, 0.5, 255)
+    lr.backward()
+    fd = feat.cuda().requires_grad_(True)
+    ld = maskunet_amd.InstanceContrastiveLoss(margin=0.5, ignore_index=255, max_instances=64)(fd, mask.cuda(), u.cuda())
+    ld.backward()
+    assert abs(float(ld) - float(lr)) <= 1e-5 * max(1.0, abs(float(lr)))
+    assert float((fd.grad.cpu() - fr.grad).abs().max()) <= 1e-5
