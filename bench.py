@@ -119,6 +119,12 @@ def main():
     net = maskunet_amd.DataParallel(model) if world > 1 else model
     scale = args.loss_scale if dtype == torch.float16 else 1.0
 
+    inst_loss = inst_labels = None
+    if args.three_head:              # synthetic instance ids: 16x16 blocks of ids 0..20 (0 = background), device-side loss (row f1b)
+        g = torch.Generator().manual_seed(7 + rank)
+        blocks = torch.randint(0, 21, (args.batch, args.hw // 16, args.hw // 16), generator=g)
+        inst_labels = blocks.repeat_interleave(16, 1).repeat_interleave(16, 2).to(dev)
+        inst_loss = maskunet_amd.InstanceContrastiveLoss(margin=1.0, ignore_index=255)
     opt = maskunet_amd.FusedAdamW(model.parameters(), lr=5e-5, weight_decay=1e-1) if args.optimizer else None
 
     def step():
@@ -131,8 +137,8 @@ def main():
             out = net(x)
             sem = out[0] if args.three_head else out
             loss = F.cross_entropy(sem, labels)
-            if args.three_head:
-                loss = loss + 0.5 * out[2].square().mean()
+            if args.three_head:          # city_instance.py:372-377: seg_loss + LAMBDA_IE * InstanceContrastiveLoss(embeddings, inst_labels)
+                loss = loss + 0.1 * inst_loss(out[2], inst_labels)
             (loss * scale).backward()
         if world > 1:
             net.finish_gradient_sync()
