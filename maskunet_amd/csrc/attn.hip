@@ -43,6 +43,17 @@
 #ifndef MU_DKV_OCC128
 #define MU_DKV_OCC128 2
 #endif
+// C = 256 (N = 1024): the forward gains from the 2-waves/SIMD bound even with 26 spilled registers (0.134 -> 0.102 ms), dQ loses
+// (115 spills: 0.092 -> 0.197 ms), dK/dV does not fit at all
+#ifndef MU_FWD_OCC256
+#define MU_FWD_OCC256 2
+#endif
+#ifndef MU_DQ_OCC256
+#define MU_DQ_OCC256 1
+#endif
+#ifndef MU_DKV_OCC256
+#define MU_DKV_OCC256 1
+#endif
 #ifndef MU_FWD_KT128
 #define MU_FWD_KT128 32
 #endif
@@ -291,7 +302,7 @@ template <int D> struct AccLd<float, D> {
 };
 
 template <typename T, int D, int KT, int NW, int OCC = 0, int NQ = 2>
-__global__ __launch_bounds__(NW * 64, OCC ? OCC : ((NW == 4 && D <= 64 && sizeof(T) == 2) ? MU_FWD_OCC : ((NW == 4 && D == 128 && sizeof(T) == 2) ? MU_FWD_OCC128 : 1))) void attn_fwd2_kernel(const T* __restrict__ qkv, const T* __restrict__ x, const int* __restrict__ kidx,
+__global__ __launch_bounds__(NW * 64, OCC ? OCC : ((NW == 4 && D <= 64 && sizeof(T) == 2) ? MU_FWD_OCC : ((NW == 4 && D == 128 && sizeof(T) == 2) ? MU_FWD_OCC128 : ((NW == 4 && D == 256 && sizeof(T) == 2) ? MU_FWD_OCC256 : 1)))) void attn_fwd2_kernel(const T* __restrict__ qkv, const T* __restrict__ x, const int* __restrict__ kidx,
                                                         const int* __restrict__ kcnt, const float* __restrict__ gamma,
                                                         const float* __restrict__ beta, T* __restrict__ out, T* __restrict__ oattn,
                                                         float* __restrict__ lse2, float* __restrict__ ln_mean, float* __restrict__ ln_rstd,
@@ -575,7 +586,7 @@ __global__ void attn_ln_bwd_final_kernel(const double* __restrict__ part, int nb
 // backward v2 kernels: LDS-DMA double-buffered tiles, swizzled images (see attn_fwd2_kernel)
 // ------------------------------------------------------------------------------------------
 template <typename T, int D, int KT, int NW>
-__global__ __launch_bounds__(NW * 64, (NW == 4 && D <= 64 && sizeof(T) == 2) ? MU_DQ_OCC : ((NW == 4 && D == 128 && sizeof(T) == 2) ? MU_DQ_OCC128 : 1)) void attn_bwd_dq2_kernel(const T* __restrict__ qkv, const T* __restrict__ dY, const int* __restrict__ kidx,
+__global__ __launch_bounds__(NW * 64, (NW == 4 && D <= 64 && sizeof(T) == 2) ? MU_DQ_OCC : ((NW == 4 && D == 128 && sizeof(T) == 2) ? MU_DQ_OCC128 : ((NW == 4 && D == 256 && sizeof(T) == 2) ? MU_DQ_OCC256 : 1))) void attn_bwd_dq2_kernel(const T* __restrict__ qkv, const T* __restrict__ dY, const int* __restrict__ kidx,
                                                            const int* __restrict__ kcnt, const float* __restrict__ lse2,
                                                            const float* __restrict__ delta, T* __restrict__ dqkv, int N, int nkmax,
                                                            float scale, float scale_log2) {
@@ -709,7 +720,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 && D <= 64 && sizeof(T) == 2) ? M
 // ring), so the counted waits are exact: each wave issues exactly 3 DMA instructions per tile.
 // ------------------------------------------------------------------------------------------
 template <typename T, int D, int NKT>
-__global__ __launch_bounds__(256, (D <= 64 && sizeof(T) == 2 && NKT <= 2) ? MU_DKV_OCC : ((D == 128 && sizeof(T) == 2 && NKT <= 2) ? MU_DKV_OCC128 : 1)) void attn_bwd_dkv3_kernel(
+__global__ __launch_bounds__(256, (D <= 64 && sizeof(T) == 2 && NKT <= 2) ? MU_DKV_OCC : ((D == 128 && sizeof(T) == 2 && NKT <= 2) ? MU_DKV_OCC128 : ((D == 256 && sizeof(T) == 2 && NKT == 1) ? MU_DKV_OCC256 : 1))) void attn_bwd_dkv3_kernel(
     const T* __restrict__ qkv, const T* __restrict__ dY, const int* __restrict__ kidx, const int* __restrict__ kcnt,
     const float* __restrict__ rowc, T* __restrict__ dqkv, int N, int nkmax, float scale, float scale_log2) {
     using A = AT<T>;
