@@ -45,6 +45,13 @@ def main():
             return lambda: lib.mu_attn_bwd_phases(qkv.data_ptr(), x.data_ptr(), oattn.data_ptr(), gout.data_ptr(), kidx.data_ptr(), kcnt.data_ptr(), lse.data_ptr(), mean.data_ptr(), rstd.data_ptr(), g.data_ptr(), dY.data_ptr(), delta.data_ptr(), dqkv.data_ptr(), dg.data_ptr(), db.data_ptr(), B, N, C, N, ws.data_ptr(), ws.numel(), 1, phase, st)
         cases = [("fwd", 0), ("dq", 2), ("dkv", 4)]
         first = libs[names[0]]; mk(first, 0)(); mk(first, 1)()
+    elif what == "conv1":
+        shapes = [(64, 128, 64, 192), (64, 64, 128, 384), (64, 128, 192, 64), (64, 128, 64, 160), (64, 32, 256, 768)]
+        bufs = [(torch.randn(B, H, H, Cin, device=dev, dtype=dt), (torch.randn(1, Cout, Cin, device=dev) * 0.05).to(dt), torch.empty(B, H, H, Cout, device=dev, dtype=dt)) for (B, H, Cin, Cout) in shapes]
+        def mk(lib, phase):
+            (B, H, Cin, Cout), (x, w, y) = shapes[phase], bufs[phase]
+            return lambda: lib.mu_conv_fwd(x.data_ptr(), w.data_ptr(), None, y.data_ptr(), B, H, H, Cin, Cout, 1, Cin, Cout, 1, st)
+        cases = [(f"1x1 {shapes[p]} {2e-6 * shapes[p][0] * shapes[p][1] ** 2 * (shapes[p][2] + shapes[p][3]):.0f} MB", p) for p in range(len(shapes))]
     elif what == "bn":
         M, C = (int(v) for v in os.environ.get("MU_BN_SHAPE", "1048576,128").split(","))
         x = torch.randn(M, C, device=dev, dtype=dt); y = torch.empty_like(x); gy = torch.randn_like(x); dx = torch.empty_like(x)
