@@ -93,3 +93,33 @@ def test_unet_other_resolution_vs_oracle():
         g = v.grad.float().cpu()
         worst = max(worst, 1.0 - float((g.double() * r.double()).sum() / (g.double().norm() * r.double().norm())))
     assert worst <= 1e-3, worst      # 8x8 bottleneck with B=2: 128 samples per BN channel amplify fp32 reassociation noise
+
+
+def test_training_step_is_bitwise_reproducible():
+    """No float atomics, fixed reduction orders, and -- for the LDS-DMA ring kernels whose ordering is hand-counted -- no
+    races: three fp16 training steps of the full-resolution model from identical state give bit-identical gradients."""
+    import torch.nn.functional as F
+    import maskunet_amd
+    import bench
+    torch.manual_seed(3)
+    B = 12
+    model = maskunet_amd.UNet(3, 150).cuda()
+    model.set_compute_dtype(torch.float16).train()
+    x, labels, keeps = bench.synth(B, 150, 128, 9, torch.device("cuda"))
+    model.set_keep_masks(keeps)
+    g = torch.Generator().manual_seed(5)
+    model.dropout_masks = [torch.randint(0, 2, (B, 32, 32, 128), generator=g, dtype=torch.uint8).cuda(),      # NHWC keep-masks of the
+                           torch.randint(0, 2, (B, 64, 64, 64), generator=g, dtype=torch.uint8).cuda()]       # two dropout sites
+    state = {k: v.clone() for k, v in model.state_dict().items()}
+    runs = []
+    for _ in range(3):
+        model.load_state_dict(state)
+        model.zero_grad(set_to_none=True)
+        out = model(x)
+        loss = F.cross_entropy(out, labels)          # (torch's own loss reduction uses atomics: its VALUE is not compared)
+        (loss * 1024.0).backward()
+        runs.append((out.detach().clone(), {n: p.grad.detach().clone() for n, p in model.named_parameters() if p.grad is not None}))
+    for out, grads in runs[1:]:
+        assert torch.equal(out, runs[0][0]), "forward output differs between identical runs"
+        for n, gref in runs[0][1].items():
+            assert torch.equal(grads[n], gref), f"gradient of {n} differs between identical runs"
