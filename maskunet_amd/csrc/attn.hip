@@ -91,6 +91,22 @@ __device__ __forceinline__ void glds16s(const void* sbase, uint32_t voff, void* 
 
 #define LDS_TR16(ptr) __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) fp16x4v*)(ptr))
 
+// Block -> (image, tile) through the XCD-aware remap: the tiles of one image run on ONE XCD, so the K/V (forward, dQ) or Q/dO (dK/dV)
+// rows that every block of the image streams are fetched into that XCD's L2 once instead of once per XCD.
+#ifndef MU_ATTN_XCD
+#define MU_ATTN_XCD 1
+#endif
+__device__ __forceinline__ void attn_block(int& bx, int& b) {
+    if (MU_ATTN_XCD) {
+        const int L = xcd_remap(blockIdx.y * gridDim.x + blockIdx.x, gridDim.x * gridDim.y);
+        b = L / gridDim.x;
+        bx = L - b * gridDim.x;
+    } else {
+        b = blockIdx.y;
+        bx = blockIdx.x;
+    }
+}
+
 template <typename T> struct AT;
 template <> struct AT<h16> {
     static constexpr int VN = 8, KR = 32;
@@ -313,9 +329,11 @@ __global__ __launch_bounds__(NW * 64, OCC ? OCC : ((NW == 4 && D <= 64 && sizeof
     constexpr int VN = A::VN, KR = A::KR, NKS = D / KR, NDT = D / 16, NKT = KT / 16, NH = KT / 32;
     __shared__ __attribute__((aligned(16))) T lds[2 * 2 * KT * D];      // [buf][K|V][KT][D]
 
-    const int b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    int bx_, b;
+    attn_block(bx_, b);
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r16 = lane & 15, g = lane >> 4;
-    const int q0 = blockIdx.x * (NW * NQ * 16) + wave * (NQ * 16);     // NQ 16-query tiles per wave
+    const int q0 = bx_ * (NW * NQ * 16) + wave * (NQ * 16);     // NQ 16-query tiles per wave
     const T* qkv_b = qkv + (long)b * N * 3 * D;
     const int Nk = kcnt[b];
     const int* kidx_b = kidx + (long)b * nkmax;
@@ -596,9 +614,11 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 && D <= 64 && sizeof(T) == 2) ? M
     constexpr int VN = A::VN, KR = A::KR, NKS = D / KR, NDT = D / 16, NKT = KT / 16, NH = KT / 32;
     __shared__ __attribute__((aligned(16))) T lds[2 * 2 * KT * D];
 
-    const int b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    int bx_, b;
+    attn_block(bx_, b);
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r16 = lane & 15, g = lane >> 4;
-    const int q0 = blockIdx.x * (NW * 32) + wave * 32;
+    const int q0 = bx_ * (NW * 32) + wave * 32;
     const T* qkv_b = qkv + (long)b * N * 3 * D;
     const int Nk = kcnt[b];
     const int* kidx_b = kidx + (long)b * nkmax;
@@ -735,10 +755,12 @@ __global__ __launch_bounds__(256, (D <= 64 && sizeof(T) == 2 && NKT <= 2) ? MU_D
     __shared__ __attribute__((aligned(16))) T lds[DKV_RING * STG];
     __shared__ __attribute__((aligned(16))) float rcs[DKV_RING * 256 + 256];   // 1 KB per slot: [{-lse2},{-delta*scale}][32] in its first 256 B; + 1 KB dump
 
-    const int b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    int bx_, b;
+    attn_block(bx_, b);
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r16 = lane & 15, g = lane >> 4;
     const int Nk = kcnt[b];
-    const int kb0 = blockIdx.x * (4 * NKT * 16);
+    const int kb0 = bx_ * (4 * NKT * 16);
     if (kb0 >= Nk) return;
     const int* kidx_b = kidx + (long)b * nkmax;
     const T* qkv_b = qkv + (long)b * N * 3 * D;

@@ -35,12 +35,6 @@ template <> struct Mma<float> {
 // conflict-free within each of the instruction's four 16-lane service groups.
 __device__ __forceinline__ int swz64(int row, int chunk) { return chunk ^ ((0x78 >> (2 * ((row >> 2) & 3))) & 3); }
 
-// XCD-aware block id: blocks b and b+8 share an XCD (private L2); hand each XCD a contiguous
-// range of logical tiles so that tiles sharing an activation panel hit the same L2.
-__device__ __forceinline__ int xcd_remap(int bid, int nblk) {
-    const int q = nblk >> 3, r = nblk & 7, x = bid & 7;
-    return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (bid >> 3);
-}
 
 // ------------------------------------------------------------------------------------------
 // y[p][co] = bias[co] + sum_{tap,ci} x[p + shift(tap)][ci] * w[tap][co][ci]
