@@ -1712,6 +1712,16 @@ static inline void wgrad_tile(int Cin, int Cout, int* bco, int* bci) {
 #ifndef MU_WG_MIXED
 #define MU_WG_MIXED 0
 #endif
+// Blocks per launch = exactly what is resident at once (8-wave tiles: one per CU; 4-wave tiles: two per CU): every block does the
+// same work, so one whole round has no tail, and the fp32 slab traffic (write + reduce: 2.4 GB/step at 512 / 1536 blocks, the reduce
+// kernel at HBM rate) shrinks with the split count.  In-process A/B: 128->128 @128^2 341 -> 324 us, 512->512 @16^2 123 -> 105 us,
+// 64->64 @128^2 147 -> 125 us; 768 blocks (1.5 rounds) for the 4-wave tiles is 10 % WORSE than 512.
+#ifndef MU_WG_BLOCKS128
+#define MU_WG_BLOCKS128 256
+#endif
+#ifndef MU_WG_BLOCKS64
+#define MU_WG_BLOCKS64 512
+#endif
 static inline bool wgrad3_choose(int H, int W, int Cin, int Cout, int taps, int dtype, int* tco, int* tci) {
     if (dtype != MU_F16 || taps != 9 || !(W % 32 == 0 || (W == 16 && H % 2 == 0))) return false;
     const int a = Cout % 128 == 0 ? 128 : (Cout % 64 == 0 ? 64 : 0), b = Cin % 128 == 0 ? 128 : (Cin % 64 == 0 ? 64 : 0);
@@ -1722,9 +1732,7 @@ static inline bool wgrad3_choose(int H, int W, int Cin, int Cout, int taps, int 
 }
 static inline void wgrad3_plan(long M, int Cin, int Cout, int tco, int tci, int* nsplit, long* pps) {
     long tiles = 3L * (Cout / tco) * (Cin / tci);
-    // 128x128 tiles: one block per CU (192 accumulator registers) -> ~2 rounds of blocks; fewer, longer splits also halve
-    // the fp32 slab traffic of the reduce.  The 4-wave tiles run two blocks per CU and want more blocks in flight.
-    long want = ((tco == 128 && tci == 128) ? 512 : 1536) / tiles;
+    long want = ((tco == 128 && tci == 128) ? MU_WG_BLOCKS128 : MU_WG_BLOCKS64) / tiles;
     if (want < 1) want = 1;
     long max_split = (M + 511) / 512;
     if (want > max_split) want = max_split;
