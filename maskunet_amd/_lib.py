@@ -118,9 +118,10 @@ def call(name: str, *args):
     probe = PROBE
     if probe is not None and probe["pred"](name, args):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
+        st = torch.cuda.ExternalStream(args[-1]) if isinstance(args[-1], int) and args[-1] else torch.cuda.current_stream()
+        e0.record(st)                # on the stream the kernel is launched on (the last argument of every entry point)
         rc = getattr(load(), name)(*args)
-        e1.record()
+        e1.record(st)
         probe["events"].append((name, e0, e1))
     else:
         rc = getattr(load(), name)(*args)
