@@ -8,6 +8,9 @@
 #include "../../include/maskunet_hip.h"
 
 #define MU_STAT_MAXBLK 1024
+#ifndef MU_BN_BLK1
+#define MU_BN_BLK1 768
+#endif
 #ifndef MU_BN_U1
 #define MU_BN_U1 2
 #endif
@@ -409,7 +412,10 @@ static int bn_act_bwd_t(const T* x, const T* res, const T* g, T* dx, T* dres, lo
     int cv = C / N;
     if (cv > 256) return MU_ERR_SHAPE;
     int rpi = 256 / cv;
+    // the backward statistics kernel holds 3 blocks per CU (136 VGPRs): 768 resident blocks = one whole round (1024 would leave a
+    // second round one third full)
     int nblk = stat_blocks(M);
+    if (nblk > MU_BN_BLK1) nblk = MU_BN_BLK1;
     size_t lds = (size_t)rpi * C * 2 * sizeof(double);
     double* part = (double*)ws;
     float* s1 = (float*)((char*)ws + (size_t)MU_STAT_MAXBLK * C * 2 * sizeof(double));
