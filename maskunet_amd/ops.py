@@ -237,11 +237,14 @@ class _Conv(torch.autograd.Function):
         if part is None:
             part = torch.empty(0, dtype=torch.float32, device=x.device)
         ctx.mark_non_differentiable(part)
+        ctx.set_materialize_grads(False)         # no zero-filled "gradient" of the statistics rows in the backward
         return y, part
 
     @staticmethod
     @once_differentiable
     def backward(ctx, gy, gpart=None):
+        if gy is None:
+            return None, None, None, None
         x, weight = ctx.saved_tensors
         gy = gy.contiguous()
         O, I = weight.shape[0], weight.shape[1]
