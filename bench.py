@@ -88,6 +88,7 @@ def main():
     ap.add_argument("--three-head", action="store_true")
     ap.add_argument("--fused-loss", action="store_true",
                     help="SURVEY 8-f1 path: fused NHWC cross-entropy on the internal logits instead of module output + torch CE")
+    ap.add_argument("--torch-loss", action="store_true", help="torch's F.cross_entropy on the module output instead of maskunet_amd.CrossEntropyLoss")
     ap.add_argument("--optimizer", action="store_true", help="also run the fused AdamW step (8-f2) inside the timed step")
     args = ap.parse_args()
 
@@ -125,6 +126,7 @@ def main():
         blocks = torch.randint(0, 21, (args.batch, args.hw // 16, args.hw // 16), generator=g)
         inst_labels = blocks.repeat_interleave(16, 1).repeat_interleave(16, 2).to(dev)
         inst_loss = maskunet_amd.InstanceContrastiveLoss(margin=1.0, ignore_index=255)
+    criterion = maskunet_amd.CrossEntropyLoss()      # the reference's nn.CrossEntropyLoss() on the module output (ade_semantic.py:377,399)
     opt = maskunet_amd.FusedAdamW(model.parameters(), lr=5e-5, weight_decay=1e-1) if args.optimizer else None
 
     def step():
@@ -136,7 +138,7 @@ def main():
         else:
             out = net(x)
             sem = out[0] if args.three_head else out
-            loss = F.cross_entropy(sem, labels)
+            loss = F.cross_entropy(sem, labels) if args.torch_loss else criterion(sem, labels)
             if args.three_head:          # city_instance.py:372-377: seg_loss + LAMBDA_IE * InstanceContrastiveLoss(embeddings, inst_labels)
                 loss = loss + 0.1 * inst_loss(out[2], inst_labels)
             (loss * scale).backward()
@@ -196,7 +198,8 @@ def main():
             "config": {"workload": f"ADE20K-semantic shape {args.hw}x{args.hw}, c_out={args.c_out}, batch={args.batch}/GPU, "
                                    f"{'3-head' if args.three_head else '1-head'} MaskAttn-UNet fwd+bwd, train mode",
                        "global_batch": args.batch * world, "parallelism": f"dp{world}", "loss_scale": scale,
-                       "loss": "fused NHWC CE kernel" if args.fused_loss else "torch CE on module output", "optimizer_in_step": bool(opt)},
+                       "loss": "fused NHWC CE kernel" if args.fused_loss else ("torch CE on module output" if args.torch_loss else
+                                                                                "maskunet_amd.CrossEntropyLoss on module output"), "optimizer_in_step": bool(opt)},
             "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
                          "frac": round(achieved / peak, 4), "traffic": traffic,
                          "kernel": f"attn_bwd_dkv3_kernel (self_attention6 dK/dV sweep, N={N6}, C=64)",

@@ -158,6 +158,12 @@ int mu_ce_fwd(const void* logits, const long* labels, long M, int Cp, int C, lon
 /* dlogits = (softmax - onehot) * grad_out[0] * grad_scale / count[0]; zeros for ignored pixels and padded channels */
 int mu_ce_bwd(const void* logits, const long* labels, const float* lse, const float* count, const float* grad_out, float grad_scale,
               long M, int Cp, int C, long ignore_index, void* dlogits, int dtype, void* stream);
+/* f1 on the module's own output: the same loss on NCHW logits [B, C, HW] (fp32 or fp16) exactly as the reference calls it,
+ * criterion(outputs, labels) (ade_semantic.py:399; city_semantic.py:341,362); labels [B, HW]; lse [B*HW]; workspace as mu_ce_fwd */
+int mu_ce_nchw_fwd(const void* logits, const long* labels, int B, int C, long HW, long ignore_index, float* lse, float* loss,
+                   float* count, void* workspace, long ws_bytes, int dtype, void* stream);
+int mu_ce_nchw_bwd(const void* logits, const long* labels, const float* lse, const float* count, const float* grad_out,
+                   float grad_scale, int B, int C, long HW, long ignore_index, void* dlogits, int dtype, void* stream);
 /* f3: mean_iou (ade_semantic.py:128-146) without host syncs.  Element (pixel r, class c) is read at
  * logits[(r / inner) * outer_stride + c * c_stride + (r % inner) * p_stride]; counts is scratch [3*C] uint32; out[0] = mean IoU. */
 int mu_mean_iou(const void* logits, const long* labels, long M, int C, long inner, long outer_stride, long c_stride, long p_stride,

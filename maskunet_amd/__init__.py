@@ -7,10 +7,10 @@ hand-written HIP kernels through the C ABI in include/maskunet_hip.h.
 from .modules import (ConvBlock, DoubleConv, Down, DownSample, InstanceUNet, Mask2FormerAttention, MaskAttention, OutConv,
                       UNet, Up, UpSample, set_default_compute_dtype)
 from .dp import DataParallel, shard_batch
-from .losses import InstanceContrastiveLoss, mean_iou, pixel_cross_entropy_nhwc
+from .losses import CrossEntropyLoss, InstanceContrastiveLoss, cross_entropy, mean_iou, pixel_cross_entropy_nhwc
 from .optim import FusedAdamW
 
 __all__ = ["ConvBlock", "DownSample", "UpSample", "Mask2FormerAttention", "UNet", "InstanceUNet", "DoubleConv", "Down", "Up",
            "MaskAttention", "OutConv", "set_default_compute_dtype", "DataParallel", "shard_batch", "pixel_cross_entropy_nhwc",
-           "mean_iou", "InstanceContrastiveLoss", "FusedAdamW"]
+           "mean_iou", "InstanceContrastiveLoss", "FusedAdamW", "CrossEntropyLoss", "cross_entropy"]
 __version__ = "0.1.0"

@@ -55,6 +55,8 @@ SIGNATURES = {
     "mu_ce_workspace_bytes": (L, []),
     "mu_ce_fwd": (I, [P, P, L, I, I, L, P, P, P, P, L, I, P]),
     "mu_ce_bwd": (I, [P, P, P, P, P, F, L, I, I, L, P, I, P]),
+    "mu_ce_nchw_fwd": (I, [P, P, I, I, L, L, P, P, P, P, L, I, P]),
+    "mu_ce_nchw_bwd": (I, [P, P, P, P, P, F, I, I, L, L, P, I, P]),
     "mu_mean_iou": (I, [P, P, L, I, L, L, L, L, F, P, P, I, P]),
     "mu_inst_triplet_workspace_bytes": (L, [I, I]),
     "mu_inst_triplet_fwd": (I, [P, P, I, I, I, I, I, F, P, I, I, P, L, P, P]),

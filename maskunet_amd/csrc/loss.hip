@@ -133,6 +133,184 @@ extern "C" int mu_ce_bwd(const void* logits, const long* labels, const float* ls
 }
 
 // ------------------------------------------------------------------------------------------
+// cross-entropy on the module's own output layout: NCHW logits [B, C, HW] (fp32 or fp16), labels [B, HW].
+// One lane owns VEC consecutive pixels and walks the channel planes (each wave reads whole 128-byte rows of a plane);
+// single pass with an online max / rescaled sum, eight planes in flight.  Same reductions and outputs as the NHWC kernels.
+// ------------------------------------------------------------------------------------------
+template <typename T, int VEC> struct PixVec;
+template <> struct PixVec<float, 4> {
+    static __device__ inline void load(const float* p, float* o) { const float4 v = *(const float4*)p; o[0] = v.x; o[1] = v.y; o[2] = v.z; o[3] = v.w; }
+    static __device__ inline void store(float* p, const float* o) { *(float4*)p = make_float4(o[0], o[1], o[2], o[3]); }
+};
+template <> struct PixVec<float, 1> {
+    static __device__ inline void load(const float* p, float* o) { o[0] = p[0]; }
+    static __device__ inline void store(float* p, const float* o) { p[0] = o[0]; }
+};
+template <> struct PixVec<h16, 4> {
+    static __device__ inline void load(const h16* p, float* o) {
+        const uint2 v = *(const uint2*)p;
+        const h16* h = (const h16*)&v;
+        for (int i = 0; i < 4; ++i) o[i] = (float)h[i];
+    }
+    static __device__ inline void store(h16* p, const float* o) {
+        uint2 v;
+        h16* h = (h16*)&v;
+        for (int i = 0; i < 4; ++i) h[i] = (h16)o[i];
+        *(uint2*)p = v;
+    }
+};
+template <> struct PixVec<h16, 1> {
+    static __device__ inline void load(const h16* p, float* o) { o[0] = (float)p[0]; }
+    static __device__ inline void store(h16* p, const float* o) { p[0] = (h16)o[0]; }
+};
+
+template <typename T, int VEC>
+__global__ __launch_bounds__(256) void ce_nchw_fwd_kernel(const T* __restrict__ logits, const long* __restrict__ labels, int B, int C, long HW,
+                                                          long ignore_index, float* __restrict__ lse_out, double* __restrict__ part) {
+    constexpr int U = 8;
+    const int tid = threadIdx.x;
+    const long groups = HW / VEC, total = (long)B * groups;
+    double loss = 0.0, cnt = 0.0;
+    for (long g = (long)blockIdx.x * 256 + tid; g < total; g += (long)gridDim.x * 256) {
+        const long b = g / groups, p0 = (g - b * groups) * VEC;
+        const T* base = logits + (b * C) * HW + p0;
+        long lab[VEC];
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) lab[i] = labels[b * HW + p0 + i];
+        float mx[VEC], se[VEC], tgt[VEC];
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) { mx[i] = -INFINITY; se[i] = 0.f; tgt[i] = 0.f; }
+        for (int c0 = 0; c0 < C; c0 += U) {
+            float v[U][VEC];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int c = c0 + u < C ? c0 + u : C - 1;
+                PixVec<T, VEC>::load(base + (long)c * HW, v[u]);
+            }
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) {
+                float m = mx[i];
+#pragma unroll
+                for (int u = 0; u < U; ++u) if (c0 + u < C) m = fmaxf(m, v[u][i]);
+                const float mm = m == -INFINITY ? 0.f : m;      // a chunk of -inf logits contributes exp(-inf) = 0, not NaN
+                float s = se[i] * __expf(mx[i] - mm);            // exp(-inf - mm) = 0 on the first chunk (se = 0 there)
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    if (c0 + u < C) {
+                        s += __expf(v[u][i] - mm);
+                        if ((long)(c0 + u) == lab[i]) tgt[i] = v[u][i];
+                    }
+                }
+                mx[i] = m;
+                se[i] = s;
+            }
+        }
+        float l[VEC];
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) {
+            l[i] = mx[i] + __logf(se[i]);
+            if (lab[i] != ignore_index) { loss += (double)(l[i] - tgt[i]); cnt += 1.0; }
+        }
+        PixVec<float, VEC>::store(lse_out + b * HW + p0, l);
+    }
+    __shared__ double sh[8];
+    loss = wave_sum_d(loss);
+    cnt = wave_sum_d(cnt);
+    if ((tid & 63) == 0) { sh[(tid >> 6) * 2] = loss; sh[(tid >> 6) * 2 + 1] = cnt; }
+    __syncthreads();
+    if (tid == 0) {
+        part[blockIdx.x * 2] = sh[0] + sh[2] + sh[4] + sh[6];
+        part[blockIdx.x * 2 + 1] = sh[1] + sh[3] + sh[5] + sh[7];
+    }
+}
+
+template <typename T, int VEC>
+__global__ __launch_bounds__(256) void ce_nchw_bwd_kernel(const T* __restrict__ logits, const long* __restrict__ labels, const float* __restrict__ lse,
+                                                          const float* __restrict__ count, const float* __restrict__ gout, float gscale,
+                                                          int B, int C, long HW, long ignore_index, T* __restrict__ dlogits) {
+    constexpr int U = 8;
+    const long groups = HW / VEC, total = (long)B * groups;
+    const float k = gout[0] * gscale / count[0];
+    for (long g = (long)blockIdx.x * 256 + threadIdx.x; g < total; g += (long)gridDim.x * 256) {
+        const long b = g / groups, p0 = (g - b * groups) * VEC;
+        const long off = (b * C) * HW + p0;
+        long lab[VEC];
+        float l[VEC];
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) lab[i] = labels[b * HW + p0 + i];
+        PixVec<float, VEC>::load(lse + b * HW + p0, l);
+        for (int c0 = 0; c0 < C; c0 += U) {
+            float v[U][VEC];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int c = c0 + u < C ? c0 + u : C - 1;
+                PixVec<T, VEC>::load(logits + off + (long)c * HW, v[u]);
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                if (c0 + u < C) {
+                    float o[VEC];
+#pragma unroll
+                    for (int i = 0; i < VEC; ++i)
+                        o[i] = lab[i] != ignore_index ? (__expf(v[u][i] - l[i]) - ((long)(c0 + u) == lab[i] ? 1.f : 0.f)) * k : 0.f;
+                    PixVec<T, VEC>::store(dlogits + off + (long)(c0 + u) * HW, o);
+                }
+            }
+        }
+    }
+}
+
+template <typename T, int VEC>
+static void ce_nchw_fwd_t(const void* logits, const long* labels, int B, int C, long HW, long ignore_index, float* lse, double* part, int nblk,
+                          hipStream_t st) {
+    ce_nchw_fwd_kernel<T, VEC><<<nblk, 256, 0, st>>>((const T*)logits, labels, B, C, HW, ignore_index, lse, part);
+}
+
+extern "C" int mu_ce_nchw_fwd(const void* logits, const long* labels, int B, int C, long HW, long ignore_index, float* lse, float* loss,
+                              float* count, void* workspace, long ws_bytes, int dtype, void* stream) {
+    if (!logits || !labels || !lse || !loss || !count || !workspace || B <= 0 || C <= 0 || HW <= 0) return MU_ERR_ARG;
+    if (ws_bytes < mu_ce_workspace_bytes()) return MU_ERR_WORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    const bool v4 = HW % 4 == 0;
+    const long groups = (long)B * (v4 ? HW / 4 : HW);
+    const int nblk = (int)((groups + 255) / 256 < CE_MAXBLK ? (groups + 255) / 256 : CE_MAXBLK);
+    if (dtype == MU_F32) {
+        if (v4) ce_nchw_fwd_t<float, 4>(logits, labels, B, C, HW, ignore_index, lse, (double*)workspace, nblk, st);
+        else ce_nchw_fwd_t<float, 1>(logits, labels, B, C, HW, ignore_index, lse, (double*)workspace, nblk, st);
+    } else if (dtype == MU_F16) {
+        if (v4) ce_nchw_fwd_t<h16, 4>(logits, labels, B, C, HW, ignore_index, lse, (double*)workspace, nblk, st);
+        else ce_nchw_fwd_t<h16, 1>(logits, labels, B, C, HW, ignore_index, lse, (double*)workspace, nblk, st);
+    } else return MU_ERR_ARG;
+    ce_final_kernel<<<1, 64, 0, st>>>((const double*)workspace, nblk, loss, count);
+    MU_CHECK_LAUNCH();
+    return MU_OK;
+}
+
+template <typename T, int VEC>
+static void ce_nchw_bwd_t(const void* logits, const long* labels, const float* lse, const float* count, const float* gout, float gscale, int B,
+                          int C, long HW, long ignore_index, void* dlogits, hipStream_t st) {
+    const long groups = (long)B * (HW / VEC);
+    const int nblk = (int)((groups + 255) / 256 < 4096 ? (groups + 255) / 256 : 4096);
+    ce_nchw_bwd_kernel<T, VEC><<<nblk, 256, 0, st>>>((const T*)logits, labels, lse, count, gout, gscale, B, C, HW, ignore_index, (T*)dlogits);
+}
+
+extern "C" int mu_ce_nchw_bwd(const void* logits, const long* labels, const float* lse, const float* count, const float* grad_out,
+                              float grad_scale, int B, int C, long HW, long ignore_index, void* dlogits, int dtype, void* stream) {
+    if (!logits || !labels || !lse || !count || !grad_out || !dlogits || B <= 0 || C <= 0 || HW <= 0) return MU_ERR_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    const bool v4 = HW % 4 == 0;
+    if (dtype == MU_F32) {
+        if (v4) ce_nchw_bwd_t<float, 4>(logits, labels, lse, count, grad_out, grad_scale, B, C, HW, ignore_index, dlogits, st);
+        else ce_nchw_bwd_t<float, 1>(logits, labels, lse, count, grad_out, grad_scale, B, C, HW, ignore_index, dlogits, st);
+    } else if (dtype == MU_F16) {
+        if (v4) ce_nchw_bwd_t<h16, 4>(logits, labels, lse, count, grad_out, grad_scale, B, C, HW, ignore_index, dlogits, st);
+        else ce_nchw_bwd_t<h16, 1>(logits, labels, lse, count, grad_out, grad_scale, B, C, HW, ignore_index, dlogits, st);
+    } else return MU_ERR_ARG;
+    MU_CHECK_LAUNCH();
+    return MU_OK;
+}
+
+// ------------------------------------------------------------------------------------------
 // mean IoU.  counts[0][c] = #(pred==c && label==c), counts[1][c] = #(pred==c), counts[2][c] = #(label==c);
 // iou_c = (I + smooth) / (U + smooth) with U = P + L - I, averaged over classes with U > 0 (ade_semantic.py:135-146).
 // logits: row r = pixel, element (r, c) at logits[(r / inner) * outer_stride + c * c_stride + (r % inner) * p_stride]

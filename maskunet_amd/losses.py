@@ -50,6 +50,58 @@ def pixel_cross_entropy_nhwc(logits_nhwc, labels, n_classes, ignore_index=-100, 
     return _PixelCE.apply(logits_nhwc, labels, int(n_classes), int(ignore_index), float(grad_scale))
 
 
+class _CrossEntropyNCHW(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, logits, labels, ignore_index, grad_scale):
+        logits = logits.contiguous()
+        labels = labels.contiguous()
+        if logits.dim() < 2 or labels.dtype != torch.int64:
+            raise RuntimeError("CrossEntropyLoss expects logits [B,C,...] and int64 class-index labels [B,...]")
+        B, C = logits.shape[0], logits.shape[1]
+        HW = logits.numel() // max(B * C, 1)
+        if tuple(labels.shape) != (B,) + tuple(logits.shape[2:]):
+            raise RuntimeError(f"CrossEntropyLoss: labels {tuple(labels.shape)} do not match logits {tuple(logits.shape)}")
+        lse = torch.empty(B * HW, dtype=torch.float32, device=logits.device)
+        loss = torch.empty(1, dtype=torch.float32, device=logits.device)
+        count = torch.empty(1, dtype=torch.float32, device=logits.device)
+        ws = workspace(_lib.load().mu_ce_workspace_bytes(), logits.device)
+        call("mu_ce_nchw_fwd", ptr(logits), ptr(labels), B, C, HW, ignore_index, ptr(lse), ptr(loss), ptr(count), ptr(ws), ws.numel(),
+             dt(logits), stream())
+        ctx.save_for_backward(logits, labels, lse, count)
+        ctx.meta = (B, C, HW, ignore_index, grad_scale)
+        return loss.view(())
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g):
+        logits, labels, lse, count = ctx.saved_tensors
+        B, C, HW, ignore_index, grad_scale = ctx.meta
+        dl = torch.empty_like(logits)
+        g = g.contiguous().float().view(1)
+        call("mu_ce_nchw_bwd", ptr(logits), ptr(labels), ptr(lse), ptr(count), ptr(g), float(grad_scale), B, C, HW, ignore_index, ptr(dl),
+             dt(logits), stream())
+        return dl, None, None, None
+
+
+def cross_entropy(logits, labels, ignore_index=-100, grad_scale=1.0):
+    """F.cross_entropy(logits, labels, ignore_index=...) (mean reduction) on the module output as it is: logits [B,C,H,W]
+    (fp32 or fp16, NCHW), labels int64 [B,H,W].  grad_scale multiplies the backward only (static fp16 loss scale)."""
+    return _CrossEntropyNCHW.apply(logits, labels, int(ignore_index), float(grad_scale))
+
+
+class CrossEntropyLoss(torch.nn.Module):
+    """The reference's criterion, nn.CrossEntropyLoss() / nn.CrossEntropyLoss(ignore_index=255) (ade_semantic.py:377,399;
+    city_semantic.py:341,362), as one HIP sweep forward and one backward over the NCHW logits (class weights, label smoothing
+    and probability targets are not used by the reference and are not supported)."""
+
+    def __init__(self, ignore_index: int = -100, grad_scale: float = 1.0):
+        super().__init__()
+        self.ignore_index, self.grad_scale = int(ignore_index), float(grad_scale)
+
+    def forward(self, input, target):
+        return cross_entropy(input, target, self.ignore_index, self.grad_scale)
+
+
 def mean_iou(y_pred, y_true, num_classes, smooth=1e-6):
     """mean_iou of the reference (ade_semantic.py:128-146) on device, no host synchronisation.
     y_pred: NCHW [B,C,H,W] (the module output) or NHWC channel-padded [B,H,W,Cp]; y_true: int64 [B,H,W]."""

@@ -30,6 +30,44 @@ def test_pixel_cross_entropy_matches_torch(dtype, tol, C, ignore):
     assert err <= 20 * tol, err
 
 
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 1e-5), (torch.float16, 2e-3)])
+@pytest.mark.parametrize("shape,ignore", [((3, 150, 16, 12), -100), ((2, 19, 9, 7), 255), ((4, 133, 32, 32), 255), ((1, 1, 4, 4), -100)])
+def test_cross_entropy_nchw_matches_torch(dtype, tol, shape, ignore):
+    """maskunet_amd.CrossEntropyLoss on the module's NCHW output == nn.CrossEntropyLoss (ade_semantic.py:377,399)."""
+    import maskunet_amd
+    g = torch.Generator().manual_seed(sum(shape))
+    B, C, H, W = shape
+    x = (torch.randn(shape, generator=g) * 3).to(dtype)
+    labels = torch.randint(0, C, (B, H, W), generator=g)
+    if ignore == 255:
+        labels[torch.rand(B, H, W, generator=g) < 0.2] = 255
+    xr = x.double().requires_grad_(True)
+    ref = F.cross_entropy(xr, labels, ignore_index=ignore)
+    ref.backward()
+    xg = x.cuda().requires_grad_(True)
+    crit = maskunet_amd.CrossEntropyLoss(ignore_index=ignore)
+    loss = crit(xg, labels.cuda())
+    loss.backward()
+    assert abs(loss.item() - ref.item()) <= tol * max(1.0, abs(ref.item()))
+    gtol = 2e-7 if dtype == torch.float32 else 2e-3 * float(xr.grad.abs().max())
+    assert float((xg.grad.double().cpu() - xr.grad).abs().max()) <= gtol
+    # grad_scale multiplies the backward only
+    xs = x.cuda().requires_grad_(True)
+    l2 = maskunet_amd.cross_entropy(xs, labels.cuda(), ignore, grad_scale=64.0)
+    l2.backward()
+    assert l2.item() == loss.item()
+    assert torch.allclose(xs.grad.float() / 64.0, xg.grad.float(), rtol=2e-3, atol=2e-7)
+
+
+def test_cross_entropy_nchw_rejects_bad_labels():
+    import maskunet_amd
+    x = torch.randn(2, 5, 4, 4, device="cuda")
+    with pytest.raises(RuntimeError):
+        maskunet_amd.cross_entropy(x, torch.zeros(2, 4, 3, dtype=torch.int64, device="cuda"))
+    with pytest.raises(RuntimeError):
+        maskunet_amd.cross_entropy(x, torch.zeros(2, 4, 4, dtype=torch.int32, device="cuda"))
+
+
 def test_pixel_cross_entropy_grad_scale_and_padding():
     import maskunet_amd
     C, Cp = 19, 32
