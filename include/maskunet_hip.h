@@ -104,6 +104,21 @@ int mu_bn_act_fwd(const void* x, const void* res, void* y, long M, int C, long l
 int mu_bn_act_bwd(const void* x, const void* res, const void* grad_out, void* dx, void* dres, long M, int C, long ld,
                   const float* mean, const float* rstd, const float* gamma, const float* beta, int act, int training, float* dgamma,
                   float* dbeta, void* workspace, long ws_bytes, int dtype, void* stream);
+/* BatchNorm pair: DownSample / UpSample apply nn.BatchNorm2d directly to the output of ConvBlock's last nn.BatchNorm2d
+ * (ade_semantic.py:216-219, 237-240; maxpool_conv[2..3], conv[1..2]).  In training mode the second layer's batch statistics
+ * follow from the first's (mean = beta1, biased var = gamma1^2 * var1/(var1+eps1)), so the pair is one normalisation of the conv
+ * output: mu_bn_pair_compose turns (rstd1, gamma1, beta1, gamma2) into gamma_eff for mu_bn_act_fwd(.., gamma_eff, beta2), updates the
+ * second layer's running statistics / step counter, and leaves the per-channel factors of the backward:
+ * mu_bn_act_bwd_scaled(.., gamma_eff, .., xhat_scale) returns dx, dbeta = dbeta2 and dgamma = A;
+ * dgamma2 = dgamma2_coef * A, dgamma1 = dgamma1_coef * A, dbeta1 = 0.  All vectors have C (padded) entries. */
+int mu_bn_pair_compose(const float* rstd1, const float* gamma1, const float* beta1, const float* gamma2, int C, int c_valid, long M,
+                       float eps1, float eps2, float momentum2, float* running_mean2, float* running_var2,
+                       long* num_batches_tracked2, float* gamma_eff, float* xhat_scale, float* dgamma2_coef, float* dgamma1_coef,
+                       void* stream);
+/* mu_bn_act_bwd with the xhat term of the batch-statistics formula scaled per channel (xhat_scale NULL = mu_bn_act_bwd) */
+int mu_bn_act_bwd_scaled(const void* x, const void* res, const void* grad_out, void* dx, void* dres, long M, int C, long ld,
+                         const float* mean, const float* rstd, const float* gamma, const float* beta, int act, int training,
+                         float* dgamma, float* dbeta, const float* xhat_scale, void* workspace, long ws_bytes, int dtype, void* stream);
 
 /* ---- per-sample LayerNorm with full-shape affine: nn.LayerNorm([64,128,128]) (:281,311) ------ */
 long mu_ln_sample_workspace_bytes(int B);

@@ -155,7 +155,8 @@ __global__ void bn_eval_stats_kernel(const float* __restrict__ running_mean, con
 
 // BN backward finalize: dgamma = sum dz*xhat, dbeta = sum dz; s1 = dbeta/M, s2 = dgamma/M (0 in eval)
 __global__ void bn_bwd_final_kernel(const double* __restrict__ part, int nblk, int C, long M, int training,
-                                    float* __restrict__ dgamma, float* __restrict__ dbeta, float* __restrict__ s1, float* __restrict__ s2) {
+                                    float* __restrict__ dgamma, float* __restrict__ dbeta, float* __restrict__ s1, float* __restrict__ s2,
+                                    const float* __restrict__ xscale = nullptr) {
     const int c = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (c >= C) return;
     double a = 0.0, b = 0.0;
@@ -165,7 +166,7 @@ __global__ void bn_bwd_final_kernel(const double* __restrict__ part, int nblk, i
     dbeta[c] = (float)a;
     dgamma[c] = (float)b;
     s1[c] = training ? (float)(a / (double)M) : 0.f;
-    s2[c] = training ? (float)(b / (double)M) : 0.f;
+    s2[c] = training ? (float)((xscale ? (double)xscale[c] : 1.0) * b / (double)M) : 0.f;      // xscale: BatchNorm pair (below)
 }
 
 // Elementwise passes: grid-stride over 16-byte vectors with a stride that is a multiple of the vectors per row (ew_grid),
@@ -407,7 +408,7 @@ extern "C" int mu_bn_act_fwd(const void* x, const void* res, void* y, long M, in
 template <typename T>
 static int bn_act_bwd_t(const T* x, const T* res, const T* g, T* dx, T* dres, long M, int C, long ld, const float* mean,
                         const float* rstd, const float* gamma, const float* beta, int act, int training, float* dgamma,
-                        float* dbeta, void* ws, hipStream_t st) {
+                        float* dbeta, void* ws, hipStream_t st, const float* xscale = nullptr) {
     constexpr int N = Vec16<T>::N;
     int cv = C / N;
     if (cv > 256) return MU_ERR_SHAPE;
@@ -422,19 +423,80 @@ static int bn_act_bwd_t(const T* x, const T* res, const T* g, T* dx, T* dres, lo
     float* s2 = s1 + C;
     if (res) {                      // d(residual) == dz exactly, so it doubles as the dz buffer
         bn_partial_kernel<T, 1><<<nblk, 256, lds, st>>>(x, g, res, dres, M, C, ld, mean, rstd, gamma, beta, act, part);
-        bn_bwd_final_kernel<<<mu_cdiv(C, 4), 256, 0, st>>>(part, nblk, C, M, training, dgamma, dbeta, s1, s2);
+        bn_bwd_final_kernel<<<mu_cdiv(C, 4), 256, 0, st>>>(part, nblk, C, M, training, dgamma, dbeta, s1, s2, xscale);
         bn_bwd_apply_kernel<T, false><<<ew_grid(M * cv, cv), 256, 0, st>>>(x, dres, dx, M, C, ld, mean, rstd, gamma, beta, act, s1, s2);
     } else {                        // no residual: nothing is written by the statistics sweep, dz is recomputed in the apply pass
         bn_partial_kernel<T, 1><<<nblk, 256, lds, st>>>(x, g, nullptr, nullptr, M, C, ld, mean, rstd, gamma, beta, act, part);
-        bn_bwd_final_kernel<<<mu_cdiv(C, 4), 256, 0, st>>>(part, nblk, C, M, training, dgamma, dbeta, s1, s2);
+        bn_bwd_final_kernel<<<mu_cdiv(C, 4), 256, 0, st>>>(part, nblk, C, M, training, dgamma, dbeta, s1, s2, xscale);
         bn_bwd_apply_kernel<T, true><<<ew_grid(M * cv, cv), 256, 0, st>>>(x, g, dx, M, C, ld, mean, rstd, gamma, beta, act, s1, s2);
     }
     return MU_OK;
 }
 
+extern "C" int mu_bn_act_bwd_scaled(const void* x, const void* res, const void* grad_out, void* dx, void* dres, long M, int C, long ld,
+                                    const float* mean, const float* rstd, const float* gamma, const float* beta, int act, int training,
+                                    float* dgamma, float* dbeta, const float* xhat_scale, void* workspace, long ws_bytes, int dtype,
+                                    void* stream);
+
 extern "C" int mu_bn_act_bwd(const void* x, const void* res, const void* grad_out, void* dx, void* dres, long M, int C, long ld,
                              const float* mean, const float* rstd, const float* gamma, const float* beta, int act, int training,
                              float* dgamma, float* dbeta, void* workspace, long ws_bytes, int dtype, void* stream) {
+    return mu_bn_act_bwd_scaled(x, res, grad_out, dx, dres, M, C, ld, mean, rstd, gamma, beta, act, training, dgamma, dbeta, nullptr,
+                                workspace, ws_bytes, dtype, stream);
+}
+
+// ------------------------------------------------------------------------------------------
+// BatchNorm pair.  DownSample / UpSample end with nn.BatchNorm2d directly behind the last BatchNorm2d of their ConvBlock
+// (ade_semantic.py:216-219, 237-240).  In training mode the second layer's batch statistics follow from the first's:
+//   y1 = gamma1*u + beta1 (u = xhat of the conv output z, sum u = 0, mean u^2 = var1/(var1+eps1) =: q)
+//   => mean(y1) = beta1, biased var(y1) = gamma1^2 * q, r2 = 1/sqrt(gamma1^2*q + eps2), y2 = gamma2*gamma1*r2*u + beta2.
+// So the pair is ONE normalisation of z with gamma_eff = gamma1*gamma2*r2 and beta2 (mu_bn_act_fwd), and its backward is the single-layer
+// formula with the xhat term scaled by k = r2^2*(gamma1^2 + eps2) (mu_bn_act_bwd_scaled):
+//   dz = gamma_eff*r1*(g - mean g - u*k*mean(g*u));  dbeta2 = sum g;  dgamma2 = gamma1*r2*A;  dgamma1 = gamma2*r2^3*eps2*A;  dbeta1 = 0
+// with A = sum g*u (what mu_bn_act_bwd_scaled returns in dgamma).  One statistics sweep, one apply pass and their backward less.
+// ------------------------------------------------------------------------------------------
+__global__ void bn_pair_compose_kernel(const float* __restrict__ rstd1, const float* __restrict__ gamma1, const float* __restrict__ beta1,
+                                       const float* __restrict__ gamma2, int C, int c_valid, long M, float eps1, float eps2, float momentum2,
+                                       float* __restrict__ running_mean2, float* __restrict__ running_var2, long* __restrict__ nbt2,
+                                       float* __restrict__ gamma_eff, float* __restrict__ xhat_scale, float* __restrict__ dgamma2_coef,
+                                       float* __restrict__ dgamma1_coef) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (nbt2 && c == 0) *nbt2 += 1;
+    if (c >= C) return;
+    const double r1 = (double)rstd1[c], g1 = (double)gamma1[c], g2 = (double)gamma2[c];
+    double q = 1.0 - (double)eps1 * r1 * r1;          // var1 / (var1 + eps1)
+    if (q < 0.0) q = 0.0;
+    const double var2 = g1 * g1 * q;
+    const double r2 = 1.0 / sqrt(var2 + (double)eps2);
+    gamma_eff[c] = (float)(g1 * g2 * r2);
+    xhat_scale[c] = (float)(r2 * r2 * (g1 * g1 + (double)eps2));
+    dgamma2_coef[c] = (float)(g1 * r2);
+    dgamma1_coef[c] = (float)(g2 * r2 * r2 * r2 * (double)eps2);
+    if (running_mean2 && c < c_valid) {
+        const double unb = M > 1 ? var2 * ((double)M / (double)(M - 1)) : var2;
+        running_mean2[c] = (float)((1.0 - (double)momentum2) * (double)running_mean2[c] + (double)momentum2 * (double)beta1[c]);
+        running_var2[c] = (float)((1.0 - (double)momentum2) * (double)running_var2[c] + (double)momentum2 * unb);
+    }
+}
+
+extern "C" int mu_bn_pair_compose(const float* rstd1, const float* gamma1, const float* beta1, const float* gamma2, int C, int c_valid,
+                                  long M, float eps1, float eps2, float momentum2, float* running_mean2, float* running_var2,
+                                  long* num_batches_tracked2, float* gamma_eff, float* xhat_scale, float* dgamma2_coef,
+                                  float* dgamma1_coef, void* stream) {
+    if (!rstd1 || !gamma1 || !beta1 || !gamma2 || !gamma_eff || !xhat_scale || !dgamma2_coef || !dgamma1_coef || C <= 0 || M <= 0)
+        return MU_ERR_ARG;
+    if ((running_mean2 != nullptr) != (running_var2 != nullptr)) return MU_ERR_ARG;
+    bn_pair_compose_kernel<<<mu_cdiv(C, 64), 64, 0, (hipStream_t)stream>>>(rstd1, gamma1, beta1, gamma2, C, c_valid, M, eps1, eps2, momentum2,
+                                                                          running_mean2, running_var2, num_batches_tracked2, gamma_eff,
+                                                                          xhat_scale, dgamma2_coef, dgamma1_coef);
+    MU_CHECK_LAUNCH();
+    return MU_OK;
+}
+
+extern "C" int mu_bn_act_bwd_scaled(const void* x, const void* res, const void* grad_out, void* dx, void* dres, long M, int C, long ld,
+                                    const float* mean, const float* rstd, const float* gamma, const float* beta, int act, int training,
+                                    float* dgamma, float* dbeta, const float* xhat_scale, void* workspace, long ws_bytes, int dtype,
+                                    void* stream) {
     if (!x || !grad_out || !dx || !mean || !rstd || !gamma || !beta || !dgamma || !dbeta || !workspace) return MU_ERR_ARG;
     if ((res != nullptr) != (dres != nullptr)) return MU_ERR_ARG;
     if (M <= 0 || C <= 0 || C % 8 || ld < C) return MU_ERR_ARG;
@@ -442,9 +504,9 @@ extern "C" int mu_bn_act_bwd(const void* x, const void* res, const void* grad_ou
     hipStream_t st = (hipStream_t)stream;
     int rc;
     if (dtype == MU_F32)
-        rc = bn_act_bwd_t<float>((const float*)x, (const float*)res, (const float*)grad_out, (float*)dx, (float*)dres, M, C, ld, mean, rstd, gamma, beta, act, training, dgamma, dbeta, workspace, st);
+        rc = bn_act_bwd_t<float>((const float*)x, (const float*)res, (const float*)grad_out, (float*)dx, (float*)dres, M, C, ld, mean, rstd, gamma, beta, act, training, dgamma, dbeta, workspace, st, xhat_scale);
     else if (dtype == MU_F16)
-        rc = bn_act_bwd_t<h16>((const h16*)x, (const h16*)res, (const h16*)grad_out, (h16*)dx, (h16*)dres, M, C, ld, mean, rstd, gamma, beta, act, training, dgamma, dbeta, workspace, st);
+        rc = bn_act_bwd_t<h16>((const h16*)x, (const h16*)res, (const h16*)grad_out, (h16*)dx, (h16*)dres, M, C, ld, mean, rstd, gamma, beta, act, training, dgamma, dbeta, workspace, st, xhat_scale);
     else return MU_ERR_ARG;
     if (rc) return rc;
     MU_CHECK_LAUNCH();

@@ -156,13 +156,18 @@ class ConvBlock(_HipModule):
             nn.BatchNorm2d(out_channels),
         )
 
-    def forward_nhwc(self, x):
+    def forward_nhwc(self, x, tail_bn=None):
+        """tail_bn: the nn.BatchNorm2d DownSample / UpSample apply right behind this block (:219,240); in training mode it is
+        folded into the block's last BatchNorm (ops.bn_pair)."""
         cb = self.conv_block
         y, st = ops.conv_stats(x, cb[0].weight, want=cb[1].training)   # BatchNorm statistics from the conv epilogue where it has one
         y = ops.bn_act(y, cb[1], ACT_GELU, stats=st)
         y, st = ops.conv_stats(y, cb[3].weight, want=cb[4].training)
         if self.residual:
-            return ops.bn_act(y, cb[4], ACT_GELU, res=x, stats=st)      # gelu(x + BN(conv(...)))  (:208)
+            y = ops.bn_act(y, cb[4], ACT_GELU, res=x, stats=st)         # gelu(x + BN(conv(...)))  (:208)
+            return y if tail_bn is None else ops.bn_act(y, tail_bn, ACT_NONE)
+        if tail_bn is not None:
+            return ops.bn_pair(y, cb[4], tail_bn, stats=st)
         return ops.bn_act(y, cb[4], ACT_NONE, stats=st)
 
     def forward(self, x):
@@ -189,8 +194,7 @@ class DownSample(_HipModule):
         mc = self.maxpool_conv
         x = ops.maxpool2(x)
         x = mc[1].forward_nhwc(x)
-        x = mc[2].forward_nhwc(x)
-        return ops.bn_act(x, mc[3], ACT_NONE)
+        return mc[2].forward_nhwc(x, tail_bn=mc[3])       # ConvBlock + the BatchNorm behind it (:218-219)
 
     def forward(self, x):
         self._check_device(x)
@@ -214,8 +218,7 @@ class UpSample(_HipModule):
     def forward_nhwc(self, x, skip_x):
         x = ops.upcat(x, skip_x)                 # cat([skip_x, up(x)], dim=1)  (:250-253)
         x = self.conv[0].forward_nhwc(x)
-        x = self.conv[1].forward_nhwc(x)
-        return ops.bn_act(x, self.conv[2], ACT_NONE)
+        return self.conv[1].forward_nhwc(x, tail_bn=self.conv[2])      # ConvBlock + the BatchNorm behind it (:239-240)
 
     def forward(self, x, skip_x):
         self._check_device(x)

@@ -333,6 +333,69 @@ class _BNAct(torch.autograd.Function):
         return dx, dres, dgamma[:ctx.cv], dbeta[:ctx.cv], None, None, None, None, None, None, None, None
 
 
+class _BNPair(torch.autograd.Function):
+    """BatchNorm2d(BatchNorm2d(x)) in training mode as ONE normalisation of x (ade_semantic.py:216-219, 237-240: the BatchNorm behind
+    ConvBlock's last BatchNorm in DownSample / UpSample); see mu_bn_pair_compose in include/maskunet_hip.h for the algebra."""
+
+    @staticmethod
+    def forward(ctx, x, g1, b1, g2, b2, rm1, rv1, nbt1, mom1, eps1, rm2, rv2, nbt2, mom2, eps2, stats):
+        x = x.contiguous()
+        C = x.shape[-1]
+        M = x.numel() // C
+        cv = g1.numel()
+        g1p, b1p, g2p, b2p = _pad_vec(g1, C, 1.0), _pad_vec(b1, C, 0.0), _pad_vec(g2, C, 1.0), _pad_vec(b2, C, 0.0)
+        dev = x.device
+        mean = torch.empty(C, dtype=torch.float32, device=dev)
+        rstd = torch.empty_like(mean)
+        coef = torch.empty(4, C, dtype=torch.float32, device=dev)      # gamma_eff, xhat_scale, dgamma2_coef, dgamma1_coef
+        ws = workspace(_lib.load().mu_bn_workspace_bytes(C), dev)
+        if stats is not None and stats.numel() > 0:
+            call("mu_bn_train_stats_rows", ptr(stats), stats.shape[0], M, C, ptr(mean), ptr(rstd), ptr(rm1), ptr(rv1), ptr(nbt1), cv,
+                 float(mom1), float(eps1), ptr(ws), ws.numel(), stream())
+        else:
+            call("mu_bn_train_stats", ptr(x), M, C, C, ptr(mean), ptr(rstd), ptr(rm1), ptr(rv1), ptr(nbt1), cv, float(mom1), float(eps1),
+                 ptr(ws), ws.numel(), dt(x), stream())
+        call("mu_bn_pair_compose", ptr(rstd), ptr(g1p), ptr(b1p), ptr(g2p), C, cv, M, float(eps1), float(eps2), float(mom2), ptr(rm2),
+             ptr(rv2), ptr(nbt2), ptr(coef[0]), ptr(coef[1]), ptr(coef[2]), ptr(coef[3]), stream())
+        y = torch.empty_like(x)
+        call("mu_bn_act_fwd", ptr(x), None, ptr(y), M, C, C, ptr(mean), ptr(rstd), ptr(coef[0]), ptr(b2p), ACT_NONE, dt(x), stream())
+        ctx.save_for_backward(x, mean, rstd, coef, b2p)
+        ctx.cv = cv
+        return y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, gy):
+        x, mean, rstd, coef, b2p = ctx.saved_tensors
+        gy = gy.contiguous()
+        C = x.shape[-1]
+        M = x.numel() // C
+        dx = torch.empty_like(x)
+        a = torch.empty(C, dtype=torch.float32, device=x.device)
+        dbeta2 = torch.empty_like(a)
+        ws = workspace(_lib.load().mu_bn_workspace_bytes(C), x.device)
+        call("mu_bn_act_bwd_scaled", ptr(x), None, ptr(gy), ptr(dx), None, M, C, C, ptr(mean), ptr(rstd), ptr(coef[0]), ptr(b2p), ACT_NONE, 1,
+             ptr(a), ptr(dbeta2), ptr(coef[1]), ptr(ws), ws.numel(), dt(x), stream())
+        dg = coef[2:4] * a                                   # rows: dgamma2, dgamma1
+        cv = ctx.cv
+        return (dx, dg[1, :cv], torch.zeros(cv, dtype=torch.float32, device=x.device), dg[0, :cv], dbeta2[:cv]) + (None,) * 11
+
+
+BN_PAIR = os.environ.get("MU_BN_PAIR", "1") != "0"          # debug switch: 0 = the two layers one after the other
+
+
+def bn_pair(x, bn1, bn2, stats=None):
+    """bn2(bn1(x)) for two nn.BatchNorm2d containers applied back to back (no activation, no residual in between)."""
+    both_train = (bn1.training and bn2.training and bn1.running_mean is not None and bn2.running_mean is not None
+                  and bn1.weight is not None and bn2.weight is not None)
+    ok = both_train and BN_PAIR and all(t is not None and t.device == x.device and t.dtype == torch.int64
+                                        for t in (bn1.num_batches_tracked, bn2.num_batches_tracked))
+    if not ok or bn1.momentum is None or bn2.momentum is None:
+        return bn_act(bn_act(x, bn1, ACT_NONE, stats=stats), bn2, ACT_NONE)
+    return _BNPair.apply(x, bn1.weight, bn1.bias, bn2.weight, bn2.bias, bn1.running_mean, bn1.running_var, bn1.num_batches_tracked,
+                         bn1.momentum, bn1.eps, bn2.running_mean, bn2.running_var, bn2.num_batches_tracked, bn2.momentum, bn2.eps, stats)
+
+
 def bn_act(x, bn, act=ACT_NONE, res=None, stats=None):
     """Apply the BatchNorm2d parameter container `bn` (an nn.BatchNorm2d used only for its
     parameters/buffers/flags) followed by `act`, optionally adding `res` before the activation.

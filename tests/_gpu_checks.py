@@ -230,6 +230,59 @@ def check_bn_act(dtype):
     return out
 
 
+def check_bn_pair(dtype):
+    """ops.bn_pair == bn2(bn1(x)) of two nn.BatchNorm2d in training mode (fp64 reference): output, input gradient, all four
+    parameter gradients, both layers' running statistics and step counters (ade_semantic.py:216-219, 237-240)."""
+    from maskunet_amd import ops
+    import torch.nn as nn
+    gen = np.random.default_rng(41)
+    out = []
+    # large eps values make the eps-proportional terms (dgamma1, var/(var+eps) < 1) first-order effects
+    for (B, C, H, W, eps1, eps2) in [(2, 32, 6, 6, 1e-5, 1e-5), (3, 64, 5, 7, 1e-5, 1e-5), (2, 19, 8, 8, 1e-5, 1e-5),
+                                     (1, 256, 16, 16, 1e-5, 1e-5), (2, 32, 6, 6, 0.2, 0.3)]:
+        x = _rnd(gen, B, C, H, W) * 1.5 + 0.3
+        if C == 64:
+            x[:, 3] *= 1e-3                       # a channel whose variance is comparable to eps (var/(var+eps) well below 1)
+        g = _rnd(gen, B, C, H, W)
+        refs, devs = [], []
+        for eps in (eps1, eps2):
+            bn = nn.BatchNorm2d(C, eps=eps)
+            with torch.no_grad():
+                bn.weight.copy_(torch.from_numpy(gen.uniform(0.5, 1.5, C).astype(np.float32)))
+                bn.bias.copy_(torch.from_numpy(gen.uniform(-0.2, 0.2, C).astype(np.float32)))
+                bn.running_mean.copy_(_rnd(gen, C, scale=0.1))
+                bn.running_var.copy_(torch.from_numpy(gen.uniform(0.5, 1.5, C).astype(np.float32)))
+            d = nn.BatchNorm2d(C, eps=eps)
+            d.load_state_dict(bn.state_dict())
+            refs.append(bn.double().train())
+            devs.append(d.to(DEV).train())
+        xr = x.to(dtype).double().clone().requires_grad_(True)
+        yr = refs[1](refs[0](xr))
+        yr.backward(g.to(dtype).double())
+        xd = x.to(DEV).requires_grad_(True)
+        y = ops.to_nchw(ops.bn_pair(ops.to_nhwc(xd, dtype), devs[0], devs[1]), C, torch.float32)
+        y.backward(g.to(DEV))
+        tol = TOL[dtype]
+        tag = f"bnpair{(B, C, H, W, eps1, eps2)}"
+        gscale = float(refs[1].weight.grad.abs().max())
+        out += [(tag + " y", _err(y, yr.float()), tol), (tag + " dx", _rel_err(xd.grad, xr.grad.float()), tol),
+                (tag + " dgamma2", _rel_err(devs[1].weight.grad, refs[1].weight.grad.float()), tol),
+                (tag + " dbeta2", _rel_err(devs[1].bias.grad, refs[1].bias.grad.float()), tol),
+                (tag + " dgamma1", _err(devs[0].weight.grad, refs[0].weight.grad.float()) / gscale, tol * 1e-2),
+                (tag + " dbeta1", _err(devs[0].bias.grad, refs[0].bias.grad.float()) / gscale, tol * 1e-2)]
+        for i in range(2):
+            out += [(tag + f" rmean{i}", _err(devs[i].running_mean, refs[i].running_mean.float()), tol),
+                    (tag + f" rvar{i}", _err(devs[i].running_var, refs[i].running_var.float()), tol),
+                    (tag + f" nbt{i}", abs(int(devs[i].num_batches_tracked) - int(refs[i].num_batches_tracked)), 0.0)]
+        # eval mode falls back to the two layers one after the other
+        for m in refs + devs:
+            m.eval()
+        ye = refs[1](refs[0](x.to(dtype).double()))
+        yd = ops.to_nchw(ops.bn_pair(ops.to_nhwc(x.to(DEV), dtype), devs[0], devs[1]), C, torch.float32)
+        out.append((tag + " eval y", _err(yd, ye.float()), tol))
+    return out
+
+
 def check_pool_up(dtype):
     from maskunet_amd import ops
     gen = np.random.default_rng(5)

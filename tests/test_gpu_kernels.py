@@ -36,7 +36,7 @@ def test_conv_fwd_dgrad_wgrad(dtype):
 @pytest.mark.parametrize("dtype", DTYPES)
 def test_bn_act(dtype):
     from tests import _gpu_checks as G
-    _assert_all(G.check_bn_act(dtype) + G.check_conv_stats(dtype))
+    _assert_all(G.check_bn_act(dtype) + G.check_conv_stats(dtype) + G.check_bn_pair(dtype))
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
