@@ -199,8 +199,22 @@ __device__ __forceinline__ void glds16a(const void* gsrc, void* lds_wave_base) {
     asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(l), "v"(gsrc) : "memory");
 }
 
-template <typename T, int TM, int TN, int WR, int TAPS>
-__global__ __launch_bounds__(256) void conv_nt2_kernel(const T* __restrict__ x, const T* __restrict__ w, const float* __restrict__ bias,
+#ifndef MU_NT2_SB_OCC
+#define MU_NT2_SB_OCC 3
+#endif
+#ifndef MU_NT2_OCC
+#define MU_NT2_OCC 2
+#endif
+#ifndef MU_NT2_EPI
+#define MU_NT2_EPI 1        // fp16: stage the output tile in LDS and store whole rows
+#endif
+// SB: the whole reduction is ONE stage (1x1, Cin == one 128-byte row): a single LDS buffer, so more blocks fit a CU -- the block is
+// load -> multiply -> store with nothing to pipeline inside it, only other resident blocks hide its latencies.
+#ifndef MU_NT2_SB
+#define MU_NT2_SB 1
+#endif
+template <typename T, int TM, int TN, int WR, int TAPS, bool SB = false>
+__global__ __launch_bounds__(256, SB ? MU_NT2_SB_OCC : MU_NT2_OCC) void conv_nt2_kernel(const T* __restrict__ x, const T* __restrict__ w, const float* __restrict__ bias,
                                                        T* __restrict__ y, int B, int H, int W, int Cin, int Cout, long x_ld, long y_ld) {
     using M_ = Mma<T>;
     using Frag = typename M_::Frag;
@@ -211,7 +225,12 @@ __global__ __launch_bounds__(256) void conv_nt2_kernel(const T* __restrict__ x, 
     static_assert(BCO % 32 == 0 && BPX % 32 == 0, "tiles must be multiples of 32 rows");
     constexpr int STAGE = (BCO + BPX) * 128;
 
-    __shared__ __attribute__((aligned(16))) char lds[2 * STAGE];
+    constexpr int OPITCH = BCO * 2 + 16;                    // fp16 epilogue: the block's output tile staged as [pixel][channel] rows
+    constexpr bool EPI = sizeof(T) == 2 && (SB || MU_NT2_EPI);
+    constexpr int LDS0 = (SB ? 1 : 2) * STAGE;
+    constexpr int LDSB = EPI && BPX * OPITCH > LDS0 ? BPX * OPITCH : LDS0;
+
+    __shared__ __attribute__((aligned(16))) char lds[LDSB];
 
     const long Mtot = (long)B * H * W;
     const int npb = (int)((Mtot + BPX - 1) / BPX), ncb = (Cout + BCO - 1) / BCO;
@@ -235,8 +254,8 @@ __global__ __launch_bounds__(256) void conv_nt2_kernel(const T* __restrict__ x, 
         ph[i] = (int)((pp / W) % H);
         prow[i] = pp;
     }
-    const int kchunks = Cin / KC;
-    const int nsteps = TAPS * kchunks;
+    const int kchunks = SB ? 1 : Cin / KC;
+    const int nsteps = SB ? 1 : TAPS * kchunks;
 
     auto stage = [&](int s, int buf) {
         const int tap = s / kchunks, ci0 = (s % kchunks) * KC;
@@ -295,6 +314,32 @@ __global__ __launch_bounds__(256) void conv_nt2_kernel(const T* __restrict__ x, 
         __syncthreads();          // drains the LDS-DMA of stage s+1 (vmcnt(0)) and fences the reads of stage s
     }
 
+    if constexpr (EPI) {
+        // the block's BPX x BCO tile goes through LDS (the loop's last barrier fenced the fragment reads) and leaves as whole
+        // 16-byte chunks of contiguous output rows: the streams these layers are need full-line writes
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int px = (wc * TN + j) * 16 + r16;
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                const int co = (wr * TM + i) * 16 + 4 * g;
+                float v[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = acc[i][j][r] + (bias && co0 + co + r < Cout ? bias[co0 + co + r] : 0.f);
+                h16x4 o = {(h16)v[0], (h16)v[1], (h16)v[2], (h16)v[3]};
+                *reinterpret_cast<h16x4*>(lds + px * OPITCH + co * 2) = o;
+            }
+        }
+        __syncthreads();
+        constexpr int CH = BCO / 8;
+        for (int idx = tid; idx < BPX * CH; idx += 256) {
+            const int px = idx / CH, ch = idx - px * CH;
+            const long p = px0 + px;
+            if (p < Mtot && co0 + ch * 8 < Cout)
+                *reinterpret_cast<uint4*>(y + p * y_ld + co0 + ch * 8) = *reinterpret_cast<const uint4*>(lds + px * OPITCH + ch * 16);
+        }
+        return;
+    }
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
         const long p = px0 + (wc * TN + j) * 16 + r16;
@@ -1120,11 +1165,13 @@ static int conv_fwd_launch(const T* x, const T* w, const float* bias, T* y, int 
         // 1x1 layers are HBM-bound streams (q/k/v projection of the N = 16384 block: 134 MB in, 402 MB out): a tile that spans all
         // output channels reads the activations once instead of once per 64-channel tile
         if ((Cin * 2) % 128 == 0 && Cout % 192 == 0) {
-            conv_nt2_kernel<T, 6, 4, 2, 1><<<npb * (Cout / 192), 256, 0, st>>>(x, w, bias, y, B, H, W, Cin, Cout, x_ld, y_ld);
+            if (Cin == 64 && MU_NT2_SB) conv_nt2_kernel<T, 6, 4, 2, 1, true><<<npb * (Cout / 192), 256, 0, st>>>(x, w, bias, y, B, H, W, Cin, Cout, x_ld, y_ld);
+            else conv_nt2_kernel<T, 6, 4, 2, 1><<<npb * (Cout / 192), 256, 0, st>>>(x, w, bias, y, B, H, W, Cin, Cout, x_ld, y_ld);
             return MU_OK;
         }
         if ((Cin * 2) % 128 == 0 && Cout == 160) {
-            conv_nt2_kernel<T, 5, 4, 2, 1><<<npb, 256, 0, st>>>(x, w, bias, y, B, H, W, Cin, Cout, x_ld, y_ld);
+            if (Cin == 64 && MU_NT2_SB) conv_nt2_kernel<T, 5, 4, 2, 1, true><<<npb, 256, 0, st>>>(x, w, bias, y, B, H, W, Cin, Cout, x_ld, y_ld);
+            else conv_nt2_kernel<T, 5, 4, 2, 1><<<npb, 256, 0, st>>>(x, w, bias, y, B, H, W, Cin, Cout, x_ld, y_ld);
             return MU_OK;
         }
     }

@@ -46,7 +46,8 @@ def main():
         cases = [("fwd", 0), ("dq", 2), ("dkv", 4)]
         first = libs[names[0]]; mk(first, 0)(); mk(first, 1)()
     elif what == "conv1":
-        shapes = [(64, 128, 64, 192), (64, 64, 128, 384), (64, 128, 192, 64), (64, 128, 64, 160), (64, 32, 256, 768)]
+        shapes = [(64, 128, 64, 192), (64, 64, 128, 384), (64, 128, 192, 64), (64, 128, 64, 160), (64, 32, 256, 768), (64, 64, 384, 128), (64, 32, 768, 256),
+                  (64, 64, 64, 192), (64, 64, 192, 64), (64, 128, 160, 64)]
         bufs = [(torch.randn(B, H, H, Cin, device=dev, dtype=dt), (torch.randn(1, Cout, Cin, device=dev) * 0.05).to(dt), torch.empty(B, H, H, Cout, device=dev, dtype=dt)) for (B, H, Cin, Cout) in shapes]
         def mk(lib, phase):
             (B, H, Cin, Cout), (x, w, y) = shapes[phase], bufs[phase]
