@@ -494,6 +494,36 @@ __global__ __launch_bounds__(NWV * 64, NWV == 4 ? 2 : 1) void conv_nt3_kernel(co
         }
     }
 
+#ifndef MU_NT3_EPI
+#define MU_NT3_EPI 1
+#endif
+    if constexpr (sizeof(T) == 2 && TM == 4 && MU_NT3_EPI) {
+        // wave-private staged epilogue (as conv_nt4_kernel): the wave's (TN x 16) px x 64 co tile goes through its own LDS slice
+        // (every fragment read and DMA of the loop is behind its last barrier) and leaves as whole 128-byte rows
+        char* Os = lds + wave * (TN * 16 * 128);
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int p = j * 16 + r16;
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                const int co = i * 16 + 4 * g;
+                float v[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = acc[i][j][r] + (bias ? bias[co0 + wr * 64 + co + r] : 0.f);
+                h16x4 o = {(h16)v[0], (h16)v[1], (h16)v[2], (h16)v[3]};
+                *reinterpret_cast<h16x4*>(Os + p * 128 + (((co >> 2) ^ (((p >> 1) & 7) << 1)) << 3)) = o;
+            }
+        }
+        const int q = lane & 7;
+#pragma unroll
+        for (int it = 0; it < TN * 2; ++it) {
+            const int p = it * 8 + (lane >> 3);
+            const h16x8 o = *reinterpret_cast<const h16x8*>(Os + p * 128 + ((q ^ ((p >> 1) & 7)) << 4));
+            const long gp = ((long)bimg * H + h0 + wc * TN + (p >> 4)) * W + w0 + (p & 15);
+            *reinterpret_cast<h16x8*>(y + gp * y_ld + co0 + wr * 64 + q * 8) = o;
+        }
+        return;
+    }
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
         const long p = ((long)bimg * H + h0 + wc * TN + j) * W + w0 + r16;
@@ -1731,22 +1761,37 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
     }
 }
 
+#ifndef MU_WG1_WIDE
+#define MU_WG1_WIDE 1           // fp16 1x1 layers: tiles that span all (or 192) output channels, both operands read once
+#endif
+#ifndef MU_WG1_SPLITS
+#define MU_WG1_SPLITS 512       // pixel ranges per wide tile: these launches are HBM streams and want ~2 blocks per CU in flight
+#endif
+static inline bool wgrad_is_wide(int bco) { return bco == 192 || bco == 160; }
+
 static inline void wgrad_plan(long M, int Cin, int Cout, int taps, int bco, int bci, int* nsplit, long* pps) {
     long tiles = (long)taps * ((Cout + bco - 1) / bco) * ((Cin + bci - 1) / bci);
     long want = 2048 / tiles;
     if (want < 1) want = 1;
     long max_split = (M + 255) / 256;           // at least 256 pixels per split
     if (want > max_split) want = max_split;
-    if (want > 256) want = 256;
+    const long cap = wgrad_is_wide(bco) ? MU_WG1_SPLITS / tiles > 64 ? MU_WG1_SPLITS / tiles : 64 : 256;
+    if (want > cap) want = cap;
     long p = (M + want - 1) / want;
     p = (p + 31) / 32 * 32;                    // multiple of both stage depths (32 / 16)
     *pps = p;
     *nsplit = (int)((M + p - 1) / p);
 }
 
-static inline void wgrad_tile(int Cin, int Cout, int* bco, int* bci) {
+static inline void wgrad_tile(int Cin, int Cout, int* bco, int* bci, int taps = 9, bool fp16 = false) {
     *bco = (Cout % 128 == 0) ? 128 : (Cout % 64 == 0 ? 64 : 32);
     *bci = (Cin % 128 == 0) ? 128 : (Cin % 64 == 0 ? 64 : 32);
+    if (MU_WG1_WIDE && fp16 && taps == 1 && *bci >= 64 && (Cout % 192 == 0 || Cout == 160)) {
+        // q/k/v projection (Cout = 3C) and the 150 -> 160 class head: with square tiles the narrow operand was re-read per
+        // output-channel tile (64 -> 192: 804 MB instead of 537; 64 -> 160 with 32x32 tiles: 1.34 GB instead of 470 MB)
+        *bco = Cout == 160 ? 160 : 192;
+        return;
+    }
     // supported tile pairs: 128x128, 64x64, 32x32 (+ mixed via the smaller square)
     int m = *bco < *bci ? *bco : *bci;
     *bco = m; *bci = m;
@@ -1892,6 +1937,9 @@ extern "C" long mu_conv_wgrad_workspace_bytes(int B, int H, int W, int Cin, int 
     wgrad_tile(Cin, Cout, &bco, &bci);
     wgrad_plan((long)B * H * W, Cin, Cout, taps, bco, bci, &nsplit, &pps);
     long a = (long)nsplit * taps * Cout * Cin * sizeof(float);
+    wgrad_tile(Cin, Cout, &bco, &bci, taps, true);          // the fp16 plan of a 1x1 layer may use more pixel ranges
+    wgrad_plan((long)B * H * W, Cin, Cout, taps, bco, bci, &nsplit, &pps);
+    if ((long)nsplit * taps * Cout * Cin * (long)sizeof(float) > a) a = (long)nsplit * taps * Cout * Cin * sizeof(float);
     int tco, tci;
     if (wgrad3_choose(H, W, Cin, Cout, taps, MU_F16, &tco, &tci)) {
         wgrad3_plan((long)B * H * W, Cin, Cout, tco, tci, &nsplit, &pps);
@@ -1907,7 +1955,19 @@ extern "C" long mu_conv_wgrad_workspace_bytes(int B, int H, int W, int Cin, int 
 
 template <typename T, int TAPS>
 static int wgrad_launch(const T* x, const T* dy, float* part, int B, int H, int W, int Cin, int Cout, long x_ld, long dy_ld, int bt,
-                        int nsplit, long pps, hipStream_t st) {
+                        int nsplit, long pps, hipStream_t st, int bci = 0) {
+    if constexpr (TAPS == 1 && sizeof(T) == 2) {
+        if (wgrad_is_wide(bt)) {                            // bt x bci tiles (bci = 64 or 128)
+            const int grid = ((Cout + bt - 1) / bt) * ((Cin + bci - 1) / bci) * nsplit;
+#define WG1(TM_, TN_) conv_wgrad_kernel<T, TM_, TN_, 2, 1><<<grid, 256, 0, st>>>(x, dy, part, B, H, W, Cin, Cout, x_ld, dy_ld, nsplit, pps)
+            if (bt == 192 && bci == 64) WG1(6, 2);
+            else if (bt == 192) WG1(6, 4);
+            else if (bci == 64) WG1(5, 2);
+            else WG1(5, 4);
+#undef WG1
+            return MU_OK;
+        }
+    }
     const int nt = ((Cout + bt - 1) / bt) * ((Cin + bt - 1) / bt);
     const int grid = TAPS * nt * nsplit;
     if (bt == 128) conv_wgrad_kernel<T, 4, 4, 2, TAPS><<<grid, 256, 0, st>>>(x, dy, part, B, H, W, Cin, Cout, x_ld, dy_ld, nsplit, pps);
@@ -1924,7 +1984,7 @@ extern "C" int mu_conv_wgrad(const void* x, const void* dy, float* dw_oihw, int 
     if (cin_valid <= 0 || cin_valid > Cin || cout_valid <= 0 || cout_valid > Cout) return MU_ERR_ARG;
     if (taps != 1 && taps != 9) return MU_ERR_ARG;
     int bco, bci, nsplit; long pps;
-    wgrad_tile(Cin, Cout, &bco, &bci);
+    wgrad_tile(Cin, Cout, &bco, &bci, taps, dtype == MU_F16);
     wgrad_plan((long)B * H * W, Cin, Cout, taps, bco, bci, &nsplit, &pps);
     hipStream_t st = (hipStream_t)stream;
     float* part = (float*)workspace;
@@ -1973,7 +2033,7 @@ extern "C" int mu_conv_wgrad(const void* x, const void* dy, float* dw_oihw, int 
         return MU_ERR_WORKSPACE;
     } else if (dtype == MU_F16) {
         if (taps == 9) wgrad_launch<h16, 9>((const h16*)x, (const h16*)dy, part, B, H, W, Cin, Cout, x_ld, dy_ld, bco, nsplit, pps, st);
-        else wgrad_launch<h16, 1>((const h16*)x, (const h16*)dy, part, B, H, W, Cin, Cout, x_ld, dy_ld, bco, nsplit, pps, st);
+        else wgrad_launch<h16, 1>((const h16*)x, (const h16*)dy, part, B, H, W, Cin, Cout, x_ld, dy_ld, bco, nsplit, pps, st, bci);
     } else if (dtype == MU_F32) {
         if (taps == 9) wgrad_launch<float, 9>((const float*)x, (const float*)dy, part, B, H, W, Cin, Cout, x_ld, dy_ld, bco, nsplit, pps, st);
         else wgrad_launch<float, 1>((const float*)x, (const float*)dy, part, B, H, W, Cin, Cout, x_ld, dy_ld, bco, nsplit, pps, st);

@@ -140,7 +140,11 @@ def check_conv(dtype, cases=None):
                       # shapes around the kernel-selection edges: 80-wide (16x16 conv tiles, one-tap weight-grad), 192-wide (64-pixel
                       # weight-grad stages), 32-wide with even / odd height (two-row stages / flat stages), persistent conv with a tail
                       (2, 48, 80, 64, 128, 3), (1, 32, 192, 128, 128, 3), (2, 6, 32, 128, 128, 3), (1, 5, 32, 128, 128, 3),
-                      (5, 64, 64, 64, 128, 3)]
+                      (5, 64, 64, 64, 128, 3),
+                      # 1x1 layers: q/k/v projection shapes (Cout = 3C: row-staged epilogue, single-stage Cin = 64 kernel, wide
+                      # weight-grad tiles), their data-gradient shape, the 150-class head with a ragged pixel count
+                      (2, 9, 7, 64, 192, 1), (1, 16, 16, 128, 384, 1), (2, 5, 5, 256, 768, 1), (3, 7, 9, 192, 64, 1), (2, 33, 17, 64, 150, 1),
+                      (1, 40, 40, 64, 192, 1)]
     for (B, H, W, Cin, Cout, k) in cases:
         x = _rnd(gen, B, Cin, H, W)
         w = _rnd(gen, Cout, Cin, k, k, scale=1.0 / math.sqrt(Cin * k * k))

@@ -53,6 +53,14 @@ def main():
             (B, H, Cin, Cout), (x, w, y) = shapes[phase], bufs[phase]
             return lambda: lib.mu_conv_fwd(x.data_ptr(), w.data_ptr(), None, y.data_ptr(), B, H, H, Cin, Cout, 1, Cin, Cout, 1, st)
         cases = [(f"1x1 {shapes[p]} {2e-6 * shapes[p][0] * shapes[p][1] ** 2 * (shapes[p][2] + shapes[p][3]):.0f} MB", p) for p in range(len(shapes))]
+    elif what == "wgrad1":
+        shapes = [(64, 128, 64, 192), (64, 128, 64, 160), (64, 64, 128, 384), (64, 64, 64, 192), (64, 32, 256, 768), (64, 32, 128, 384)]
+        bufs = [(torch.randn(B, H, H, Cin, device=dev, dtype=dt), torch.randn(B, H, H, Cout, device=dev, dtype=dt), torch.empty(Cout, Cin, 1, 1, device=dev),
+                 torch.empty(max(l.mu_conv_wgrad_workspace_bytes(B, H, H, Cin, Cout, 1) for l in libs.values()), dtype=torch.uint8, device=dev)) for (B, H, Cin, Cout) in shapes]
+        def mk(lib, phase):
+            (B, H, Cin, Cout), (x, dy, gw, ws) = shapes[phase], bufs[phase]
+            return lambda: lib.mu_conv_wgrad(x.data_ptr(), dy.data_ptr(), gw.data_ptr(), B, H, H, Cin, Cout, 1, Cin, Cout, Cin, Cout, ws.data_ptr(), ws.numel(), 1, st)
+        cases = [(f"1x1 wgrad {shapes[p]} {2e-6 * shapes[p][0] * shapes[p][1] ** 2 * (shapes[p][2] + shapes[p][3]):.0f} MB", p) for p in range(len(shapes))]
     elif what == "bn":
         M, C = (int(v) for v in os.environ.get("MU_BN_SHAPE", "1048576,128").split(","))
         x = torch.randn(M, C, device=dev, dtype=dt); y = torch.empty_like(x); gy = torch.randn_like(x); dx = torch.empty_like(x)
