@@ -76,6 +76,13 @@ int mu_conv_fwd_stats(const void* x, const void* w, const float* bias, void* y, 
 long mu_conv_wgrad_workspace_bytes(int B, int H, int W, int Cin, int Cout, int taps);
 int mu_conv_wgrad(const void* x, const void* dy, float* dw_oihw, int B, int H, int W, int Cin, int Cout, int taps, int cin_valid,
                   int cout_valid, long x_ld, long dy_ld, void* workspace, long ws_bytes, int dtype, void* stream);
+/* mu_conv_wgrad that also returns the bias gradient db[cout_valid] = sum over pixels of dy (nn.Linear query/key/value biases
+ * :170-172, final_layer / head Conv2d biases :284) from the same sweep: the dy tiles are multiplied with one more column of ones.
+ * Only where mu_conv_wgrad_bias_supported(...) == 1 (fp16 1x1 layers served by the wide tiles); MU_ERR_SHAPE otherwise --
+ * callers then use mu_conv_wgrad + mu_colsum.  Same workspace size. */
+int mu_conv_wgrad_bias_supported(int Cin, int Cout, int taps, int dtype);
+int mu_conv_wgrad_bias(const void* x, const void* dy, float* dw_oihw, float* db, int B, int H, int W, int Cin, int Cout, int taps,
+                       int cin_valid, int cout_valid, long x_ld, long dy_ld, void* workspace, long ws_bytes, int dtype, void* stream);
 /* out[c] = sum_r x[r][c]  (bias gradients) */
 long mu_colsum_workspace_bytes(int C);
 int mu_colsum(const void* x, long M, int C, long ld, float* out, void* workspace, long ws_bytes, int dtype, void* stream);

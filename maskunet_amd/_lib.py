@@ -32,6 +32,8 @@ SIGNATURES = {
     "mu_conv_fwd_stats": (I, [P, P, P, P, I, I, I, I, I, I, L, L, I, P, P]),
     "mu_conv_wgrad_workspace_bytes": (L, [I, I, I, I, I, I]),
     "mu_conv_wgrad": (I, [P, P, P, I, I, I, I, I, I, I, I, L, L, P, L, I, P]),
+    "mu_conv_wgrad_bias_supported": (I, [I, I, I, I]),
+    "mu_conv_wgrad_bias": (I, [P, P, P, P, I, I, I, I, I, I, I, I, L, L, P, L, I, P]),
     "mu_colsum_workspace_bytes": (L, [I]),
     "mu_colsum": (I, [P, L, I, L, P, P, L, I, P]),
     "mu_bn_workspace_bytes": (L, [I]),

@@ -1271,10 +1271,12 @@ template <> struct WgTile<float> { static constexpr int PAD = 16; static constex
 
 typedef __fp16 fp16x4v __attribute__((__vector_size__(4 * sizeof(__fp16))));
 
-template <typename T, int TM, int TN, int WR, int TAPS>
+// BIAS (fp16): the bias gradient db[co] = sum_p dy[p][co] rides along as one more column tile of ones -- the dy fragments are in
+// registers anyway, so the separate column-sum sweep over dy (402 MB for the N = 16384 q/k/v projection) disappears.
+template <typename T, int TM, int TN, int WR, int TAPS, bool BIAS = false>
 __global__ __launch_bounds__(256) void conv_wgrad_kernel(const T* __restrict__ x, const T* __restrict__ dy, float* __restrict__ part,
                                                          int B, int H, int W, int Cin, int Cout, long x_ld, long dy_ld, int nsplit,
-                                                         long pix_per_split) {
+                                                         long pix_per_split, float* __restrict__ bias_part = nullptr) {
     constexpr int VN = Mma<T>::VN;
     constexpr int WC = 4 / WR;
     constexpr int BCO = WR * TM * 16, BCI = WC * TN * 16;
@@ -1343,6 +1345,9 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const T* __restrict__ x
     for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    f32x4 accb[BIAS ? TM : 1];
+#pragma unroll
+    for (int i = 0; i < (BIAS ? TM : 1); ++i) accb[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
     const int nsteps = (int)((p_end - p_begin + KP - 1) / KP);
     if (nsteps > 0) {
@@ -1378,6 +1383,13 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const T* __restrict__ x
             for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[i], b[j], acc[i][j], 0, 0, 0);
+            if constexpr (BIAS) {
+                if (wc == 0) {                               // the waves of one row group share their dy rows: one of them sums
+                    const h16x8 ones = {(h16)1.f, (h16)1.f, (h16)1.f, (h16)1.f, (h16)1.f, (h16)1.f, (h16)1.f, (h16)1.f};
+#pragma unroll
+                    for (int i = 0; i < TM; ++i) accb[i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[i], ones, accb[i], 0, 0, 0);
+                }
+            }
         } else {
 #pragma unroll
             for (int ks = 0; ks < KP / 4; ++ks) {
@@ -1409,6 +1421,31 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const T* __restrict__ x
                 if (co < Cout && ci < Cin) out[(long)co * Cin + ci] = acc[i][j][r];
             }
         }
+    if constexpr (BIAS) {
+        if (wc == 0 && cib == 0 && r16 == 0) {               // every column of the ones tile holds the same sums: lane column 0 writes
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int co = co0 + (wr * TM + i) * 16 + 4 * g + r;
+                    if (co < Cout) bias_part[(long)split * Cout + co] = accb[i][r];
+                }
+        }
+    }
+}
+
+// db[co] = sum over the pixel ranges of the bias partials (fixed order)
+__global__ void wgrad_bias_reduce_kernel(const float* __restrict__ bias_part, int nsplit, int Cout, int cout_valid, float* __restrict__ db) {
+    const int co = blockIdx.x * blockDim.x + threadIdx.x;
+    if (co >= cout_valid) return;
+    float a[4] = {0.f, 0.f, 0.f, 0.f};
+    int k = 0;
+    for (; k + 3 < nsplit; k += 4) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) a[u] += bias_part[(long)(k + u) * Cout + co];
+    }
+    for (; k < nsplit; ++k) a[0] += bias_part[(long)k * Cout + co];
+    db[co] = (a[0] + a[1]) + (a[2] + a[3]);
 }
 
 
@@ -1940,6 +1977,7 @@ extern "C" long mu_conv_wgrad_workspace_bytes(int B, int H, int W, int Cin, int 
     wgrad_tile(Cin, Cout, &bco, &bci, taps, true);          // the fp16 plan of a 1x1 layer may use more pixel ranges
     wgrad_plan((long)B * H * W, Cin, Cout, taps, bco, bci, &nsplit, &pps);
     if ((long)nsplit * taps * Cout * Cin * (long)sizeof(float) > a) a = (long)nsplit * taps * Cout * Cin * sizeof(float);
+    if (taps == 1) a += (long)nsplit * Cout * (long)sizeof(float);          // bias partials of mu_conv_wgrad_bias
     int tco, tci;
     if (wgrad3_choose(H, W, Cin, Cout, taps, MU_F16, &tco, &tci)) {
         wgrad3_plan((long)B * H * W, Cin, Cout, tco, tci, &nsplit, &pps);
@@ -1955,11 +1993,15 @@ extern "C" long mu_conv_wgrad_workspace_bytes(int B, int H, int W, int Cin, int 
 
 template <typename T, int TAPS>
 static int wgrad_launch(const T* x, const T* dy, float* part, int B, int H, int W, int Cin, int Cout, long x_ld, long dy_ld, int bt,
-                        int nsplit, long pps, hipStream_t st, int bci = 0) {
+                        int nsplit, long pps, hipStream_t st, int bci = 0, float* bias_part = nullptr) {
     if constexpr (TAPS == 1 && sizeof(T) == 2) {
         if (wgrad_is_wide(bt)) {                            // bt x bci tiles (bci = 64 or 128)
             const int grid = ((Cout + bt - 1) / bt) * ((Cin + bci - 1) / bci) * nsplit;
-#define WG1(TM_, TN_) conv_wgrad_kernel<T, TM_, TN_, 2, 1><<<grid, 256, 0, st>>>(x, dy, part, B, H, W, Cin, Cout, x_ld, dy_ld, nsplit, pps)
+#define WG1(TM_, TN_)                                                                                                                  \
+    do {                                                                                                                               \
+        if (bias_part) conv_wgrad_kernel<T, TM_, TN_, 2, 1, true><<<grid, 256, 0, st>>>(x, dy, part, B, H, W, Cin, Cout, x_ld, dy_ld, nsplit, pps, bias_part); \
+        else conv_wgrad_kernel<T, TM_, TN_, 2, 1><<<grid, 256, 0, st>>>(x, dy, part, B, H, W, Cin, Cout, x_ld, dy_ld, nsplit, pps);    \
+    } while (0)
             if (bt == 192 && bci == 64) WG1(6, 2);
             else if (bt == 192) WG1(6, 4);
             else if (bci == 64) WG1(5, 2);
@@ -1968,6 +2010,7 @@ static int wgrad_launch(const T* x, const T* dy, float* part, int B, int H, int 
             return MU_OK;
         }
     }
+    if (bias_part) return MU_ERR_SHAPE;
     const int nt = ((Cout + bt - 1) / bt) * ((Cin + bt - 1) / bt);
     const int grid = TAPS * nt * nsplit;
     if (bt == 128) conv_wgrad_kernel<T, 4, 4, 2, TAPS><<<grid, 256, 0, st>>>(x, dy, part, B, H, W, Cin, Cout, x_ld, dy_ld, nsplit, pps);
@@ -1976,10 +2019,17 @@ static int wgrad_launch(const T* x, const T* dy, float* part, int B, int H, int 
     return MU_OK;
 }
 
-extern "C" int mu_conv_wgrad(const void* x, const void* dy, float* dw_oihw, int B, int H, int W, int Cin, int Cout, int taps,
-                             int cin_valid, int cout_valid, long x_ld, long dy_ld, void* workspace, long ws_bytes, int dtype,
-                             void* stream) {
+extern "C" int mu_conv_wgrad_bias_supported(int Cin, int Cout, int taps, int dtype) {
+    int bco, bci;
+    wgrad_tile(Cin, Cout, &bco, &bci, taps, dtype == MU_F16);
+    return dtype == MU_F16 && taps == 1 && Cin % 32 == 0 && Cout % 32 == 0 && wgrad_is_wide(bco) ? 1 : 0;
+}
+
+static int conv_wgrad_impl(const void* x, const void* dy, float* dw_oihw, float* db, int B, int H, int W, int Cin, int Cout, int taps,
+                           int cin_valid, int cout_valid, long x_ld, long dy_ld, void* workspace, long ws_bytes, int dtype,
+                           void* stream) {
     if (!x || !dy || !dw_oihw || !workspace || B <= 0 || H <= 0 || W <= 0) return MU_ERR_ARG;
+    if (db && !mu_conv_wgrad_bias_supported(Cin, Cout, taps, dtype)) return MU_ERR_SHAPE;
     if (Cin % 32 || Cout % 32 || x_ld < Cin || dy_ld < Cout || x_ld % 8 || dy_ld % 8) return MU_ERR_SHAPE;
     if (cin_valid <= 0 || cin_valid > Cin || cout_valid <= 0 || cout_valid > Cout) return MU_ERR_ARG;
     if (taps != 1 && taps != 9) return MU_ERR_ARG;
@@ -2033,7 +2083,13 @@ extern "C" int mu_conv_wgrad(const void* x, const void* dy, float* dw_oihw, int 
         return MU_ERR_WORKSPACE;
     } else if (dtype == MU_F16) {
         if (taps == 9) wgrad_launch<h16, 9>((const h16*)x, (const h16*)dy, part, B, H, W, Cin, Cout, x_ld, dy_ld, bco, nsplit, pps, st);
-        else wgrad_launch<h16, 1>((const h16*)x, (const h16*)dy, part, B, H, W, Cin, Cout, x_ld, dy_ld, bco, nsplit, pps, st, bci);
+        else {
+            float* bias_part = db ? part + (long)nsplit * Cout * Cin : nullptr;
+            if (db && ws_bytes < ((long)nsplit * Cout * Cin + (long)nsplit * Cout) * (long)sizeof(float)) return MU_ERR_WORKSPACE;
+            int rc = wgrad_launch<h16, 1>((const h16*)x, (const h16*)dy, part, B, H, W, Cin, Cout, x_ld, dy_ld, bco, nsplit, pps, st, bci, bias_part);
+            if (rc) return rc;
+            if (db) wgrad_bias_reduce_kernel<<<mu_cdiv(cout_valid, 64), 64, 0, st>>>(bias_part, nsplit, Cout, cout_valid, db);
+        }
     } else if (dtype == MU_F32) {
         if (taps == 9) wgrad_launch<float, 9>((const float*)x, (const float*)dy, part, B, H, W, Cin, Cout, x_ld, dy_ld, bco, nsplit, pps, st);
         else wgrad_launch<float, 1>((const float*)x, (const float*)dy, part, B, H, W, Cin, Cout, x_ld, dy_ld, bco, nsplit, pps, st);
@@ -2048,4 +2104,18 @@ extern "C" int mu_conv_wgrad(const void* x, const void* dy, float* dw_oihw, int 
     }
     MU_CHECK_LAUNCH();
     return MU_OK;
+}
+
+extern "C" int mu_conv_wgrad(const void* x, const void* dy, float* dw_oihw, int B, int H, int W, int Cin, int Cout, int taps,
+                             int cin_valid, int cout_valid, long x_ld, long dy_ld, void* workspace, long ws_bytes, int dtype,
+                             void* stream) {
+    return conv_wgrad_impl(x, dy, dw_oihw, nullptr, B, H, W, Cin, Cout, taps, cin_valid, cout_valid, x_ld, dy_ld, workspace, ws_bytes, dtype,
+                           stream);
+}
+
+extern "C" int mu_conv_wgrad_bias(const void* x, const void* dy, float* dw_oihw, float* db, int B, int H, int W, int Cin, int Cout,
+                                  int taps, int cin_valid, int cout_valid, long x_ld, long dy_ld, void* workspace, long ws_bytes,
+                                  int dtype, void* stream) {
+    if (!db) return MU_ERR_ARG;
+    return conv_wgrad_impl(x, dy, dw_oihw, db, B, H, W, Cin, Cout, taps, cin_valid, cout_valid, x_ld, dy_ld, workspace, ws_bytes, dtype, stream);
 }

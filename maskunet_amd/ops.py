@@ -145,6 +145,25 @@ def _wgrad_raw(x, gy, w_shape, taps, st=None, ws=None):
     return gw
 
 
+WGRAD_BIAS = os.environ.get("MU_WGRAD_BIAS", "1") != "0"        # debug switch: 0 = separate column-sum sweep for the bias gradients
+
+
+def _wgrad_bias_raw(x, gy, w_shape, taps):
+    """(dW, db) from one sweep where the library supports it (fp16 1x1 layers on the wide tiles), else None."""
+    B, H, W, Cin_p = x.shape
+    Cout_p = gy.shape[-1]
+    lib = _lib.load()
+    if not WGRAD_BIAS or not lib.mu_conv_wgrad_bias_supported(Cin_p, Cout_p, taps, dt(x)):
+        return None
+    O, I = w_shape[0], w_shape[1]
+    gw = torch.empty(w_shape, dtype=torch.float32, device=x.device)
+    gb = torch.empty(O, dtype=torch.float32, device=x.device)
+    ws = workspace(lib.mu_conv_wgrad_workspace_bytes(B, H, W, Cin_p, Cout_p, taps), x.device)
+    call("mu_conv_wgrad_bias", ptr(x), ptr(gy), ptr(gw), ptr(gb), B, H, W, Cin_p, Cout_p, taps, I, O, Cin_p, Cout_p, ptr(ws), ws.numel(),
+         dt(x), stream())
+    return gw, gb
+
+
 # Weight gradients on a side stream.  dW of a layer is needed by nobody until the backward pass is over, while the chain
 # dgrad -> BatchNorm backward -> ... of the layers below is mostly HBM-bound: the MFMA-bound weight-gradient kernels run
 # beside it (one 8-wave block per CU leaves room for the elementwise kernels' waves).  Ordering:
@@ -259,8 +278,12 @@ class _Conv(torch.autograd.Function):
         if side and gw is None:                  # behind the data gradient (both want every CU's LDS): it then runs beside the
             gw = _wgrad_side(x, gy, tuple(weight.shape), ctx.taps)      # HBM-bound kernels that follow on the main stream
         if ctx.needs_input_grad[1] and not side:
-            gw = _wgrad_raw(x, gy, tuple(weight.shape), ctx.taps)
-        if ctx.has_bias and ctx.needs_input_grad[2]:
+            both = _wgrad_bias_raw(x, gy, tuple(weight.shape), ctx.taps) if (ctx.has_bias and ctx.needs_input_grad[2]) else None
+            if both is not None:
+                gw, gb = both
+            else:
+                gw = _wgrad_raw(x, gy, tuple(weight.shape), ctx.taps)
+        if ctx.has_bias and ctx.needs_input_grad[2] and gb is None:
             gb = _colsum(gy, O)
         return gx, gw, gb, None
 
@@ -615,8 +638,12 @@ class _MaskAttention(torch.autograd.Function):
             ctx.wd = None
             gx = _conv_raw(dqkv4, wd, None, C, 1)
             call("mu_add", ptr(gx), ptr(dY), ptr(gx), gx.numel(), dt(gx), stream())
-        gw = _wgrad_raw(x, dqkv4, (3 * C, C, 1, 1), 1).view(3 * C, C)
-        gb = _colsum(dqkv4, 3 * C)
+        both = _wgrad_bias_raw(x, dqkv4, (3 * C, C, 1, 1), 1)       # projection weight and bias gradients from one sweep over dqkv
+        if both is not None:
+            gw, gb = both[0].view(3 * C, C), both[1]
+        else:
+            gw = _wgrad_raw(x, dqkv4, (3 * C, C, 1, 1), 1).view(3 * C, C)
+            gb = _colsum(dqkv4, 3 * C)
         return (gx, gw[:C], gb[:C], gw[C:2 * C], gb[C:2 * C], gw[2 * C:], gb[2 * C:], dg, db, None, None, None, None)
 
 

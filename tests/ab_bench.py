@@ -61,6 +61,13 @@ def main():
             (B, H, Cin, Cout), (x, dy, gw, ws) = shapes[phase], bufs[phase]
             return lambda: lib.mu_conv_wgrad(x.data_ptr(), dy.data_ptr(), gw.data_ptr(), B, H, H, Cin, Cout, 1, Cin, Cout, Cin, Cout, ws.data_ptr(), ws.numel(), 1, st)
         cases = [(f"1x1 wgrad {shapes[p]} {2e-6 * shapes[p][0] * shapes[p][1] ** 2 * (shapes[p][2] + shapes[p][3]):.0f} MB", p) for p in range(len(shapes))]
+    elif what == "rgb":
+        B, H, Cin, Cout = 64, 128, 32, 64
+        x = torch.randn(B, H, H, Cin, device=dev, dtype=dt); dy = torch.randn(B, H, H, Cout, device=dev, dtype=dt); gw = torch.empty(Cout, 3, 3, 3, device=dev)
+        ws = torch.empty(max(l.mu_conv_wgrad_workspace_bytes(B, H, H, Cin, Cout, 9) for l in libs.values()), dtype=torch.uint8, device=dev)
+        def mk(lib, phase):
+            return lambda: lib.mu_conv_wgrad(x.data_ptr(), dy.data_ptr(), gw.data_ptr(), B, H, H, Cin, Cout, 9, 3, Cout, Cin, Cout, ws.data_ptr(), ws.numel(), 1, st)
+        cases = [("first-layer wgrad 3->64 @128^2", 0)]
     elif what == "bn":
         M, C = (int(v) for v in os.environ.get("MU_BN_SHAPE", "1048576,128").split(","))
         x = torch.randn(M, C, device=dev, dtype=dt); y = torch.empty_like(x); gy = torch.randn_like(x); dx = torch.empty_like(x)
