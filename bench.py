@@ -6,8 +6,9 @@
 Metric (BASELINE.json): 128x128 images/sec, forward + backward, whole job (all N GPUs).
 Workload at N=1: configs[1] = "ADE20K semantic 128x128, batch=64, 1xMI355X fp16": UNet(3,150), B=64 per GPU,
 fp16 storage / fp32 accumulate, synthetic images/labels/key-masks, random-init weights, train mode (batch-stat
-BatchNorm, dropout 0.3), loss = mean pixel cross-entropy (torch op on the module's NCHW fp32 output; the loss is
-not part of the path) with a static loss scale for the fp16 backward.  N>1: one process per GPU,
+BatchNorm, dropout 0.3), loss = mean pixel cross-entropy on the module's NCHW fp32 output (maskunet_amd.CrossEntropyLoss,
+the reference's criterion as HIP kernels; --torch-loss = torch's F.cross_entropy) with a static loss scale
+for the fp16 backward.  N>1: one process per GPU,
 the same per-GPU batch (weak scaling), one bucketed RCCL all-reduce of the gradients per step overlapped with the
 backward (maskunet_amd/dp.py).
 
