@@ -51,7 +51,10 @@ __global__ __launch_bounds__(256) void conv_nt_kernel(const T* __restrict__ x, c
     constexpr int NA = (BCO * 4 + 255) / 256, NB = (BPX * 4) / 256;
     static_assert(BPX * 4 % 256 == 0, "pixel tile must be a multiple of 64");
 
-    __shared__ __attribute__((aligned(16))) char lds[2 * (BCO + BPX) * 64];
+    constexpr int OPITCH = BCO * 2 + 16;                    // fp16 epilogue: output tile staged as [pixel][channel] rows
+    constexpr int LDS0 = 2 * (BCO + BPX) * 64;
+    constexpr int LDSB = (sizeof(T) == 2 && BPX * OPITCH > LDS0) ? BPX * OPITCH : LDS0;
+    __shared__ __attribute__((aligned(16))) char lds[LDSB];
     char* As = lds;
     char* Bs = lds + 2 * BCO * 64;
 
@@ -148,6 +151,32 @@ __global__ __launch_bounds__(256) void conv_nt_kernel(const T* __restrict__ x, c
         __syncthreads();
     }
 
+    if constexpr (sizeof(T) == 2) {
+        // fp16: the block's tile goes through LDS (all fragment reads are behind the loop's last barrier) and leaves as 16-byte
+        // chunks of contiguous output rows (as conv_nt2_kernel) instead of 8-byte pieces of sixteen rows per store
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int px = (wc * TN + j) * 16 + r16;
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                const int co = (wr * TM + i) * 16 + 4 * g;
+                float v[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = acc[i][j][r] + (bias && co0 + co + r < Cout ? bias[co0 + co + r] : 0.f);
+                h16x4 o = {(h16)v[0], (h16)v[1], (h16)v[2], (h16)v[3]};
+                *reinterpret_cast<h16x4*>(lds + px * OPITCH + co * 2) = o;
+            }
+        }
+        __syncthreads();
+        constexpr int CH = BCO / 8;
+        for (int idx = tid; idx < BPX * CH; idx += 256) {
+            const int px = idx / CH, ch8 = idx - px * CH;
+            const long p = px0 + px;
+            if (p < Mtot && co0 + ch8 * 8 < Cout)
+                *reinterpret_cast<uint4*>(y + p * y_ld + co0 + ch8 * 8) = *reinterpret_cast<const uint4*>(lds + px * OPITCH + ch8 * 16);
+        }
+        return;
+    }
     // epilogue: lane holds 4 consecutive output channels of one pixel per (i,j) tile
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
