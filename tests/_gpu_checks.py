@@ -378,7 +378,9 @@ def check_attention(dtype, cases=None):
     gen = np.random.default_rng(7)
     out = []
     cases = cases or [(2, 8, 8, 32), (2, 16, 16, 64), (1, 24, 8, 128), (1, 16, 16, 256), (2, 40, 40, 64), (1, 12, 12, 128),
-                      (1, 32, 32, 256), (2, 64, 64, 64), (1, 36, 20, 128)]
+                      (1, 32, 32, 256), (2, 64, 64, 64), (1, 36, 20, 128),
+                      # batches of 8 / 16 images: every XCD owns whole images (XCD-aware block order)
+                      (8, 32, 32, 64), (16, 24, 24, 128), (8, 16, 16, 256), (8, 48, 48, 64)]
     for (B, H, W, C) in cases:
         m, sd = _attn_modules(C, gen)
         m.to(DEV).set_compute_dtype(dtype)
