@@ -6,6 +6,8 @@ step needs neither the NHWC->NCHW fp32 output conversion nor torch's log-softmax
 """
 from __future__ import annotations
 
+import os
+
 import torch
 from torch.autograd.function import once_differentiable
 
@@ -83,9 +85,29 @@ class _CrossEntropyNCHW(torch.autograd.Function):
         return dl, None, None, None
 
 
+NHWC_SOURCE = os.environ.get("MU_CE_NHWC_SOURCE", "1") != "0"     # debug switch: 0 = always read the NCHW tensor
+
+
+def _nhwc_source(t):
+    """The NHWC tensor a module output was converted from (ops.to_nchw), if `t` is still that untouched output."""
+    src = getattr(t, "_mu_nhwc", None)
+    if src is None or not NHWC_SOURCE or t.dim() != 4:
+        return None
+    x, C, version = src
+    if t._version != version or x.shape[0] != t.shape[0] or C != t.shape[1] or tuple(x.shape[1:3]) != tuple(t.shape[2:]):
+        return None
+    return x, C
+
+
 def cross_entropy(logits, labels, ignore_index=-100, grad_scale=1.0):
     """F.cross_entropy(logits, labels, ignore_index=...) (mean reduction) on the module output as it is: logits [B,C,H,W]
-    (fp32 or fp16, NCHW), labels int64 [B,H,W].  grad_scale multiplies the backward only (static fp16 loss scale)."""
+    (fp32 or fp16, NCHW), labels int64 [B,H,W].  grad_scale multiplies the backward only (static fp16 loss scale).
+    When `logits` is the untouched output of a maskunet_amd module, the loss reads the NHWC tensor that output was converted from
+    (identical values: the NCHW fp32 output is an exact widening of it) and the gradient flows into that tensor directly -- the
+    training step then skips the NCHW gradient and its transposition."""
+    src = _nhwc_source(logits)
+    if src is not None and labels.dim() == 3 and labels.dtype == torch.int64:
+        return pixel_cross_entropy_nhwc(src[0], labels, src[1], ignore_index, grad_scale)
     return _CrossEntropyNCHW.apply(logits, labels, int(ignore_index), float(grad_scale))
 
 

@@ -96,7 +96,12 @@ def u8_hwc_to_nhwc(img_u8, dtype):
 
 
 def to_nchw(x, C, out_dtype=torch.float32):
-    return _ToNCHW.apply(x, C, out_dtype)
+    """NHWC channel-padded -> NCHW [B,C,H,W] (the layout the reference's callers see).  The result remembers its NHWC source
+    (`_mu_nhwc` = (source, C, version)): maskunet_amd.cross_entropy / mean_iou use the source when they are handed the untouched
+    output, which is the same numbers in the layout the kernels prefer."""
+    y = _ToNCHW.apply(x, C, out_dtype)
+    y._mu_nhwc = (x, C, y._version)
+    return y
 
 
 # ------------------------------------------------------------------------------------------------

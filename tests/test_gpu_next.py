@@ -60,6 +60,46 @@ def test_cross_entropy_nchw_matches_torch(dtype, tol, shape, ignore):
     assert torch.allclose(xs.grad.float() / 64.0, xg.grad.float(), rtol=2e-3, atol=2e-7)
 
 
+def test_cross_entropy_on_module_output_uses_nhwc_source():
+    """criterion(model(x), labels): the loss on the untouched module output (read through its NHWC source) equals the loss on a copy
+    of that output (read as NCHW), value and parameter gradients; a modified output falls back to the NCHW kernels."""
+    import maskunet_amd
+    from maskunet_amd import losses
+    from tests import _gpu_checks as G
+    model, params, keeps, x, labels = G.build_unet(19, False, 501, torch.float16, True, 2)
+    x, labels = x.cuda(), labels.cuda()
+    labels[:, :3] = 255
+    crit = maskunet_amd.CrossEntropyLoss(ignore_index=255)
+
+    def run(copy):
+        for bn in model.modules():
+            if isinstance(bn, torch.nn.BatchNorm2d):
+                bn.reset_running_stats()
+        model.zero_grad(set_to_none=True)
+        out = model(x)
+        assert losses._nhwc_source(out) is not None
+        if copy:
+            out = out * 1.0                                   # same values, no NHWC source
+            assert losses._nhwc_source(out) is None
+        loss = crit(out, labels)
+        (loss * 256.0).backward()
+        return loss.item(), {k: v.grad.clone() for k, v in model.named_parameters() if v.grad is not None}
+
+    l0, g0 = run(False)
+    l1, g1 = run(True)
+    assert abs(l0 - l1) <= 1e-5 * max(1.0, abs(l1))
+    assert g0.keys() == g1.keys()
+    worst = 0.0
+    for k in g0:
+        if float(g1[k].abs().max()) > 1e-3 * 256:             # parameters with analytically zero gradients carry rounding noise only
+            c = 1.0 - float((g0[k].double() * g1[k].double()).sum() / (g0[k].double().norm() * g1[k].double().norm()))
+            worst = max(worst, c)
+    assert worst <= 1e-3, worst
+    out = model(x)
+    out.add_(0.0)                                             # in-place use invalidates the remembered source
+    assert losses._nhwc_source(out) is None
+
+
 def test_cross_entropy_nchw_rejects_bad_labels():
     import maskunet_amd
     x = torch.randn(2, 5, 4, 4, device="cuda")
