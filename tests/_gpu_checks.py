@@ -175,7 +175,7 @@ def check_conv_stats(dtype):
     from maskunet_amd import ops
     gen = np.random.default_rng(12)
     out = []
-    if dtype != torch.float16:
+    if dtype != torch.float16 or not ops.CONV_STATS:          # MU_CONV_STATS=0 (debug switch): nothing to check
         return [("conv_stats (fp16 only)", 0.0, 0.0)]
     for (B, H, W, Cin, Cout) in [(2, 16, 32, 64, 128), (3, 32, 32, 128, 256), (8, 64, 64, 64, 128)]:     # the last runs the persistent kernel
         x = ops.to_nhwc(_rnd(gen, B, Cin, H, W).to(DEV), dtype)
@@ -267,13 +267,15 @@ def check_bn_pair(dtype):
         y = ops.to_nchw(ops.bn_pair(ops.to_nhwc(xd, dtype), devs[0], devs[1]), C, torch.float32)
         y.backward(g.to(DEV))
         tol = TOL[dtype]
+        # the two layers one after the other (MU_BN_PAIR=0) carry fp16 rounding noise in the first layer's near-zero gradients
+        ztol = tol * 1e-2 if ops.BN_PAIR else tol
         tag = f"bnpair{(B, C, H, W, eps1, eps2)}"
         gscale = float(refs[1].weight.grad.abs().max())
         out += [(tag + " y", _err(y, yr.float()), tol), (tag + " dx", _rel_err(xd.grad, xr.grad.float()), tol),
                 (tag + " dgamma2", _rel_err(devs[1].weight.grad, refs[1].weight.grad.float()), tol),
                 (tag + " dbeta2", _rel_err(devs[1].bias.grad, refs[1].bias.grad.float()), tol),
-                (tag + " dgamma1", _err(devs[0].weight.grad, refs[0].weight.grad.float()) / gscale, tol * 1e-2),
-                (tag + " dbeta1", _err(devs[0].bias.grad, refs[0].bias.grad.float()) / gscale, tol * 1e-2)]
+                (tag + " dgamma1", _err(devs[0].weight.grad, refs[0].weight.grad.float()) / gscale, ztol),
+                (tag + " dbeta1", _err(devs[0].bias.grad, refs[0].bias.grad.float()) / gscale, ztol)]
         for i in range(2):
             out += [(tag + f" rmean{i}", _err(devs[i].running_mean, refs[i].running_mean.float()), tol),
                     (tag + f" rvar{i}", _err(devs[i].running_var, refs[i].running_var.float()), tol),

@@ -66,6 +66,8 @@ def test_cross_entropy_on_module_output_uses_nhwc_source():
     import maskunet_amd
     from maskunet_amd import losses
     from tests import _gpu_checks as G
+    if not losses.NHWC_SOURCE:
+        pytest.skip("MU_CE_NHWC_SOURCE=0")
     model, params, keeps, x, labels = G.build_unet(19, False, 501, torch.float16, True, 2)
     x, labels = x.cuda(), labels.cuda()
     labels[:, :3] = 255
