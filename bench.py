@@ -90,6 +90,8 @@ def main():
     ap.add_argument("--fused-loss", action="store_true",
                     help="SURVEY 8-f1 path: fused NHWC cross-entropy on the internal logits instead of module output + torch CE")
     ap.add_argument("--torch-loss", action="store_true", help="torch's F.cross_entropy on the module output instead of maskunet_amd.CrossEntropyLoss")
+    ap.add_argument("--graph", action="store_true", help="replay the step (forward + criterion + backward) as one HIP graph "
+                    "(maskunet_amd.GraphedStep; single GPU; pays off below B ~ 16 where host enqueue time is the bound)")
     ap.add_argument("--optimizer", action="store_true", help="also run the fused AdamW step (8-f2) inside the timed step")
     args = ap.parse_args()
 
@@ -130,7 +132,18 @@ def main():
     criterion = maskunet_amd.CrossEntropyLoss()      # the reference's nn.CrossEntropyLoss() on the module output (ade_semantic.py:377,399)
     opt = maskunet_amd.FusedAdamW(model.parameters(), lr=5e-5, weight_decay=1e-1) if args.optimizer else None
 
+    graphed = None
+    if args.graph:
+        if world > 1 or args.fused_loss or args.three_head or args.torch_loss:
+            raise SystemExit("--graph: single GPU, maskunet_amd.CrossEntropyLoss, 1-head model only")
+        graphed = maskunet_amd.GraphedStep(model, criterion, x, labels, loss_scale=scale)
+
     def step():
+        if graphed is not None:
+            loss = graphed(x, labels)
+            if opt is not None:
+                opt.step(grad_scale=scale)
+            return loss
         if args.fused_loss and not args.three_head:
             if world > 1:
                 net._arm()
@@ -200,7 +213,7 @@ def main():
                                    f"{'3-head' if args.three_head else '1-head'} MaskAttn-UNet fwd+bwd, train mode",
                        "global_batch": args.batch * world, "parallelism": f"dp{world}", "loss_scale": scale,
                        "loss": "fused NHWC CE kernel" if args.fused_loss else ("torch CE on module output" if args.torch_loss else
-                                                                                "maskunet_amd.CrossEntropyLoss on module output"), "optimizer_in_step": bool(opt)},
+                                                                                "maskunet_amd.CrossEntropyLoss on module output"), "optimizer_in_step": bool(opt), "hip_graph": bool(args.graph)},
             "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
                          "frac": round(achieved / peak, 4), "traffic": traffic,
                          "kernel": f"attn_bwd_dkv3_kernel (self_attention6 dK/dV sweep, N={N6}, C=64)",

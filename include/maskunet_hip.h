@@ -145,6 +145,11 @@ int mu_upcat_bwd(const void* dy, void* dx, void* dskip, int B, int h, int w, int
  * The backward is the same call on the gradient with the same seed/mask. mask_out (may be NULL) receives keep. */
 int mu_dropout(const void* x, void* y, long n, float p, unsigned long long seed, const unsigned char* mask, unsigned char* mask_out,
                int dtype, void* stream);
+/* the same with a device-resident step counter mixed into the seed (seed_step[0], read by the kernel): a training step captured in
+ * a HIP graph bakes `seed` into the launch, the counter -- bumped inside the graph -- gives every replay its own mask, and the
+ * backward launch of the same replay regenerates the same one.  seed_step NULL = mu_dropout. */
+int mu_dropout_step(const void* x, void* y, long n, float p, unsigned long long seed, const unsigned long long* seed_step,
+                    const unsigned char* mask, unsigned char* mask_out, int dtype, void* stream);
 
 /* out = a + b over n elements (joins the residual and projection gradients of the attention block, :187) */
 int mu_add(const void* a, const void* b, void* out, long n, int dtype, void* stream);

@@ -52,6 +52,7 @@ SIGNATURES = {
     "mu_upcat_fwd": (I, [P, P, P, I, I, I, I, I, I, P]),
     "mu_upcat_bwd": (I, [P, P, P, I, I, I, I, I, I, P]),
     "mu_dropout": (I, [P, P, L, F, c_ulonglong, P, P, I, P]),
+    "mu_dropout_step": (I, [P, P, L, F, c_ulonglong, P, P, P, I, P]),
     "mu_add": (I, [P, P, P, L, I, P]),
     "mu_attn_fwd": (I, [P, P, P, P, P, P, P, P, P, P, P, I, I, I, I, F, I, P]),
     "mu_attn_bwd_workspace_bytes": (L, [I, I, I]),

@@ -412,9 +412,11 @@ __device__ __forceinline__ uint64_t splitmix64(uint64_t z) {
 
 template <typename T>
 __global__ __launch_bounds__(256) void dropout_kernel(const T* __restrict__ x, T* __restrict__ y, long nvec, float p, float scale,
-                                                      uint64_t seed, const uint8_t* __restrict__ mask, uint8_t* __restrict__ mask_out) {
+                                                      uint64_t seed, const uint8_t* __restrict__ mask, uint8_t* __restrict__ mask_out,
+                                                      const unsigned long long* __restrict__ seed_step) {
     constexpr int N = Vec16<T>::N;
     const uint32_t thr = (uint32_t)(p * 65536.0f);
+    if (seed_step) seed ^= splitmix64(0x9E3779B97F4A7C15ull * (uint64_t)seed_step[0]);     // per-replay stream of a captured step
     for (long v = (long)blockIdx.x * 256 + threadIdx.x; v < nvec; v += (long)gridDim.x * 256) {
         Vec16<T> a, o;
         a.load(x + v * N);
@@ -438,17 +440,25 @@ __global__ __launch_bounds__(256) void dropout_kernel(const T* __restrict__ x, T
     }
 }
 
+extern "C" int mu_dropout_step(const void* x, void* y, long n, float p, unsigned long long seed, const unsigned long long* seed_step,
+                               const unsigned char* mask, unsigned char* mask_out, int dtype, void* stream);
+
 extern "C" int mu_dropout(const void* x, void* y, long n, float p, unsigned long long seed, const unsigned char* mask,
                           unsigned char* mask_out, int dtype, void* stream) {
+    return mu_dropout_step(x, y, n, p, seed, nullptr, mask, mask_out, dtype, stream);
+}
+
+extern "C" int mu_dropout_step(const void* x, void* y, long n, float p, unsigned long long seed, const unsigned long long* seed_step,
+                               const unsigned char* mask, unsigned char* mask_out, int dtype, void* stream) {
     if (!x || !y || n <= 0 || p < 0.f || p >= 1.f) return MU_ERR_ARG;
     hipStream_t st = (hipStream_t)stream;
     float scale = 1.0f / (1.0f - p);
     if (dtype == MU_F32) {
         if (n % 4) return MU_ERR_SHAPE;
-        dropout_kernel<float><<<ew_grid(n / 4), 256, 0, st>>>((const float*)x, (float*)y, n / 4, p, scale, seed, mask, mask_out);
+        dropout_kernel<float><<<ew_grid(n / 4), 256, 0, st>>>((const float*)x, (float*)y, n / 4, p, scale, seed, mask, mask_out, seed_step);
     } else if (dtype == MU_F16) {
         if (n % 8) return MU_ERR_SHAPE;
-        dropout_kernel<h16><<<ew_grid(n / 8), 256, 0, st>>>((const h16*)x, (h16*)y, n / 8, p, scale, seed, mask, mask_out);
+        dropout_kernel<h16><<<ew_grid(n / 8), 256, 0, st>>>((const h16*)x, (h16*)y, n / 8, p, scale, seed, mask, mask_out, seed_step);
     } else return MU_ERR_ARG;
     MU_CHECK_LAUNCH();
     return MU_OK;

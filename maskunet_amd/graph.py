@@ -1,0 +1,71 @@
+"""Whole training step (forward, criterion, backward) captured in ONE HIP graph.
+
+One step of the path is ~700 kernel launches; enqueueing them from Python costs ~9 ms of host time, which is hidden behind the GPU at
+B >= 32 per GPU and becomes the bound below B ~ 16.  Every launch of the path is stream-ordered on torch's current
+stream with no host synchronisation, so the step can be captured (torch.cuda.CUDAGraph == hipGraph) and replayed with a single launch:
+
+    step = maskunet_amd.GraphedStep(model, criterion, example_inputs, example_labels, loss_scale=1024.0)
+    for inputs, labels in loader:
+        loss = step(inputs, labels)          # gradients are in p.grad afterwards (the same tensors every replay)
+        optimizer.step()                     # eager, after the replay; do NOT zero_grad(set_to_none=True) between replays
+
+What changes under capture: the dropout seed drawn on the host is baked into the graph, so a device step counter -- incremented inside the
+graph -- is mixed into it (mu_dropout_step); BatchNorm running statistics / step counters are updated on the device as always; the
+attention keep-masks are whatever the modules hold at capture time (set_keep_masks / the lazily drawn, cached masks of the reference).
+Not for maskunet_amd.DataParallel (its bucket hooks launch collectives on another stream).
+"""
+from __future__ import annotations
+
+import torch
+
+from . import ops
+
+
+class GraphedStep:
+    def __init__(self, model, criterion, example_inputs, example_labels, loss_scale: float = 1.0, warmup: int = 2):
+        if not example_inputs.is_cuda:
+            raise RuntimeError("GraphedStep needs CUDA example inputs (the HIP path has no CPU fallback)")
+        self.model, self.criterion, self.scale = model, criterion, float(loss_scale)
+        named = [(n, p) for n, p in model.named_parameters() if p.requires_grad]
+        self.names, self.params = [n for n, _ in named], [p for _, p in named]
+        self.inputs = example_inputs.detach().clone()
+        self.labels = example_labels.detach().clone()
+        dev = self.inputs.device
+        self.step_counter = torch.zeros(1, dtype=torch.int64, device=dev)
+        # eager warm-up on a side stream (allocator pools, workspaces, lazily drawn masks), as torch's graph recipe prescribes
+        side = torch.cuda.Stream(dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side):
+            for _ in range(max(int(warmup), 1)):
+                self._body()
+                model.zero_grad(set_to_none=True)
+        torch.cuda.current_stream(dev).wait_stream(side)
+        torch.cuda.synchronize(dev)
+        self.graph = torch.cuda.CUDAGraph()
+        ops.SEED_STEP = self.step_counter
+        try:
+            with torch.cuda.graph(self.graph):
+                self.step_counter.add_(1)
+                self.loss, self.outputs = self._body()
+        finally:
+            ops.SEED_STEP = None
+
+    def _body(self):
+        # The forward runs on fresh leaves aliasing the parameters (functional_call), and the gradients are taken with
+        # torch.autograd.grad.  A parameter's AccumulateGrad node is bound to the stream of the forward that created it; one kept alive
+        # by an earlier eager step (e.g. through a loss tensor the caller still holds) makes the engine synchronise the capture stream
+        # with that stream, which is not capturable (segfault in hipStreamEndCapture on this stack).  Fresh leaves have fresh nodes.
+        fresh = {n: p.detach().requires_grad_(True) for n, p in zip(self.names, self.params)}
+        out = torch.func.functional_call(self.model, fresh, (self.inputs,))
+        sem = out[0] if isinstance(out, (tuple, list)) else out
+        loss = self.criterion(sem, self.labels)
+        grads = torch.autograd.grad(loss * self.scale if self.scale != 1.0 else loss, list(fresh.values()), allow_unused=True)
+        for p, g in zip(self.params, grads):
+            p.grad = g
+        return loss.detach(), sem.detach()
+
+    def __call__(self, inputs, labels):
+        self.inputs.copy_(inputs, non_blocking=True)
+        self.labels.copy_(labels, non_blocking=True)
+        self.graph.replay()
+        return self.loss

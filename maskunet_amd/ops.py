@@ -499,6 +499,9 @@ def upcat(x, skip):
     return _UpCat.apply(x, skip)
 
 
+SEED_STEP = None        # int64 device tensor [1] or None; set by maskunet_amd.graph.GraphedStep during capture
+
+
 class _Dropout(torch.autograd.Function):
     """nn.Dropout(p) in training (ade_semantic.py:273,304,307).  mask (uint8, same shape) overrides the generator."""
 
@@ -508,8 +511,9 @@ class _Dropout(torch.autograd.Function):
         y = torch.empty_like(x)
         if mask is not None:
             mask = mask.to(device=x.device, dtype=torch.uint8).contiguous()
-        call("mu_dropout", ptr(x), ptr(y), x.numel(), float(p), int(seed), ptr(mask), None, dt(x), stream())
-        ctx.p, ctx.seed = p, seed
+        step = SEED_STEP                                     # device step counter while a step is being captured (graph.py)
+        call("mu_dropout_step", ptr(x), ptr(y), x.numel(), float(p), int(seed), ptr(step), ptr(mask), None, dt(x), stream())
+        ctx.p, ctx.seed, ctx.step = p, seed, step
         ctx.save_for_backward(mask)
         return y
 
@@ -519,7 +523,7 @@ class _Dropout(torch.autograd.Function):
         (mask,) = ctx.saved_tensors
         gy = gy.contiguous()
         gx = torch.empty_like(gy)
-        call("mu_dropout", ptr(gy), ptr(gx), gy.numel(), float(ctx.p), int(ctx.seed), ptr(mask), None, dt(gy), stream())
+        call("mu_dropout_step", ptr(gy), ptr(gx), gy.numel(), float(ctx.p), int(ctx.seed), ptr(ctx.step), ptr(mask), None, dt(gy), stream())
         return gx, None, None, None
 
 

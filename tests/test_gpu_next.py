@@ -102,6 +102,42 @@ def test_cross_entropy_on_module_output_uses_nhwc_source():
     assert losses._nhwc_source(out) is None
 
 
+def test_graphed_step_equals_eager_step():
+    """maskunet_amd.GraphedStep (forward + criterion + backward as one HIP graph) reproduces the eager step bit for bit when dropout is
+    off, and draws a new dropout mask per replay when it is on (device step counter mixed into the captured seed)."""
+    import maskunet_amd
+    from tests import _gpu_checks as G
+    model, params, keeps, x, labels = G.build_unet(19, False, 502, torch.float16, True, 2)
+    x, labels = x.cuda(), labels.cuda()
+    crit = maskunet_amd.CrossEntropyLoss()
+    state = {k: v.clone() for k, v in model.state_dict().items()}
+    model.dropout.p = 0.0
+    loss_e = crit(model(x), labels)
+    (loss_e * 128.0).backward()
+    ge = {k: v.grad.clone() for k, v in model.named_parameters() if v.grad is not None}
+    rm_e = model.downsample1.maxpool_conv[3].running_mean.clone()
+    model.zero_grad(set_to_none=True)
+    model.load_state_dict(state)
+    step = maskunet_amd.GraphedStep(model, crit, x, labels, loss_scale=128.0, warmup=1)
+    model.load_state_dict(state)                              # warm-up and capture advanced the BatchNorm buffers
+    loss_g = step(x, labels)
+    assert loss_g.item() == loss_e.item()
+    for k, v in model.named_parameters():
+        if k in ge:
+            assert torch.equal(v.grad, ge[k]), k
+    assert torch.equal(model.downsample1.maxpool_conv[3].running_mean, rm_e)
+    # other inputs through the same graph
+    x2 = torch.rand_like(x)
+    l2 = step(x2, labels).item()
+    model.zero_grad(set_to_none=True)
+    # dropout on: a fresh capture; two replays on the same inputs see different masks
+    model.dropout.p = 0.3
+    step = maskunet_amd.GraphedStep(model, crit, x, labels, loss_scale=128.0, warmup=1)
+    a = step(x, labels).item()
+    b = step(x, labels).item()
+    assert a != b and a == a and b == b and l2 == l2
+
+
 def test_cross_entropy_nchw_rejects_bad_labels():
     import maskunet_amd
     x = torch.randn(2, 5, 4, 4, device="cuda")
