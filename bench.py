@@ -139,6 +139,7 @@ def main():
         graphed = maskunet_amd.GraphedStep(model, criterion, x, labels, loss_scale=scale)
 
     def step():
+        nonlocal graphed
         if graphed is not None:
             loss = graphed(x, labels)
             if opt is not None:
@@ -180,6 +181,11 @@ def main():
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     probe = _lib.PROBE
+    if graphed is not None and rank == 0:       # a replayed graph makes no Python calls to probe: time the kernel in two eager steps
+        graphed = None                          # (after the timed region)
+        for _ in range(2):
+            step()
+        torch.cuda.synchronize()
     _lib.PROBE = None
     if world > 1:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
