@@ -123,3 +123,35 @@ def test_training_step_is_bitwise_reproducible():
         assert torch.equal(out, runs[0][0]), "forward output differs between identical runs"
         for n, gref in runs[0][1].items():
             assert torch.equal(grads[n], gref), f"gradient of {n} differs between identical runs"
+
+
+def test_training_trajectory_matches_oracle():
+    """Four optimisation steps (fp32 compute, FusedAdamW, maskunet_amd.CrossEntropyLoss) follow the CPU oracle trained with
+    torch.optim.AdamW on the same batch: the loss after every step agrees, and it moves by far more than the tolerance."""
+    import maskunet_amd
+    from oracle import maskunet_oracle as O
+    from tests import _gpu_checks as G
+    model, params, keeps, x, labels = G.build_unet(19, False, 610, torch.float32, True, 2)
+    p = {k: (v.clone().requires_grad_(True) if v.dtype.is_floating_point and "running" not in k else v.clone()) for k, v in params.items()}
+    lr, wd = 1e-3, 1e-2
+    ref_opt = torch.optim.AdamW([v for v in p.values() if v.requires_grad], lr=lr, weight_decay=wd)
+    ref_losses = []
+    for _ in range(4):
+        loss = O.pixel_cross_entropy(O.unet_forward(p, x, keeps, training=True), labels)
+        ref_opt.zero_grad(set_to_none=True)
+        loss.backward()
+        ref_opt.step()
+        ref_losses.append(float(loss.detach()))
+    opt = maskunet_amd.FusedAdamW(model.parameters(), lr=lr, weight_decay=wd)
+    crit = maskunet_amd.CrossEntropyLoss()
+    xd, yd = x.cuda(), labels.cuda()
+    got = []
+    for _ in range(4):
+        loss = crit(model(xd), yd)
+        model.zero_grad(set_to_none=True)
+        loss.backward()
+        opt.step()
+        got.append(float(loss.detach()))
+    assert abs(ref_losses[-1] - ref_losses[0]) > 2e-2, ref_losses           # the steps do change the loss
+    for a, b in zip(got, ref_losses):
+        assert abs(a - b) <= 2e-3 * max(1.0, abs(b)), (got, ref_losses)
