@@ -91,7 +91,7 @@ def main():
                     help="SURVEY 8-f1 path: fused NHWC cross-entropy on the internal logits instead of module output + torch CE")
     ap.add_argument("--torch-loss", action="store_true", help="torch's F.cross_entropy on the module output instead of maskunet_amd.CrossEntropyLoss")
     ap.add_argument("--graph", action="store_true", help="replay the step (forward + criterion + backward) as one HIP graph "
-                    "(maskunet_amd.GraphedStep; single GPU; pays off below B ~ 16 where host enqueue time is the bound)")
+                    "(maskunet_amd.GraphedStep; single GPU)")
     ap.add_argument("--optimizer", action="store_true", help="also run the fused AdamW step (8-f2) inside the timed step")
     args = ap.parse_args()
 
@@ -135,6 +135,8 @@ def main():
     graphed = None
     if args.graph:
         if world > 1 or args.fused_loss or args.three_head or args.torch_loss:
+            # N > 1 is not offered: a replay runs no autograd hooks (the bucket all-reduces would follow it instead of overlapping the
+            # backward), and the only multi-rank rig of this round -- two gloo ranks sharing one GPU -- ran it 10x slower than eager
             raise SystemExit("--graph: single GPU, maskunet_amd.CrossEntropyLoss, 1-head model only")
         graphed = maskunet_amd.GraphedStep(model, criterion, x, labels, loss_scale=scale)
 
@@ -181,8 +183,8 @@ def main():
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     probe = _lib.PROBE
-    if graphed is not None and rank == 0:       # a replayed graph makes no Python calls to probe: time the kernel in two eager steps
-        graphed = None                          # (after the timed region)
+    if graphed is not None:                     # a replayed graph makes no Python calls to probe: time the kernel in two eager steps
+        graphed = None                          # after the timed region (on every rank: eager steps all-reduce)
         for _ in range(2):
             step()
         torch.cuda.synchronize()
