@@ -12,10 +12,14 @@ for the fp16 backward.  N>1: one process per GPU,
 the same per-GPU batch (weak scaling), one bucketed RCCL all-reduce of the gradients per step overlapped with the
 backward (maskunet_amd/dp.py).
 
-One JSON line on rank 0.  `roofline` is for the dominant kernel group (the N=16384 attention block), its duration
-measured live with HIP events on the launch stream during the timed steps.  `cpu_baseline` is the CPU oracle
-(oracle/maskunet_oracle.py == restatement of the reference's PyTorch CPU path) timed on this host's cores on a
-bounded sample (B=1) -- a reported baseline, not the target.
+One JSON line on rank 0.
+  * `roofline`: the dominant kernel (the dK/dV sweep of self_attention6), duration measured live with HIP events on the launch
+    stream during the timed steps.  `achieved`/`frac` count the matrix products the kernel EXECUTES (masked keys are skipped
+    exactly, so they are not work); the SURVEY 8-d4 full-key-set convention is carried as `algorithmic_*`.
+  * `step_roofline`: the whole step and the forward alone against both rooflines (SURVEY 8-d3/d4 per-image figures: 136.2 GF /
+    200.7 MB forward, ~450 GF / 602 MB forward+backward at 128x128, c_out=150; computed analytically for other shapes).
+  * `cpu_baseline`: the CPU oracle (oracle/maskunet_oracle.py == restatement of the reference's PyTorch CPU path) timed on this
+    host's cores on configs[0] (B=4, fp32, train mode) -- a reported baseline, not the target.
 """
 import argparse
 import json
@@ -32,35 +36,80 @@ sys.path.insert(0, ROOT)
 
 PEAK_MFMA_TFLOPS = {"fp16": 2500.0, "fp32": 157.3}      # dense, MI355X_MICROARCH.md
 PEAK_HBM_GBS = 8000.0
+DOMINANT_KERNEL = "attn_bwd_dkv3_kernel"
+TRAFFIC_JSON = "r01_dkv_traffic.json"
 
 
-def synth(B, c_out, hw, seed, device):
-    g = torch.Generator().manual_seed(seed)
-    x = torch.rand((B, 3, hw, hw), generator=g)
-    y = torch.randint(0, c_out, (B, hw, hw), generator=g)
+def synth(B, c_out, hw, seed, device, ignore_frac=0.0):
+    """SURVEY 8-d2 synthetic batch from numpy default_rng(seed) (42 = the reference's nominal seed, ade_semantic.py:24; + rank for
+    the other ranks): images uniform [0,1) like ToTensor(), int64 labels (a fraction set to 255 for the Cityscapes shape), one
+    Bernoulli(0.5) key keep-mask per attention block."""
+    import numpy as np
+    rng = np.random.default_rng(seed)
+    x = torch.from_numpy(rng.random((B, 3, hw, hw), dtype=np.float32))
+    lab = rng.integers(0, c_out, (B, hw, hw))
+    if ignore_frac > 0:
+        lab[rng.random((B, hw, hw)) < ignore_frac] = 255
+    y = torch.from_numpy(lab.astype(np.int64))
     ns = [(hw // 2) ** 2, (hw // 4) ** 2, (hw // 8) ** 2, (hw // 4) ** 2, (hw // 2) ** 2, hw ** 2]
-    keeps = [torch.randint(0, 2, (B, n), generator=g, dtype=torch.uint8) for n in ns]
+    keeps = [torch.from_numpy(rng.integers(0, 2, (B, n)).astype(np.uint8)) for n in ns]
     return x.to(device), y.to(device), [k.to(device) for k in keeps]
 
 
-def cpu_baseline(c_out, hw, seconds_budget=20.0):
-    """Oracle (kind 'port') fwd+bwd, fp32, train mode, on all host cores; bounded sample B=1."""
+def algorithmic_counts(c_out, hw, three_head=False, embed_dim=16):
+    """Per-image algorithmic FLOPs and HBM elements of the forward (SURVEY 8-d4 convention: every conv reads its input and writes
+    its output once, every BatchNorm-apply reads + writes once, attention moves 8*N*C elements and NO N x N tensor, the final
+    LayerNorm reads + writes + two affine tensors).  Reproduces the survey's 136.2 GF and 100.4 M elements at 128x128, c_out=150."""
+    convs, bns = [], []
+
+    def block(cin, cout, h, mid=None):
+        mid = mid or cout
+        convs.extend([(cin, mid, h, 9), (mid, cout, h, 9)])
+        bns.extend([(mid, h), (cout, h)])
+
+    block(3, 64, hw)
+    for cin, cout, h in ((64, 128, hw // 2), (128, 256, hw // 4), (256, 256, hw // 8)):
+        block(cin, cin, h)
+        block(cin, cout, h)
+        bns.append((cout, h))
+    for cin, cout in ((256, 512), (512, 512), (512, 256)):
+        block(cin, cout, hw // 8)
+    for cin, cout, h in ((512, 128, hw // 4), (256, 64, hw // 2), (128, 64, hw)):
+        block(cin, cin, h)
+        block(cin, cout, h, cin // 2)
+        bns.append((cout, h))
+    heads = [(64, c_out, 1)] + ([(64, embed_dim, 1), (c_out, 32, 9), (32, 1, 1)] if three_head else [])
+    attn = [(128, hw // 2), (256, hw // 4), (256, hw // 8), (128, hw // 4), (64, hw // 2), (64, hw)]
+    conv_fl = sum(2.0 * ci * co * h * h * t for ci, co, h, t in convs) + sum(2.0 * ci * co * t * hw * hw for ci, co, t in heads)
+    proj_fl = sum(6.0 * c * c * h * h for c, h in attn)
+    attn_fl = sum(4.0 * float(h * h) ** 2 * c for c, h in attn)
+    elems = (sum((ci + co) * h * h for ci, co, h, _ in convs) + sum((ci + co) * hw * hw for ci, co, _ in heads)
+             + sum(2 * c * h * h for c, h in bns) + 2 * sum(co for _, co, _ in heads[:3 if three_head else 1]) * hw * hw
+             + sum(8 * c * h * h for c, h in attn) + 4 * 64 * hw * hw)
+    return {"conv_proj_flops": conv_fl + proj_fl, "attn_flops": attn_fl, "fwd_flops": conv_fl + proj_fl + attn_fl, "fwd_elems": elems,
+            # backward = 2x the conv/projection products (data + weight gradient) and 2.5x attention (recompute), traffic ~2x forward
+            "step_flops": 3.0 * (conv_fl + proj_fl) + 3.5 * attn_fl, "step_elems": 3 * elems}
+
+
+def cpu_baseline(c_out, hw, B=4, iters=3, budget_s=150.0):
+    """Oracle (kind 'port') fwd+bwd on the host cores: configs[0] = "ADE20K semantic 128x128, batch=4, PyTorch CPU reference"
+    (fp32, train mode, B=4, warm-up 1 + median of >= 3 iterations, inputs from default_rng(42))."""
     from oracle import maskunet_oracle as O
     # torch's intra-op scaling collapses with hundreds of threads on this path (256 threads on the GPU box's
     # host: 232 s/iteration); 32 threads is the fastest setting found, `cores` reports the threads actually used
     cores = min(os.cpu_count() or 1, 32)
     torch.set_num_threads(cores)
-    B = 1
     shapes = O.unet_state_shapes(3, c_out, False, hw=hw)
     p = O.make_params(shapes, 1)
     for v in p.values():
         if v.dtype.is_floating_point:
             v.requires_grad_(True)
-    keeps = O.make_keeps(2, B, hw)
-    x, labels = O.make_inputs(3, B, c_out, hw)
+    x, labels, keeps = synth(B, c_out, hw, 42, "cpu")
     times = []
     t_all = time.time()
-    for it in range(3):
+    for it in range(iters + 1):
+        if it >= 2 and time.time() - t_all + times[-1] > budget_s:      # bounded sample: stop early on a slow host (>= 1 timed iteration)
+            break
         t0 = time.time()
         out = O.unet_forward(p, x, keeps, training=True)
         loss = O.pixel_cross_entropy(out, labels)
@@ -68,11 +117,10 @@ def cpu_baseline(c_out, hw, seconds_budget=20.0):
         for v in p.values():
             v.grad = None
         times.append(time.time() - t0)
-        if it >= 1 and time.time() - t_all > seconds_budget:
-            break
-    steady = sorted(times[1:])[len(times[1:]) // 2] if len(times) > 1 else times[0]
+    steady = sorted(times[1:])[len(times[1:]) // 2]
     return {"value": round(B / steady, 4), "unit": "images/sec", "cores": cores, "kind": "port",
-            "sample": f"oracle fwd+bwd, fp32, train mode, B={B}, c_out={c_out}, {hw}x{hw}, median of {max(len(times) - 1, 1)} after 1 warm-up"}
+            "sample": f"configs[0]: oracle fwd+bwd, fp32, train mode, B={B}, c_out={c_out}, {hw}x{hw}, default_rng(42) inputs, "
+                      f"median of {len(times) - 1} after 1 warm-up ({steady:.2f} s/iteration)"}
 
 
 def main():
@@ -107,7 +155,11 @@ def main():
         else:
             dist.init_process_group(backend)
             local = local % max(ndev, 1)
-    assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    if world != args.gpus:
+        # N > 1 is launched by `python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...` (one rank per GPU); a bare
+        # `bench.py --gpus N` must not silently bench one GPU
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: launch N>1 with torch.distributed.run "
+                         f"(--nproc-per-node {args.gpus}), which sets RANK/LOCAL_RANK/WORLD_SIZE")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
 
@@ -118,7 +170,7 @@ def main():
     model = (maskunet_amd.InstanceUNet(3, args.c_out, 16, hw=args.hw) if args.three_head
              else maskunet_amd.UNet(3, args.c_out, hw=args.hw)).to(dev)
     model.set_compute_dtype(dtype).train()
-    x, labels, keeps = synth(args.batch, args.c_out, args.hw, 42 + rank, dev)
+    x, labels, keeps = synth(args.batch, args.c_out, args.hw, 42 + rank, dev, ignore_frac=0.1 if args.three_head else 0.0)
     model.set_keep_masks(keeps)
     net = maskunet_amd.DataParallel(model) if world > 1 else model
     scale = args.loss_scale if dtype == torch.float16 else 1.0
@@ -129,7 +181,8 @@ def main():
         blocks = torch.randint(0, 21, (args.batch, args.hw // 16, args.hw // 16), generator=g)
         inst_labels = blocks.repeat_interleave(16, 1).repeat_interleave(16, 2).to(dev)
         inst_loss = maskunet_amd.InstanceContrastiveLoss(margin=1.0, ignore_index=255)
-    criterion = maskunet_amd.CrossEntropyLoss()      # the reference's nn.CrossEntropyLoss() on the module output (ade_semantic.py:377,399)
+    criterion = maskunet_amd.CrossEntropyLoss(ignore_index=255) if args.three_head else maskunet_amd.CrossEntropyLoss()
+    # ^ the reference's nn.CrossEntropyLoss() on the module output (ade_semantic.py:377,399)
     opt = maskunet_amd.FusedAdamW(model.parameters(), lr=5e-5, weight_decay=1e-1) if args.optimizer else None
 
     graphed = None
@@ -141,7 +194,7 @@ def main():
         graphed = maskunet_amd.GraphedStep(model, criterion, x, labels, loss_scale=scale)
 
     def step():
-        nonlocal graphed
+        nonlocal graphed, fwd_events
         if graphed is not None:
             loss = graphed(x, labels)
             if opt is not None:
@@ -153,7 +206,13 @@ def main():
             loss = maskunet_amd.pixel_cross_entropy_nhwc(model.logits_nhwc(x), labels, args.c_out, grad_scale=scale)
             loss.backward()
         else:
+            if fwd_events is not None:
+                ef0, ef1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                ef0.record()
             out = net(x)
+            if fwd_events is not None:
+                ef1.record()
+                fwd_events.append((ef0, ef1))
             sem = out[0] if args.three_head else out
             loss = F.cross_entropy(sem, labels) if args.torch_loss else criterion(sem, labels)
             if args.three_head:          # city_instance.py:372-377: seg_loss + LAMBDA_IE * InstanceContrastiveLoss(embeddings, inst_labels)
@@ -166,8 +225,10 @@ def main():
         model.zero_grad(set_to_none=True)
         return loss
 
+    fwd_events = None
     for _ in range(args.warmup):
         step()
+    fwd_events = []          # forward-only time: events around net(x) on the current stream (every launch of the path is on it)
     # HIP-event probe on the dominant kernel: the dK/dV sweep (attn_bwd_dkv3_kernel) of self_attention6, N = hw*hw.
     # mu_attn_bwd_phases(..., B, N, C, nkmax, ws, ws_bytes, dtype, phases, stream): args[16] = N, args[22] = phases
     N6 = args.hw * args.hw
@@ -199,19 +260,41 @@ def main():
     if rank == 0:
         imgs = args.batch * world * args.steps
         C6 = 64
-        # algorithmic FLOPs of one launch: the four N x N x C products of the dK/dV sweep (S, dP, dV, dK) over the FULL
-        # key set, 4 * 2*N*N*C per image; the kernel executes ~half (masked keys are skipped)
-        flops = 8.0 * N6 * N6 * C6 * args.batch
-        durs = [e0.elapsed_time(e1) * 1e-3 for _, e0, e1 in probe["events"]]
-        tk = sum(durs) / max(len(durs), 1)
-        achieved = flops / max(tk, 1e-12) / 1e12
         kept = [float(k.float().mean().item()) for k in keeps if k.shape[1] == N6]
         kept = kept[-1] if kept else 1.0     # fraction of keys the kernel really multiplies (the rest are skipped, not computed)
+        # FLOPs of one launch: the four N x Nk x C products of the dK/dV sweep (S, dP, dV, dK), 4 * 2*N*Nk*C per image, over the
+        # kept keys (executed) and over the full key set (SURVEY 8-d4's algorithmic convention)
+        flops_full = 8.0 * N6 * N6 * C6 * args.batch
+        flops_exec = flops_full * kept
+        durs = [e0.elapsed_time(e1) * 1e-3 for _, e0, e1 in probe["events"]]
+        tk = sum(durs) / max(len(durs), 1)
+        achieved = flops_exec / max(tk, 1e-12) / 1e12
         peak = PEAK_MFMA_TFLOPS[args.dtype]
         traffic = None
-        tpath = os.path.join(ROOT, "profiles", "r01_dkv_traffic.json")      # PMC FETCH_SIZE/WRITE_SIZE pass (see file)
-        if os.path.exists(tpath) and args.batch == 64 and args.dtype == "fp16":
+        tpath = os.path.join(ROOT, "profiles", TRAFFIC_JSON)      # PMC FETCH_SIZE/WRITE_SIZE pass (see file)
+        if os.path.exists(tpath) and args.batch == 64 and args.dtype == "fp16" and args.hw == 128:
             traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
+        # whole step and forward alone against both rooflines (per-image algorithmic figures)
+        cnt = algorithmic_counts(args.c_out, args.hw, args.three_head)
+        esz = 2 if dtype == torch.float16 else 4
+        t_step = elapsed / args.steps
+        nimg = args.batch                      # per GPU: the step time is per GPU too (weak scaling)
+        attn_exec = cnt["attn_flops"] * 0.5    # Bernoulli(0.5) key masks: half the keys are skipped
+        step = {"flops_per_img": round(cnt["step_flops"] / 1e9, 1), "flops_per_img_unit": "GFLOP (3x conv/proj + 3.5x attention, full key set)",
+                "bytes_per_img": round(cnt["step_elems"] * esz / 1e6, 1), "bytes_per_img_unit": "MB",
+                "mfma_frac": round(cnt["step_flops"] * nimg / t_step / (peak * 1e12), 4),
+                "mfma_frac_executed": round((3.0 * cnt["conv_proj_flops"] + 3.5 * attn_exec) * nimg / t_step / (peak * 1e12), 4),
+                "hbm_frac": round(cnt["step_elems"] * esz * nimg / t_step / (PEAK_HBM_GBS * 1e9), 4),
+                "bound": "mfma (ridge ~300 FLOP/B, the step has ~750 FLOP/B)"}
+        if fwd_events:
+            t_fwd = sum(a.elapsed_time(b) for a, b in fwd_events) * 1e-3 / len(fwd_events)
+            step.update({"fwd_ms": round(t_fwd * 1e3, 3), "fwd_flops_per_img": round(cnt["fwd_flops"] / 1e9, 1),
+                         "fwd_bytes_per_img": round(cnt["fwd_elems"] * esz / 1e6, 1),
+                         "fwd_hbm_frac": round(cnt["fwd_elems"] * esz * nimg / t_fwd / (PEAK_HBM_GBS * 1e9), 4),
+                         "fwd_mfma_frac": round(cnt["fwd_flops"] * nimg / t_fwd / (peak * 1e12), 4),
+                         "fwd_mfma_frac_executed": round((cnt["conv_proj_flops"] + attn_exec) * nimg / t_fwd / (peak * 1e12), 4),
+                         "fwd_note": "north_star target '>= 60 % of the fp16 HBM roofline for the fused forward': the fused forward is "
+                                     "MFMA-bound (680 FLOP/B), so its HBM fraction is set by its matrix time"})
         rec = {
             "metric": "128x128 images/sec (fwd+bwd)", "value": round(imgs / elapsed, 3), "unit": "images/sec",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 3),
@@ -224,12 +307,15 @@ def main():
                                                                                 "maskunet_amd.CrossEntropyLoss on module output"), "optimizer_in_step": bool(opt), "hip_graph": bool(args.graph)},
             "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
                          "frac": round(achieved / peak, 4), "traffic": traffic,
-                         "kernel": f"attn_bwd_dkv3_kernel (self_attention6 dK/dV sweep, N={N6}, C=64)",
+                         "kernel": f"{DOMINANT_KERNEL} (self_attention6 dK/dV sweep, N={N6}, C=64)",
                          "ms_per_launch": round(tk * 1e3, 3), "launches_timed": len(durs),
-                         "kept_keys": round(kept, 4), "executed_achieved": round(achieved * kept, 2),
-                         "executed_frac": round(achieved * kept / peak, 4),
-                         "note": "achieved = algorithmic FLOPs (8*N*N*C per image over the FULL key set, SURVEY 8-d4) / time; the kernel "
-                                 "skips masked keys, executed_* count only the products it really performs"},
+                         "kept_keys": round(kept, 4), "flops_per_launch": flops_exec,
+                         "algorithmic_achieved": round(flops_full / max(tk, 1e-12) / 1e12, 2),
+                         "algorithmic_frac": round(flops_full / max(tk, 1e-12) / 1e12 / peak, 4),
+                         "algorithmic_bytes_per_launch": 8.0 * N6 * C6 * 2 * args.batch if dtype == torch.float16 else 8.0 * N6 * C6 * 4 * args.batch,
+                         "note": "achieved/frac = matrix FLOPs the kernel EXECUTES (8*N*Nk*C per image, Nk = kept keys; masked keys are "
+                                 "skipped exactly) / HIP-event time; algorithmic_* = SURVEY 8-d4's full-key-set count 8*N*N*C"},
+            "step_roofline": step,
         }
         if world == 1 and not args.no_cpu_baseline:
             rec["cpu_baseline"] = cpu_baseline(args.c_out, args.hw)

@@ -141,6 +141,13 @@ int mu_maxpool2_bwd(const void* x, const void* dy, void* dx, int B, int H, int W
 /* y = cat([skip, bilinear_x2(x, align_corners=True)], channel)  (:235,250-253); x [B,h,w,Cx], skip [B,2h,2w,Cs] */
 int mu_upcat_fwd(const void* x, const void* skip, void* y, int B, int h, int w, int Cx, int Cs, int dtype, void* stream);
 int mu_upcat_bwd(const void* dy, void* dx, void* dskip, int B, int h, int w, int Cx, int Cs, int dtype, void* stream);
+/* the same for channel counts that are not multiples of the 32-channel padding (stand-alone UpSample, :231-256): x holds
+ * Cx_valid of Cx_ld stored channels, skip Cs_valid of Cs_ld; y rows are [skip valid | up valid | zeros] with Ct_ld stored channels.
+ * The backward writes exact zeros into the padded channels of dx / dskip. */
+int mu_upcat_compact_fwd(const void* x, const void* skip, void* y, int B, int h, int w, int Cx_ld, int Cx_valid, int Cs_ld, int Cs_valid,
+                         int Ct_ld, int dtype, void* stream);
+int mu_upcat_compact_bwd(const void* dy, void* dx, void* dskip, int B, int h, int w, int Cx_ld, int Cx_valid, int Cs_ld, int Cs_valid,
+                         int Ct_ld, int dtype, void* stream);
 /* nn.Dropout (:273,304,307): y = x*keep/(1-p); keep from `mask` (uint8, may be NULL) or the (seed,index) generator.
  * The backward is the same call on the gradient with the same seed/mask. mask_out (may be NULL) receives keep. */
 int mu_dropout(const void* x, void* y, long n, float p, unsigned long long seed, const unsigned char* mask, unsigned char* mask_out,

@@ -51,6 +51,8 @@ SIGNATURES = {
     "mu_maxpool2_bwd": (I, [P, P, P, I, I, I, I, I, P]),
     "mu_upcat_fwd": (I, [P, P, P, I, I, I, I, I, I, P]),
     "mu_upcat_bwd": (I, [P, P, P, I, I, I, I, I, I, P]),
+    "mu_upcat_compact_fwd": (I, [P, P, P, I, I, I, I, I, I, I, I, I, P]),
+    "mu_upcat_compact_bwd": (I, [P, P, P, I, I, I, I, I, I, I, I, I, P]),
     "mu_dropout": (I, [P, P, L, F, c_ulonglong, P, P, I, P]),
     "mu_dropout_step": (I, [P, P, L, F, c_ulonglong, P, P, P, I, P]),
     "mu_add": (I, [P, P, P, L, I, P]),

@@ -370,6 +370,110 @@ __global__ __launch_bounds__(256) void upcat_bwd_kernel(const T* __restrict__ dy
     }
 }
 
+// Compacting variants for channel counts that are not multiples of the 32-channel padding (stand-alone UpSample with any
+// channel counts, ade_semantic.py:231-256): x has Cxv valid of Cxl stored channels, skip Csv of Csl; the output row is
+// [skip valid | up valid | zeros] with Ctl stored channels.  One element per thread (not a hot path: inside the UNet every
+// count is a multiple of 32 and the vector kernels above run).
+template <typename T>
+__global__ __launch_bounds__(256) void upcat_compact_fwd_kernel(const T* __restrict__ x, const T* __restrict__ skip, T* __restrict__ y,
+                                                                int B, int h, int w, int Cxl, int Cxv, int Csl, int Csv, int Ctl) {
+    const int Ho = 2 * h, Wo = 2 * w;
+    const float sh = h > 1 ? (float)(h - 1) / (float)(Ho - 1) : 0.f, sw = w > 1 ? (float)(w - 1) / (float)(Wo - 1) : 0.f;
+    const long total = (long)B * Ho * Wo * Ctl;
+    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+        int c = idx % Ctl;
+        long p = idx / Ctl;
+        float o = 0.f;
+        if (c < Csv) {
+            o = (float)skip[p * Csl + c];
+        } else if (c < Csv + Cxv) {
+            int wo = p % Wo, ho = (p / Wo) % Ho, b = p / ((long)Wo * Ho);
+            int h0, h1, w0, w1; float fh, fw;
+            lerp_axis(ho, sh, h, h0, h1, fh);
+            lerp_axis(wo, sw, w, w0, w1, fw);
+            const T* xb = x + (long)b * h * w * Cxl + (c - Csv);
+            float a00 = (float)xb[((long)h0 * w + w0) * Cxl], a01 = (float)xb[((long)h0 * w + w1) * Cxl];
+            float a10 = (float)xb[((long)h1 * w + w0) * Cxl], a11 = (float)xb[((long)h1 * w + w1) * Cxl];
+            float r0 = a00 * (1.f - fh) + a10 * fh, r1 = a01 * (1.f - fh) + a11 * fh;
+            o = r0 * (1.f - fw) + r1 * fw;
+        }
+        y[idx] = (T)o;
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void upcat_compact_bwd_kernel(const T* __restrict__ dy, T* __restrict__ dx, T* __restrict__ dskip,
+                                                                int B, int h, int w, int Cxl, int Cxv, int Csl, int Csv, int Ctl) {
+    const int Ho = 2 * h, Wo = 2 * w;
+    const float sh = h > 1 ? (float)(h - 1) / (float)(Ho - 1) : 0.f, sw = w > 1 ? (float)(w - 1) / (float)(Wo - 1) : 0.f;
+    const long n_skip = (long)B * Ho * Wo * Csl, n_x = (long)B * h * w * Cxl;
+    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < n_skip + n_x; idx += (long)gridDim.x * 256) {
+        if (idx < n_skip) {
+            int c = idx % Csl;
+            long p = idx / Csl;
+            dskip[idx] = c < Csv ? dy[p * Ctl + c] : (T)0.f;
+            continue;
+        }
+        long j = idx - n_skip;
+        int c = j % Cxl;
+        long p = j / Cxl;
+        float acc = 0.f;
+        if (c < Cxv) {
+            int wi = p % w, hi = (p / w) % h, b = p / ((long)w * h);
+            for (int ho = max(0, 2 * hi - 2); ho <= min(Ho - 1, 2 * hi + 3); ++ho) {
+                int h0, h1; float fh;
+                lerp_axis(ho, sh, h, h0, h1, fh);
+                float wh = (h0 == hi ? 1.f - fh : 0.f) + (h1 == hi ? fh : 0.f);
+                if (h0 == hi && h1 == hi) wh = 1.f;
+                if (wh == 0.f) continue;
+                for (int wo = max(0, 2 * wi - 2); wo <= min(Wo - 1, 2 * wi + 3); ++wo) {
+                    int w0, w1; float fw;
+                    lerp_axis(wo, sw, w, w0, w1, fw);
+                    float ww = (w0 == wi ? 1.f - fw : 0.f) + (w1 == wi ? fw : 0.f);
+                    if (w0 == wi && w1 == wi) ww = 1.f;
+                    if (ww == 0.f) continue;
+                    acc += wh * ww * (float)dy[(((long)b * Ho + ho) * Wo + wo) * Ctl + Csv + c];
+                }
+            }
+        }
+        dx[j] = (T)acc;
+    }
+}
+
+extern "C" int mu_upcat_compact_fwd(const void* x, const void* skip, void* y, int B, int h, int w, int Cx_ld, int Cx_valid, int Cs_ld,
+                                    int Cs_valid, int Ct_ld, int dtype, void* stream) {
+    if (!x || !skip || !y || B <= 0 || h <= 0 || w <= 0) return MU_ERR_ARG;
+    if (Cx_valid <= 0 || Cs_valid <= 0 || Cx_valid > Cx_ld || Cs_valid > Cs_ld || Cx_valid + Cs_valid > Ct_ld) return MU_ERR_SHAPE;
+    hipStream_t st = (hipStream_t)stream;
+    long total = (long)B * 4 * h * w * Ct_ld;
+    if (dtype == MU_F32)
+        upcat_compact_fwd_kernel<float><<<ew_grid(total), 256, 0, st>>>((const float*)x, (const float*)skip, (float*)y, B, h, w, Cx_ld,
+                                                                        Cx_valid, Cs_ld, Cs_valid, Ct_ld);
+    else if (dtype == MU_F16)
+        upcat_compact_fwd_kernel<h16><<<ew_grid(total), 256, 0, st>>>((const h16*)x, (const h16*)skip, (h16*)y, B, h, w, Cx_ld, Cx_valid,
+                                                                      Cs_ld, Cs_valid, Ct_ld);
+    else return MU_ERR_ARG;
+    MU_CHECK_LAUNCH();
+    return MU_OK;
+}
+
+extern "C" int mu_upcat_compact_bwd(const void* dy, void* dx, void* dskip, int B, int h, int w, int Cx_ld, int Cx_valid, int Cs_ld,
+                                    int Cs_valid, int Ct_ld, int dtype, void* stream) {
+    if (!dy || !dx || !dskip || B <= 0 || h <= 0 || w <= 0) return MU_ERR_ARG;
+    if (Cx_valid <= 0 || Cs_valid <= 0 || Cx_valid > Cx_ld || Cs_valid > Cs_ld || Cx_valid + Cs_valid > Ct_ld) return MU_ERR_SHAPE;
+    hipStream_t st = (hipStream_t)stream;
+    long total = (long)B * 4 * h * w * Cs_ld + (long)B * h * w * Cx_ld;
+    if (dtype == MU_F32)
+        upcat_compact_bwd_kernel<float><<<ew_grid(total), 256, 0, st>>>((const float*)dy, (float*)dx, (float*)dskip, B, h, w, Cx_ld,
+                                                                        Cx_valid, Cs_ld, Cs_valid, Ct_ld);
+    else if (dtype == MU_F16)
+        upcat_compact_bwd_kernel<h16><<<ew_grid(total), 256, 0, st>>>((const h16*)dy, (h16*)dx, (h16*)dskip, B, h, w, Cx_ld, Cx_valid,
+                                                                      Cs_ld, Cs_valid, Ct_ld);
+    else return MU_ERR_ARG;
+    MU_CHECK_LAUNCH();
+    return MU_OK;
+}
+
 extern "C" int mu_upcat_fwd(const void* x, const void* skip, void* y, int B, int h, int w, int Cx, int Cs, int dtype, void* stream) {
     if (!x || !skip || !y || B <= 0 || h <= 0 || w <= 0 || Cx % 8 || Cs % 8) return MU_ERR_ARG;
     hipStream_t st = (hipStream_t)stream;

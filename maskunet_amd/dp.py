@@ -3,16 +3,27 @@ dim 0, ONE exchange per step = bucketed all-reduce (mean) of the parameter gradi
 
 Replaces the reference's ``torch.nn.DataParallel(model)`` (code/ade20k/ade_semantic.py:373), whose implicit
 per-forward broadcast / scatter / gather / reduce-add collapses to a single gradient all-reduce:
-  * BatchNorm statistics stay per replica (the reference has no SyncBN) -- faithful semantics;
+  * BatchNorm statistics stay per replica (the reference has no SyncBN) -- faithful semantics.  Running statistics
+    therefore differ between ranks; a checkpoint written by rank 0 (``state_dict()`` on rank 0, the usual recipe)
+    holds RANK 0's running statistics, exactly what the reference saves (nn.DataParallel keeps replica 0's buffers,
+    SURVEY 8-e1).  ``broadcast_buffers()`` copies rank 0's buffers to every rank where all ranks must evaluate
+    with the same statistics;
   * parameters that never receive gradients (``emb_layer``; ``boundary_head`` under the reference loss)
-    are skipped identically on every rank;
-  * buckets are launched from post-accumulate-grad hooks as soon as all their gradients exist, on a side
+    are skipped identically on every rank.  They are learned on the first step (parameters whose ``.grad`` is still
+    None after the backward) and from then on are not waited for, so every bucket launches from the hooks;
+  * buckets are launched from post-accumulate-grad hooks as soon as all their live gradients exist, on a side
     stream, so the all-reduce of late layers overlaps the backward of early layers.
 The collective backend is whatever ``torch.distributed`` was initialised with: "nccl" (= RCCL) on GPUs,
 "gloo" in the CPU tests.
+
+Stream order on GPUs (the part a blocking CPU backend cannot test): gradients are produced on the current (main)
+stream; the comm stream waits for the main stream, flattens the bucket and issues the all-reduce; ``Work.wait()`` is
+called WITH THE COMM STREAM CURRENT, so the divide and the copy back into ``p.grad`` (also on the comm stream) are
+ordered behind the collective; the main stream finally waits for the comm stream.
 """
 from __future__ import annotations
 
+import contextlib
 from typing import List
 
 import torch
@@ -35,6 +46,7 @@ class _Bucket:
         self.pending = 0
         self.flat = None
         self.work = None
+        self.included: List[nn.Parameter] = []
 
 
 class DataParallel(nn.Module):
@@ -70,6 +82,9 @@ class DataParallel(nn.Module):
             for p in params:
                 self._hooks.append(p.register_post_accumulate_grad_hook(self._on_grad))
         self._armed = False
+        self._sync = True
+        # ids of parameters that produced no gradient in the last synchronised step (None until one step has been seen)
+        self._dead = None
 
     # ------------------------------------------------------------------------------------------
     def broadcast_parameters(self, src: int = 0):
@@ -77,77 +92,113 @@ class DataParallel(nn.Module):
         for t in list(self.module.parameters()) + list(self.module.buffers()):
             dist.broadcast(t.data, src, group=self.group)
 
+    def broadcast_buffers(self, src: int = 0):
+        """Copy rank ``src``'s buffers (BatchNorm running statistics / step counters) to every rank."""
+        if self.world > 1:
+            for t in self.module.buffers():
+                dist.broadcast(t.data, src, group=self.group)
+
+    @contextlib.contextmanager
+    def no_sync(self):
+        """Gradient accumulation: backward passes inside this context launch no all-reduce; the first synchronised
+        ``finish_gradient_sync()`` afterwards reduces the accumulated gradients."""
+        old, self._sync = self._sync, False
+        try:
+            yield
+        finally:
+            self._sync = old
+
     def forward(self, *args, **kwargs):
         self._arm()
         return self.module(*args, **kwargs)
 
     def _arm(self):
+        dead = self._dead or ()
         for b in self.buckets:
-            b.pending = len(b.params)
-            b.flat, b.work = None, None
-        self._armed = True
+            b.pending = sum(1 for p in b.params if id(p) not in dead)
+            b.flat, b.work, b.included = None, None, []
+        self._armed = self._sync
 
     def _on_grad(self, p):
         if not self._armed:
             return
+        if self._dead is not None and id(p) in self._dead:
+            return                      # a parameter believed dead got a gradient: picked up as a straggler at finish
         b = self._bucket_of[id(p)]
         b.pending -= 1
-        if b.pending == 0:
+        if b.pending == 0 and b.work is None:
             self._launch(b)
 
-    def _launch(self, b: _Bucket):
-        grads = [p.grad for p in b.params if p.grad is not None]
-        if not grads:
-            return
+    def _comm(self, dev):
+        if self._comm_stream is None:
+            self._comm_stream = torch.cuda.Stream(device=dev)
+        return self._comm_stream
+
+    def _reduce(self, params):
+        """Flatten the gradients of `params` and start their all-reduce -> (flat, work).  On a GPU both are issued with the
+        comm stream current, after it has waited for the producing stream(s)."""
+        grads = [p.grad for p in params]
         dev = grads[0].device
         if dev.type == "cuda":
-            if self._comm_stream is None:
-                self._comm_stream = torch.cuda.Stream(device=dev)
-            self._comm_stream.wait_stream(torch.cuda.current_stream(dev))
+            comm = self._comm(dev)
+            comm.wait_stream(torch.cuda.current_stream(dev))
             from . import ops
-            side = ops.wgrad_stream(dev)          # conv weight gradients are produced on their own stream (ops._wgrad_side)
+            side = ops.wgrad_stream(dev)          # conv weight gradients may be produced on their own stream (ops._wgrad_side)
             if side is not None:
-                self._comm_stream.wait_stream(side)
-            with torch.cuda.stream(self._comm_stream):
-                b.flat = torch.cat([g.reshape(-1).float() for g in grads])
-                b.work = dist.all_reduce(b.flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+                comm.wait_stream(side)
+            with torch.cuda.stream(comm):
+                flat = torch.cat([g.reshape(-1).float() for g in grads])
+                work = dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
         else:
-            b.flat = torch.cat([g.reshape(-1).float() for g in grads])
-            b.work = dist.all_reduce(b.flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+            flat = torch.cat([g.reshape(-1).float() for g in grads])
+            work = dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        return flat, work
+
+    def _launch(self, b: _Bucket):
+        b.included = [p for p in b.params if p.grad is not None]
+        if not b.included:
+            return
+        b.flat, b.work = self._reduce(b.included)
+
+    def _write_back(self, params, flat, work):
+        dev = flat.device
+        ctx = torch.cuda.stream(self._comm(dev)) if dev.type == "cuda" else contextlib.nullcontext()
+        with ctx:
+            # wait() with the comm stream current: on the nccl/RCCL backend it orders the CURRENT stream behind the
+            # collective, and the divide / copy-back below run on that same stream
+            work.wait()
+            flat.div_(self.world)
+            off = 0
+            for p in params:
+                g = p.grad
+                n = g.numel()
+                g.copy_(flat[off:off + n].view_as(g))
+                off += n
 
     def finish_gradient_sync(self):
         """Wait for the bucket all-reduces and write the averaged gradients back.  Buckets whose hooks did not
         all fire (parameters without gradients this step) are reduced here with what they have."""
-        if self.world == 1:
+        if self.world == 1 or not self._sync:
             self._armed = False
             return
         for b in self.buckets:
             if b.work is None:
                 self._launch(b)
+        late = []
         for b in self.buckets:
-            if b.work is None:
-                continue
-            b.work.wait()
-            grads = [p.grad for p in b.params if p.grad is not None]
-            dev = grads[0].device
-            ctx = torch.cuda.stream(self._comm_stream) if dev.type == "cuda" else _null()
-            with ctx:
-                b.flat.div_(self.world)
-                off = 0
-                for g in grads:
-                    n = g.numel()
-                    g.copy_(b.flat[off:off + n].view_as(g))
-                    off += n
+            if b.work is not None:
+                self._write_back(b.included, b.flat, b.work)
+            inc = {id(p) for p in b.included}
+            late += [p for p in b.params if p.grad is not None and id(p) not in inc]
+        if late:            # gradients that appeared after their bucket had been launched (a parameter that used to be dead)
+            flat, work = self._reduce(late)
+            self._write_back(late, flat, work)
         if self._comm_stream is not None:
-            torch.cuda.current_stream().wait_stream(self._comm_stream)
+            torch.cuda.current_stream(self._comm_stream.device).wait_stream(self._comm_stream)
+        # the same autograd graph runs on every rank, so this set is identical everywhere
+        self._dead = {id(p) for b in self.buckets for p in b.params if p.grad is None}
+        for b in self.buckets:
+            b.flat, b.work, b.included = None, None, []
         self._armed = False
 
     sync_gradients = finish_gradient_sync
-
-
-class _null:
-    def __enter__(self):
-        return self
-
-    def __exit__(self, *a):
-        return False

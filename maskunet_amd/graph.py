@@ -7,7 +7,8 @@ stream with no host synchronisation, so the step can be captured (torch.cuda.CUD
     step = maskunet_amd.GraphedStep(model, criterion, example_inputs, example_labels, loss_scale=1024.0)
     for inputs, labels in loader:
         loss = step(inputs, labels)          # gradients are in p.grad afterwards (the same tensors every replay)
-        optimizer.step()                     # eager, after the replay; do NOT zero_grad(set_to_none=True) between replays
+        optimizer.step()                     # eager, after the replay; zero_grad() in between is harmless: every call re-attaches
+                                             # the graph's gradient tensors to p.grad, and the replay overwrites them
 
 What changes under capture: the dropout seed drawn on the host is baked into the graph, so a device step counter -- incremented inside the
 graph -- is mixed into it (mu_dropout_step); BatchNorm running statistics / step counters are updated on the device as always; the
@@ -60,6 +61,7 @@ class GraphedStep:
         sem = out[0] if isinstance(out, (tuple, list)) else out
         loss = self.criterion(sem, self.labels)
         grads = torch.autograd.grad(loss * self.scale if self.scale != 1.0 else loss, list(fresh.values()), allow_unused=True)
+        self.grads = grads
         for p, g in zip(self.params, grads):
             p.grad = g
         return loss.detach(), sem.detach()
@@ -68,4 +70,6 @@ class GraphedStep:
         self.inputs.copy_(inputs, non_blocking=True)
         self.labels.copy_(labels, non_blocking=True)
         self.graph.replay()
-        return self.loss
+        for p, g in zip(self.params, self.grads):     # optimizer.zero_grad(set_to_none=True) between replays detaches them
+            p.grad = g
+        return self.loss.clone()                      # self.loss is overwritten by the next replay

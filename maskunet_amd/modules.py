@@ -215,16 +215,15 @@ class UpSample(_HipModule):
         )
         self.emb_layer = nn.Sequential(nn.SiLU(), nn.Linear(emb_dim, out_channels))
 
-    def forward_nhwc(self, x, skip_x):
-        x = ops.upcat(x, skip_x)                 # cat([skip_x, up(x)], dim=1)  (:250-253)
+    def forward_nhwc(self, x, skip_x, cx=None, cs=None):
+        """cx / cs: true channel counts of x / skip_x when they are not multiples of the 32-channel storage padding."""
+        x = ops.upcat(x, skip_x, cx, cs)         # cat([skip_x, up(x)], dim=1)  (:250-253)
         x = self.conv[0].forward_nhwc(x)
         return self.conv[1].forward_nhwc(x, tail_bn=self.conv[2])      # ConvBlock + the BatchNorm behind it (:239-240)
 
     def forward(self, x, skip_x):
         self._check_device(x)
-        if x.shape[1] % 32 or skip_x.shape[1] % 32:
-            raise RuntimeError("maskunet_amd: stand-alone UpSample needs channel counts that are multiples of 32")
-        y = self.forward_nhwc(ops.to_nhwc(x, self.compute_dtype), ops.to_nhwc(skip_x, self.compute_dtype))
+        y = self.forward_nhwc(ops.to_nhwc(x, self.compute_dtype), ops.to_nhwc(skip_x, self.compute_dtype), x.shape[1], skip_x.shape[1])
         return ops.to_nchw(y, self.out_channels, x.dtype)
 
 

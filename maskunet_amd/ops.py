@@ -470,33 +470,42 @@ def maxpool2(x):
 
 
 class _UpCat(torch.autograd.Function):
-    """cat([skip, bilinear_x2(x, align_corners=True)], dim=C) (ade_semantic.py:235,250-253)."""
+    """cat([skip, bilinear_x2(x, align_corners=True)], dim=C) (ade_semantic.py:235,250-253).  cx / cs: the true channel counts of
+    x / skip; where they are not the stored (32-padded) counts the concat compacts [skip valid | up valid | zero pad]."""
 
     @staticmethod
-    def forward(ctx, x, skip):
+    def forward(ctx, x, skip, cx, cs):
         x, skip = x.contiguous(), skip.contiguous()
         B, h, w, Cx = x.shape
         Cs = skip.shape[-1]
         if skip.shape[:3] != (B, 2 * h, 2 * w):
             raise RuntimeError(f"upsample/concat: skip {tuple(skip.shape)} does not match 2x of {tuple(x.shape)}")
-        y = torch.empty((B, 2 * h, 2 * w, Cs + Cx), dtype=x.dtype, device=x.device)
-        call("mu_upcat_fwd", ptr(x), ptr(skip), ptr(y), B, h, w, Cx, Cs, dt(x), stream())
-        ctx.dims = (B, h, w, Cx, Cs)
+        ctx.compact = (cx != Cx or cs != Cs)
+        Ct = pad32(cx + cs) if ctx.compact else Cs + Cx
+        y = torch.empty((B, 2 * h, 2 * w, Ct), dtype=x.dtype, device=x.device)
+        if ctx.compact:
+            call("mu_upcat_compact_fwd", ptr(x), ptr(skip), ptr(y), B, h, w, Cx, cx, Cs, cs, Ct, dt(x), stream())
+        else:
+            call("mu_upcat_fwd", ptr(x), ptr(skip), ptr(y), B, h, w, Cx, Cs, dt(x), stream())
+        ctx.dims = (B, h, w, Cx, Cs, cx, cs, Ct)
         return y
 
     @staticmethod
     @once_differentiable
     def backward(ctx, gy):
-        B, h, w, Cx, Cs = ctx.dims
+        B, h, w, Cx, Cs, cx, cs, Ct = ctx.dims
         gy = gy.contiguous()
         dx = torch.empty((B, h, w, Cx), dtype=gy.dtype, device=gy.device)
         dskip = torch.empty((B, 2 * h, 2 * w, Cs), dtype=gy.dtype, device=gy.device)
-        call("mu_upcat_bwd", ptr(gy), ptr(dx), ptr(dskip), B, h, w, Cx, Cs, dt(gy), stream())
-        return dx, dskip
+        if ctx.compact:
+            call("mu_upcat_compact_bwd", ptr(gy), ptr(dx), ptr(dskip), B, h, w, Cx, cx, Cs, cs, Ct, dt(gy), stream())
+        else:
+            call("mu_upcat_bwd", ptr(gy), ptr(dx), ptr(dskip), B, h, w, Cx, Cs, dt(gy), stream())
+        return dx, dskip, None, None
 
 
-def upcat(x, skip):
-    return _UpCat.apply(x, skip)
+def upcat(x, skip, cx=None, cs=None):
+    return _UpCat.apply(x, skip, x.shape[-1] if cx is None else int(cx), skip.shape[-1] if cs is None else int(cs))
 
 
 SEED_STEP = None        # int64 device tensor [1] or None; set by maskunet_amd.graph.GraphedStep during capture

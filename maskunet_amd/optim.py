@@ -33,7 +33,9 @@ class FusedAdamW(torch.optim.Optimizer):
             ring = [(torch.empty((len(params), 6), dtype=torch.int64).pin_memory(),
                      torch.empty((len(params), 6), dtype=torch.int64, device=dev), torch.cuda.Event()) for _ in range(4)]
             plan = (torch.tensor(bt, dtype=torch.int32, device=dev), torch.tensor(bc, dtype=torch.int32, device=dev), len(bt), ring, [0])
-            self._plans = {key: plan}
+            for k in [k for k in self._plans if k[0] == gi]:      # a re-allocated parameter list of THIS group: drop its old plan
+                del self._plans[k]
+            self._plans[key] = plan
         return plan
 
     @torch.no_grad()

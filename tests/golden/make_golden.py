@@ -185,6 +185,9 @@ def main():
     # channels-last strides (the permuted attention grad); the reference autograd then disagrees with
     # its own finite differences.  Verified with FD; see DESIGN.md "oracle pinning".
     unet_case("unet3_c19_b2_train", ns3["UNet"], 19, 2, True, True, 200)
+    # BASELINE configs[2] (COCO panoptic): the script's own UNet class with its c_out = 133 (coco_panoptic.py:279,472)
+    nsc = load_reference(os.path.join(REF, "coco/coco_panoptic.py"))
+    unet_case("unet1_c133_b2_train", nsc["UNet"], 133, 2, True, False, 133)
 
 
 if __name__ == "__main__":

@@ -60,7 +60,36 @@ def case(name, cls, B, C, H, W, ids, ignore, seed):
     print("wrote", name, "loss", float(loss), "draws", draws)
 
 
+def load_function(path, name):
+    tree = ast.parse(open(path).read())
+    body = [n for n in tree.body if isinstance(n, ast.FunctionDef) and n.name == name]
+    ns = {"torch": torch, "nn": nn, "F": F}
+    exec(compile(ast.Module(body=body, type_ignores=[]), path, "exec"), ns)
+    return ns[name]
+
+
+def miou_case(name, fn, B, C, H, W, seed, label_hi, never_predicted=(), tie=False):
+    """mean_iou (ade_semantic.py:128-146) on random logits.  label_hi < C leaves classes absent from the labels;
+    `never_predicted` classes get -10 logits (absent from both sides when also >= label_hi: union == 0, skipped);
+    tie: two classes share the maximal logit on some pixels (argmax must pick the first, as torch.argmax does)."""
+    rng = np.random.default_rng(seed)
+    y = rng.standard_normal((B, C, H, W)).astype(np.float32)
+    for c in never_predicted:
+        y[:, c] = -10.0
+    if tie:
+        y[:, 3, ::2] = y.max(axis=1)[:, ::2] + 1.0
+        y[:, 5, ::2] = y[:, 3, ::2]
+    t = rng.integers(0, label_hi, (B, H, W)).astype(np.int64)
+    out = fn(torch.from_numpy(y), torch.from_numpy(t), C)
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), y=y, t=t, num_classes=np.array(C), miou=np.array(float(out), dtype=np.float64))
+    print("wrote", name, "mean_iou", float(out))
+
+
 def main():
+    miou = load_function(os.path.join(REF, "ade20k/ade_semantic.py"), "mean_iou")
+    miou_case("miou_dense", miou, 2, 7, 12, 12, 601, 7)
+    miou_case("miou_absent_classes", miou, 2, 21, 16, 16, 602, 18, never_predicted=(20,))     # class 20: union == 0 -> skipped
+    miou_case("miou_ties_150", miou, 1, 150, 24, 20, 603, 150, never_predicted=(7, 149), tie=True)
     ade = load_class(os.path.join(REF, "ade20k/ade_panoptic.py"), "InstanceContrastiveLoss")
     city = load_class(os.path.join(REF, "cityscapes/city_instance.py"), "InstanceContrastiveLoss")
     case("instloss_ade_small", ade, 2, 5, 8, 8, [0, 1, 2, 3, 7], None, 501)

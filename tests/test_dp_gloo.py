@@ -34,25 +34,50 @@ def _worker(rank, world, port, overlap, q):
             dist.broadcast(r, 0)
             assert torch.equal(r, p.data), "parameters not broadcast from rank 0"
         assert len(ddp.buckets) > 1
-        ddp._arm()
-        # synthetic gradients: rank-dependent; emb_layer never gets one (dead weights)
-        expected = {}
-        for name, p in model.named_parameters():
-            if "emb_layer" in name:
-                continue
-            g0 = torch.full_like(p, 1.0) * (len(name) % 7 + 1)
-            expected[name] = g0 * 1.5                      # mean of g0*(rank+1) over ranks 0,1
-            p.grad = None
-            # emulate autograd: accumulate then fire the post-accumulate hook path
-            p.grad = g0 * (rank + 1)
-            if overlap:
-                ddp._on_grad(p)
-        ddp.finish_gradient_sync()
-        for name, p in model.named_parameters():
-            if "emb_layer" in name:
-                assert p.grad is None
-            else:
-                assert torch.allclose(p.grad, expected[name]), name
+        emb = [p for n, p in model.named_parameters() if "emb_layer" in n]
+
+        def one_step(revive=False):
+            """emulate autograd: accumulate a rank-dependent gradient per live parameter, fire the post-accumulate hook"""
+            ddp._arm()
+            expected = {}
+            for name, p in model.named_parameters():
+                p.grad = None
+                if "emb_layer" in name and not revive:         # dead weights (SURVEY 2 #15): never a gradient
+                    continue
+                g0 = torch.full_like(p, 1.0) * (len(name) % 7 + 1)
+                expected[name] = g0 * 1.5                      # mean of g0*(rank+1) over ranks 0,1
+                p.grad = g0 * (rank + 1)
+                if overlap:
+                    ddp._on_grad(p)
+            launched = sum(b.work is not None for b in ddp.buckets)
+            ddp.finish_gradient_sync()
+            for name, p in model.named_parameters():
+                if name in expected:
+                    assert torch.allclose(p.grad, expected[name]), name
+                else:
+                    assert p.grad is None
+            return launched
+
+        first = one_step()
+        assert ddp._dead == {id(p) for p in emb}, "parameters without a gradient must be learned on the first step"
+        second = one_step()
+        if overlap:
+            # from the second step on no bucket waits for a dead parameter: every bucket with a live gradient is launched
+            # from the hooks, before finish_gradient_sync()
+            live_buckets = sum(any(id(p) not in ddp._dead for p in b.params) for b in ddp.buckets)
+            assert second == live_buckets and second >= first, (first, second, live_buckets)
+        one_step(revive=True)                                   # a parameter believed dead gets a gradient: still averaged
+        assert not ddp._dead
+        one_step()
+        with ddp.no_sync():                                     # accumulation step: nothing is reduced
+            ddp._arm()
+            for p in model.parameters():
+                p.grad = torch.full_like(p, float(rank + 1))
+                if overlap:
+                    ddp._on_grad(p)
+            assert all(b.work is None for b in ddp.buckets)
+            ddp.finish_gradient_sync()
+            assert all(torch.equal(p.grad, torch.full_like(p, float(rank + 1))) for p in model.parameters())
         # state_dict keys carry the nn.DataParallel "module." prefix
         assert all(k.startswith("module.") for k in ddp.state_dict().keys())
         q.put((rank, "ok"))

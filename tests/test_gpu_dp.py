@@ -1,0 +1,187 @@
+"""GPU tests of the data-parallel exchange step (maskunet_amd/dp.py; replaces nn.DataParallel, ade_semantic.py:373).
+
+The single-GPU boxes of the test pool cannot run RCCL across devices, so the stream ordering is tested two ways:
+  * a stub collective with RCCL's semantics (the reduction runs on the backend's own stream, late; ``Work.wait()`` only makes
+    the stream that is CURRENT at the call wait for it) -- fails if the divide / copy-back are not ordered behind the collective;
+  * two gloo ranks sharing the one GPU run a REAL forward + backward on the two halves of a batch through the autograd hooks and
+    must reproduce the mean of the two shard gradients computed without any wrapper.
+"""
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+class _LateWork:
+    """all_reduce stand-in: 'reduces' (x3) on a private stream after a long spin; wait() orders only the current stream."""
+
+    streams_at_wait = []
+
+    def __init__(self, flat, issue_stream):
+        self.stream = torch.cuda.Stream()
+        self.stream.wait_stream(issue_stream)
+        with torch.cuda.stream(self.stream):
+            torch.cuda._sleep(200_000_000)          # ~0.1 s: anything not ordered behind the collective runs first
+            flat.mul_(3.0)
+        flat.record_stream(self.stream)
+
+    def wait(self):
+        cur = torch.cuda.current_stream()
+        _LateWork.streams_at_wait.append(cur)
+        cur.wait_stream(self.stream)
+        return True
+
+
+def test_wait_is_issued_on_the_comm_stream(monkeypatch):
+    import torch.distributed as dist
+    import maskunet_amd
+    from maskunet_amd.dp import DataParallel
+    monkeypatch.setattr(dist, "is_initialized", lambda: True)
+    monkeypatch.setattr(dist, "get_world_size", lambda group=None: 2)
+    monkeypatch.setattr(dist, "broadcast", lambda *a, **k: None)
+    monkeypatch.setattr(dist, "all_reduce", lambda flat, op=None, group=None, async_op=False: _LateWork(flat, torch.cuda.current_stream()))
+    _LateWork.streams_at_wait = []
+    torch.manual_seed(0)
+    model = maskunet_amd.DownSample(32, 64).cuda()
+    ddp = DataParallel(model, bucket_mb=0.05)
+    assert ddp.world == 2 and len(ddp.buckets) > 1
+    x = torch.randn(4, 32, 16, 16, device="cuda")
+    for step in range(2):                       # step 0 learns the dead parameters, step 1 launches every bucket from the hooks
+        model.zero_grad(set_to_none=True)
+        model(x).square().mean().backward()     # reference gradients without the wrapper
+        ref = {n: p.grad.clone() for n, p in model.named_parameters() if p.grad is not None}
+        model.zero_grad(set_to_none=True)
+        ddp(x).square().mean().backward()
+        if step == 1:
+            assert all(b.work is not None for b in ddp.buckets if any(id(p) not in ddp._dead for p in b.params)), \
+                "live buckets must be launched from the autograd hooks"
+        ddp.finish_gradient_sync()
+        torch.cuda.synchronize()
+        assert _LateWork.streams_at_wait and all(s == ddp._comm_stream for s in _LateWork.streams_at_wait), \
+            "Work.wait() must be called with the comm stream current"
+        for n, p in model.named_parameters():
+            if n in ref:
+                assert torch.allclose(p.grad, ref[n] * 1.5, rtol=1e-5, atol=1e-7), f"{n}: divide/copy-back raced the collective"
+            else:
+                assert p.grad is None
+
+
+_WORKER = r"""
+import os, sys
+sys.path.insert(0, {root!r})
+import numpy as np, torch, torch.distributed as dist, torch.nn.functional as F
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+dist.init_process_group("gloo", rank=rank, world_size=world)
+torch.cuda.set_device(0)
+import maskunet_amd
+from maskunet_amd.dp import DataParallel, shard_batch
+from oracle import maskunet_oracle as O          # deterministic parameter / input recipe only
+c_out, B = 19, 4
+params = O.make_params(O.unet_state_shapes(3, c_out, False), 77)
+keeps = O.make_keeps(78, B)
+x, labels = O.make_inputs(79, B, c_out)
+def fresh():
+    m = maskunet_amd.UNet(3, c_out)
+    m.load_state_dict(params)
+    m.cuda().train()
+    m.dropout.p = 0.0
+    return m
+def shard_grads(m, s):
+    a, b = shard_batch(B, world, s)
+    m.set_keep_masks([k[a:b] for k in keeps])
+    out = m(x[a:b].cuda())
+    F.cross_entropy(out, labels[a:b].cuda()).backward()
+# expected: every shard from the SAME initial state (per-replica BatchNorm statistics), gradients averaged over the shards
+exp = None
+for s in range(world):
+    m = fresh()
+    shard_grads(m, s)
+    g = {{n: p.grad.double() for n, p in m.named_parameters() if p.grad is not None}}
+    exp = g if exp is None else {{n: exp[n] + v for n, v in g.items()}}
+    if s == rank:
+        own_stats = {{k: v.clone() for k, v in m.state_dict().items() if "running" in k}}
+exp = {{n: v / world for n, v in exp.items()}}
+model = fresh()
+ddp = DataParallel(model, bucket_mb=4.0)
+worst = 0.0
+for step in range(2):                      # the second step runs with the learned dead-parameter set (all buckets from hooks)
+    model.load_state_dict(params)
+    model.zero_grad(set_to_none=True)
+    a, b = shard_batch(B, world, rank)
+    model.set_keep_masks([k[a:b] for k in keeps])
+    out = ddp(x[a:b].cuda())
+    F.cross_entropy(out, labels[a:b].cuda()).backward()
+    if step == 1:
+        assert all(bk.work is not None for bk in ddp.buckets if any(id(p) not in ddp._dead for p in bk.params))
+    ddp.finish_gradient_sync()
+    for n, p in model.named_parameters():
+        if n in exp:
+            e = float((p.grad.double() - exp[n]).abs().max()) / max(float(exp[n].abs().max()), 1e-12)
+            worst = max(worst, e)
+        else:
+            assert p.grad is None, n
+for k, v in model.state_dict().items():     # per-replica BatchNorm: this rank's running statistics are its own shard's
+    if "running" in k:
+        assert torch.allclose(v, own_stats[k], rtol=1e-5, atol=1e-6), k
+assert all(k.startswith("module.") for k in ddp.state_dict())
+print("RANK", rank, "worst", worst, flush=True)
+# identical shard runs are bit-reproducible (no float atomics), the cross-rank mean goes through fp32 on the host: ~1e-7
+assert worst <= 1e-5, worst
+dist.destroy_process_group()
+"""
+
+
+def test_two_ranks_one_gpu_real_backward_matches_shard_mean():
+    port = _free_port()
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, "-c", _WORKER.format(root=ROOT)], env=env, stdout=subprocess.PIPE,
+                                      stderr=subprocess.STDOUT, text=True))
+    outs = []
+    for p in procs:
+        try:
+            o, _ = p.communicate(timeout=900)
+        except subprocess.TimeoutExpired:
+            p.kill()
+            o, _ = p.communicate()
+        outs.append(o)
+    assert all(p.returncode == 0 for p in procs), "\n----\n".join(o[-3000:] for o in outs)
+
+
+def test_bench_starts_under_torchrun_world2_gloo():
+    """The driver's N>1 invocation (`python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...`) with two gloo
+    ranks on the one GPU: must initialise, step through DataParallel and print ONE JSON line with n_gpus = 2."""
+    import json
+    env = dict(os.environ, MU_DIST_BACKEND="gloo")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+           "--batch", "2", "--no-cpu-baseline"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["config"]["global_batch"] == 4 and rec["value"] > 0
+
+
+def test_bench_refuses_gpus_without_launcher():
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                       env={k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")},
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "WORLD_SIZE" in (r.stdout + r.stderr)

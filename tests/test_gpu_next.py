@@ -129,6 +129,13 @@ def test_graphed_step_equals_eager_step():
     # other inputs through the same graph
     x2 = torch.rand_like(x)
     l2 = step(x2, labels).item()
+    # optimizer.zero_grad() (set_to_none=True is torch's default) between replays must not lose the gradients, and a returned
+    # loss must not alias the next replay's
+    model.zero_grad(set_to_none=True)
+    l3 = step(x, labels)
+    assert all(v.grad is not None and torch.equal(v.grad, ge[k]) for k, v in model.named_parameters() if k in ge)
+    l4 = step(x2, labels)
+    assert l3.item() == loss_e.item() and l4.item() == l2 and l3.data_ptr() != l4.data_ptr()
     model.zero_grad(set_to_none=True)
     # dropout on: a fresh capture; two replays on the same inputs see different masks
     model.dropout.p = 0.3
@@ -176,6 +183,20 @@ def test_mean_iou_matches_reference_definition(layout):
     pred = y.cuda() if layout == "nchw" else ops.to_nhwc(y.cuda(), torch.float32)
     got = maskunet_amd.mean_iou(pred, t.cuda(), C)
     assert abs(got.item() - ref.item()) <= 1e-6
+
+
+@pytest.mark.parametrize("layout", ["nchw", "nhwc"])
+@pytest.mark.parametrize("name", ["miou_dense", "miou_absent_classes", "miou_ties_150"])
+def test_mean_iou_matches_reference_goldens(name, layout):
+    """mu_mean_iou against fixtures produced by the reference's own mean_iou (tests/golden/make_golden_losses.py)."""
+    import os
+    import maskunet_amd
+    from maskunet_amd import ops
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", name + ".npz"))
+    y, t, C = torch.from_numpy(g["y"]).cuda(), torch.from_numpy(g["t"]).cuda(), int(g["num_classes"])
+    pred = y if layout == "nchw" else ops.to_nhwc(y, torch.float32)
+    got = maskunet_amd.mean_iou(pred, t, C)
+    assert abs(got.item() - float(g["miou"])) <= 1e-6
 
 
 def test_fused_adamw_matches_torch():

@@ -37,7 +37,7 @@ def _check(a, b, tol=TOL, what=""):
 
 
 MODULE_CASES = sorted(os.path.basename(p)[:-4] for p in glob.glob(
-    os.path.join(os.path.dirname(__file__), "golden", "*.npz")) if not os.path.basename(p).startswith(("unet", "instloss")))
+    os.path.join(os.path.dirname(__file__), "golden", "*.npz")) if not os.path.basename(p).startswith(("unet", "instloss", "miou")))
 
 
 def test_have_module_cases():
@@ -149,6 +149,20 @@ def test_unet1_train(golden_dir):
 
 def test_unet3_train(golden_dir):
     _unet_case(golden_dir, "unet3_c19_b2_train", True)
+
+
+def test_unet1_c133_train(golden_dir):
+    """BASELINE configs[2] (COCO panoptic, c_out = 133): vectors from coco_panoptic.py's own UNet class (:279,472)."""
+    _unet_case(golden_dir, "unet1_c133_b2_train", False)
+
+
+@pytest.mark.parametrize("name", ["miou_dense", "miou_absent_classes", "miou_ties_150"])
+def test_oracle_mean_iou(golden_dir, name):
+    """oracle.mean_iou == the reference's mean_iou (ade_semantic.py:128-146) on the fixtures written by
+    tests/golden/make_golden_losses.py (absent classes, union == 0 skip, argmax ties)."""
+    g = np.load(os.path.join(golden_dir, name + ".npz"))
+    got = O.mean_iou(torch.from_numpy(g["y"]), torch.from_numpy(g["t"]), int(g["num_classes"]))
+    assert abs(float(got) - float(g["miou"])) <= 1e-7
 
 
 @pytest.mark.parametrize("name", ["instloss_ade_small", "instloss_ade_sparse", "instloss_city_ignore", "instloss_none"])
