@@ -63,6 +63,27 @@
 #ifndef MU_DQ_KT
 #define MU_DQ_KT 32
 #endif
+// forward: optimistic sweep without per-tile running-max tracking, verified afterwards (see attn_fwd2_kernel); 0 = always exact
+#ifndef MU_FWD_OPTIMISTIC
+#define MU_FWD_OPTIMISTIC 1
+#endif
+// s_setprio(1) around the MFMA clusters.  In-process A/B (B=64, N=16384, C=64, fp16): dQ 2.94 -> 2.87 ms, dK/dV 3.98 -> 3.90 ms,
+// forward 2.03 -> 2.02 ms (noise); at C=128 the dK/dV sweep LOSES 1.5 %.  1 = the C <= 64 backward sweeps only, 2 = everywhere, 0 = off
+#ifndef MU_ATTN_SETPRIO
+#define MU_ATTN_SETPRIO 1
+#endif
+// LDS operand prefetch ahead of the VALU phase (number of 16-column blocks; 0 = off)
+#ifndef MU_DKV_PREFETCH
+#define MU_DKV_PREFETCH 0
+#endif
+#ifndef MU_DQ_PREFETCH
+#define MU_DQ_PREFETCH 0
+#endif
+#ifndef MU_FWD_PREFETCH
+#define MU_FWD_PREFETCH 0
+#endif
+#define MU_PRIO_ON(bwd) (MU_ATTN_SETPRIO == 2 || (MU_ATTN_SETPRIO == 1 && (bwd) && D <= 64 && sizeof(T) == 2))
+#define MU_PRIO(x) do { if (MU_PRIO_ON(MU_PRIO_BWD)) __builtin_amdgcn_s_setprio(x); } while (0)
 
 typedef __fp16 fp16x4v __attribute__((__vector_size__(4 * sizeof(__fp16))));
 // LDS-DMA through inline asm (see conv.hip glds16a): hipcc's waitcnt pass puts s_waitcnt vmcnt(0) in front of every
@@ -327,6 +348,7 @@ __global__ __launch_bounds__(NW * 64, OCC ? OCC : ((NW == 4 && D <= 64 && sizeof
     using Frag = typename A::Frag;
     using Z = SwzTile<T, D>;
     constexpr int VN = A::VN, KR = A::KR, NKS = D / KR, NDT = D / 16, NKT = KT / 16, NH = KT / 32;
+    constexpr bool MU_PRIO_BWD = false;
     __shared__ __attribute__((aligned(16))) T lds[2 * 2 * KT * D];      // [buf][K|V][KT][D]
 
     int bx_, b;
@@ -373,27 +395,45 @@ __global__ __launch_bounds__(NW * 64, OCC ? OCC : ((NW == 4 && D <= 64 && sizeof
     // one KT-key tile out of LDS buffer BUF.  S' = K (c Q)^T - m comes straight out of the matrix core (C operand =
     // -m broadcast), so the common case is p = exp2(S') with no per-element subtract; only when some row's maximum
     // moves (or on the very first tile) is the correction path taken.
-    auto tile = [&](auto BUFC, int j0) {
+    auto tile = [&](auto BUFC, auto EXACTC, int j0) {
         constexpr int BUF = decltype(BUFC)::value;
+        constexpr bool EXACT = decltype(EXACTC)::value;
         const T* Kt = lds + BUF * 2 * KT * D;
         const T* Vt = Kt + KT * D;
+#ifndef MU_FWD_ABL_NODMA
         if (j0 + KT < Nk) {
             T* Kn = lds + (BUF ^ 1) * 2 * KT * D;
             stg.issue(Kn, Kn + KT * D, qkv_b, wave, lane);
             stg.load_idx(kidx_b, j0 + 2 * KT, Nk, wave, lane);
         }
+#endif
         f32x4 s[NKT][NQ];
+        MU_PRIO(1);
 #pragma unroll
         for (int ks = 0; ks < NKS; ++ks)
 #pragma unroll
             for (int kt = 0; kt < NKT; ++kt) {
+#ifdef MU_FWD_ABL_NOS
+                // timing-only ablation: no K reads, no score MFMAs
+                if (ks == 0)
+                    for (int t = 0; t < NQ; ++t) { s[kt][t] = negm[t]; asm volatile("" : "+v"(s[kt][t])); }
+#else
                 Frag a = ld16<T>(Kt + Z::off(kt * 16 + r16, ks * KR + g * VN));
 #pragma unroll
                 for (int t = 0; t < NQ; ++t) {
                     if (ks == 0) s[kt][t] = A::mma_row_from(a, qf[t][0], negm[t]);     // -m rides in as the C operand
                     else A::mma_row(a, qf[t][ks], s[kt][t]);
                 }
+#endif
             }
+        MU_PRIO(0);
+        constexpr int PREV = (MU_FWD_PREFETCH && sizeof(T) == 2) ? (MU_FWD_PREFETCH < NDT ? MU_FWD_PREFETCH : NDT) : 0;
+        typename A::AccA vap[PREV ? PREV : 1];
+        if constexpr (PREV > 0) {                    // transposed V operands of the first 32 keys: in flight during the softmax VALU
+#pragma unroll
+            for (int dt = 0; dt < PREV; ++dt) vap[dt] = AccLd<T, D>::ld(Vt, 0, dt * 16, g, r16);
+            __builtin_amdgcn_sched_barrier(0);
+        }
         const bool partial = j0 + KT > Nk;          // wave-uniform
 #pragma unroll
         for (int t = 0; t < NQ; ++t) {
@@ -408,13 +448,13 @@ __global__ __launch_bounds__(NW * 64, OCC ? OCC : ((NW == 4 && D <= 64 && sizeof
             // below zero -- all the fast path needs ("did any score exceed the running max?"), without the
             // canonicalising v_max hipcc puts in front of every fmaxf of an MFMA result.  The first tile takes the
             // exact float maximum (it may be negative).
-            float mx;
+            float mx = 0.f;
             if (j0 == 0) {
                 mx = fmaxf(fmaxf(s[0][t][0], s[0][t][1]), fmaxf(s[0][t][2], s[0][t][3]));
 #pragma unroll
                 for (int kt = 1; kt < NKT; ++kt) mx = fmaxf(fmaxf(mx, fmaxf(s[kt][t][0], s[kt][t][1])), fmaxf(s[kt][t][2], s[kt][t][3]));
                 mx = grp_max(mx);
-            } else {
+            } else if (EXACT) {
                 int mi = __float_as_int(s[0][t][0]);
 #pragma unroll
                 for (int kt = 0; kt < NKT; ++kt)
@@ -422,7 +462,10 @@ __global__ __launch_bounds__(NW * 64, OCC ? OCC : ((NW == 4 && D <= 64 && sizeof
                     for (int r = 0; r < 4; ++r) mi = max(mi, __float_as_int(s[kt][t][r]));
                 mx = grp_max(__int_as_float(mi < 0 ? (int)0x80000000 : mi));     // -0.0 stands for "nothing above the max"
             }
-            if (j0 == 0 || !__all(mx <= 0.f)) {      // first tile, or some row's max moved (rare afterwards)
+            // !EXACT (the optimistic sweep): after the first tile the reference maximum m stays where the first tile put it.  The
+            // softmax is invariant to m; what m must prevent is overflow of p = 2^(s-m) in the fp16 B operand (s - m > 16), and that
+            // shows up as a non-finite row sum, which the caller checks once after the sweep (then redoes it with EXACT tracking).
+            if (j0 == 0 || (EXACT && !__all(mx <= 0.f))) {      // first tile, or some row's max moved (rare afterwards)
                 const float d = (j0 == 0) ? mx : fmaxf(mx, 0.f);
                 const float alpha = __builtin_amdgcn_exp2f(-d);
                 negm[t] -= d;
@@ -435,24 +478,75 @@ __global__ __launch_bounds__(NW * 64, OCC ? OCC : ((NW == 4 && D <= 64 && sizeof
 #pragma unroll
             for (int kt = 0; kt < NKT; ++kt)
 #pragma unroll
+#ifdef MU_FWD_ABL_NOEXP
+                for (int r = 0; r < 4; ++r) s[kt][t][r] = s[kt][t][r] * 0.001f;          // timing-only ablation: no exponentials
+#else
                 for (int r = 0; r < 4; ++r) s[kt][t][r] = __builtin_amdgcn_exp2f(s[kt][t][r]);
+#endif
         }
+#ifdef MU_FWD_ABL_NOPV
+        // timing-only ablation: no V reads, no P.V / row-sum MFMAs (P kept live)
+#pragma unroll
+        for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+            for (int t = 0; t < NQ; ++t) asm volatile("" ::"v"(s[kt][t]));
+#else
+        MU_PRIO(1);
 #pragma unroll
         for (int h = 0; h < NH; ++h) {
 #pragma unroll
             for (int t = 0; t < NQ; ++t) A::mma_acc(ones, s[2 * h][t], s[2 * h + 1][t], lacc[t]);
 #pragma unroll
             for (int dt = 0; dt < NDT; ++dt) {
-                typename A::AccA va = AccLd<T, D>::ld(Vt, 32 * h, dt * 16, g, r16);
+                typename A::AccA va;
+                if (h == 0 && dt < PREV) va = vap[dt];
+                else va = AccLd<T, D>::ld(Vt, 32 * h, dt * 16, g, r16);
 #pragma unroll
                 for (int t = 0; t < NQ; ++t) A::mma_acc(va, s[2 * h][t], s[2 * h + 1][t], o[dt][t]);
             }
         }
+        MU_PRIO(0);
+#endif
+#ifdef MU_FWD_ABL_NOBAR
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#else
         MU_SYNC_DMA();        // tile j+1 landed (vmcnt(0)) and everyone is done reading tile j
+#endif
     };
-    for (int j0 = 0; j0 < Nk; j0 += 2 * KT) {
-        tile(std::integral_constant<int, 0>{}, j0);
-        if (j0 + KT < Nk) tile(std::integral_constant<int, 1>{}, j0 + KT);
+    // Optimistic sweep first (fp16 storage only): no per-tile running-max scan / cross-lane reduce / branch (13 % of the kernel at
+    // N = 16384, C = 64: a serial dependent chain between the score MFMAs and the exponentials).  A row whose later scores exceed the
+    // first tile's maximum by more than 16 (log2 units) overflows fp16 and leaves an infinite row sum: the whole block then repeats
+    // the sweep with exact tracking (wave-uniform decision through the barrier; never taken on the model's data, forced in the tests).
+    constexpr bool OPTIMISTIC = MU_FWD_OPTIMISTIC && sizeof(T) == 2;
+    bool redo = false;
+    if (OPTIMISTIC) {
+        for (int j0 = 0; j0 < Nk; j0 += 2 * KT) {
+            tile(std::integral_constant<int, 0>{}, std::false_type{}, j0);
+            if (j0 + KT < Nk) tile(std::integral_constant<int, 1>{}, std::false_type{}, j0 + KT);
+        }
+        bool bad = false;
+#pragma unroll
+        for (int t = 0; t < NQ; ++t) bad = bad || !(lacc[t][0] < 3.0e38f);
+        redo = __syncthreads_or(bad);
+        if (redo) {
+#pragma unroll
+            for (int t = 0; t < NQ; ++t) {
+                lacc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                negm[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int dt = 0; dt < NDT; ++dt) o[dt][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            }
+            stg.load_idx(kidx_b, 0, Nk, wave, lane);
+            stg.issue(lds, lds + KT * D, qkv_b, wave, lane);
+            stg.load_idx(kidx_b, KT, Nk, wave, lane);
+            MU_SYNC_DMA();
+        }
+    }
+    if (!OPTIMISTIC || redo) {
+        for (int j0 = 0; j0 < Nk; j0 += 2 * KT) {
+            tile(std::integral_constant<int, 0>{}, std::true_type{}, j0);
+            if (j0 + KT < Nk) tile(std::integral_constant<int, 1>{}, std::true_type{}, j0 + KT);
+        }
     }
     float m[NQ];
 #pragma unroll
@@ -612,6 +706,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 && D <= 64 && sizeof(T) == 2) ? M
     using Frag = typename A::Frag;
     using Z = SwzTile<T, D>;
     constexpr int VN = A::VN, KR = A::KR, NKS = D / KR, NDT = D / 16, NKT = KT / 16, NH = KT / 32;
+    constexpr bool MU_PRIO_BWD = true;
     __shared__ __attribute__((aligned(16))) T lds[2 * 2 * KT * D];
 
     int bx_, b;
@@ -667,6 +762,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 && D <= 64 && sizeof(T) == 2) ? M
             stg.load_idx(kidx_b, j0 + 2 * KT, Nk, wave, lane);
         }
         f32x4 s[NKT][2], dp[NKT][2];
+        MU_PRIO(1);
 #pragma unroll
         for (int ks = 0; ks < NKS; ++ks)
 #pragma unroll
@@ -684,6 +780,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 && D <= 64 && sizeof(T) == 2) ? M
                     }
                 }
             }
+        MU_PRIO(0);
         if (j0 + KT > Nk) {                          // wave-uniform: only the last, partial tile pays for key-range masking
 #pragma unroll
             for (int t = 0; t < 2; ++t)
@@ -693,20 +790,32 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 && D <= 64 && sizeof(T) == 2) ? M
                     for (int r = 0; r < 4; ++r)
                         if (j0 + kt * 16 + 4 * g + r >= Nk) { s[kt][t][r] = -INFINITY; dp[kt][t][r] = 0.f; }
         }
+        constexpr int PREQ = (MU_DQ_PREFETCH && sizeof(T) == 2 && NH == 1) ? (MU_DQ_PREFETCH < NDT ? MU_DQ_PREFETCH : NDT) : 0;
+        typename A::AccA kap[PREQ ? PREQ : 1];
+        if constexpr (PREQ > 0) {                    // transposed K operands of the dQ product: in flight during the exponentials
+#pragma unroll
+            for (int dt = 0; dt < PREQ; ++dt) kap[dt] = AccLd<T, D>::ld(Kt, 0, dt * 16, g, r16);
+            __builtin_amdgcn_sched_barrier(0);
+        }
 #pragma unroll
         for (int t = 0; t < 2; ++t)
 #pragma unroll
             for (int kt = 0; kt < NKT; ++kt)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) s[kt][t][r] = __builtin_amdgcn_exp2f(s[kt][t][r]) * dp[kt][t][r];
+        if constexpr (PREQ > 0) __builtin_amdgcn_sched_barrier(0);
+        MU_PRIO(1);
 #pragma unroll
         for (int h = 0; h < NH; ++h)
 #pragma unroll
             for (int dt = 0; dt < NDT; ++dt) {
-                typename A::AccA ka = AccLd<T, D>::ld(Kt, 32 * h, dt * 16, g, r16);
+                typename A::AccA ka;
+                if (h == 0 && dt < PREQ) ka = kap[dt];
+                else ka = AccLd<T, D>::ld(Kt, 32 * h, dt * 16, g, r16);
 #pragma unroll
                 for (int t = 0; t < 2; ++t) A::mma_acc(ka, s[2 * h][t], s[2 * h + 1][t], dq[dt][t]);
             }
+        MU_PRIO(0);
 #ifdef MU_DQ_ABL_NOBAR
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #else
@@ -747,6 +856,7 @@ __global__ __launch_bounds__(256, (D <= 64 && sizeof(T) == 2 && NKT <= 2) ? MU_D
     using Frag = typename A::Frag;
     using Z = SwzTile<T, D>;
     constexpr int VN = A::VN, KR = A::KR, NKS = D / KR, NDT = D / 16, QT = 32;
+    constexpr bool MU_PRIO_BWD = true;
     constexpr int NI = QT / Z::RPW;                          // DMA wave-instructions per tensor per tile
     static_assert(NI == 4 || NI == 8 || NI == 16 || NI == 32 || NI == 2, "unexpected tile geometry");
     constexpr int NPW = (NI + 3) / 4;                        // per wave (Q and dO each)
@@ -865,6 +975,7 @@ __global__ __launch_bounds__(256, (D <= 64 && sizeof(T) == 2 && NKT <= 2) ? MU_D
             nl[qt] = *reinterpret_cast<const f32x4*>(rc + qt * 16 + 4 * g);
             nd[qt] = *reinterpret_cast<const f32x4*>(rc + 32 + qt * 16 + 4 * g);
         }
+        MU_PRIO(1);
 #pragma unroll
         for (int ks = 0; ks < NKS; ++ks)
 #pragma unroll
@@ -882,6 +993,7 @@ __global__ __launch_bounds__(256, (D <= 64 && sizeof(T) == 2 && NKT <= 2) ? MU_D
                     }
                 }
             }
+        MU_PRIO(0);
         if (tl * QT + QT > N) {                              // last, partial tile: padded queries contribute nothing
 #pragma unroll
             for (int qt = 0; qt < 2; ++qt)
@@ -891,6 +1003,19 @@ __global__ __launch_bounds__(256, (D <= 64 && sizeof(T) == 2 && NKT <= 2) ? MU_D
 #pragma unroll
                         for (int kt = 0; kt < NKT; ++kt) { s[qt][kt][r] = -INFINITY; dp[qt][kt][r] = 0.f; }
                     }
+        }
+        // The transposed dO / Q operands of the dV / dK products are read from LDS BEFORE the exponentials (PRE of the NDT column
+        // blocks): their latency then hides behind the VALU phase instead of standing, once per column block, between the MFMAs
+        // (the compiler otherwise issues each block's reads right in front of its MFMAs: ~60 idle cycles per block per wave).
+        constexpr int PRE = (MU_DKV_PREFETCH && sizeof(T) == 2) ? (MU_DKV_PREFETCH < NDT ? MU_DKV_PREFETCH : NDT) : 0;
+        typename A::AccA oap[PRE ? PRE : 1], qap[PRE ? PRE : 1];
+        if constexpr (PRE > 0) {
+#pragma unroll
+            for (int dt = 0; dt < PRE; ++dt) {
+                oap[dt] = AccLd<T, D>::ld(Ot, 0, dt * 16, g, r16);
+                qap[dt] = AccLd<T, D>::ld(Qt, 0, dt * 16, g, r16);
+            }
+            __builtin_amdgcn_sched_barrier(0);
         }
 #pragma unroll
         for (int qt = 0; qt < 2; ++qt)
@@ -902,16 +1027,20 @@ __global__ __launch_bounds__(256, (D <= 64 && sizeof(T) == 2 && NKT <= 2) ? MU_D
                     s[qt][kt][r] = p;
                     dp[qt][kt][r] *= p;
                 }
+        if constexpr (PRE > 0) __builtin_amdgcn_sched_barrier(0);
+        MU_PRIO(1);
 #pragma unroll
         for (int dt = 0; dt < NDT; ++dt) {
-            typename A::AccA oa = AccLd<T, D>::ld(Ot, 0, dt * 16, g, r16);
-            typename A::AccA qa = AccLd<T, D>::ld(Qt, 0, dt * 16, g, r16);
+            typename A::AccA oa, qa;
+            if (dt < PRE) { oa = oap[dt]; qa = qap[dt]; }
+            else { oa = AccLd<T, D>::ld(Ot, 0, dt * 16, g, r16); qa = AccLd<T, D>::ld(Qt, 0, dt * 16, g, r16); }
 #pragma unroll
             for (int kt = 0; kt < NKT; ++kt) {
                 A::mma_acc(oa, s[0][kt], s[1][kt], dv[dt][kt]);
                 A::mma_acc(qa, dp[0][kt], dp[1][kt], dk[dt][kt]);
             }
         }
+        MU_PRIO(0);
         // Refill the slot tile tl-1 vacated -- issued LAST in the tile: LDS reads queue behind an in-flight LDS-DMA issue
         // (in-kernel s_memtime stamps: the row-constant reads right after the DMA cost ~980 cycles/tile, ~80 without it)
 #ifndef MU_DKV_ISSUE_FIRST

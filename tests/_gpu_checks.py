@@ -410,6 +410,64 @@ def check_attention(dtype, cases=None):
     return out
 
 
+def check_attention_overflow_redo(dtype):
+    """The forward's optimistic sweep (no per-tile running-max tracking, attn.hip) must detect a late score that overflows fp16
+    against the first tile's maximum and redo the block exactly (cdna guide rule 26: force the rare branch, full-tensor fp64
+    reference).  A kept key far down the list is aligned with a few queries so that its score exceeds every earlier one by ~35 log2
+    units; forward (out, PV/l, lse2) and the backward that consumes lse2 are compared with fp64 torch."""
+    from maskunet_amd import _lib
+    B, N, C = 2, 1024, 64
+    g_ = torch.Generator().manual_seed(77)
+    qkv = torch.randn(B, N, 3 * C, generator=g_)
+    x = torch.randn(B, N, C, generator=g_)
+    keep = torch.randint(0, 2, (B, N), generator=g_, dtype=torch.uint8)
+    keep[:, 900] = 1
+    hot_q = [3, 200, 777]
+    for b in range(B):
+        for i in hot_q:
+            qkv[b, i, :C] = qkv[b, i, :C] * (8.0 / qkv[b, i, :C].norm())
+        qkv[b, 900, C:2 * C] = 3.5 * qkv[b, 3, :C] + 3.5 * qkv[b, 200, :C] + 3.5 * qkv[b, 777, :C]     # key 900: late in the kept list
+    qkv = qkv.to(dtype)
+    x = x.to(dtype)
+    gam = torch.rand(C, generator=g_) + 0.5
+    bet = torch.randn(C, generator=g_) * 0.1
+    gout = torch.randn(B, N, C, generator=g_).to(dtype)
+    # fp64 reference
+    qr = qkv.double().clone().requires_grad_(True)
+    xr = x.double().clone().requires_grad_(True)
+    q, k, v = qr[..., :C], qr[..., C:2 * C], qr[..., 2 * C:]
+    sc = q @ k.transpose(1, 2) / (C ** 0.5)
+    sc = sc + torch.where(keep[:, None, :] > 0, 0.0, -float("inf"))
+    pv = torch.softmax(sc, -1) @ v
+    ref = F.layer_norm(pv + xr, (C,), gam.double(), bet.double(), 1e-5)
+    ref.backward(gout.double())
+    lse_ref = torch.logsumexp(sc, -1) * 1.4426950408889634
+    d = DEV
+    qd, xd, kd = qkv.to(d), x.to(d), keep.to(d)
+    kidx = torch.argsort(kd, dim=1, descending=True, stable=True).to(torch.int32).contiguous()
+    kcnt = kd.sum(1, dtype=torch.int32).contiguous()
+    gd, bd = gam.to(d), bet.to(d)
+    out, oattn = torch.empty_like(xd), torch.empty_like(xd)
+    lse = torch.empty(B, N, device=d)
+    mean, rstd, delta = torch.empty_like(lse), torch.empty_like(lse), torch.empty_like(lse)
+    st = _lib.stream()
+    _lib.call("mu_attn_fwd", qd.data_ptr(), xd.data_ptr(), kidx.data_ptr(), kcnt.data_ptr(), gd.data_ptr(), bd.data_ptr(), out.data_ptr(),
+              oattn.data_ptr(), lse.data_ptr(), mean.data_ptr(), rstd.data_ptr(), B, N, C, N, 1e-5, _lib.dt(xd), st)
+    dY, dqkv = torch.empty_like(xd), torch.empty_like(qd)
+    dg, db = torch.empty(C, device=d), torch.empty(C, device=d)
+    ws = _lib.workspace(_lib.load().mu_attn_bwd_workspace_bytes(B, N, C), torch.device(d))
+    go = gout.to(d)
+    _lib.call("mu_attn_bwd", qd.data_ptr(), xd.data_ptr(), oattn.data_ptr(), go.data_ptr(), kidx.data_ptr(), kcnt.data_ptr(), lse.data_ptr(),
+              mean.data_ptr(), rstd.data_ptr(), gd.data_ptr(), dY.data_ptr(), delta.data_ptr(), dqkv.data_ptr(), dg.data_ptr(), db.data_ptr(),
+              B, N, C, N, ws.data_ptr(), ws.numel(), _lib.dt(xd), st)
+    tol = TOL[dtype]
+    hot = float(sc[0, 3, 900].detach() * 1.4426950408889634 - lse_ref[0, 3].detach())      # ~0: key 900 dominates row 3
+    return [("attn overflow-redo out", _err(out, ref.detach()), tol), ("attn overflow-redo PV", _err(oattn, pv.detach()), tol),
+            ("attn overflow-redo lse2", _err(lse, lse_ref.detach()), tol),
+            ("attn overflow-redo hot key dominates", abs(hot), 0.5),
+            ("attn overflow-redo dqkv", _rel_err(dqkv, qr.grad), tol)]
+
+
 def check_attention_mask_semantics():
     import maskunet_amd
     m = maskunet_amd.Mask2FormerAttention(32, 32).to(DEV)

@@ -63,6 +63,12 @@ def test_attention_fwd_bwd(dtype):
     _assert_all(G.check_attention(dtype))
 
 
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_attention_forward_overflow_redo_path(dtype):
+    from tests import _gpu_checks as G
+    _assert_all(G.check_attention_overflow_redo(dtype))
+
+
 def test_attention_mask_semantics():
     from tests import _gpu_checks as G
     _assert_all(G.check_attention_mask_semantics())
