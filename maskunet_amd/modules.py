@@ -133,8 +133,8 @@ class Mask2FormerAttention(_HipModule):
         if channels != self.channels:
             raise ValueError("Input channel size does not match initialized channel size.")
         self._check_device(x)
-        if channels % 32:
-            raise RuntimeError("maskunet_amd: attention channels must be a multiple of 32")
+        if channels not in (32, 64, 128, 256):
+            raise RuntimeError("maskunet_amd: Mask2FormerAttention is built for 32, 64, 128 or 256 channels (INTEGRATION.md section 3)")
         y = self.forward_nhwc(ops.to_nhwc(x, self.compute_dtype), scramble=False)    # [B,N,C] token-major
         # the reference returns this buffer re-viewed as [B,C,H,W] (ade_semantic.py:190)
         return y.view(batch_size, channels, height, width).to(x.dtype)

@@ -7,7 +7,8 @@ args = sys.argv[1:]
 extra = []
 if "--" in args:
     i = args.index("--"); args, extra = args[:i], args[i + 1:]
-code = ("import sys, runpy; sys.path.insert(0, {root!r}); import maskunet_amd._lib as L; L.LIB_PATH = {lib!r}; "
+code = ("import sys, runpy; sys.path.insert(0, {root!r}); import ctypes, maskunet_amd._lib as L; L.LIB_PATH = {lib!r}; _c = ctypes.CDLL({lib!r}); "
+        "L.SIGNATURES = {{k: v for k, v in L.SIGNATURES.items() if hasattr(_c, k)}}; "
         "sys.argv = ['bench.py', '--no-cpu-baseline', '--steps', '8', '--warmup', '2'] + {extra!r}; runpy.run_path({bench!r}, run_name='__main__')")
 res = {n: [] for n in args}
 for rnd in range(3):
