@@ -160,9 +160,10 @@ _workspaces = {}
 
 
 def workspace(nbytes: int, device) -> torch.Tensor:
-    """Grow-only scratch buffer per device.  Kernels that use it are stream-ordered, and every
-    consumer finishes with it before the next launch on the same stream touches it."""
-    key = (device.type, device.index)
+    """Grow-only scratch buffer per (device, current stream).  Kernels that use it are stream-ordered, and every consumer finishes
+    with it before the next launch on the same stream touches it; work on another stream (side-stream weight gradients, a
+    graph-capture stream) gets a buffer of its own."""
+    key = (device.type, device.index, stream())
     ws = _workspaces.get(key)
     if ws is None or ws.numel() < nbytes:
         ws = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)

@@ -1076,27 +1076,10 @@ template <typename T>
 static int attn_fwd_t(const T* qkv, const T* x, const int* kidx, const int* kcnt, const float* gamma, const float* beta, T* out,
                       T* oattn, float* lse2, float* mean, float* rstd, int B, int N, int C, int nkmax, float eps, hipStream_t st) {
     const float sl2 = (float)(1.4426950408889634 / sqrt((double)C));
-    // 8 waves (256 queries) per block share each K/V tile when the image has enough queries: halves the L2->LDS traffic
-    const bool big = false;   // measured: 8-wave blocks are 8% SLOWER (the per-tile barrier over 8 waves costs more than the saved L2 traffic)
-    if (C == 64 && sizeof(T) == 2 && N >= 1024 && getenv("MU_FWD_NQ4")) {
-        // experiment kept for reference: 64 queries per wave (4 tiles) against 32-key tiles halves the K/V bytes per query through
-        // L2->LDS and LDS->VGPR at the same MFMA count, yet measures 4% SLOWER (3.06 vs 2.95 ms at N=16384): the forward is not
-        // bound by tile traffic
-        attn_fwd2_kernel<T, 64, 32, 4, 2, 4><<<dim3(mu_cdiv(N, 256), B), 256, 0, st>>>(qkv, x, kidx, kcnt, gamma, beta, out, oattn, lse2, mean, rstd, N, nkmax, sl2, eps);
-        return MU_OK;
-    }
-#define LAUNCH_FWD(DD, KT)                                                                                                          \
-    if (big) attn_fwd2_kernel<T, DD, KT, 8><<<dim3(mu_cdiv(N, 256), B), 512, 0, st>>>(qkv, x, kidx, kcnt, gamma, beta, out, oattn, lse2, mean, rstd, N, nkmax, sl2, eps); \
-    else attn_fwd2_kernel<T, DD, KT, 4><<<dim3(mu_cdiv(N, 128), B), 256, 0, st>>>(qkv, x, kidx, kcnt, gamma, beta, out, oattn, lse2, mean, rstd, N, nkmax, sl2, eps)
-    if (C == 64 && sizeof(T) == 2 && getenv("MU_ATTN_VARIANT")) {       // tuning experiments (debug only)
-        const int v = atoi(getenv("MU_ATTN_VARIANT"));
-        dim3 g4(mu_cdiv(N, 128), B);
-        if (v == 1) { attn_fwd2_kernel<T, 64, 128, 4><<<g4, 256, 0, st>>>(qkv, x, kidx, kcnt, gamma, beta, out, oattn, lse2, mean, rstd, N, nkmax, sl2, eps); return MU_OK; }
-        if (v == 2) { attn_fwd2_kernel<T, 64, 32, 4><<<g4, 256, 0, st>>>(qkv, x, kidx, kcnt, gamma, beta, out, oattn, lse2, mean, rstd, N, nkmax, sl2, eps); return MU_OK; }
-        if (v == 3) { attn_fwd2_kernel<T, 64, 64, 4, 3><<<g4, 256, 0, st>>>(qkv, x, kidx, kcnt, gamma, beta, out, oattn, lse2, mean, rstd, N, nkmax, sl2, eps); return MU_OK; }
-        if (v == 4) { attn_fwd2_kernel<T, 64, 32, 4, 3><<<g4, 256, 0, st>>>(qkv, x, kidx, kcnt, gamma, beta, out, oattn, lse2, mean, rstd, N, nkmax, sl2, eps); return MU_OK; }
-        if (v == 5) { attn_fwd2_kernel<T, 64, 64, 4, 1><<<g4, 256, 0, st>>>(qkv, x, kidx, kcnt, gamma, beta, out, oattn, lse2, mean, rstd, N, nkmax, sl2, eps); return MU_OK; }
-    }
+    // (measured and removed: 8-wave blocks sharing each K/V tile among 256 queries, -8 %; 64 queries per wave against 32-key tiles,
+    //  -4 %; 128- / 32-key tiles and other occupancy bounds, +-0: the sweep is bound by MFMA + VALU issue time)
+#define LAUNCH_FWD(DD, KT) \
+    attn_fwd2_kernel<T, DD, KT, 4><<<dim3(mu_cdiv(N, 128), B), 256, 0, st>>>(qkv, x, kidx, kcnt, gamma, beta, out, oattn, lse2, mean, rstd, N, nkmax, sl2, eps)
     switch (C) {
         case 32: LAUNCH_FWD(32, 64); break;
         case 64: LAUNCH_FWD(64, 64); break;
@@ -1147,10 +1130,7 @@ static int attn_bwd_t(const T* qkv, const T* x, const T* oattn, const T* gout, c
     }                                                                                                                           \
     if (phases & 2) attn_bwd_dq2_kernel<T, DD, KTQ, 4><<<gq, 256, 0, st>>>(qkv, dY, kidx, kcnt, lse2, delta, dqkv, N, nkmax, scale, sl2); \
     if (phases & 4) {                                                                                                           \
-        if (DD == 64 && sizeof(T) == 2 && getenv("MU_DKV_NKT4"))                                                                \
-            attn_bwd_dkv3_kernel<T, DD, 4><<<dim3(mu_cdiv(nkmax, 256), B), 256, 0, st>>>(qkv, dY, kidx, kcnt, rowc, dqkv, N, nkmax, scale, sl2); \
-        else                                                                                                                    \
-            attn_bwd_dkv3_kernel<T, DD, NKT><<<dim3(mu_cdiv(nkmax, 64 * NKT), B), 256, 0, st>>>(qkv, dY, kidx, kcnt, rowc, dqkv, N, nkmax, scale, sl2); \
+        attn_bwd_dkv3_kernel<T, DD, NKT><<<dim3(mu_cdiv(nkmax, 64 * NKT), B), 256, 0, st>>>(qkv, dY, kidx, kcnt, rowc, dqkv, N, nkmax, scale, sl2); \
     }
     if (N % 4) return MU_ERR_SHAPE;
     switch (C) {
