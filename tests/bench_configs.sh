@@ -1,0 +1,17 @@
+#!/bin/bash
+# bench.py on every BASELINE.json configuration shape that fits one GPU (+ opt-in variants); one JSON line each -> gpurun_out/<TAG>_configs.jsonl
+TAG=${1:-r02}
+ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
+OUT=$ROOT/gpurun_out/${TAG}_configs.jsonl
+: > $OUT
+cd $ROOT
+run() { echo "# bench.py $*" >> $OUT; timeout 900 python bench.py --no-cpu-baseline --steps 10 --warmup 3 "$@" 2>>$ROOT/gpurun_out/${TAG}_configs.err | grep '^{' >> $OUT; }
+run                                               # configs[1]: ADE20K semantic, B=64, fp16
+run --c-out 133 --batch 128                       # configs[2]: COCO panoptic shape, B=128
+run --three-head --c-out 19 --batch 64            # configs[3] per-GPU shape: Cityscapes instance, 3-head, B=64/GPU
+run --hw 256 --c-out 133 --batch 32               # configs[4] per-GPU shape: COCO semantic 256x256, B=32/GPU
+run --graph                                       # configs[1] replayed as one HIP graph
+run --optimizer                                   # configs[1] + fused AdamW inside the step
+run --dtype fp32 --steps 4 --warmup 2             # fp32 parity path
+run --batch 16
+cat $OUT | cut -c1-260
