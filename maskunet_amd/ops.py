@@ -107,8 +107,47 @@ def to_nchw(x, C, out_dtype=torch.float32):
 # ------------------------------------------------------------------------------------------------
 # convolution / linear
 # ------------------------------------------------------------------------------------------------
-def _prep_weight(w, dtype, rows_pad, cols_pad, mode):
+# Prepared (compute-layout) weights are cached on the parameter for forwards under torch.no_grad() / inference_mode -- the validation
+# loop of the reference scripts (`model.eval(); with torch.no_grad(): ...`, ade_semantic.py:421-430) converts the 45 weight tensors once
+# instead of once per batch.  The entry is keyed on the parameter's version counter and storage address: optimizer
+# steps, load_state_dict and .to() invalidate it (maskunet_amd.FusedAdamW writes through raw pointers and bumps the versions itself).
+# Training forwards never use it -- the weights change every step anyway, and an in-place edit through `p.data` (which autograd's
+# version counter does not see) must not be able to leave a training run on stale weights.  Never consulted during graph capture.
+PREP_CACHE = os.environ.get("MU_PREP_CACHE", "1") != "0"
+
+
+def _cache_ok():
+    """Evaluated OUTSIDE the autograd.Function (inside Function.forward grad mode is always off)."""
+    return PREP_CACHE and not torch.is_grad_enabled()
+
+
+def _prep_cached(w, key, make, ok):
+    if not ok or torch.cuda.is_current_stream_capturing():
+        return make()
+    cache = getattr(w, "_mu_prep", None)
+    if cache is None:
+        cache = {}
+        try:
+            w._mu_prep = cache
+        except Exception:      # tensors that do not accept attributes
+            return make()
+    tag = (w._version, w.data_ptr())
+    hit = cache.get(key)
+    if hit is not None and hit[0] == tag:
+        return hit[1]
+    out = make()
+    cache[key] = (tag, out)
+    return out
+
+
+def _prep_weight(w, dtype, rows_pad, cols_pad, mode, cache_ok=False):
     """mode 0: forward layout; 1: data-gradient layout; 2: both from one launch -> (fwd, dgrad) views of one buffer."""
+    if cache_ok and isinstance(w, torch.nn.Parameter):
+        return _prep_cached(w, (dtype, rows_pad, cols_pad, mode), lambda: _prep_weight_raw(w, dtype, rows_pad, cols_pad, mode), True)
+    return _prep_weight_raw(w, dtype, rows_pad, cols_pad, mode)
+
+
+def _prep_weight_raw(w, dtype, rows_pad, cols_pad, mode):
     O, I = w.shape[0], w.shape[1]
     taps = w.shape[2] * w.shape[3] if w.dim() == 4 else 1
     n = taps * rows_pad * cols_pad
@@ -234,7 +273,7 @@ class _Conv(torch.autograd.Function):
     """nn.Conv2d k=3/pad=1 or k=1, NHWC (ade_semantic.py:199,202,284; city_instance.py:243-249)."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, want_stats=False):
+    def forward(ctx, x, weight, bias, want_stats=False, cache_ok=False):
         x = x.contiguous()
         O, I = weight.shape[0], weight.shape[1]
         taps = weight.shape[2] * weight.shape[3]
@@ -246,7 +285,7 @@ class _Conv(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             wprep, ctx.wd = _prep_weight(weight, x.dtype, Cout_p, Cin_p, 2)
         else:
-            wprep = _prep_weight(weight, x.dtype, Cout_p, Cin_p, 0)
+            wprep = _prep_weight(weight, x.dtype, Cout_p, Cin_p, 0, cache_ok)
         bias_p = _pad_vec(bias, Cout_p, 0.0) if bias is not None else None
         part = None
         if want_stats:
@@ -268,7 +307,7 @@ class _Conv(torch.autograd.Function):
     @once_differentiable
     def backward(ctx, gy, gpart=None):
         if gy is None:
-            return None, None, None, None
+            return None, None, None, None, None
         x, weight = ctx.saved_tensors
         gy = gy.contiguous()
         O, I = weight.shape[0], weight.shape[1]
@@ -290,11 +329,11 @@ class _Conv(torch.autograd.Function):
                 gw = _wgrad_raw(x, gy, tuple(weight.shape), ctx.taps)
         if ctx.has_bias and ctx.needs_input_grad[2] and gb is None:
             gb = _colsum(gy, O)
-        return gx, gw, gb, None
+        return gx, gw, gb, None, None
 
 
 def conv(x, weight, bias=None):
-    return _Conv.apply(x, weight, bias)
+    return _Conv.apply(x, weight, bias, False, _cache_ok())
 
 
 CONV_STATS = os.environ.get("MU_CONV_STATS", "1") != "0"      # debug switch: 0 = always the separate statistics sweep
@@ -304,8 +343,8 @@ def conv_stats(x, weight, bias=None, want=True):
     """conv() that also returns the BatchNorm statistics rows of its output (an empty tensor when the kernel has none) --
     pass them to bn_act(..., stats=rows) to skip the separate statistics sweep."""
     if not want or not CONV_STATS:
-        return _Conv.apply(x, weight, bias), None
-    return _Conv.apply(x, weight, bias, True)
+        return _Conv.apply(x, weight, bias, False, _cache_ok()), None
+    return _Conv.apply(x, weight, bias, True, _cache_ok())
 
 
 # ------------------------------------------------------------------------------------------------
@@ -605,17 +644,21 @@ class _MaskAttention(torch.autograd.Function):
     consumer wants the NCHW-flat memory itself (the final LayerNorm, :311)."""
 
     @staticmethod
-    def forward(ctx, x, wq, bq, wk, bk, wv, bv, lnw, lnb, kidx, kcnt, eps, scramble):
+    def forward(ctx, x, wq, bq, wk, bk, wv, bv, lnw, lnb, kidx, kcnt, eps, scramble, cache_ok=False):
         x = x.contiguous()
         B, H, W, C = x.shape
         N = H * W
-        wqkv = torch.cat([wq.detach(), wk.detach(), wv.detach()], 0).float().view(3 * C, C, 1, 1)
-        bqkv = torch.cat([bq.detach(), bk.detach(), bv.detach()], 0).float().contiguous()
-        ctx.wd = None
-        if ctx.needs_input_grad[0]:
-            wprep, ctx.wd = _prep_weight(wqkv, x.dtype, 3 * C, C, 2)
+        def make_qkv():
+            wqkv_ = torch.cat([wq.detach(), wk.detach(), wv.detach()], 0).float().view(3 * C, C, 1, 1)
+            bqkv_ = torch.cat([bq.detach(), bk.detach(), bv.detach()], 0).float().contiguous()
+            return wqkv_, bqkv_, _prep_weight_raw(wqkv_, x.dtype, 3 * C, C, 2)
+
+        if cache_ok and isinstance(wq, torch.nn.Parameter):     # cached on the query weight, keyed on all six parameters' versions
+            vers = tuple((t._version, t.data_ptr()) for t in (wk, wv, bq, bk, bv))
+            wqkv, bqkv, (wprep, wd_) = _prep_cached(wq, ("qkv", x.dtype, vers), make_qkv, True)
         else:
-            wprep = _prep_weight(wqkv, x.dtype, 3 * C, C, 0)
+            wqkv, bqkv, (wprep, wd_) = make_qkv()
+        ctx.wd = wd_ if ctx.needs_input_grad[0] else None
         qkv = _conv_raw(x, wprep, bqkv, 3 * C, 1)                      # [B,H,W,3C] == [B,N,3C]
         out = torch.empty((B, N, C), dtype=x.dtype, device=x.device)
         oattn = torch.empty_like(out)
@@ -662,10 +705,10 @@ class _MaskAttention(torch.autograd.Function):
         else:
             gw = _wgrad_raw(x, dqkv4, (3 * C, C, 1, 1), 1).view(3 * C, C)
             gb = _colsum(dqkv4, 3 * C)
-        return (gx, gw[:C], gb[:C], gw[C:2 * C], gb[C:2 * C], gw[2 * C:], gb[2 * C:], dg, db, None, None, None, None)
+        return (gx, gw[:C], gb[:C], gw[C:2 * C], gb[C:2 * C], gw[2 * C:], gb[2 * C:], dg, db, None, None, None, None, None)
 
 
 def mask_attention(x, q, k, v, norm, kidx, kcnt, scramble=True):
     """q,k,v: nn.Linear containers; norm: nn.LayerNorm([C]) container."""
     return _MaskAttention.apply(x, q.weight, q.bias, k.weight, k.bias, v.weight, v.bias, norm.weight, norm.bias, kidx, kcnt,
-                                norm.eps, scramble)
+                                norm.eps, scramble, _cache_ok())

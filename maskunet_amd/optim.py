@@ -77,4 +77,7 @@ class FusedAdamW(torch.optim.Optimizer):
             ev.record()
             call("mu_adamw_multi", ptr(table), ptr(bt), ptr(bc), nblocks, float(group["lr"]), float(b1), float(b2), float(group["eps"]),
                  float(group["weight_decay"]), 1.0 / float(grad_scale), stream())
+            for p in params:                 # the kernel wrote the parameters through raw pointers: tell autograd / the weight-layout cache
+                if p.grad is not None:
+                    torch.autograd.graph.increment_version(p)
         return loss

@@ -308,3 +308,48 @@ def test_instance_contrastive_loss_matches_oracle_at_model_shape():
     ld.backward()
     assert abs(float(ld) - float(lr)) <= 1e-5 * max(1.0, abs(float(lr)))
     assert float((fd.grad.cpu() - fr.grad).abs().max()) <= 1e-5
+
+
+def test_weight_layout_cache_only_without_grad_and_invalidated_by_updates():
+    """Forwards under torch.no_grad() re-use the prepared weight layouts (validation loop); training forwards never do; an optimizer
+    step (FusedAdamW writes through raw pointers) or load_state_dict invalidates the entries."""
+    import maskunet_amd
+    from maskunet_amd import _lib, ops
+    torch.manual_seed(0)
+    m = maskunet_amd.ConvBlock(32, 64).cuda().eval()
+    x = torch.randn(2, 32, 16, 16, device="cuda")
+    calls = []
+    _lib.PROBE = {"pred": lambda name, a: (calls.append(name) or False) if name == "mu_prep_weight" else False, "events": []}
+    try:
+        with torch.no_grad():
+            y0 = m(x)
+            n0 = len(calls)
+            y1 = m(x)
+            assert len(calls) == n0 and n0 == 2 and torch.equal(y0, y1)          # second forward: no conversions
+        m.train()
+        xr = x.clone().requires_grad_(True)
+        m(xr).sum().backward()
+        m(xr).sum().backward()
+        assert len(calls) == n0 + 4                                               # training forwards always convert
+        opt = maskunet_amd.FusedAdamW(m.parameters(), lr=0.1)
+        opt.step()
+        m.eval()
+        with torch.no_grad():
+            y2 = m(x)
+            assert len(calls) == n0 + 6 and not torch.equal(y2, y0)              # updated weights: converted again, new result
+            sd = {k: v.clone() for k, v in m.state_dict().items()}
+            for v in sd.values():
+                if v.dtype.is_floating_point:
+                    v.mul_(0.5)
+            m.load_state_dict(sd)
+            y3 = m(x)
+            assert len(calls) == n0 + 8 and not torch.equal(y3, y2)
+            ref = maskunet_amd.ConvBlock(32, 64).cuda().eval()
+            ref.load_state_dict(sd)
+            ops_cache, ops.PREP_CACHE = ops.PREP_CACHE, False
+            try:
+                assert torch.equal(ref(x), y3)
+            finally:
+                ops.PREP_CACHE = ops_cache
+    finally:
+        _lib.PROBE = None
