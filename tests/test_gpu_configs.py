@@ -210,3 +210,39 @@ def test_batch64_training_step_matches_split_batches_statistics_free_parts():
             ops._wgrad_raw(xa[32:].contiguous(), dy[32:].contiguous(), (cout, cin, 3, 3), 9)
         rel = float((full - halves).abs().max()) / float(halves.abs().max())
         assert rel <= 1e-3, ((cin, cout, hw), rel)
+
+
+def test_three_head_batch64_training_step():
+    """configs[3] per-GPU shape: the 3-head Cityscapes model (c_out = 19, embed 16) at B = 64, fp16, with the reference's criterion
+    (CrossEntropyLoss(ignore_index=255) + 0.1 * InstanceContrastiveLoss on the embeddings, city_instance.py:372-377): finite,
+    bit-reproducible, every head's parameters get gradients except the boundary head (unused by that loss, as in the reference)."""
+    import maskunet_amd
+    import bench
+    torch.manual_seed(5)
+    B = 64
+    model = maskunet_amd.InstanceUNet(3, 19, 16).cuda()
+    model.set_compute_dtype(torch.float16).train()
+    model.dropout.p = 0.0
+    x, labels, keeps = bench.synth(B, 19, 128, 11, torch.device("cuda"), ignore_frac=0.1)
+    model.set_keep_masks(keeps)
+    g = torch.Generator().manual_seed(3)
+    blocks = torch.randint(0, 21, (B, 8, 8), generator=g)
+    inst = blocks.repeat_interleave(16, 1).repeat_interleave(16, 2).cuda()
+    u = torch.rand(1024, generator=g).cuda()
+    crit = maskunet_amd.CrossEntropyLoss(ignore_index=255)
+    iloss = maskunet_amd.InstanceContrastiveLoss(margin=1.0, ignore_index=255)
+    state = {k: v.clone() for k, v in model.state_dict().items()}
+    runs = []
+    for _ in range(2):
+        model.load_state_dict(state)
+        model.zero_grad(set_to_none=True)
+        sem, bnd, emb = model(x)
+        loss = crit(sem, labels) + 0.1 * iloss(emb, inst, u)
+        (loss * 1024.0).backward()
+        runs.append((loss.item(), {n: p.grad.clone() for n, p in model.named_parameters() if p.grad is not None}))
+    assert runs[0][0] == runs[1][0] and runs[0][0] == runs[0][0]
+    assert all(torch.equal(runs[0][1][n], runs[1][1][n]) and torch.isfinite(runs[0][1][n]).all() for n in runs[0][1])
+    names = set(runs[0][1])
+    assert any(n.startswith("embedding_head") for n in names) and any(n.startswith("final_layer") for n in names)
+    assert not any(n.startswith("boundary_head") for n in names) and not any("emb_layer" in n for n in names)
+    assert tuple(sem.shape) == (B, 19, 128, 128) and tuple(bnd.shape) == (B, 1, 128, 128) and tuple(emb.shape) == (B, 16, 128, 128)
