@@ -187,11 +187,11 @@ def main():
 
     graphed = None
     if args.graph:
-        if world > 1 or args.fused_loss or args.three_head or args.torch_loss:
-            # N > 1 is not offered: a replay runs no autograd hooks (the bucket all-reduces would follow it instead of overlapping the
-            # backward), and the only multi-rank rig of this round -- two gloo ranks sharing one GPU -- ran it 10x slower than eager
-            raise SystemExit("--graph: single GPU, maskunet_amd.CrossEntropyLoss, 1-head model only")
-        graphed = maskunet_amd.GraphedStep(model, criterion, x, labels, loss_scale=scale)
+        if args.fused_loss or args.three_head or args.torch_loss:
+            raise SystemExit("--graph: maskunet_amd.CrossEntropyLoss, 1-head model only")
+        # N > 1: each replica replays its own graph and the bucketed all-reduce follows the replay (a replay runs no autograd hooks,
+        # so the exchange does not overlap the backward) -- opt-in, for small per-GPU batches where the host enqueue is the bound
+        graphed = maskunet_amd.GraphedStep(net, criterion, x, labels, loss_scale=scale)
 
     def step():
         nonlocal graphed, fwd_events

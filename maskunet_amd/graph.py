@@ -13,19 +13,26 @@ stream with no host synchronisation, so the step can be captured (torch.cuda.CUD
 What changes under capture: the dropout seed drawn on the host is baked into the graph, so a device step counter -- incremented inside the
 graph -- is mixed into it (mu_dropout_step); BatchNorm running statistics / step counters are updated on the device as always; the
 attention keep-masks are whatever the modules hold at capture time (set_keep_masks / the lazily drawn, cached masks of the reference).
-Not for maskunet_amd.DataParallel (its bucket hooks launch collectives on another stream).
+
+With a maskunet_amd.DataParallel model the replica's step is captured (the graph holds no collective) and the gradient exchange runs
+eagerly after every replay: the same bucketed all-reduce on the comm stream, without overlap with the backward -- the hooks of
+DataParallel sit on the parameters' AccumulateGrad nodes, which the captured torch.autograd.grad on fresh leaves never runs.  The
+averaged gradients land in the graph's own gradient tensors (p.grad); `no_sync()` around a call skips the exchange as usual.
 """
 from __future__ import annotations
 
 import torch
 
 from . import ops
+from .dp import DataParallel
 
 
 class GraphedStep:
     def __init__(self, model, criterion, example_inputs, example_labels, loss_scale: float = 1.0, warmup: int = 2):
         if not example_inputs.is_cuda:
             raise RuntimeError("GraphedStep needs CUDA example inputs (the HIP path has no CPU fallback)")
+        self.dp = model if isinstance(model, DataParallel) else None
+        model = model.module if self.dp is not None else model
         self.model, self.criterion, self.scale = model, criterion, float(loss_scale)
         named = [(n, p) for n, p in model.named_parameters() if p.requires_grad]
         self.names, self.params = [n for n, _ in named], [p for _, p in named]
@@ -72,4 +79,7 @@ class GraphedStep:
         self.graph.replay()
         for p, g in zip(self.params, self.grads):     # optimizer.zero_grad(set_to_none=True) between replays detaches them
             p.grad = g
+        if self.dp is not None:                       # one exchange per step, after the replay (ade_semantic.py:373)
+            self.dp._arm()
+            self.dp.finish_gradient_sync()
         return self.loss.clone()                      # self.loss is overwritten by the next replay

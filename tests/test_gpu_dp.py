@@ -142,6 +142,23 @@ assert all(k.startswith("module.") for k in ddp.state_dict())
 print("RANK", rank, "worst", worst, flush=True)
 # identical shard runs are bit-reproducible (no float atomics), the cross-rank mean goes through fp32 on the host: ~1e-7
 assert worst <= 1e-5, worst
+# the same step as ONE captured graph per replica + the eager exchange after each replay (GraphedStep over DataParallel)
+model.load_state_dict(params)
+model.zero_grad(set_to_none=True)
+step_fn = maskunet_amd.GraphedStep(ddp, F.cross_entropy, x[a:b].cuda(), labels[a:b].cuda())
+worst_g = 0.0
+for it in range(2):
+    loss = step_fn(x[a:b].cuda(), labels[a:b].cuda())
+    assert torch.isfinite(loss).all()
+    for n, p in model.named_parameters():
+        if n in exp:
+            e = float((p.grad.double() - exp[n]).abs().max()) / max(float(exp[n].abs().max()), 1e-12)
+            worst_g = max(worst_g, e)
+        else:
+            assert p.grad is None, n
+    model.zero_grad(set_to_none=True)         # the next call re-attaches the graph's gradient tensors
+print("RANK", rank, "worst graphed", worst_g, flush=True)
+assert worst_g <= 1e-5, worst_g
 dist.destroy_process_group()
 """
 
