@@ -55,13 +55,17 @@ class DataParallel(nn.Module):
     ``module.`` prefix exactly like nn.DataParallel checkpoints (ade_semantic.py:412; stripped on load at
     ade_panoptic.py:434)."""
 
-    def __init__(self, module: nn.Module, bucket_mb: float = 32.0, overlap: bool = True, process_group=None):
+    def __init__(self, module: nn.Module, bucket_mb: float = 32.0, overlap: bool = True, process_group=None,
+                 force_sync: bool = False):
         super().__init__()
         self.module = module
         self.group = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
-        self.overlap = overlap and self.world > 1
-        if self.world > 1:
+        # force_sync: run the whole exchange (broadcast, hooks, buckets, collectives) in a group of ONE rank too -- lets a
+        # single-GPU box exercise the RCCL calls and their stream ordering (tests/test_gpu_dp.py)
+        self.multi = self.world > 1 or (force_sync and dist.is_initialized())
+        self.overlap = overlap and self.multi
+        if self.multi:
             self.broadcast_parameters()
         # buckets in reverse registration order (roughly the order gradients become ready)
         params = [p for p in module.parameters() if p.requires_grad]
@@ -94,7 +98,7 @@ class DataParallel(nn.Module):
 
     def broadcast_buffers(self, src: int = 0):
         """Copy rank ``src``'s buffers (BatchNorm running statistics / step counters) to every rank."""
-        if self.world > 1:
+        if self.multi:
             for t in self.module.buffers():
                 dist.broadcast(t.data, src, group=self.group)
 
@@ -178,7 +182,7 @@ class DataParallel(nn.Module):
     def finish_gradient_sync(self):
         """Wait for the bucket all-reduces and write the averaged gradients back.  Buckets whose hooks did not
         all fire (parameters without gradients this step) are reduced here with what they have."""
-        if self.world == 1 or not self._sync:
+        if not self.multi or not self._sync:
             self._armed = False
             return
         for b in self.buckets:

@@ -181,6 +181,66 @@ def test_two_ranks_one_gpu_real_backward_matches_shard_mean():
     assert all(p.returncode == 0 for p in procs), "\n----\n".join(o[-3000:] for o in outs)
 
 
+_RCCL_WORKER = r"""
+import os, sys
+sys.path.insert(0, {root!r})
+import torch, torch.distributed as dist, torch.nn.functional as F
+torch.cuda.set_device(0)
+dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))     # exactly bench.py's call
+import maskunet_amd
+from maskunet_amd.dp import DataParallel
+from oracle import maskunet_oracle as O          # deterministic parameter / input recipe only
+c_out, B = 19, 2
+params = O.make_params(O.unet_state_shapes(3, c_out, False), 77)
+keeps = O.make_keeps(78, B)
+x, labels = O.make_inputs(79, B, c_out)
+model = maskunet_amd.UNet(3, c_out)
+model.load_state_dict(params)
+model.cuda().train()
+model.dropout.p = 0.0
+model.set_keep_masks(keeps)
+xd, ld = x.cuda(), labels.cuda()
+F.cross_entropy(model(xd), ld).backward()
+ref = {{n: p.grad.clone() for n, p in model.named_parameters() if p.grad is not None}}
+ddp = DataParallel(model, bucket_mb=4.0, force_sync=True)
+assert ddp.multi and ddp.overlap and len(ddp.buckets) > 3
+for step in range(3):                      # step 0 learns the dead parameters; later steps launch every bucket from the hooks
+    model.zero_grad(set_to_none=True)
+    F.cross_entropy(ddp(xd), ld).backward()
+    if step:
+        assert all(bk.work is not None for bk in ddp.buckets if any(id(p) not in ddp._dead for p in bk.params))
+    ddp.finish_gradient_sync()
+    for n, p in model.named_parameters():
+        if n in ref:
+            assert torch.equal(p.grad, ref[n]), n        # sum over one rank / 1: bit-exact through the fp32 buckets
+        else:
+            assert p.grad is None, n
+# the same through one captured graph per replica + the exchange after the replay
+step_fn = maskunet_amd.GraphedStep(ddp, F.cross_entropy, xd, ld)
+step_fn(xd, ld)
+for n, p in model.named_parameters():
+    if n in ref:
+        assert torch.equal(p.grad, ref[n]), n
+# the other collectives bench.py issues
+dist.barrier()
+t = torch.tensor([1.5], device="cuda", dtype=torch.float64)
+dist.all_reduce(t, op=dist.ReduceOp.MAX)
+assert float(t.item()) == 1.5
+ddp.broadcast_buffers()
+torch.cuda.synchronize()
+dist.destroy_process_group()
+print("RCCL single-rank exchange ok", flush=True)
+"""
+
+
+def test_rccl_backend_single_rank_exchange():
+    """The nccl (= RCCL) backend itself, in a group of one rank (all the single-GPU pool offers): init with device_id as bench.py does,
+    async all-reduces issued from the autograd hooks on the comm stream, Work.wait() there, write-back, barrier, broadcast."""
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, "-c", _RCCL_WORKER.format(root=ROOT)], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and "exchange ok" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
+
+
 def test_bench_starts_under_torchrun_world2_gloo():
     """The driver's N>1 invocation (`python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...`) with two gloo
     ranks on the one GPU: must initialise, step through DataParallel and print ONE JSON line with n_gpus = 2."""
