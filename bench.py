@@ -232,7 +232,7 @@ def main():
     # HIP-event probe on the dominant kernel: the dK/dV sweep (attn_bwd_dkv3_kernel) of self_attention6, N = hw*hw.
     # mu_attn_bwd_phases(..., B, N, C, nkmax, ws, ws_bytes, dtype, phases, stream): args[16] = N, args[22] = phases
     N6 = args.hw * args.hw
-    _lib.PROBE = {"pred": lambda name, a: name == "mu_attn_bwd_phases" and a[16] == N6 and a[22] == 4, "events": []}
+    _lib.PROBE = {"pred": lambda name, a: name == "mu_attn_bwd_phases" and a[16] == N6 and (a[22] & 7) == 4, "events": []}
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()

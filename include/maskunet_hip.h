@@ -180,7 +180,11 @@ int mu_attn_bwd(const void* qkv, const void* x, const void* oattn, const void* g
                 const float* lse2, const float* ln_mean, const float* ln_rstd, const float* gamma, void* dY, float* delta, void* dqkv,
                 float* dgamma, float* dbeta, int B, int N, int C, int nkmax, void* workspace, long ws_bytes, int dtype, void* stream);
 /* the same, one phase group at a time (bit mask): 1 = zero dqkv + LayerNorm backward / delta / dgamma,dbeta,
- * 2 = dQ sweep, 4 = dK/dV sweep.  Phases 2 and 4 need phase 1's dY, delta and workspace contents. */
+ * 2 = dQ sweep, 4 = dK/dV sweep.  Phases 2 and 4 need phase 1's dY, delta and workspace contents.
+ * 8 (MU_ATTN_KIDX_PERMUTATION, OR-ed into every call of one backward) = a promise about kidx: nkmax == N and every row is a whole
+ * permutation of 0..N-1 with the masked keys listed after the kept ones (what a stable descending argsort of the keep mask
+ * gives).  The dK/dV sweep then writes the masked keys' zero rows itself and phase 1 skips the memset of the whole dqkv buffer. */
+#define MU_ATTN_KIDX_PERMUTATION 8
 int mu_attn_bwd_phases(const void* qkv, const void* x, const void* oattn, const void* grad_out, const int* kidx, const int* kcnt,
                        const float* lse2, const float* ln_mean, const float* ln_rstd, const float* gamma, void* dY, float* delta,
                        void* dqkv, float* dgamma, float* dbeta, int B, int N, int C, int nkmax, void* workspace, long ws_bytes,

@@ -57,6 +57,9 @@
 #ifndef MU_FWD_KT128
 #define MU_FWD_KT128 32
 #endif
+#ifndef MU_FWD_NW128
+#define MU_FWD_NW128 4
+#endif
 #ifndef MU_DKV_NKT128
 #define MU_DKV_NKT128 1
 #endif
@@ -851,7 +854,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 && D <= 64 && sizeof(T) == 2) ? M
 template <typename T, int D, int NKT>
 __global__ __launch_bounds__(256, (D <= 64 && sizeof(T) == 2 && NKT <= 2) ? MU_DKV_OCC : ((D == 128 && sizeof(T) == 2 && NKT <= 2) ? MU_DKV_OCC128 : ((D == 256 && sizeof(T) == 2 && NKT == 1) ? MU_DKV_OCC256 : 1))) void attn_bwd_dkv3_kernel(
     const T* __restrict__ qkv, const T* __restrict__ dY, const int* __restrict__ kidx, const int* __restrict__ kcnt,
-    const float* __restrict__ rowc, T* __restrict__ dqkv, int N, int nkmax, float scale, float scale_log2) {
+    const float* __restrict__ rowc, T* __restrict__ dqkv, int N, int nkmax, float scale, float scale_log2, int zero_masked) {
     using A = AT<T>;
     using Frag = typename A::Frag;
     using Z = SwzTile<T, D>;
@@ -871,8 +874,22 @@ __global__ __launch_bounds__(256, (D <= 64 && sizeof(T) == 2 && NKT <= 2) ? MU_D
     const int r16 = lane & 15, g = lane >> 4;
     const int Nk = kcnt[b];
     const int kb0 = bx_ * (4 * NKT * 16);
-    if (kb0 >= Nk) return;
     const int* kidx_b = kidx + (long)b * nkmax;
+    if (kb0 >= Nk) {
+        // zero_masked (kidx rows are whole permutations, the masked keys listed after the kept ones): this block's keys are all
+        // masked -- their dK / dV rows are exact zeros, written here instead of by a memset of the whole dqkv buffer
+        if (zero_masked) {
+            constexpr int LPK = 2 * D * (int)sizeof(T) / 16;             // 16-byte lanes per key row (K and V parts are adjacent)
+            for (int i = threadIdx.x; i < 4 * NKT * 16 * LPK; i += 256) {
+                const int j = kb0 + i / LPK;
+                if (j < nkmax) {
+                    T* dst = dqkv + ((long)b * N + kidx_b[j]) * 3 * D + D;
+                    reinterpret_cast<float4*>(dst)[i % LPK] = make_float4(0.f, 0.f, 0.f, 0.f);
+                }
+            }
+        }
+        return;
+    }
     const T* qkv_b = qkv + (long)b * N * 3 * D;
     const T* dY_b = dY + (long)b * N * D;
     const int ntile = (N + QT - 1) / QT;
@@ -1057,12 +1074,22 @@ __global__ __launch_bounds__(256, (D <= 64 && sizeof(T) == 2 && NKT <= 2) ? MU_D
     }
 #pragma unroll
     for (int kt = 0; kt < NKT; ++kt) {
-        if (keyrow[kt] < 0) continue;
-        T* dst = dqkv + ((long)b * N + keyrow[kt]) * 3 * D;
+        int row = keyrow[kt];
+        const bool live = row >= 0;
+        if (!live) {                                         // masked key inside the last kept block: exact zeros (see above)
+            const int j = kb0 + (wave * NKT + kt) * 16 + r16;
+            if (!zero_masked || j >= nkmax) continue;
+            row = kidx_b[j];
+        }
+        T* dst = dqkv + ((long)b * N + row) * 3 * D;
 #pragma unroll
         for (int dt = 0; dt < NDT; ++dt) {
             float kv[4] = {dk[dt][kt][0], dk[dt][kt][1], dk[dt][kt][2], dk[dt][kt][3]};
             float vv[4] = {dv[dt][kt][0], dv[dt][kt][1], dv[dt][kt][2], dv[dt][kt][3]};
+            if (!live) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { kv[r] = 0.f; vv[r] = 0.f; }
+            }
             store4<T>(dst + D + dt * 16 + 4 * g, kv);
             store4<T>(dst + 2 * D + dt * 16 + 4 * g, vv);
         }
@@ -1083,7 +1110,13 @@ static int attn_fwd_t(const T* qkv, const T* x, const int* kidx, const int* kcnt
     switch (C) {
         case 32: LAUNCH_FWD(32, 64); break;
         case 64: LAUNCH_FWD(64, 64); break;
-        case 128: LAUNCH_FWD(128, MU_FWD_KT128); break;
+        case 128:
+#if MU_FWD_NW128 == 8
+            attn_fwd2_kernel<T, 128, MU_FWD_KT128, 8, 1><<<dim3(mu_cdiv(N, 256), B), 512, 0, st>>>(qkv, x, kidx, kcnt, gamma, beta, out, oattn, lse2, mean, rstd, N, nkmax, sl2, eps);
+#else
+            LAUNCH_FWD(128, MU_FWD_KT128);
+#endif
+            break;
         case 256: LAUNCH_FWD(256, 32); break;
         default: return MU_ERR_SHAPE;
     }
@@ -1122,7 +1155,10 @@ static int attn_bwd_t(const T* qkv, const T* x, const T* oattn, const T* gout, c
     const float scale = (float)(1.0 / sqrt((double)C));
     const float sl2 = (float)(1.4426950408889634 / sqrt((double)C));
     dim3 gq(mu_cdiv(N, 128), B);
-    if ((phases & 1) && hipMemsetAsync(dqkv, 0, (size_t)rows * 3 * C * sizeof(T), st) != hipSuccess) return MU_ERR_LAUNCH;
+    // phases & 8 (MU_ATTN_KIDX_PERMUTATION): every kidx row is a whole permutation of 0..N-1 with the masked keys after the kept
+    // ones, so the dK/dV sweep writes the masked keys' zero rows itself (dQ parts are written for every row by the dQ sweep)
+    const int zero_masked = ((phases & 8) && nkmax == N) ? 1 : 0;
+    if ((phases & 1) && !zero_masked && hipMemsetAsync(dqkv, 0, (size_t)rows * 3 * C * sizeof(T), st) != hipSuccess) return MU_ERR_LAUNCH;
 #define LAUNCH_BWD(DD, NKT)                                                                                                     \
     if (phases & 1) {                                                                                                           \
         attn_ln_bwd_kernel<T, DD><<<nblk, 256, 0, st>>>(gout, oattn, x, mean, rstd, gamma, dY, delta, (double*)ws, rows, lse2, rowc, N, scale); \
@@ -1130,7 +1166,7 @@ static int attn_bwd_t(const T* qkv, const T* x, const T* oattn, const T* gout, c
     }                                                                                                                           \
     if (phases & 2) attn_bwd_dq2_kernel<T, DD, KTQ, 4><<<gq, 256, 0, st>>>(qkv, dY, kidx, kcnt, lse2, delta, dqkv, N, nkmax, scale, sl2); \
     if (phases & 4) {                                                                                                           \
-        attn_bwd_dkv3_kernel<T, DD, NKT><<<dim3(mu_cdiv(nkmax, 64 * NKT), B), 256, 0, st>>>(qkv, dY, kidx, kcnt, rowc, dqkv, N, nkmax, scale, sl2); \
+        attn_bwd_dkv3_kernel<T, DD, NKT><<<dim3(mu_cdiv(nkmax, 64 * NKT), B), 256, 0, st>>>(qkv, dY, kidx, kcnt, rowc, dqkv, N, nkmax, scale, sl2, zero_masked); \
     }
     if (N % 4) return MU_ERR_SHAPE;
     switch (C) {

@@ -52,7 +52,10 @@ class GraphedStep:
         self.graph = torch.cuda.CUDAGraph()
         ops.SEED_STEP = self.step_counter
         try:
-            with torch.cuda.graph(self.graph):
+            # thread_local: with an initialised nccl (RCCL) process group the backend's watchdog thread polls the events of finished
+            # collectives (hipEventQuery) at any time; under the default "global" capture mode that call from ANOTHER thread is an
+            # error ("operation not permitted when stream is capturing") and takes the process down
+            with torch.cuda.graph(self.graph, capture_error_mode="thread_local"):
                 self.step_counter.add_(1)
                 self.loss, self.outputs = self._body()
         finally:

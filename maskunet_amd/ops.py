@@ -688,10 +688,13 @@ class _MaskAttention(torch.autograd.Function):
         dg = torch.empty(C, dtype=torch.float32, device=x.device)
         db = torch.empty_like(dg)
         ws = workspace(_lib.load().mu_attn_bwd_workspace_bytes(B, N, C), x.device)
+        # kidx rows are stable descending argsorts of the keep masks (modules.Mask2FormerAttention._compact): whole permutations,
+        # masked keys last -> MU_ATTN_KIDX_PERMUTATION (8): the dK/dV sweep zeroes the masked rows, no memset of dqkv
+        perm = 8 if kidx.shape[1] == N else 0
         for phase in (1, 2, 4):      # LayerNorm-backward prepass, dQ sweep, dK/dV sweep (separate calls: each can be timed)
             call("mu_attn_bwd_phases", ptr(qkv), ptr(x), ptr(oattn), ptr(gout), ptr(kidx), ptr(kcnt), ptr(lse2), ptr(mean), ptr(rstd),
-                 ptr(g), ptr(dY), ptr(delta), ptr(dqkv), ptr(dg), ptr(db), B, N, C, kidx.shape[1], ptr(ws), ws.numel(), dt(x), phase,
-                 stream())
+                 ptr(g), ptr(dY), ptr(delta), ptr(dqkv), ptr(dg), ptr(db), B, N, C, kidx.shape[1], ptr(ws), ws.numel(), dt(x),
+                 phase | perm, stream())
         dqkv4 = dqkv.view(B, H, W, 3 * C)
         gx = None
         if ctx.needs_input_grad[0]:

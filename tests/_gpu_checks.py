@@ -689,3 +689,47 @@ def check_unet_vs_oracle(dtype, B=2, c_out=150, three_head=False, seed=300, with
                 worst = (e, k)
     res.append((f"unet worst running stat [{worst[1]}]", worst[0], tol))
     return res
+
+
+def check_attention_bwd_masked_rows(dtype):
+    """mu_attn_bwd_phases with and without MU_ATTN_KIDX_PERMUTATION (8): the dqkv buffer starts as NaN garbage; either way the masked
+    keys' dK / dV rows must be exact zeros and everything else identical bit for bit (memset path vs rows zeroed by the dK/dV sweep).
+    Shapes cover a key count that ends inside a block, whole masked blocks, and images whose kept keys fill the last block."""
+    from maskunet_amd import _lib
+    res = []
+    for (B, N, C, kept) in ((3, 1024, 64, (1, 500, 1024)), (2, 512, 128, (130, 64)), (2, 256, 256, (255, 17)), (2, 1024, 32, (700, 3))):
+        g_ = torch.Generator().manual_seed(5 + C)
+        qkv = torch.randn(B, N, 3 * C, generator=g_).to(dtype).to(DEV)
+        x = torch.randn(B, N, C, generator=g_).to(dtype).to(DEV)
+        gout = torch.randn(B, N, C, generator=g_).to(dtype).to(DEV)
+        keep = torch.zeros(B, N, dtype=torch.uint8)
+        for b in range(B):
+            keep[b, torch.randperm(N, generator=g_)[:kept[b]]] = 1
+        kd = keep.to(DEV)
+        kidx = torch.argsort(kd, dim=1, descending=True, stable=True).to(torch.int32).contiguous()
+        kcnt = kd.sum(1, dtype=torch.int32).contiguous()
+        gam, bet = torch.ones(C, device=DEV), torch.zeros(C, device=DEV)
+        out, oattn = torch.empty_like(x), torch.empty_like(x)
+        lse = torch.empty(B, N, device=DEV)
+        mean, rstd, delta = torch.empty_like(lse), torch.empty_like(lse), torch.empty_like(lse)
+        st = _lib.stream()
+        _lib.call("mu_attn_fwd", qkv.data_ptr(), x.data_ptr(), kidx.data_ptr(), kcnt.data_ptr(), gam.data_ptr(), bet.data_ptr(), out.data_ptr(),
+                  oattn.data_ptr(), lse.data_ptr(), mean.data_ptr(), rstd.data_ptr(), B, N, C, N, 1e-5, _lib.dt(x), st)
+        ws = _lib.workspace(_lib.load().mu_attn_bwd_workspace_bytes(B, N, C), torch.device(DEV))
+        outs = []
+        for flag in (0, 8):
+            dY = torch.empty_like(x)
+            dqkv = torch.full_like(qkv, float("nan"))
+            dg, db = torch.empty(C, device=DEV), torch.empty(C, device=DEV)
+            for phase in (1, 2, 4):
+                _lib.call("mu_attn_bwd_phases", qkv.data_ptr(), x.data_ptr(), oattn.data_ptr(), gout.data_ptr(), kidx.data_ptr(), kcnt.data_ptr(),
+                          lse.data_ptr(), mean.data_ptr(), rstd.data_ptr(), gam.data_ptr(), dY.data_ptr(), delta.data_ptr(), dqkv.data_ptr(),
+                          dg.data_ptr(), db.data_ptr(), B, N, C, N, ws.data_ptr(), ws.numel(), _lib.dt(x), phase | flag, st)
+            torch.cuda.synchronize()
+            outs.append(dqkv)
+        masked = (kd == 0)
+        z = outs[1][..., C:][masked]
+        res.append((f"attn bwd C={C} masked rows exact zero with flag 8", float(z.abs().max()) if z.numel() else 0.0, 0.0))
+        res.append((f"attn bwd C={C} flag 8 == memset path", 0.0 if torch.equal(outs[0], outs[1]) else 1.0, 0.0))
+        res.append((f"attn bwd C={C} finite", 0.0 if torch.isfinite(outs[1].float()).all() else 1.0, 0.0))
+    return res

@@ -69,6 +69,12 @@ def test_attention_forward_overflow_redo_path(dtype):
     _assert_all(G.check_attention_overflow_redo(dtype))
 
 
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_attention_bwd_masked_rows_zeroed_by_sweep_or_memset(dtype):
+    from tests import _gpu_checks as G
+    _assert_all(G.check_attention_bwd_masked_rows(dtype))
+
+
 def test_attention_mask_semantics():
     from tests import _gpu_checks as G
     _assert_all(G.check_attention_mask_semantics())
