@@ -148,7 +148,10 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     ndev = torch.cuda.device_count()
     backend = os.environ.get("MU_DIST_BACKEND", "nccl")      # "gloo" lets two ranks share one GPU in a debug run
-    if world > 1:
+    # MU_BENCH_FORCE_DP=1: run the multi-rank code path (process group, DataParallel hooks and buckets, barrier, max-over-ranks) in a
+    # group of ONE rank -- what a single-GPU box can exercise of the N > 1 invocation over RCCL (tests/test_gpu_dp.py)
+    multi = world > 1 or os.environ.get("MU_BENCH_FORCE_DP") == "1"
+    if multi:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", local))
@@ -172,7 +175,7 @@ def main():
     model.set_compute_dtype(dtype).train()
     x, labels, keeps = synth(args.batch, args.c_out, args.hw, 42 + rank, dev, ignore_frac=0.1 if args.three_head else 0.0)
     model.set_keep_masks(keeps)
-    net = maskunet_amd.DataParallel(model) if world > 1 else model
+    net = maskunet_amd.DataParallel(model, force_sync=True) if multi else model
     scale = args.loss_scale if dtype == torch.float16 else 1.0
 
     inst_loss = inst_labels = None
@@ -201,7 +204,7 @@ def main():
                 opt.step(grad_scale=scale)
             return loss
         if args.fused_loss and not args.three_head:
-            if world > 1:
+            if multi:
                 net._arm()
             loss = maskunet_amd.pixel_cross_entropy_nhwc(model.logits_nhwc(x), labels, args.c_out, grad_scale=scale)
             loss.backward()
@@ -218,7 +221,7 @@ def main():
             if args.three_head:          # city_instance.py:372-377: seg_loss + LAMBDA_IE * InstanceContrastiveLoss(embeddings, inst_labels)
                 loss = loss + 0.1 * inst_loss(out[2], inst_labels)
             (loss * scale).backward()
-        if world > 1:
+        if multi:
             net.finish_gradient_sync()
         if opt is not None:
             opt.step(grad_scale=scale)
@@ -233,13 +236,13 @@ def main():
     # mu_attn_bwd_phases(..., B, N, C, nkmax, ws, ws_bytes, dtype, phases, stream): args[16] = N, args[22] = phases
     N6 = args.hw * args.hw
     _lib.PROBE = {"pred": lambda name, a: name == "mu_attn_bwd_phases" and a[16] == N6 and (a[22] & 7) == 4, "events": []}
-    if world > 1:
+    if multi:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss = step()
-    if world > 1:
+    if multi:
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
@@ -250,7 +253,7 @@ def main():
             step()
         torch.cuda.synchronize()
     _lib.PROBE = None
-    if world > 1:
+    if multi:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -320,7 +323,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             rec["cpu_baseline"] = cpu_baseline(args.c_out, args.hw)
         print(json.dumps(rec), flush=True)
-    if world > 1:
+    if multi:
         dist.destroy_process_group()
 
 

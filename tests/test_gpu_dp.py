@@ -257,6 +257,24 @@ def test_bench_starts_under_torchrun_world2_gloo():
     assert rec["n_gpus"] == 2 and rec["config"]["global_batch"] == 4 and rec["value"] > 0
 
 
+@pytest.mark.parametrize("graph", [False, True])
+def test_bench_multi_rank_path_over_rccl_one_rank(graph):
+    """bench.py's N > 1 code path (nccl init with device_id, DataParallel hooks / buckets on the comm stream, barrier, max over ranks;
+    with --graph: replay + exchange) on the RCCL backend in a group of one rank, launched exactly as the driver launches N > 1."""
+    import json
+    env = dict(os.environ, MU_BENCH_FORCE_DP="1")
+    env.pop("MU_DIST_BACKEND", None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "2",
+           "--batch", "8", "--no-cpu-baseline"] + (["--graph"] if graph else [])
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 1 and rec["value"] > 0 and rec["roofline"]["frac"] > 0
+
+
 def test_bench_refuses_gpus_without_launcher():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
                        env={k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")},
