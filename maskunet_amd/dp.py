@@ -65,6 +65,7 @@ class DataParallel(nn.Module):
         # single-GPU box exercise the RCCL calls and their stream ordering (tests/test_gpu_dp.py)
         self.multi = self.world > 1 or (force_sync and dist.is_initialized())
         self.overlap = overlap and self.multi
+        self._avg = dist.is_initialized() and dist.get_backend(process_group) == "nccl"
         if self.multi:
             self.broadcast_parameters()
         # buckets in reverse registration order (roughly the order gradients become ready)
@@ -152,7 +153,8 @@ class DataParallel(nn.Module):
                 comm.wait_stream(side)
             with torch.cuda.stream(comm):
                 flat = torch.cat([g.reshape(-1).float() for g in grads])
-                work = dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+                # RCCL averages inside the collective (ncclAvg); other backends sum and _write_back divides
+                work = dist.all_reduce(flat, op=dist.ReduceOp.AVG if self._avg else dist.ReduceOp.SUM, group=self.group, async_op=True)
         else:
             flat = torch.cat([g.reshape(-1).float() for g in grads])
             work = dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
@@ -171,13 +173,17 @@ class DataParallel(nn.Module):
             # wait() with the comm stream current: on the nccl/RCCL backend it orders the CURRENT stream behind the
             # collective, and the divide / copy-back below run on that same stream
             work.wait()
-            flat.div_(self.world)
-            off = 0
+            if not (self._avg and dev.type == "cuda"):
+                flat.div_(self.world)
+            grads, views, off = [], [], 0
             for p in params:
                 g = p.grad
                 n = g.numel()
-                g.copy_(flat[off:off + n].view_as(g))
+                grads.append(g)
+                views.append(flat[off:off + n].view_as(g))
                 off += n
+            # one multi-tensor copy per bucket: ~330 separate copy launches cost ~1 ms of GPU time per step after the backward
+            torch._foreach_copy_(grads, views)
 
     def finish_gradient_sync(self):
         """Wait for the bucket all-reduces and write the averaged gradients back.  Buckets whose hooks did not

@@ -54,6 +54,7 @@ def test_wait_is_issued_on_the_comm_stream(monkeypatch):
     monkeypatch.setattr(dist, "is_initialized", lambda: True)
     monkeypatch.setattr(dist, "get_world_size", lambda group=None: 2)
     monkeypatch.setattr(dist, "broadcast", lambda *a, **k: None)
+    monkeypatch.setattr(dist, "get_backend", lambda group=None: "stub")       # not "nccl": the sum is divided in _write_back
     monkeypatch.setattr(dist, "all_reduce", lambda flat, op=None, group=None, async_op=False: _LateWork(flat, torch.cuda.current_stream()))
     _LateWork.streams_at_wait = []
     torch.manual_seed(0)
