@@ -772,12 +772,19 @@ __device__ __forceinline__ void tile_stats_store(float (&ssum)[8], float (&ssq)[
 //   block : 512 threads = 8 waves, tile 128 output channels x (16 x 16) pixels of one image; wave = 64 co x (4 rows x 16) px
 //   LDS   : halo 18 x 18 x 128 B double-buffered (2 x 41 KB) + ring of FOUR 16 KB weight tiles (tap x 64 ci) + 1 KB dump
 //   phase : half a tap (32 of the 64 ci): 8 ds_read_b128 -> s_barrier -> 16 MFMA -> s_barrier; 4 barriers per tap
-//   DMA   : issued in the second phase of tap s: one halo piece of the next 64-channel chunk (taps 0..6; a dummy afterwards,
-//           so that every wave issues exactly 3 DMAs per tap and vmcnt counts stay uniform) + the 2 instructions of this
-//           wave's share of W(s+3) into ring slot (s+3)&3 == (s-1)&3, whose last readers passed a barrier a full phase ago
-//   wait  : s_waitcnt vmcnt(3) in the first phase's MFMA section of tap s retires W(s+1) (issued in tap s-2) and leaves
-//           tap s-1's three DMAs in flight; two barriers separate that wait from the first read of W(s+1) -- one more
-//           than the unstaggered rule needs, because group B trails group A by one barrier.
+//   DMA   : first phase of tap s: one halo piece of the next 64-channel chunk (taps 1..6; a dummy afterwards, so that every
+//           wave issues exactly 3 DMAs per tap and vmcnt counts stay uniform) -- its target, the other halo buffer, has no
+//           readers during this chunk (tap 0's piece waits for the second phase: that buffer was read until the previous
+//           chunk's last phase); second phase: the 2 instructions of this wave's share of W(s+3) into ring slot
+//           (s+3)&3 == (s-1)&3, whose last readers passed a barrier a full phase ago.  (All three in the second phase made
+//           that read section twice as long as the MFMA section it hides behind: 1 + 2 is 3 % faster on the 32^2 / 16^2 layers.)
+//   wait  : s_waitcnt vmcnt(4) (tap 0: 3) in the first phase's MFMA section of tap s retires W(s+1) (issued in tap s-2) and
+//           leaves H(s-1), W(s+2) and H(s) in flight; two barriers separate that wait from the first read of W(s+1) -- one
+//           more than the unstaggered rule needs, because group B trails group A by one barrier.  The last halo piece H(6)
+//           is retired by tap 8's wait, two phases before the next chunk reads it.
+//   NOTE  : timing ablations that drop the DMAs (or feed the zero page) leave ZERO operands in LDS; the chip then holds a
+//           higher clock and the kernel looks 25-30 % faster (cdna guide rule 25) -- an L2-resident halo source, with real
+//           data, changes nothing: the DMA stream does not bound this kernel.
 // Versus v3 the weight tile is shared by 256 instead of 128 pixels (half the L2->LDS bytes per flop) and the DMA
 // lookahead grows from one tap (~0.25 us, less than an L2 hit under load) to three phases.
 // ------------------------------------------------------------------------------------------
@@ -907,10 +914,12 @@ __global__ __launch_bounds__(512, 1) void conv_nt4_kernel(const h16* __restrict_
                 for (int i = 0; i < TM; ++i) a[i] = *reinterpret_cast<const Frag*>(wa + i * 2048);
 #pragma unroll
                 for (int j = 0; j < TN; ++j) b[j] = *reinterpret_cast<const Frag*>(hb + j * (HW_ * 128));
-                if (kk == 1) {                               // exactly three DMAs per wave per tap
+                // exactly three DMAs per wave per tap: the halo piece in the first phase (tap 0: in the second -- the buffer it
+                // refills was read until the previous chunk's last phase), the two weight pieces in the second
+                if ((kk == 0) == (t != 0)) {
                     if (t < HPW) stage_h(t, c + 1); else glds16(mu_zero_page, dump);
-                    stage_w(s + 3);
                 }
+                if (kk == 1) stage_w(s + 3);
                 __builtin_amdgcn_s_barrier();
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 __builtin_amdgcn_sched_barrier(0);
@@ -925,7 +934,10 @@ __global__ __launch_bounds__(512, 1) void conv_nt4_kernel(const h16* __restrict_
                 __builtin_amdgcn_s_setprio(0);
 #endif
 #ifndef MU_NT4_ABL_NOWAIT
-                if (kk == 0) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+                if (kk == 0) {
+                    if (t == 0) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");      // younger: H(8), W(s+2) x2
+                    else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");             // younger: H(t-1), W(s+2) x2, H(t)
+                }
 #endif
                 __builtin_amdgcn_sched_barrier(0);
                 __builtin_amdgcn_s_barrier();
@@ -975,7 +987,7 @@ __global__ __launch_bounds__(512, 1) void conv_nt4_kernel(const h16* __restrict_
 // boundary: the last chunk of a tile prefetches the NEXT tile's first halo (pieces at taps 0..6) and its first three weight
 // tiles, so only the first tile of a block has a prologue.  The epilogue stages the output through the just-freed halo
 // buffer in two 32 KB halves (the other buffer already holds the next tile's halo).  Its 8 global stores per thread count
-// in vmcnt like the DMAs: the first two taps of a tile wait with vmcnt(11) = 3 DMAs + 8 younger stores, afterwards vmcnt(3).
+// in vmcnt like the DMAs: the first two taps of a tile wait with vmcnt(11) / vmcnt(12) = 3 / 4 DMAs + 8 younger stores, afterwards vmcnt(4).
 // LDS-DMA through inline asm (glds16a): the epilogue's LDS writes would otherwise be fenced with vmcnt(0) by the compiler.
 // ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(512, 1) void conv_nt4p_kernel(const h16* __restrict__ x, const h16* __restrict__ w, const float* __restrict__ bias,
@@ -1105,9 +1117,14 @@ __global__ __launch_bounds__(512, 1) void conv_nt4p_kernel(const h16* __restrict
                     for (int i = 0; i < TM; ++i) a[i] = *reinterpret_cast<const Frag*>(wa + i * 2048);
 #pragma unroll
                     for (int j = 0; j < TN; ++j) b[j] = *reinterpret_cast<const Frag*>(hb + j * (HW_ * 128));
-                    if (kk == 1) {                           // exactly three DMAs per wave per tap
+                    // exactly three DMAs per wave per tap: the halo piece in the first phase (tap 0: in the second, behind two more
+                    // barriers -- its buffer was read until the previous chunk's last phase and staged the previous tile's output),
+                    // the two weight pieces in the second
+                    if ((kk == 0) == (t != 0)) {
                         if (t < HPW) stage_h(t, pf_chunk, (G + 1) & 1, pf_real);
                         else glds16a(mu_zero_page, dump);
+                    }
+                    if (kk == 1) {
                         const int t3 = (t + 3) % 9, c3 = c + (t + 3) / 9;       // the tap three steps ahead (may be the next tile's)
                         if (c3 < kchunks) stage_w((sg + 3) & 3, t3, c3, true);
                         else stage_w((sg + 3) & 3, t3, 0, has_next);
@@ -1123,8 +1140,11 @@ __global__ __launch_bounds__(512, 1) void conv_nt4p_kernel(const h16* __restrict
                     __builtin_amdgcn_s_setprio(0);
                     if (kk == 0) {
                         // taps 0 and 1 of a tile: the previous tile's 8 output stores are younger than the awaited weight tile
-                        if (t < 2) { if (c == 0) asm volatile("s_waitcnt vmcnt(11)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); }
-                        else asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+                        // younger than the awaited weight tile: tap 0: H(8), W(s+2) x2 [+ 8 stores]; tap 1: [8 stores +] H(0), W(s+2) x2,
+                        // H(1); later taps: H(t-1), W(s+2) x2, H(t)
+                        if (t == 0) { if (c == 0) asm volatile("s_waitcnt vmcnt(11)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); }
+                        else if (t == 1) { if (c == 0) asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); }
+                        else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
                     }
                     __builtin_amdgcn_sched_barrier(0);
                     __builtin_amdgcn_s_barrier();
