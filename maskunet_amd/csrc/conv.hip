@@ -1546,6 +1546,9 @@ template <int N> __device__ __forceinline__ void wait_vmcnt_c() {
 #ifndef MU_WG_PP
 #define MU_WG_PP 0
 #endif
+#ifndef MU_WG_SPLIT_DMA
+#define MU_WG_SPLIT_DMA 1
+#endif
 // SPS = 32-pixel k-steps per DMA stage.  SPS = 2 (W % 64 == 0): one barrier / DMA batch / ring step per 64 pixels -- the two
 // waves of a SIMD run in lockstep behind the per-stage barrier, so the ~500 cycles of scalar + address work per ring step sit
 // in front of both waves' MFMA bursts (PMC: SQ_ACTIVE_INST_SCA 18 % of wave cycles, MFMA pipe 44 % busy at SPS = 1).
@@ -1628,9 +1631,10 @@ __global__ __launch_bounds__(NWV * 64, 1) void conv_wgrad3_kernel(const h16* __r
     const h16* dyp = dy + p_begin * dy_ld;
     const h16* xp = x + (p_begin + (long)dh * W) * x_ld;
 
-    auto stage = [&](int buf) {                  // past p_end: an all-zero stage (keeps the per-wave DMA count uniform)
+    // (stage = stage_a + stage_b: the two-k-step kernels issue the dy pieces in front of the first k-step's MFMAs and the x pieces
+    //  in front of the second's instead of all of them in one burst)
+    auto stage_a = [&](int buf) {                // past p_end: an all-zero stage (keeps the per-wave DMA count uniform)
         h16* At = lds + buf * STAGE;
-        h16* Bt = At + SP * BCO;
         const bool live = pis < p_end;
 #pragma unroll
         for (int k = 0; k < NAW; ++k) {
@@ -1640,6 +1644,11 @@ __global__ __launch_bounds__(NWV * 64, 1) void conv_wgrad3_kernel(const h16* __r
                 glds16a(src, At + i * RPWA * BCO);
             }
         }
+    };
+    auto stage_b = [&](int buf) {
+        h16* At = lds + buf * STAGE;
+        h16* Bt = At + SP * BCO;
+        const bool live = pis < p_end;
         const int hh = hi + dh;
         const bool rowok = live && hh >= 0 && hh < H, rowok1 = live && hh + 1 >= 0 && hh + 1 < H;
         const bool lok = wi > 0, rok = wi + SP < W;
@@ -1664,6 +1673,7 @@ __global__ __launch_bounds__(NWV * 64, 1) void conv_wgrad3_kernel(const h16* __r
             if (wi >= W) { wi = 0; hi = hi + 1 == H ? 0 : hi + 1; }
         }
     };
+    auto stage = [&](int buf) { stage_a(buf); stage_b(buf); };
 
     f32x4 acc[3][TM][TN];
 #pragma unroll
@@ -1779,7 +1789,10 @@ __global__ __launch_bounds__(NWV * 64, 1) void conv_wgrad3_kernel(const h16* __r
         if (HALF == 0) {
             wait_ring();
             __builtin_amdgcn_s_barrier();
-            stage(buf == 0 ? NS - 1 : buf - 1);
+            if (SPS == 2 && MU_WG_SPLIT_DMA) stage_a(buf == 0 ? NS - 1 : buf - 1);
+            else stage(buf == 0 ? NS - 1 : buf - 1);
+        } else if (SPS == 2 && MU_WG_SPLIT_DMA) {
+            stage_b(buf == 0 ? NS - 1 : buf - 1);
         }
         compute(cur);
         if (s + 1 < nsteps) {
