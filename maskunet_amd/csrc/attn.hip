@@ -63,6 +63,12 @@
 #ifndef MU_DKV_NKT128
 #define MU_DKV_NKT128 1
 #endif
+#ifndef MU_DKV_NW128
+#define MU_DKV_NW128 8
+#endif
+#ifndef MU_DKV_NW256
+#define MU_DKV_NW256 4
+#endif
 #ifndef MU_DQ_KT
 #define MU_DQ_KT 32
 #endif
@@ -76,6 +82,9 @@
 #define MU_ATTN_SETPRIO 1
 #endif
 // LDS operand prefetch ahead of the VALU phase (number of 16-column blocks; 0 = off)
+#ifndef MU_DKV_PREFETCH128
+#define MU_DKV_PREFETCH128 8
+#endif
 #ifndef MU_DKV_PREFETCH
 #define MU_DKV_PREFETCH 0
 #endif
@@ -251,9 +260,19 @@ template <typename T, int D> struct SwzTile {
     static constexpr int CPR = ROWB / 16;                 // 16-byte chunks per row
     static constexpr int RPW = 1024 / ROWB;               // rows per wave LDS-DMA instruction
     static constexpr int SW = CPR < 8 ? CPR - 1 : 7;
+    // XOR key of a row (applied to the 16-byte chunk index by the DMA source permutation and by every read).
+    //  * rows of <= 128 bytes: row & 7 -- both the ds_read_b128 row reads and the transposed ds_read_b64_tr_b16 reads are conflict-free;
+    //  * fp16 rows of 256 / 512 bytes (C = 128 / 256): every row starts on bank 0, so the bank slot is the chunk index mod 16.
+    //    row & 7 left BOTH read kinds 2-way conflicting (SQ_LDS_BANK_CONFLICT = 50 % of SQ_LDS_IDX_ACTIVE on all three C = 128
+    //    kernels): the 16 lanes of a b128 group (rows {0-3, 12-15} at chunk c, rows {4-11} at chunk c+1) fell on 8 slots, and the
+    //    8 rows x 2 chunks of a transposed read on 8 slots.  (row & 7) << 1 puts each of 8 consecutive rows on its own even/odd slot
+    //    PAIR (transposed reads touch {c, c+1} with c even) and makes row -> slot injective over the 16 rows of a b128 group.
+    static __device__ __forceinline__ constexpr int key(int row) {
+        return (sizeof(T) == 2 && ROWB >= 256) ? ((row & 7) << 1) : (row & SW);
+    }
     // element offset of (row, col) in the swizzled image
     static __device__ __forceinline__ int off(int row, int col) {
-        return row * D + ((((col / VN) ^ (row & SW))) * VN) + (col % VN);
+        return row * D + ((((col / VN) ^ key(row))) * VN) + (col % VN);
     }
 };
 
@@ -290,7 +309,7 @@ template <typename T, int D, int KT, int NW> struct KvStage {
 #pragma unroll
         for (int n = 0; n < NPW; ++n) {
             const int row = (wave + NW * n) * Z::RPW + lrow;
-            const int sc = lch ^ (row & Z::SW);
+            const int sc = lch ^ Z::key(row);
             off[n] = (uint32_t)((idx[n] * 3 * D + sc * Z::VN) * (int)sizeof(T));
             asm volatile("" ::"v"(off[n]));
         }
@@ -851,8 +870,10 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 && D <= 64 && sizeof(T) == 2) ? M
 // vector-memory op in the loop is an LDS-DMA (the row constants -lse2 and -delta/sqrt(C) come in through the same
 // ring), so the counted waits are exact: each wave issues exactly 3 DMA instructions per tile.
 // ------------------------------------------------------------------------------------------
-template <typename T, int D, int NKT>
-__global__ __launch_bounds__(256, (D <= 64 && sizeof(T) == 2 && NKT <= 2) ? MU_DKV_OCC : ((D == 128 && sizeof(T) == 2 && NKT <= 2) ? MU_DKV_OCC128 : ((D == 256 && sizeof(T) == 2 && NKT == 1) ? MU_DKV_OCC256 : 1))) void attn_bwd_dkv3_kernel(
+// NW = waves per block (16 * NKT keys each).  The Q / dO stream a block pulls through L2 -> LDS is shared by NW * NKT * 16 keys: at
+// C = 128 with 4 waves of 16 keys every launch moved 4.2 GB in 0.7 ms (6 TB/s, the L2 -> LDS ceiling) -- 8 waves halve that.
+template <typename T, int D, int NKT, int NW = 4>
+__global__ __launch_bounds__(NW * 64, NW == 8 ? 1 : ((D <= 64 && sizeof(T) == 2 && NKT <= 2) ? MU_DKV_OCC : ((D == 128 && sizeof(T) == 2 && NKT <= 2) ? MU_DKV_OCC128 : ((D == 256 && sizeof(T) == 2 && NKT == 1) ? MU_DKV_OCC256 : 1)))) void attn_bwd_dkv3_kernel(
     const T* __restrict__ qkv, const T* __restrict__ dY, const int* __restrict__ kidx, const int* __restrict__ kcnt,
     const float* __restrict__ rowc, T* __restrict__ dqkv, int N, int nkmax, float scale, float scale_log2, int zero_masked) {
     using A = AT<T>;
@@ -862,7 +883,7 @@ __global__ __launch_bounds__(256, (D <= 64 && sizeof(T) == 2 && NKT <= 2) ? MU_D
     constexpr bool MU_PRIO_BWD = true;
     constexpr int NI = QT / Z::RPW;                          // DMA wave-instructions per tensor per tile
     static_assert(NI == 4 || NI == 8 || NI == 16 || NI == 32 || NI == 2, "unexpected tile geometry");
-    constexpr int NPW = (NI + 3) / 4;                        // per wave (Q and dO each)
+    constexpr int NPW = (NI + NW - 1) / NW;                  // per wave (Q and dO each)
     constexpr int STG = 2 * QT * D;                          // elements per ring slot (Q | dO)
     constexpr int DKV_RING = (STG * (int)sizeof(T) <= 32768) ? 4 : 2;      // ring depth; prefetch distance = depth - 1
     __shared__ __attribute__((aligned(16))) T lds[DKV_RING * STG];
@@ -873,14 +894,14 @@ __global__ __launch_bounds__(256, (D <= 64 && sizeof(T) == 2 && NKT <= 2) ? MU_D
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r16 = lane & 15, g = lane >> 4;
     const int Nk = kcnt[b];
-    const int kb0 = bx_ * (4 * NKT * 16);
+    const int kb0 = bx_ * (NW * NKT * 16);
     const int* kidx_b = kidx + (long)b * nkmax;
     if (kb0 >= Nk) {
         // zero_masked (kidx rows are whole permutations, the masked keys listed after the kept ones): this block's keys are all
         // masked -- their dK / dV rows are exact zeros, written here instead of by a memset of the whole dqkv buffer
         if (zero_masked) {
             constexpr int LPK = 2 * D * (int)sizeof(T) / 16;             // 16-byte lanes per key row (K and V parts are adjacent)
-            for (int i = threadIdx.x; i < 4 * NKT * 16 * LPK; i += 256) {
+            for (int i = threadIdx.x; i < NW * NKT * 16 * LPK; i += NW * 64) {
                 const int j = kb0 + i / LPK;
                 if (j < nkmax) {
                     T* dst = dqkv + ((long)b * N + kidx_b[j]) * 3 * D + D;
@@ -902,10 +923,10 @@ __global__ __launch_bounds__(256, (D <= 64 && sizeof(T) == 2 && NKT <= 2) ? MU_D
         const int lrow = lane / Z::CPR, lch = lane % Z::CPR;
 #pragma unroll
         for (int n = 0; n < NPW; ++n) {
-            const int i = wave + 4 * n;
+            const int i = wave + NW * n;
             const int ii = i < NI ? i : 0;                   // (NI >= 4 for every instantiation: never clamps)
             const int row = ii * Z::RPW + lrow;
-            const int sc = lch ^ (row & Z::SW);
+            const int sc = lch ^ Z::key(row);
             rowl[n] = row;
             qlane[n] = row * 3 * D + sc * Z::VN;
             olane[n] = row * D + sc * Z::VN;
@@ -920,7 +941,7 @@ __global__ __launch_bounds__(256, (D <= 64 && sizeof(T) == 2 && NKT <= 2) ? MU_D
         const bool full = tile * QT + QT <= N;               // wave-uniform: only the last tile can be partial
 #pragma unroll
         for (int n = 0; n < NPW; ++n) {
-            const int ii = (wave + 4 * n) < NI ? (wave + 4 * n) : 0;
+            const int ii = (wave + NW * n) < NI ? (wave + NW * n) : 0;
             int qo = qlane[n], oo = olane[n];
             if (!full && tile * QT + rowl[n] >= N) {          // rows past N: re-read row N-1 (finite); their row constants
                 const int back = tile * QT + rowl[n] - (N - 1);      // (-inf, 0) zero the probabilities
@@ -1024,7 +1045,10 @@ __global__ __launch_bounds__(256, (D <= 64 && sizeof(T) == 2 && NKT <= 2) ? MU_D
         // The transposed dO / Q operands of the dV / dK products are read from LDS BEFORE the exponentials (PRE of the NDT column
         // blocks): their latency then hides behind the VALU phase instead of standing, once per column block, between the MFMAs
         // (the compiler otherwise issues each block's reads right in front of its MFMAs: ~60 idle cycles per block per wave).
-        constexpr int PRE = (MU_DKV_PREFETCH && sizeof(T) == 2) ? (MU_DKV_PREFETCH < NDT ? MU_DKV_PREFETCH : NDT) : 0;
+        // (C = 128, 16 keys per wave: every transposed read feeds ONE MFMA and only two waves share a SIMD -- all NDT blocks
+        //  prefetched: 0.675 -> 0.639 ms at N = 4096; at C = 64 the extra registers spill: 3.6 -> 5.0 ms)
+        constexpr int PFN = D == 128 ? MU_DKV_PREFETCH128 : MU_DKV_PREFETCH;
+        constexpr int PRE = (PFN && sizeof(T) == 2) ? (PFN < NDT ? PFN : NDT) : 0;
         typename A::AccA oap[PRE ? PRE : 1], qap[PRE ? PRE : 1];
         if constexpr (PRE > 0) {
 #pragma unroll
@@ -1166,7 +1190,10 @@ static int attn_bwd_t(const T* qkv, const T* x, const T* oattn, const T* gout, c
     }                                                                                                                           \
     if (phases & 2) attn_bwd_dq2_kernel<T, DD, KTQ, 4><<<gq, 256, 0, st>>>(qkv, dY, kidx, kcnt, lse2, delta, dqkv, N, nkmax, scale, sl2); \
     if (phases & 4) {                                                                                                           \
-        attn_bwd_dkv3_kernel<T, DD, NKT><<<dim3(mu_cdiv(nkmax, 64 * NKT), B), 256, 0, st>>>(qkv, dY, kidx, kcnt, rowc, dqkv, N, nkmax, scale, sl2, zero_masked); \
+        if constexpr (sizeof(T) == 2 && ((DD == 128 && MU_DKV_NW128 == 8) || (DD == 256 && MU_DKV_NW256 == 8)))                           \
+            attn_bwd_dkv3_kernel<T, DD, NKT, 8><<<dim3(mu_cdiv(nkmax, 128 * NKT), B), 512, 0, st>>>(qkv, dY, kidx, kcnt, rowc, dqkv, N, nkmax, scale, sl2, zero_masked); \
+        else                                                                                                                    \
+            attn_bwd_dkv3_kernel<T, DD, NKT><<<dim3(mu_cdiv(nkmax, 64 * NKT), B), 256, 0, st>>>(qkv, dY, kidx, kcnt, rowc, dqkv, N, nkmax, scale, sl2, zero_masked); \
     }
     if (N % 4) return MU_ERR_SHAPE;
     switch (C) {
