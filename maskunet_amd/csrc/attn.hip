@@ -35,7 +35,7 @@
 // dQ 0.520 -> 0.374 ms with the bound alone (226 VGPRs, no spills), dK/dV 1.174 -> 0.959 ms with 16 keys per wave (NKT = 1,
 // 150 VGPRs; the 32-key version spills under the bound).  3 waves/SIMD: no further gain.
 #ifndef MU_FWD_OCC128
-#define MU_FWD_OCC128 2
+#define MU_FWD_OCC128 3       // (round 2, with the conflict-free swizzle of the 256-byte rows: 0.346 -> 0.301 ms; dQ spills under the same bound)
 #endif
 #ifndef MU_DQ_OCC128
 #define MU_DQ_OCC128 2
@@ -64,7 +64,7 @@
 #define MU_DKV_NKT128 1
 #endif
 #ifndef MU_DKV_NW128
-#define MU_DKV_NW128 8
+#define MU_DKV_NW128 12      // 12-wave blocks = 3 waves/SIMD at 168 VGPRs (in-process, N = 4096: 4 waves x 2 blocks 0.68, 8 waves 0.67, 12 waves 0.58 ms)
 #endif
 #ifndef MU_DKV_NW256
 #define MU_DKV_NW256 4
@@ -83,7 +83,7 @@
 #endif
 // LDS operand prefetch ahead of the VALU phase (number of 16-column blocks; 0 = off)
 #ifndef MU_DKV_PREFETCH128
-#define MU_DKV_PREFETCH128 8
+#define MU_DKV_PREFETCH128 0   // (8 = all blocks prefetched: -5 % with 8-wave blocks, spills under the 3-waves/SIMD bound of the 12-wave blocks)
 #endif
 #ifndef MU_DKV_PREFETCH
 #define MU_DKV_PREFETCH 0
@@ -873,7 +873,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 && D <= 64 && sizeof(T) == 2) ? M
 // NW = waves per block (16 * NKT keys each).  The Q / dO stream a block pulls through L2 -> LDS is shared by NW * NKT * 16 keys: at
 // C = 128 with 4 waves of 16 keys every launch moved 4.2 GB in 0.7 ms (6 TB/s, the L2 -> LDS ceiling) -- 8 waves halve that.
 template <typename T, int D, int NKT, int NW = 4>
-__global__ __launch_bounds__(NW * 64, NW == 8 ? 1 : ((D <= 64 && sizeof(T) == 2 && NKT <= 2) ? MU_DKV_OCC : ((D == 128 && sizeof(T) == 2 && NKT <= 2) ? MU_DKV_OCC128 : ((D == 256 && sizeof(T) == 2 && NKT == 1) ? MU_DKV_OCC256 : 1)))) void attn_bwd_dkv3_kernel(
+__global__ __launch_bounds__(NW * 64, NW >= 8 ? 1 : ((D <= 64 && sizeof(T) == 2 && NKT <= 2) ? MU_DKV_OCC : ((D == 128 && sizeof(T) == 2 && NKT <= 2) ? MU_DKV_OCC128 : ((D == 256 && sizeof(T) == 2 && NKT == 1) ? MU_DKV_OCC256 : 1)))) void attn_bwd_dkv3_kernel(
     const T* __restrict__ qkv, const T* __restrict__ dY, const int* __restrict__ kidx, const int* __restrict__ kcnt,
     const float* __restrict__ rowc, T* __restrict__ dqkv, int N, int nkmax, float scale, float scale_log2, int zero_masked) {
     using A = AT<T>;
@@ -962,6 +962,9 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 1 : ((D <= 64 && sizeof(T) == 2 
     if (DKV_RING == 4) {
         if (ntile > 1) issue(1);
         if (ntile > 2) issue(2);
+#ifdef MU_DKV_ABL_NODMA
+        if (ntile > 3) issue(3);                             // timing-only ablation: all four slots hold real data, no DMA in the loop
+#endif
     }
 
     Frag kf[NKT][NKS], vf[NKT][NKS];
@@ -994,6 +997,10 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 1 : ((D <= 64 && sizeof(T) == 2 
         constexpr int SLOT = decltype(SLOTC)::value;
         // tile tl's DMAs were issued RING-1 issue-groups ago; newer groups still in flight: min(RING-2, tiles left after tl)
         const int newer = ntile - 1 - tl;
+#ifdef MU_DKV_ABL_NODMA
+        if (tl == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        else
+#endif
         if (DKV_RING == 4 && newer >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * OPS) : "memory");
         else if (DKV_RING == 4 && newer == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(OPS) : "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1045,8 +1052,6 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 1 : ((D <= 64 && sizeof(T) == 2 
         // The transposed dO / Q operands of the dV / dK products are read from LDS BEFORE the exponentials (PRE of the NDT column
         // blocks): their latency then hides behind the VALU phase instead of standing, once per column block, between the MFMAs
         // (the compiler otherwise issues each block's reads right in front of its MFMAs: ~60 idle cycles per block per wave).
-        // (C = 128, 16 keys per wave: every transposed read feeds ONE MFMA and only two waves share a SIMD -- all NDT blocks
-        //  prefetched: 0.675 -> 0.639 ms at N = 4096; at C = 64 the extra registers spill: 3.6 -> 5.0 ms)
         constexpr int PFN = D == 128 ? MU_DKV_PREFETCH128 : MU_DKV_PREFETCH;
         constexpr int PRE = (PFN && sizeof(T) == 2) ? (PFN < NDT ? PFN : NDT) : 0;
         typename A::AccA oap[PRE ? PRE : 1], qap[PRE ? PRE : 1];
@@ -1084,7 +1089,7 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 1 : ((D <= 64 && sizeof(T) == 2 
         MU_PRIO(0);
         // Refill the slot tile tl-1 vacated -- issued LAST in the tile: LDS reads queue behind an in-flight LDS-DMA issue
         // (in-kernel s_memtime stamps: the row-constant reads right after the DMA cost ~980 cycles/tile, ~80 without it)
-#ifndef MU_DKV_ISSUE_FIRST
+#if !defined(MU_DKV_ISSUE_FIRST) && !defined(MU_DKV_ABL_NODMA)
         if (tl + DKV_RING - 1 < ntile) issue(tl + DKV_RING - 1);
 #endif
     };
@@ -1190,7 +1195,9 @@ static int attn_bwd_t(const T* qkv, const T* x, const T* oattn, const T* gout, c
     }                                                                                                                           \
     if (phases & 2) attn_bwd_dq2_kernel<T, DD, KTQ, 4><<<gq, 256, 0, st>>>(qkv, dY, kidx, kcnt, lse2, delta, dqkv, N, nkmax, scale, sl2); \
     if (phases & 4) {                                                                                                           \
-        if constexpr (sizeof(T) == 2 && ((DD == 128 && MU_DKV_NW128 == 8) || (DD == 256 && MU_DKV_NW256 == 8)))                           \
+        if constexpr (sizeof(T) == 2 && DD == 128 && MU_DKV_NW128 != 4)                                                         \
+            attn_bwd_dkv3_kernel<T, DD, NKT, MU_DKV_NW128><<<dim3(mu_cdiv(nkmax, 16 * MU_DKV_NW128 * NKT), B), 64 * MU_DKV_NW128, 0, st>>>(qkv, dY, kidx, kcnt, rowc, dqkv, N, nkmax, scale, sl2, zero_masked); \
+        else if constexpr (sizeof(T) == 2 && DD == 256 && MU_DKV_NW256 == 8)                                                    \
             attn_bwd_dkv3_kernel<T, DD, NKT, 8><<<dim3(mu_cdiv(nkmax, 128 * NKT), B), 512, 0, st>>>(qkv, dY, kidx, kcnt, rowc, dqkv, N, nkmax, scale, sl2, zero_masked); \
         else                                                                                                                    \
             attn_bwd_dkv3_kernel<T, DD, NKT><<<dim3(mu_cdiv(nkmax, 64 * NKT), B), 256, 0, st>>>(qkv, dY, kidx, kcnt, rowc, dqkv, N, nkmax, scale, sl2, zero_masked); \
