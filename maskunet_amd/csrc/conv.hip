@@ -1520,8 +1520,11 @@ __global__ __launch_bounds__(256) void wgrad_bias_reduce_kernel(const float* __r
 // tap, so they are zeroed at load time (zero page).  Tiles arrive by LDS-DMA, double-buffered; the LDS
 // image XORs the 32-byte chunk index with a row hash so the transposed reads are conflict-free.
 // ------------------------------------------------------------------------------------------
+// 64-channel tiles (128-byte rows, four 32-byte chunks): a transposed read touches rows {a..a+3, a+8..a+11}; two rows share a
+// 256-byte bank line, so the rows of equal parity -- a, a+2, a+8, a+10 -- must land on four different chunks: row bits 1 and 3.
+// (row & 3 put rows a and a+8 on the same chunk: SQ_LDS_BANK_CONFLICT = 50 % of the LDS cycles of the 64 x 64 kernel.)
 template <int BCH> __device__ __forceinline__ int wg_hash(int row) {
-    return (BCH >= 128) ? ((row & 3) | (((row >> 3) & 1) << 2)) : (row & 3);
+    return (BCH >= 128) ? ((row & 3) | (((row >> 3) & 1) << 2)) : (((row >> 1) & 1) | (((row >> 3) & 1) << 1));
 }
 
 template <int N> __device__ __forceinline__ void wait_vmcnt_c() {
