@@ -399,7 +399,10 @@ __global__ __launch_bounds__(256, SB ? MU_NT2_SB_OCC : MU_NT2_OCC) void conv_nt2
 // activation L2->LDS traffic 9x (v2 is pinned at the ~10 TB/s L2->LDS ceiling on the Cin<=256 layers).
 // The next chunk's halo is streamed in 1/6 pieces behind the first six tap steps.
 // ------------------------------------------------------------------------------------------
-template <typename T, int TM, int TN, int WR, int NWV = 4>
+#ifndef MU_NT3_RING
+#define MU_NT3_RING 1
+#endif
+template <typename T, int TM, int TN, int WR, int NWV = 4, bool RINGP = false>
 __global__ __launch_bounds__(NWV * 64, NWV == 4 ? 2 : 1) void conv_nt3_kernel(const T* __restrict__ x, const T* __restrict__ w, const float* __restrict__ bias,
                                                        T* __restrict__ y, int B, int H, int W, int Cin, int Cout, long x_ld, long y_ld) {
     using M_ = Mma<T>;
@@ -414,10 +417,18 @@ __global__ __launch_bounds__(NWV * 64, NWV == 4 ? 2 : 1) void conv_nt3_kernel(co
     constexpr int PA = BCO / (8 * NWV);
     static_assert(BCO % (8 * NWV) == 0, "weight tile rows must split over the waves");
     constexpr int HBYTES = HINST * 1024, WBYTES = BCO * 128;
+    // RING (fp16, 64-channel blocks = the Cout = 64 layers): THREE weight slots, W(s+2) issued at tap s, counted s_waitcnt vmcnt +
+    // raw s_barrier per tap instead of __syncthreads() (= vmcnt(0): every tap waited for a DMA issued ~0.3 us earlier; PMC: waves
+    // parked 48 %, MFMA pipe 26 % busy).  Exactly PA + 1 DMAs per wave per tap (dummies to a dump page keep the counts uniform).
+    // In-process A/B: 128 -> 64 @128^2 0.226 -> 0.203 ms; with a single 64-channel chunk (9 taps per tile) the longer prologue
+    // costs more than the waits it removes (64 -> 64 @128^2 0.110 -> 0.116 ms), so the launcher picks RINGP for Cin >= 128 only.
+    constexpr bool RING = RINGP && MU_NT3_RING && sizeof(T) == 2 && BCO == 64 && NWV == 4;
+    constexpr int NWS = RING ? 3 : 2;
 
-    __shared__ __attribute__((aligned(16))) char lds[2 * HBYTES + 2 * WBYTES];
+    __shared__ __attribute__((aligned(16))) char lds[2 * HBYTES + NWS * WBYTES + (RING ? 1024 : 0)];
     char* Hs = lds;
     char* Ws = lds + 2 * HBYTES;
+    char* dump = lds + 2 * HBYTES + NWS * WBYTES;
 
     const int tiles_w = W / TW, tiles_h = H / TH;
     const int ntile = B * tiles_h * tiles_w, ncb = Cout / BCO;
@@ -486,12 +497,13 @@ __global__ __launch_bounds__(NWV * 64, NWV == 4 ? 2 : 1) void conv_nt3_kernel(co
     }
 
     stage_w(0, 0);
+    if constexpr (RING) { if (nsteps > 1) stage_w(1, 1); }
 #pragma unroll
     for (int k = 0; k < HPW; ++k)
         if (k * NWV + wave < HINST) stage_h(k, 0, 0);
     __syncthreads();
 
-    int s = 0;
+    int s = 0, wslot = 0;                                    // RING: slot of W(s) = s % 3, carried
     for (int c = 0; c < kchunks; ++c) {
         const int hbuf = (c & 1) * HBYTES;
 #pragma unroll
@@ -499,10 +511,21 @@ __global__ __launch_bounds__(NWV * 64, NWV == 4 ? 2 : 1) void conv_nt3_kernel(co
 #pragma unroll
             for (int dw = 0; dw < 3; ++dw, ++s) {
                 const int t = dh * 3 + dw;
+                if constexpr (RING) {
+                    const int nslot = wslot == 0 ? 2 : wslot - 1;              // (s + 2) % 3
+                    if (s + 2 < nsteps) stage_w(s + 2, nslot);
+                    else {
+#pragma unroll
+                        for (int i = 0; i < PA; ++i) glds16(mu_zero_page, dump);
+                    }
+                    if (t < HPW && c + 1 < kchunks && t * NWV + wave < HINST) stage_h(t, (c + 1) * KC, (c + 1) & 1);
+                    else glds16(mu_zero_page, dump);
+                } else {
                 if (s + 1 < nsteps) stage_w(s + 1, (s + 1) & 1);
                 if (t < HPW && c + 1 < kchunks && t * NWV + wave < HINST)        // one halo piece of the next chunk per tap step
                     stage_h(t, (c + 1) * KC, (c + 1) & 1);
-                const char* Wb = Ws + (s & 1) * WBYTES;
+                }
+                const char* Wb = Ws + (RING ? wslot : (s & 1)) * WBYTES;
                 const char* Hb = Hs + hbuf + dh * (HW_ * 128);
 #pragma unroll
                 for (int kk = 0; kk < 2; ++kk) {
@@ -518,9 +541,23 @@ __global__ __launch_bounds__(NWV * 64, NWV == 4 ? 2 : 1) void conv_nt3_kernel(co
 #pragma unroll
                         for (int j = 0; j < TN; ++j) M_::mma(a[i], b[j], acc[i][j]);
                 }
-                __syncthreads();
+                if constexpr (RING) {
+                    // all but this tap's PA + 1 DMAs have landed: W(s+1) (issued at tap s-1) and every older halo piece.  The MFMAs
+                    // above consumed this tap's fragment reads, so behind the barrier slot s % 3 is free for W(s+3)
+                    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PA + 1) : "memory");
+                    __builtin_amdgcn_sched_barrier(0);
+                    __builtin_amdgcn_s_barrier();
+                    __builtin_amdgcn_sched_barrier(0);
+                    wslot = wslot == 2 ? 0 : wslot + 1;
+                } else {
+                    __syncthreads();
+                }
             }
         }
+    }
+    if constexpr (RING) {                                    // trailing dummies: drained before the epilogue re-uses the LDS
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
     }
 
 #ifndef MU_NT3_EPI
@@ -791,6 +828,7 @@ __device__ __forceinline__ void tile_stats_store(float (&ssum)[8], float (&ssq)[
 #ifndef MU_CONV_NT4
 #define MU_CONV_NT4 1
 #endif
+
 #ifndef MU_CONV_NT4P
 #define MU_CONV_NT4P 1
 #endif
@@ -1236,7 +1274,9 @@ static int conv_fwd_launch(const T* x, const T* w, const float* bias, T* y, int 
             return MU_OK;
         }
         if (Cout % 64 == 0 && H % 8 == 0) {
-            conv_nt3_kernel<T, 4, 2, 1><<<B * (H / 8) * (W / 16) * (Cout / 64), 256, 0, st>>>(x, w, bias, y, B, H, W, Cin, Cout, x_ld, y_ld);
+            const int grid3 = B * (H / 8) * (W / 16) * (Cout / 64);
+            if (Cin * (int)sizeof(T) >= 256) conv_nt3_kernel<T, 4, 2, 1, 4, true><<<grid3, 256, 0, st>>>(x, w, bias, y, B, H, W, Cin, Cout, x_ld, y_ld);
+            else conv_nt3_kernel<T, 4, 2, 1><<<grid3, 256, 0, st>>>(x, w, bias, y, B, H, W, Cin, Cout, x_ld, y_ld);
             return MU_OK;
         }
     }
