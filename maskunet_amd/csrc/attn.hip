@@ -66,6 +66,9 @@
 #ifndef MU_DKV_NW128
 #define MU_DKV_NW128 12      // 12-wave blocks = 3 waves/SIMD at 168 VGPRs (in-process, N = 4096: 4 waves x 2 blocks 0.68, 8 waves 0.67, 12 waves 0.58 ms)
 #endif
+#ifndef MU_DKV_NW64
+#define MU_DKV_NW64 4
+#endif
 #ifndef MU_DKV_NW256
 #define MU_DKV_NW256 4
 #endif
@@ -941,7 +944,8 @@ __global__ __launch_bounds__(NW * 64, NW >= 8 ? 1 : ((D <= 64 && sizeof(T) == 2 
         const bool full = tile * QT + QT <= N;               // wave-uniform: only the last tile can be partial
 #pragma unroll
         for (int n = 0; n < NPW; ++n) {
-            const int ii = (wave + NW * n) < NI ? (wave + NW * n) : 0;
+            if (NW > NI && wave + NW * n >= NI) break;       // blocks with more waves than pieces: the extra waves issue nothing (and
+            const int ii = (wave + NW * n) < NI ? (wave + NW * n) : 0;      // their vmcnt waits pass at once; the barrier orders them)
             int qo = qlane[n], oo = olane[n];
             if (!full && tile * QT + rowl[n] >= N) {          // rows past N: re-read row N-1 (finite); their row constants
                 const int back = tile * QT + rowl[n] - (N - 1);      // (-inf, 0) zero the probabilities
@@ -954,7 +958,8 @@ __global__ __launch_bounds__(NW * 64, NW >= 8 ? 1 : ((D <= 64 && sizeof(T) == 2 
         // row constants: 16 lanes x 16 B = the tile's 64 floats.  Every wave issues one DMA so that all waves count the same
         // number of vector-memory ops: wave 0's lanes >= 16 repeat the constants into the unused rest of the slot, waves 1-3
         // write theirs to a dump area
-        glds16s(rowc_b + (long)tile * 64, (uint32_t)((lane & 15) * 16), rcs + (wave == 0 ? slot * 256 : DKV_RING * 256));
+        if (NW <= NI || wave < NI)
+            glds16s(rowc_b + (long)tile * 64, (uint32_t)((lane & 15) * 16), rcs + (wave == 0 ? slot * 256 : DKV_RING * 256));
     };
     constexpr int OPS = 2 * NPW + 1;
 
@@ -1195,7 +1200,9 @@ static int attn_bwd_t(const T* qkv, const T* x, const T* oattn, const T* gout, c
     }                                                                                                                           \
     if (phases & 2) attn_bwd_dq2_kernel<T, DD, KTQ, 4><<<gq, 256, 0, st>>>(qkv, dY, kidx, kcnt, lse2, delta, dqkv, N, nkmax, scale, sl2); \
     if (phases & 4) {                                                                                                           \
-        if constexpr (sizeof(T) == 2 && DD == 128 && MU_DKV_NW128 != 4)                                                         \
+        if constexpr (sizeof(T) == 2 && DD == 64 && MU_DKV_NW64 != 4)                                                           \
+            attn_bwd_dkv3_kernel<T, DD, NKT, MU_DKV_NW64><<<dim3(mu_cdiv(nkmax, 16 * MU_DKV_NW64 * NKT), B), 64 * MU_DKV_NW64, 0, st>>>(qkv, dY, kidx, kcnt, rowc, dqkv, N, nkmax, scale, sl2, zero_masked); \
+        else if constexpr (sizeof(T) == 2 && DD == 128 && MU_DKV_NW128 != 4)                                                         \
             attn_bwd_dkv3_kernel<T, DD, NKT, MU_DKV_NW128><<<dim3(mu_cdiv(nkmax, 16 * MU_DKV_NW128 * NKT), B), 64 * MU_DKV_NW128, 0, st>>>(qkv, dY, kidx, kcnt, rowc, dqkv, N, nkmax, scale, sl2, zero_masked); \
         else if constexpr (sizeof(T) == 2 && DD == 256 && MU_DKV_NW256 == 8)                                                    \
             attn_bwd_dkv3_kernel<T, DD, NKT, 8><<<dim3(mu_cdiv(nkmax, 128 * NKT), B), 512, 0, st>>>(qkv, dY, kidx, kcnt, rowc, dqkv, N, nkmax, scale, sl2, zero_masked); \
