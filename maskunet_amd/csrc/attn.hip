@@ -297,7 +297,11 @@ template <typename T, int D, int KT, int NW> struct KvStage {
             const int i = wave + NW * n;
             int j = j0 + i * Z::RPW + lrow;
             j = j < Nk ? j : Nk - 1;
+#ifdef MU_ATTN_ABL_NOIDX
+            idx[n] = j < 0 ? 0 : j;                          // timing-only ablation: contiguous rows instead of the kept-key gather
+#else
             idx[n] = kidx_b[j < 0 ? 0 : j];
+#endif
         }
     }
     // Rows past the end re-read a valid key row instead of a zero page: every consumer masks those keys through the score
