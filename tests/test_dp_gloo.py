@@ -115,3 +115,50 @@ def test_shard_batch_partitions_like_scatter():
         assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
         sizes = [b - a for a, b in spans]
         assert max(sizes) - min(sizes) <= 1
+
+
+def _single_rank_worker(port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=0, world_size=1)
+    try:
+        import maskunet_amd
+        torch.manual_seed(3)
+        model = maskunet_amd.DownSample(32, 64)
+        plain = DataParallel(model, bucket_mb=0.05)
+        assert not plain.multi and not plain.overlap                  # a group of one rank: no exchange by default
+        ddp = DataParallel(model, bucket_mb=0.05, force_sync=True)
+        assert ddp.multi and ddp.overlap and len(ddp.buckets) > 1
+        for step in range(2):
+            ddp._arm()
+            exp = {}
+            for name, p in model.named_parameters():
+                p.grad = None
+                if "emb_layer" in name:
+                    continue
+                p.grad = torch.full_like(p, float(len(name) % 5 + 1))
+                exp[name] = p.grad.clone()
+                ddp._on_grad(p)
+            if step:
+                assert all(b.work is not None for b in ddp.buckets if any(id(p) not in ddp._dead for p in b.params))
+            ddp.finish_gradient_sync()
+            for name, p in model.named_parameters():
+                if name in exp:
+                    assert torch.equal(p.grad, exp[name]), name       # mean over one rank
+                else:
+                    assert p.grad is None
+        q.put("ok")
+    except Exception as e:                                             # noqa: BLE001
+        q.put(repr(e))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_force_sync_runs_the_exchange_in_a_group_of_one_rank():
+    """DataParallel(force_sync=True): hooks, buckets, collectives and write-back with world_size 1 (what the single-GPU boxes use to
+    exercise the RCCL path, tests/test_gpu_dp.py)."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_single_rank_worker, args=(_free_port(), q))
+    p.start()
+    p.join(120)
+    assert q.get(timeout=5) == "ok"
