@@ -37,7 +37,7 @@ sys.path.insert(0, ROOT)
 PEAK_MFMA_TFLOPS = {"fp16": 2500.0, "fp32": 157.3}      # dense, MI355X_MICROARCH.md
 PEAK_HBM_GBS = 8000.0
 DOMINANT_KERNEL = "attn_bwd_dkv3_kernel"
-TRAFFIC_JSON = "r01_dkv_traffic.json"
+TRAFFIC_JSON = "r02_dkv_traffic.json"
 
 
 def synth(B, c_out, hw, seed, device, ignore_frac=0.0):
