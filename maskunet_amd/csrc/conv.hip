@@ -1584,10 +1584,13 @@ template <int N> __device__ __forceinline__ void wait_vmcnt_c() {
 #ifndef MU_WG_SPS2_64
 #define MU_WG_SPS2_64 1
 #endif
-// ping-pong schedule of the weight-grad kernel: parity-clean but neutral (in-process A/B: 128->128 @128^2 369 vs 371 us,
-// 256->256 @64^2 339 vs 348, 128->128 @64^2 106 vs 102) -- kept opt-in as the starting point for a finer-grained interleave
+// ping-pong schedule of the weight-grad kernel (W % 64 == 0 layers, 128 x 128 tiles).  With the whole stage's DMAs in the first
+// k-step's load section it was neutral to slower (that section ran 1.6x as long as the 24-MFMA section it hides behind); with the dy
+// pieces in the first and the x pieces in the second load section: 128->128 @128^2 0.330 -> 0.307 ms, 256->256 @64^2 0.297 -> 0.277 ms.
+// (Timing builds with real data: no DMA in the loop -23 %, the same DMA instructions on L1-resident data -4 % -- it is the
+// ISSUE of the LDS-DMA instructions, not the bytes, that the lockstep schedule exposed.)
 #ifndef MU_WG_PP
-#define MU_WG_PP 0
+#define MU_WG_PP 1
 #endif
 #ifndef MU_WG_SPLIT_DMA
 #define MU_WG_SPLIT_DMA 1
@@ -1786,18 +1789,19 @@ __global__ __launch_bounds__(NWV * 64, 1) void conv_wgrad3_kernel(const h16* __r
         int buf = 0;
         auto kstep = [&](auto HALFC) {
             constexpr int HALF = decltype(HALFC)::value;
-            if (HALF == 0) stage(buf >= 2 ? buf - 2 : buf + 2);          // stage S+2 -> slot (S+2) & 3
+            // stage S+2 -> slot (S+2) & 3: the dy pieces in the first k-step's load section, the x pieces in the second's, so that
+            // both sections are about as long as a 24-MFMA section (all DMAs in the first made it 1.6x as long)
+            if (HALF == 0) stage_a(buf >= 2 ? buf - 2 : buf + 2);
+            else stage_b(buf >= 2 ? buf - 2 : buf + 2);
             load_frags(buf, HALF, f);
             __builtin_amdgcn_s_barrier();
             __builtin_amdgcn_sched_barrier(0);
             __builtin_amdgcn_s_setprio(1);
             compute(f);
             __builtin_amdgcn_s_setprio(0);
-            if (HALF == 0) {                                             // stage S+1 landed, stage S+2 may stay in flight
-                constexpr int FULL = NAW + NBW;
-                if (n_w == FULL) wait_vmcnt_c<FULL>();
-                else if (n_w == FULL - 1) wait_vmcnt_c<FULL - 1>();
-                else wait_vmcnt_c<(FULL > 2 ? FULL - 2 : 0)>();
+            if (HALF == 0) {                                             // stage S+1 landed; the dy pieces of stage S+2 may stay in flight
+                static_assert(NIA % NWV == 0, "every wave issues the same number of dy pieces");
+                wait_vmcnt_c<NAW>();
             } else {
                 buf = (buf + 1) & 3;
             }
@@ -2180,6 +2184,7 @@ static int conv_wgrad_impl(const void* x, const void* dy, float* dw_oihw, float*
         const bool two_row32 = W == 32 && H % 2 == 0, flat64 = W % 64 == 0;
         if (tco == 128 && tci == 128) {   // 8 waves, 64x32 tile x 3 taps per wave (96 accumulators): 2 waves/SIMD
             if (W == 16) WG3(4, 2, 2, 8, true);
+            else if (two_row32 && MU_WG_SPS2 && MU_WG_PP == 2) WG3(4, 2, 2, 8, true, 2, true);      // (W = 32: +2.6 % slower, opt-in)
             else if (two_row32 && MU_WG_SPS2) WG3(4, 2, 2, 8, true, 2);
             else if (flat64 && MU_WG_SPS2 && MU_WG_PP) WG3(4, 2, 2, 8, false, 2, true);
             else if (flat64 && MU_WG_SPS2) WG3(4, 2, 2, 8, false, 2);
