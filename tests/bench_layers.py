@@ -61,4 +61,6 @@ def main():
     for k in tot:
         print(f"{k}: {tot[k]:.3f} ms per step over all layers, {totfl[k] / tot[k] / 1e9:.0f} TF/s aggregate")
 
-main()
+
+if __name__ == "__main__":
+    main()
