@@ -10,7 +10,8 @@ BatchNorm, dropout 0.3), loss = mean pixel cross-entropy on the module's NCHW fp
 the reference's criterion as HIP kernels; --torch-loss = torch's F.cross_entropy) with a static loss scale
 for the fp16 backward.  N>1: one process per GPU,
 the same per-GPU batch (weak scaling), one bucketed RCCL all-reduce of the gradients per step overlapped with the
-backward (maskunet_amd/dp.py).
+backward (maskunet_amd/dp.py), and -- like the reference under multi-GPU nn.DataParallel -- fresh attention key masks every step
+(`config.mask_mode` = "resample": randint + mu_compact_keys on the device).
 
 One JSON line on rank 0.
   * `roofline`: the dominant kernel (the dK/dV sweep of self_attention6), duration measured live with HIP events on the launch
@@ -37,7 +38,9 @@ sys.path.insert(0, ROOT)
 PEAK_MFMA_TFLOPS = {"fp16": 2500.0, "fp32": 157.3}      # dense, MI355X_MICROARCH.md
 PEAK_HBM_GBS = 8000.0
 DOMINANT_KERNEL = "attn_bwd_dkv3_kernel"
-TRAFFIC_JSON = "r02_dkv_traffic.json"
+# PMC traffic of the dominant kernel per workload shape (key: b{batch}_c{c_out}_hw{hw}_{dtype}[_3head]); see profiles/README.md
+TRAFFIC_JSON = {"b64_c150_hw128_fp16": "r02_dkv_traffic.json"}
+DATASET_BY_COUT = {150: "ADE20K-semantic", 151: "ADE20K-semantic", 133: "COCO-panoptic", 19: "Cityscapes", 81: "COCO-instance"}
 
 
 def synth(B, c_out, hw, seed, device, ignore_frac=0.0):
@@ -118,7 +121,7 @@ def cpu_baseline(c_out, hw, B=4, iters=3, budget_s=150.0):
             v.grad = None
         times.append(time.time() - t0)
     steady = sorted(times[1:])[len(times[1:]) // 2]
-    return {"value": round(B / steady, 4), "unit": "images/sec", "cores": cores, "kind": "port",
+    return {"value": round(B / steady, 4), "unit": "images/sec", "cores": cores, "host_cores": os.cpu_count(), "kind": "port",
             "sample": f"configs[0]: oracle fwd+bwd, fp32, train mode, B={B}, c_out={c_out}, {hw}x{hw}, default_rng(42) inputs, "
                       f"median of {len(times) - 1} after 1 warm-up ({steady:.2f} s/iteration)"}
 
@@ -141,6 +144,10 @@ def main():
     ap.add_argument("--graph", action="store_true", help="replay the step (forward + criterion + backward) as one HIP graph "
                     "(maskunet_amd.GraphedStep; single GPU)")
     ap.add_argument("--optimizer", action="store_true", help="also run the fused AdamW step (8-f2) inside the timed step")
+    ap.add_argument("--mask-mode", default="auto", choices=["auto", "fixed", "resample"],
+                    help="attention key masks: 'fixed' = drawn once and cached (the reference on ONE GPU, ade_semantic.py:177), 'resample' = "
+                         "redrawn + re-compacted on the device every step (what the reference does under multi-GPU nn.DataParallel, whose "
+                         "replicas are discarded each step, :373); auto = fixed at N = 1, resample at N > 1")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -175,6 +182,10 @@ def main():
     model.set_compute_dtype(dtype).train()
     x, labels, keeps = synth(args.batch, args.c_out, args.hw, 42 + rank, dev, ignore_frac=0.1 if args.three_head else 0.0)
     model.set_keep_masks(keeps)
+    # N > 1 times the step the reference runs under nn.DataParallel: every replica forward draws a fresh mask (SURVEY 0 trap #2,
+    # 8-e1), i.e. per step six randint draws + six key compactions (mu_compact_keys) on the device stream, no host sync
+    mask_mode = args.mask_mode if args.mask_mode != "auto" else ("resample" if (multi and not args.graph) else "fixed")
+    model.set_mask_mode(mask_mode)
     net = maskunet_amd.DataParallel(model, force_sync=True) if multi else model
     scale = args.loss_scale if dtype == torch.float16 else 1.0
 
@@ -192,6 +203,8 @@ def main():
     if args.graph:
         if args.fused_loss or args.three_head or args.torch_loss:
             raise SystemExit("--graph: maskunet_amd.CrossEntropyLoss, 1-head model only")
+        if mask_mode == "resample":
+            raise SystemExit("--graph: a captured step replays the masks it was captured with; use --mask-mode fixed")
         # N > 1: each replica replays its own graph and the bucketed all-reduce follows the replay (a replay runs no autograd hooks,
         # so the exchange does not overlap the backward) -- opt-in, for small per-GPU batches where the host enqueue is the bound
         graphed = maskunet_amd.GraphedStep(net, criterion, x, labels, loss_scale=scale)
@@ -263,8 +276,8 @@ def main():
     if rank == 0:
         imgs = args.batch * world * args.steps
         C6 = 64
-        kept = [float(k.float().mean().item()) for k in keeps if k.shape[1] == N6]
-        kept = kept[-1] if kept else 1.0     # fraction of keys the kernel really multiplies (the rest are skipped, not computed)
+        # fraction of keys the kernel really multiplies (the rest are skipped, not computed): of the mask the last step ran with
+        kept = float(model.self_attention6._keep.float().mean().item())
         # FLOPs of one launch: the four N x Nk x C products of the dK/dV sweep (S, dP, dV, dK), 4 * 2*N*Nk*C per image, over the
         # kept keys (executed) and over the full key set (SURVEY 8-d4's algorithmic convention)
         flops_full = 8.0 * N6 * N6 * C6 * args.batch
@@ -273,10 +286,16 @@ def main():
         tk = sum(durs) / max(len(durs), 1)
         achieved = flops_exec / max(tk, 1e-12) / 1e12
         peak = PEAK_MFMA_TFLOPS[args.dtype]
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", TRAFFIC_JSON)      # PMC FETCH_SIZE/WRITE_SIZE pass (see file)
-        if os.path.exists(tpath) and args.batch == 64 and args.dtype == "fp16" and args.hw == 128:
+        # HBM-side bytes of that launch from the PMC passes (FETCH_SIZE x 2 + WRITE_SIZE, MI355X_MICROARCH.md): counters cannot be
+        # read inside this process, so the figure comes from the committed rocprofv3 --pmc run of the same command -- one file per
+        # workload shape, named in `traffic_source`; null where no counter pass was taken for the shape
+        traffic = traffic_source = None
+        tkey = f"b{args.batch}_c{args.c_out}_hw{args.hw}_{args.dtype}" + ("_3head" if args.three_head else "")
+        tfile = TRAFFIC_JSON.get(tkey)
+        tpath = os.path.join(ROOT, "profiles", tfile) if tfile else None
+        if tpath and os.path.exists(tpath):
             traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
+            traffic_source = f"profiles/{tfile} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over this command on another box, not this run)"
         # whole step and forward alone against both rooflines (per-image algorithmic figures)
         cnt = algorithmic_counts(args.c_out, args.hw, args.three_head)
         esz = 2 if dtype == torch.float16 else 4
@@ -303,21 +322,24 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f16" if dtype == torch.float16 else "f32",
             "data": "synthetic",
-            "config": {"workload": f"ADE20K-semantic shape {args.hw}x{args.hw}, c_out={args.c_out}, batch={args.batch}/GPU, "
+            "config": {"workload": f"{DATASET_BY_COUT.get(args.c_out, 'custom')} shape {args.hw}x{args.hw}, c_out={args.c_out}, batch={args.batch}/GPU, "
                                    f"{'3-head' if args.three_head else '1-head'} MaskAttn-UNet fwd+bwd, train mode",
-                       "global_batch": args.batch * world, "parallelism": f"dp{world}", "loss_scale": scale,
+                       "global_batch": args.batch * world, "parallelism": f"dp{world}", "loss_scale": scale, "mask_mode": mask_mode,
                        "loss": "fused NHWC CE kernel" if args.fused_loss else ("torch CE on module output" if args.torch_loss else
                                                                                 "maskunet_amd.CrossEntropyLoss on module output"), "optimizer_in_step": bool(opt), "hip_graph": bool(args.graph)},
             "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
-                         "frac": round(achieved / peak, 4), "traffic": traffic,
+                         "frac": round(achieved / peak, 4), "traffic": traffic, "traffic_source": traffic_source,
                          "kernel": f"{DOMINANT_KERNEL} (self_attention6 dK/dV sweep, N={N6}, C=64)",
                          "ms_per_launch": round(tk * 1e3, 3), "launches_timed": len(durs),
                          "kept_keys": round(kept, 4), "flops_per_launch": flops_exec,
                          "algorithmic_achieved": round(flops_full / max(tk, 1e-12) / 1e12, 2),
                          "algorithmic_frac": round(flops_full / max(tk, 1e-12) / 1e12 / peak, 4),
-                         "algorithmic_bytes_per_launch": 8.0 * N6 * C6 * 2 * args.batch if dtype == torch.float16 else 8.0 * N6 * C6 * 4 * args.batch,
+                         # the dK/dV sweep's own operands, each once: reads Q, dO, K, V; writes dK, dV ([N, C] each; the 8*N*C of
+                         # SURVEY 8-d4 is the whole attention block) -- the unit `traffic` is measured in
+                         "algorithmic_bytes_per_launch": 6.0 * N6 * C6 * (2 if dtype == torch.float16 else 4) * args.batch,
                          "note": "achieved/frac = matrix FLOPs the kernel EXECUTES (8*N*Nk*C per image, Nk = kept keys; masked keys are "
-                                 "skipped exactly) / HIP-event time; algorithmic_* = SURVEY 8-d4's full-key-set count 8*N*N*C"},
+                                 "skipped exactly) / HIP-event time; algorithmic_* FLOPs = SURVEY 8-d4's full-key-set count 8*N*N*C; "
+                                 "algorithmic_bytes = Q, dO, K, V read + dK, dV written once (6*N*C elements per image)"},
             "step_roofline": step,
         }
         if world == 1 and not args.no_cpu_baseline:

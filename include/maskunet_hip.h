@@ -58,6 +58,12 @@ int mu_cast(const void* src, int src_dtype, void* dst, int dst_dtype, long n, vo
 int mu_prep_weight(const float* w_oihw, void* dst, int dtype, int O, int I, int taps, int rows_pad, int cols_pad, int mode,
                    void* stream);
 
+/* The q/k/v projection of one attention block -- three nn.Linear(C, C) with bias (ade_semantic.py:157-159,170-172) -- as ONE [3C, C]
+ * 1x1 layer: dst = the forward block [3C][C] followed by the data-gradient block [C][3C] (mu_prep_weight mode 2 of the concatenated
+ * weight), bias[3C] = the concatenated fp32 biases.  C % 32 == 0. */
+int mu_prep_qkv(const float* wq, const float* wk, const float* wv, const float* bq, const float* bk, const float* bv, void* dst,
+                float* bias, int dtype, int C, void* stream);
+
 /* ---- convolution / linear (MFMA implicit GEMM) --------------------------------------------- */
 /* y[p][co] = bias[co] + sum_{tap,ci} x[p+shift(tap)][ci] * w[tap][co][ci]; taps = 9 (3x3, pad 1) or 1.
  * Replaces nn.Conv2d in ConvBlock (ade_semantic.py:199,202), the 1x1 heads (:284, city_instance.py:243-249)
@@ -65,6 +71,12 @@ int mu_prep_weight(const float* w_oihw, void* dst, int dtype, int O, int I, int 
  * data-gradient of the same layer. */
 int mu_conv_fwd(const void* x, const void* w, const float* bias, void* y, int B, int H, int W, int Cin, int Cout, int taps, long x_ld,
                 long y_ld, int dtype, void* stream);
+/* y = conv1x1(x, w) + addend over M rows (addend has y's row stride): the two gradients of Mask2FormerAttention's input -- the
+ * data-gradient of the q/k/v projection and the residual branch of `attention_output += x` (ade_semantic.py:187) -- joined in the
+ * projection's epilogue.  Only where mu_conv1x1_add_supported(...) == 1; MU_ERR_SHAPE otherwise (callers then use mu_conv_fwd + mu_add). */
+int mu_conv1x1_add_supported(int Cin, int Cout, int dtype);
+int mu_conv1x1_fwd_add(const void* x, const void* w, const void* addend, void* y, long M, int Cin, int Cout, long x_ld, long y_ld, int dtype,
+                       void* stream);
 /* mu_conv_fwd that also leaves per-tile BatchNorm statistics of its (rounded) output: stat_part[rows][Cout][2] floats =
  * (sum, sum of squares) per output channel, rows = mu_conv_stats_rows(...) (0 = this shape has no statistics epilogue;
  * stat_part must then be NULL).  Feeds mu_bn_train_stats_rows and saves the separate statistics sweep of
@@ -138,9 +150,17 @@ int mu_ln_sample_bwd(const void* x, const void* dy, const float* w, const float*
 /* nn.MaxPool2d(2) (:216); backward recomputes the arg-max (first maximum in scan order) */
 int mu_maxpool2_fwd(const void* x, void* y, int B, int H, int W, int C, int dtype, void* stream);
 int mu_maxpool2_bwd(const void* x, const void* dy, void* dx, int B, int H, int W, int C, int dtype, void* stream);
+/* mu_maxpool2_bwd with gradient joins that autograd would otherwise run as separate elementwise kernels: dy2 (may be NULL, pooled
+ * resolution) is a second gradient of the pooled tensor -- the residual branch of the ConvBlock behind the pool, F.gelu(x + block(x))
+ * (:208, 216-217) -- and dx_add (may be NULL, input resolution) a gradient the pool's input received from its other consumer, the skip
+ * connection into UpSample (:253, 303-309):  dx = scatter(dy + dy2) + dx_add. */
+int mu_maxpool2_bwd_acc(const void* x, const void* dy, const void* dy2, const void* dx_add, void* dx, int B, int H, int W, int C, int dtype,
+                        void* stream);
 /* y = cat([skip, bilinear_x2(x, align_corners=True)], channel)  (:235,250-253); x [B,h,w,Cx], skip [B,2h,2w,Cs] */
 int mu_upcat_fwd(const void* x, const void* skip, void* y, int B, int h, int w, int Cx, int Cs, int dtype, void* stream);
 int mu_upcat_bwd(const void* dy, void* dx, void* dskip, int B, int h, int w, int Cx, int Cs, int dtype, void* stream);
+/* mu_upcat_bwd of (dy + dy2): dy2 (may be NULL) is the residual-branch gradient of the ConvBlock behind the concat (:208, 237-238) */
+int mu_upcat_bwd_acc(const void* dy, const void* dy2, void* dx, void* dskip, int B, int h, int w, int Cx, int Cs, int dtype, void* stream);
 /* the same for channel counts that are not multiples of the 32-channel padding (stand-alone UpSample, :231-256): x holds
  * Cx_valid of Cx_ld stored channels, skip Cs_valid of Cs_ld; y rows are [skip valid | up valid | zeros] with Ct_ld stored channels.
  * The backward writes exact zeros into the padded channels of dx / dskip. */
@@ -162,6 +182,11 @@ int mu_dropout_step(const void* x, void* y, long n, float p, unsigned long long 
 int mu_add(const void* a, const void* b, void* out, long n, int dtype, void* stream);
 
 /* ---- masked attention (flash-style) ---------------------------------------------------------- */
+/* The key mask of Mask2FormerAttention (`torch.randint(0, 2, (B,H,W))` -> {0,-inf} per KEY, ade_semantic.py:177-183) as the index list
+ * the kernels below iterate over: kidx[b] = the visible keys in ascending order followed by the masked keys in ascending order (a whole
+ * permutation of 0..N-1 == torch.argsort(keep, descending=True, stable=True): the MU_ATTN_KIDX_PERMUTATION form), kcnt[b] = visible
+ * keys.  keep: [B][N], 1-byte or 8-byte integers (keep_elem_bytes), non-zero = visible; keep8 (may be NULL) receives the {0,1} bytes. */
+int mu_compact_keys(const void* keep, int keep_elem_bytes, int B, int N, int* kidx, int* kcnt, unsigned char* keep8, void* stream);
 /* Mask2FormerAttention core (ade_semantic.py:174-188) on projected qkv [B,N,3C]:
  *   out = LayerNorm_C( softmax_keys( q k^T / sqrt(C) + keymask ) v + x ), token-major [B,N,C].
  * The {0,-inf} key mask is given as the compacted list of kept keys: kidx[b][0..kcnt[b]) (int32, row

@@ -71,6 +71,12 @@ SIGNATURES = {
     "mu_u8_to_nhwc": (I, [P, P, L, I, I, I, P]),
     "mu_adamw_chunk": (I, []),
     "mu_adamw_multi": (I, [P, P, P, I, F, F, F, F, F, F, P]),
+    "mu_prep_qkv": (I, [P, P, P, P, P, P, P, P, I, I, P]),
+    "mu_conv1x1_add_supported": (I, [I, I, I]),
+    "mu_conv1x1_fwd_add": (I, [P, P, P, P, L, I, I, L, L, I, P]),
+    "mu_maxpool2_bwd_acc": (I, [P, P, P, P, P, I, I, I, I, I, P]),
+    "mu_upcat_bwd_acc": (I, [P, P, P, P, I, I, I, I, I, I, P]),
+    "mu_compact_keys": (I, [P, I, I, I, P, P, P, P]),
     "mu_attn_bwd_phases": (I, [P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, I, I, I, I, P, L, I, I, P]),
 }
 

@@ -74,10 +74,11 @@ __device__ __forceinline__ float mu_phi_fast(float x, float* e_out) {
 // The BatchNorm passes are VALU-bound on GELU, not HBM-bound (30 instructions per element against 4-6 bytes: the backward statistics
 // sweep ran at 3.8 TB/s), so the fp16-storage path evaluates Phi and GELU' as odd minimax polynomials in fp32 -- no v_exp / v_rcp, 10-12
 // instructions instead of ~20 (two of them quarter-rate):
-//   Phi(x)   ~ 0.5 + xc P(xc^2),  xc = clamp(x, +-4.25), deg P = 8:  |x Phi~(x) - gelu(x)| <= 5.5e-5 for every x (fp32 Horner included)
-//   GELU'(x) ~ 0.5 + xc R(xc^2),  xc = clamp(x, +-4.5),  deg R = 9:  |error| <= 1.9e-4 (fp32 Horner included)
+//   Phi(x)   ~ 0.5 + xc P(xc^2),  xc = clamp(x, +-4.25), deg P = 8:  |x Phi~(x) - gelu(x)| <= 5.9e-5 for |x| <= 1e2 (fp32 Horner included)
+//   GELU'(x) ~ 0.5 + xc R(xc^2),  xc = clamp(x, +-4.5),  deg R = 9:  |error| <= 2.05e-4 (fp32 Horner included)
 // i.e. below half an fp16 ulp of the stored results around |y| >= 0.25 and far inside the fp16 path's 3e-2 parity gate; fp32 storage
-// keeps erff (exact).  Fitted against erf in fp64 (weighted least squares iterated to equi-ripple); MU_GELU_POLY=0 restores the
+// keeps erff (exact).  Beyond the clamp the polynomials are constants, not the exact limits: Phi~(-4.25) = 3e-7, so x Phi~(x) is
+// -3e-7 |x| instead of 0 for large negative x (-0.018 at x = -6e4, the edge of fp16), and GELU' saturates at 1.00007 / -7e-5.  Fitted against erf in fp64 (weighted least squares iterated to equi-ripple); MU_GELU_POLY=0 restores the
 // erfc rational form above (|error| < 2e-7).
 #ifndef MU_GELU_POLY
 #define MU_GELU_POLY 1

@@ -244,7 +244,8 @@ __device__ __forceinline__ void glds16a(const void* gsrc, void* lds_wave_base) {
 #endif
 template <typename T, int TM, int TN, int WR, int TAPS, bool SB = false>
 __global__ __launch_bounds__(256, SB ? MU_NT2_SB_OCC : MU_NT2_OCC) void conv_nt2_kernel(const T* __restrict__ x, const T* __restrict__ w, const float* __restrict__ bias,
-                                                       T* __restrict__ y, int B, int H, int W, int Cin, int Cout, long x_ld, long y_ld) {
+                                                       T* __restrict__ y, int B, int H, int W, int Cin, int Cout, long x_ld, long y_ld,
+                                                       const T* __restrict__ addend = nullptr) {
     using M_ = Mma<T>;
     using Frag = typename M_::Frag;
     constexpr int VN = M_::VN, KC = 8 * VN;                 // elements per 128-byte stage row
@@ -364,8 +365,18 @@ __global__ __launch_bounds__(256, SB ? MU_NT2_SB_OCC : MU_NT2_OCC) void conv_nt2
         for (int idx = tid; idx < BPX * CH; idx += 256) {
             const int px = idx / CH, ch = idx - px * CH;
             const long p = px0 + px;
-            if (p < Mtot && co0 + ch * 8 < Cout)
-                *reinterpret_cast<uint4*>(y + p * y_ld + co0 + ch * 8) = *reinterpret_cast<const uint4*>(lds + px * OPITCH + ch * 16);
+            if (p < Mtot && co0 + ch * 8 < Cout) {
+                uint4 o = *reinterpret_cast<const uint4*>(lds + px * OPITCH + ch * 16);
+                if (addend) {                   // y = conv(x) + addend (same row layout as y): the residual-branch gradient of the attention block
+                    const uint4 a4 = *reinterpret_cast<const uint4*>(addend + p * y_ld + co0 + ch * 8);
+                    const h16x8 ov = *reinterpret_cast<const h16x8*>(&o), av = *reinterpret_cast<const h16x8*>(&a4);
+                    h16x8 r;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) r[e] = (h16)((float)ov[e] + (float)av[e]);
+                    o = *reinterpret_cast<const uint4*>(&r);
+                }
+                *reinterpret_cast<uint4*>(y + p * y_ld + co0 + ch * 8) = o;
+            }
         }
         return;
     }
@@ -380,6 +391,10 @@ __global__ __launch_bounds__(256, SB ? MU_NT2_SB_OCC : MU_NT2_OCC) void conv_nt2
             float v[4];
 #pragma unroll
             for (int r = 0; r < 4; ++r) v[r] = acc[i][j][r] + (bias ? bias[co + r] : 0.f);
+            if (addend) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] += (float)addend[p * y_ld + co + r];
+            }
             if constexpr (sizeof(T) == 2) {
                 h16x4 o = {(h16)v[0], (h16)v[1], (h16)v[2], (h16)v[3]};
                 *reinterpret_cast<h16x4*>(y + p * y_ld + co) = o;
@@ -1343,6 +1358,35 @@ extern "C" int mu_conv_fwd(const void* x, const void* w, const float* bias, void
         if (taps == 9) conv_fwd_launch<float, 9>((const float*)x, (const float*)w, bias, (float*)y, B, H, W, Cin, Cout, x_ld, y_ld, st);
         else conv_fwd_launch<float, 1>((const float*)x, (const float*)w, bias, (float*)y, B, H, W, Cin, Cout, x_ld, y_ld, st);
     } else return MU_ERR_ARG;
+    MU_CHECK_LAUNCH();
+    return MU_OK;
+}
+
+// y = conv1x1(x) + addend (addend and y share the row stride y_ld; they may be the same buffer only if y == addend exactly).
+// Joins the two gradients of Mask2FormerAttention's input -- the data-gradient of the q/k/v projection and the residual branch dY
+// (`attention_output += x`, ade_semantic.py:187) -- inside the projection's epilogue instead of a separate elementwise pass.
+// Only shapes served by the LDS-DMA 1x1 kernel (Cin * elem_size % 128 == 0, Cout % 64 == 0); MU_ERR_SHAPE otherwise.
+extern "C" int mu_conv1x1_add_supported(int Cin, int Cout, int dtype) {
+    const int es = dtype == MU_F16 ? 2 : 4;
+    return (dtype == MU_F16 || dtype == MU_F32) && Cin > 0 && Cout > 0 && (Cin * es) % 128 == 0 && Cout % 64 == 0 ? 1 : 0;
+}
+
+template <typename T>
+static void conv1x1_add_launch(const T* x, const T* w, const T* addend, T* y, long M, int Cin, int Cout, long x_ld, long y_ld, hipStream_t st) {
+    const int npb = (int)((M + 127) / 128);
+    if (Cout % 128 == 0)
+        conv_nt2_kernel<T, 4, 4, 2, 1><<<npb * (Cout / 128), 256, 0, st>>>(x, w, nullptr, y, 1, 1, (int)M, Cin, Cout, x_ld, y_ld, addend);
+    else
+        conv_nt2_kernel<T, 4, 4, 1, 1><<<(int)((M + 255) / 256) * (Cout / 64), 256, 0, st>>>(x, w, nullptr, y, 1, 1, (int)M, Cin, Cout, x_ld, y_ld, addend);
+}
+
+extern "C" int mu_conv1x1_fwd_add(const void* x, const void* w, const void* addend, void* y, long M, int Cin, int Cout, long x_ld, long y_ld,
+                                  int dtype, void* stream) {
+    if (!x || !w || !addend || !y || M <= 0 || M > 0x7fffffffL) return MU_ERR_ARG;
+    if (!mu_conv1x1_add_supported(Cin, Cout, dtype) || x_ld < Cin || y_ld < Cout || x_ld % 8 || y_ld % 8) return MU_ERR_SHAPE;
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == MU_F16) conv1x1_add_launch<h16>((const h16*)x, (const h16*)w, (const h16*)addend, (h16*)y, M, Cin, Cout, x_ld, y_ld, st);
+    else conv1x1_add_launch<float>((const float*)x, (const float*)w, (const float*)addend, (float*)y, M, Cin, Cout, x_ld, y_ld, st);
     MU_CHECK_LAUNCH();
     return MU_OK;
 }

@@ -207,9 +207,13 @@ __global__ __launch_bounds__(256) void maxpool_fwd_kernel(const T* __restrict__ 
     }
 }
 
+// dy2 (optional, pooled resolution): a second gradient of the pooled output, summed on the fly -- the residual branch of the ConvBlock
+// behind the pool (ade_semantic.py:208: gelu(x + block(x)) makes x a consumer twice).  dx_add (optional, input resolution): a gradient
+// the pooled tensor's INPUT received from elsewhere (the skip connection into UpSample, :253), added to the scattered result.
+// Both replace an elementwise autograd accumulation kernel (read 2 + write 1 tensors) by one extra read here.
 template <typename T>
-__global__ __launch_bounds__(256) void maxpool_bwd_kernel(const T* __restrict__ x, const T* __restrict__ dy, T* __restrict__ dx,
-                                                          int B, int H, int W, int C) {
+__global__ __launch_bounds__(256) void maxpool_bwd_kernel(const T* __restrict__ x, const T* __restrict__ dy, const T* __restrict__ dy2,
+                                                          const T* __restrict__ dx_add, T* __restrict__ dx, int B, int H, int W, int C) {
     constexpr int N = Vec16<T>::N;
     const int cv = C / N, Ho = H / 2, Wo = W / 2;
     const long total = (long)B * Ho * Wo * cv;
@@ -218,9 +222,12 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const T* __restrict__ 
         long p = idx / cv;
         int wo = p % Wo, ho = (p / Wo) % Ho, b = p / ((long)Wo * Ho);
         long off = (((long)b * H + 2 * ho) * W + 2 * wo) * C + c;
-        Vec16<T> v[4], g, o[4];
-        v[0].load(x + off); v[1].load(x + off + C); v[2].load(x + off + (long)W * C); v[3].load(x + off + (long)W * C + C);
+        const long offs[4] = {off, off + C, off + (long)W * C, off + (long)W * C + C};
+        Vec16<T> v[4], g, g2, a[4], o[4];
+        v[0].load(x + offs[0]); v[1].load(x + offs[1]); v[2].load(x + offs[2]); v[3].load(x + offs[3]);
         g.load(dy + p * C + c);
+        if (dy2) g2.load(dy2 + p * C + c);
+        if (dx_add) { a[0].load(dx_add + offs[0]); a[1].load(dx_add + offs[1]); a[2].load(dx_add + offs[2]); a[3].load(dx_add + offs[3]); }
 #pragma unroll
         for (int i = 0; i < N; ++i) {
             int best = 0;
@@ -230,10 +237,12 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const T* __restrict__ 
                 float t = v[k].get(i);
                 if (t > m) { m = t; best = k; }
             }
+            float gi = g.get(i);
+            if (dy2) gi += g2.get(i);
 #pragma unroll
-            for (int k = 0; k < 4; ++k) o[k].set(i, k == best ? g.get(i) : 0.f);
+            for (int k = 0; k < 4; ++k) o[k].set(i, (k == best ? gi : 0.f) + (dx_add ? a[k].get(i) : 0.f));
         }
-        o[0].store(dx + off); o[1].store(dx + off + C); o[2].store(dx + off + (long)W * C); o[3].store(dx + off + (long)W * C + C);
+        o[0].store(dx + offs[0]); o[1].store(dx + offs[1]); o[2].store(dx + offs[2]); o[3].store(dx + offs[3]);
     }
 }
 
@@ -256,18 +265,25 @@ extern "C" int mu_maxpool2_fwd(const void* x, void* y, int B, int H, int W, int 
     return MU_OK;
 }
 
-extern "C" int mu_maxpool2_bwd(const void* x, const void* dy, void* dx, int B, int H, int W, int C, int dtype, void* stream) {
+extern "C" int mu_maxpool2_bwd_acc(const void* x, const void* dy, const void* dy2, const void* dx_add, void* dx, int B, int H, int W, int C,
+                                   int dtype, void* stream) {
     if (!x || !dy || !dx || B <= 0 || (H & 1) || (W & 1) || C % 8) return MU_ERR_ARG;
     hipStream_t st = (hipStream_t)stream;
     if (dtype == MU_F32) {
         long total = (long)B * (H / 2) * (W / 2) * (C / 4);
-        maxpool_bwd_kernel<float><<<ew_grid(total), 256, 0, st>>>((const float*)x, (const float*)dy, (float*)dx, B, H, W, C);
+        maxpool_bwd_kernel<float><<<ew_grid(total), 256, 0, st>>>((const float*)x, (const float*)dy, (const float*)dy2, (const float*)dx_add,
+                                                                  (float*)dx, B, H, W, C);
     } else if (dtype == MU_F16) {
         long total = (long)B * (H / 2) * (W / 2) * (C / 8);
-        maxpool_bwd_kernel<h16><<<ew_grid(total), 256, 0, st>>>((const h16*)x, (const h16*)dy, (h16*)dx, B, H, W, C);
+        maxpool_bwd_kernel<h16><<<ew_grid(total), 256, 0, st>>>((const h16*)x, (const h16*)dy, (const h16*)dy2, (const h16*)dx_add, (h16*)dx,
+                                                                B, H, W, C);
     } else return MU_ERR_ARG;
     MU_CHECK_LAUNCH();
     return MU_OK;
+}
+
+extern "C" int mu_maxpool2_bwd(const void* x, const void* dy, void* dx, int B, int H, int W, int C, int dtype, void* stream) {
+    return mu_maxpool2_bwd_acc(x, dy, nullptr, nullptr, dx, B, H, W, C, dtype, stream);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -319,9 +335,11 @@ __global__ __launch_bounds__(256) void upcat_fwd_kernel(const T* __restrict__ x,
 }
 
 // backward: dskip = dy[..., :Cs];  dx = bilinear^T(dy[..., Cs:]) as a deterministic gather
+// dy2 (optional): a second gradient of the concatenated tensor, summed on the fly (the residual branch of the ConvBlock behind the
+// concat, ade_semantic.py:208,237-238) instead of an autograd accumulation kernel in front of this one.
 template <typename T>
-__global__ __launch_bounds__(256) void upcat_bwd_kernel(const T* __restrict__ dy, T* __restrict__ dx, T* __restrict__ dskip,
-                                                        int B, int h, int w, int Cx, int Cs) {
+__global__ __launch_bounds__(256) void upcat_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ dy2, T* __restrict__ dx,
+                                                        T* __restrict__ dskip, int B, int h, int w, int Cx, int Cs) {
     constexpr int N = Vec16<T>::N;
     const int Ho = 2 * h, Wo = 2 * w, Ct = Cx + Cs;
     const float sh = h > 1 ? (float)(h - 1) / (float)(Ho - 1) : 0.f, sw = w > 1 ? (float)(w - 1) / (float)(Wo - 1) : 0.f;
@@ -333,6 +351,12 @@ __global__ __launch_bounds__(256) void upcat_bwd_kernel(const T* __restrict__ dy
             long p = idx / cvs;
             Vec16<T> v;
             v.load(dy + p * Ct + c);
+            if (dy2) {
+                Vec16<T> v2;
+                v2.load(dy2 + p * Ct + c);
+#pragma unroll
+                for (int i = 0; i < N; ++i) v.set(i, v.get(i) + v2.get(i));
+            }
             v.store(dskip + p * Cs + c);
             continue;
         }
@@ -357,10 +381,18 @@ __global__ __launch_bounds__(256) void upcat_bwd_kernel(const T* __restrict__ dy
                 if (w0 == wi && w1 == wi) ww = 1.f;
                 if (ww == 0.f) continue;
                 Vec16<T> g;
-                g.load(dy + (((long)b * Ho + ho) * Wo + wo) * Ct + Cs + c);
+                const long goff = (((long)b * Ho + ho) * Wo + wo) * Ct + Cs + c;
+                g.load(dy + goff);
                 float wt = wh * ww;
+                if (dy2) {
+                    Vec16<T> g2;
+                    g2.load(dy2 + goff);
 #pragma unroll
-                for (int i = 0; i < N; ++i) acc[i] += wt * g.get(i);
+                    for (int i = 0; i < N; ++i) acc[i] += wt * (g.get(i) + g2.get(i));
+                } else {
+#pragma unroll
+                    for (int i = 0; i < N; ++i) acc[i] += wt * g.get(i);
+                }
             }
         }
         Vec16<T> o;
@@ -488,18 +520,23 @@ extern "C" int mu_upcat_fwd(const void* x, const void* skip, void* y, int B, int
     return MU_OK;
 }
 
-extern "C" int mu_upcat_bwd(const void* dy, void* dx, void* dskip, int B, int h, int w, int Cx, int Cs, int dtype, void* stream) {
+extern "C" int mu_upcat_bwd_acc(const void* dy, const void* dy2, void* dx, void* dskip, int B, int h, int w, int Cx, int Cs, int dtype,
+                                void* stream) {
     if (!dy || !dx || !dskip || B <= 0 || h <= 0 || w <= 0 || Cx % 8 || Cs % 8) return MU_ERR_ARG;
     hipStream_t st = (hipStream_t)stream;
     if (dtype == MU_F32) {
         long total = (long)B * 4 * h * w * (Cs / 4) + (long)B * h * w * (Cx / 4);
-        upcat_bwd_kernel<float><<<ew_grid(total), 256, 0, st>>>((const float*)dy, (float*)dx, (float*)dskip, B, h, w, Cx, Cs);
+        upcat_bwd_kernel<float><<<ew_grid(total), 256, 0, st>>>((const float*)dy, (const float*)dy2, (float*)dx, (float*)dskip, B, h, w, Cx, Cs);
     } else if (dtype == MU_F16) {
         long total = (long)B * 4 * h * w * (Cs / 8) + (long)B * h * w * (Cx / 8);
-        upcat_bwd_kernel<h16><<<ew_grid(total), 256, 0, st>>>((const h16*)dy, (h16*)dx, (h16*)dskip, B, h, w, Cx, Cs);
+        upcat_bwd_kernel<h16><<<ew_grid(total), 256, 0, st>>>((const h16*)dy, (const h16*)dy2, (h16*)dx, (h16*)dskip, B, h, w, Cx, Cs);
     } else return MU_ERR_ARG;
     MU_CHECK_LAUNCH();
     return MU_OK;
+}
+
+extern "C" int mu_upcat_bwd(const void* dy, void* dx, void* dskip, int B, int h, int w, int Cx, int Cs, int dtype, void* stream) {
+    return mu_upcat_bwd_acc(dy, nullptr, dx, dskip, B, h, w, Cx, Cs, dtype, stream);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -614,6 +651,100 @@ extern "C" int mu_u8_to_nhwc(const unsigned char* src, void* dst, long npix, int
     hipStream_t st = (hipStream_t)stream;
     if (dtype == MU_F32) u8_to_nhwc_kernel<float><<<ew_grid(npix * (Cp / 4)), 256, 0, st>>>(src, (float*)dst, npix, C, Cp);
     else if (dtype == MU_F16) u8_to_nhwc_kernel<h16><<<ew_grid(npix * (Cp / 8)), 256, 0, st>>>(src, (h16*)dst, npix, C, Cp);
+    else return MU_ERR_ARG;
+    MU_CHECK_LAUNCH();
+    return MU_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// Key-mask compaction.  Mask2FormerAttention draws keep = randint(0,2,(B,H,W)) and adds {0,-inf} per KEY (ade_semantic.py:177-183);
+// the attention kernels iterate over the kept keys only, through an index list.  kidx[b] = the kept keys in ascending order followed
+// by the masked keys in ascending order -- a whole permutation of 0..N-1, exactly torch.argsort(keep, descending=True, stable=True)
+// (the MU_ATTN_KIDX_PERMUTATION promise) -- and kcnt[b] = the number kept.  One 1024-thread block per image: every thread owns a
+// contiguous run of keys, counts its kept ones, a block-wide exclusive scan places both partitions.  `keep` is uint8 or int64 (what
+// torch.randint returns), non-zero = visible; keep8 (optional) receives the {0,1} bytes.  Under mask_mode="resample" (the reference's
+// behaviour under multi-GPU nn.DataParallel) this runs six times per step in place of six torch.argsort calls.
+// ------------------------------------------------------------------------------------------
+template <typename KT>
+__global__ __launch_bounds__(1024) void compact_keys_kernel(const KT* __restrict__ keep, int N, int* __restrict__ kidx, int* __restrict__ kcnt,
+                                                            uint8_t* __restrict__ keep8) {
+    __shared__ int wsum[16];
+    const int b = blockIdx.x, t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const KT* kp = keep + (long)b * N;
+    const int per = (N + 1023) / 1024;
+    const long s0 = (long)t * per;
+    const int i0 = (int)(s0 < N ? s0 : N), i1 = i0 + per < N ? i0 + per : N;
+    int c = 0;
+    for (int i = i0; i < i1; ++i) c += kp[i] != 0 ? 1 : 0;
+    int s = c;                                               // inclusive scan over the wave, then over the 16 waves
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int v = __shfl_up(s, o);
+        if (lane >= o) s += v;
+    }
+    if (lane == 63) wsum[wave] = s;
+    __syncthreads();
+    int base = 0, total = 0;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) {
+        const int v = wsum[w];
+        if (w < wave) base += v;
+        total += v;
+    }
+    int kpos = base + s - c;                                 // kept keys in front of this thread's run
+    int mpos = total + (i0 - kpos);                          // masked keys in front of it, behind all the kept ones
+    int* row = kidx + (long)b * N;
+    for (int i = i0; i < i1; ++i) {
+        const bool f = kp[i] != 0;
+        if (f) row[kpos++] = i; else row[mpos++] = i;
+        if (keep8) keep8[(long)b * N + i] = f ? 1 : 0;
+    }
+    if (t == 0) kcnt[b] = total;
+}
+
+extern "C" int mu_compact_keys(const void* keep, int keep_elem_bytes, int B, int N, int* kidx, int* kcnt, unsigned char* keep8,
+                               void* stream) {
+    if (!keep || !kidx || !kcnt || B <= 0 || N <= 0) return MU_ERR_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    if (keep_elem_bytes == 1) compact_keys_kernel<uint8_t><<<B, 1024, 0, st>>>((const uint8_t*)keep, N, kidx, kcnt, keep8);
+    else if (keep_elem_bytes == 8) compact_keys_kernel<long><<<B, 1024, 0, st>>>((const long*)keep, N, kidx, kcnt, keep8);
+    else return MU_ERR_ARG;
+    MU_CHECK_LAUNCH();
+    return MU_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// q/k/v projection weights of one attention block (three nn.Linear(C,C) with bias, ade_semantic.py:157-159) -> the compute layouts
+// of ONE [3C, C] 1x1 layer in one launch: the forward block [3C][C], the data-gradient block [C][3C] (mu_prep_weight mode 2 of the
+// concatenated weight) and the concatenated fp32 bias [3C].  Replaces two torch.cat + two .float() launches per block and step.
+// ------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void prep_qkv_kernel(const float* __restrict__ wq, const float* __restrict__ wk, const float* __restrict__ wv,
+                                const float* __restrict__ bq, const float* __restrict__ bk, const float* __restrict__ bv,
+                                T* __restrict__ dst, float* __restrict__ bias, int C) {
+    const long n = 3L * C * C;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < 2 * n + 3 * C; idx += (long)gridDim.x * blockDim.x) {
+        if (idx >= 2 * n) {
+            const int j = (int)(idx - 2 * n), which = j / C, c = j - which * C;
+            bias[j] = (which == 0 ? bq : (which == 1 ? bk : bv))[c];
+            continue;
+        }
+        int o, i;                                             // output row (0..3C) and input column (0..C) of the concatenated weight
+        if (idx < n) { o = (int)(idx / C); i = (int)(idx % C); }
+        else { const long j = idx - n; i = (int)(j / (3 * C)); o = (int)(j % (3 * C)); }
+        const int which = o / C, r = o - which * C;
+        dst[idx] = (T)(which == 0 ? wq : (which == 1 ? wk : wv))[(long)r * C + i];
+    }
+}
+
+extern "C" int mu_prep_qkv(const float* wq, const float* wk, const float* wv, const float* bq, const float* bk, const float* bv, void* dst,
+                           float* bias, int dtype, int C, void* stream) {
+    if (!wq || !wk || !wv || !bq || !bk || !bv || !dst || !bias || C <= 0 || C % 32) return MU_ERR_ARG;
+    const long n = 6L * C * C + 3 * C;
+    const int grid = (int)((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048);
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == MU_F32) prep_qkv_kernel<float><<<grid, 256, 0, st>>>(wq, wk, wv, bq, bk, bv, (float*)dst, bias, C);
+    else if (dtype == MU_F16) prep_qkv_kernel<h16><<<grid, 256, 0, st>>>(wq, wk, wv, bq, bk, bv, (h16*)dst, bias, C);
     else return MU_ERR_ARG;
     MU_CHECK_LAUNCH();
     return MU_OK;

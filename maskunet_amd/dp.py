@@ -96,6 +96,12 @@ class DataParallel(nn.Module):
         """Replicas start identical (nn.DataParallel re-broadcasts GPU0's parameters/buffers every forward)."""
         for t in list(self.module.parameters()) + list(self.module.buffers()):
             dist.broadcast(t.data, src, group=self.group)
+        # the write above goes through `.data`, which autograd's version counter does not see: bump it so that the weight layouts
+        # cached for no-grad forwards (ops._prep_cached, keyed on version + address) are rebuilt from the broadcast values
+        for p in self.module.parameters():
+            torch.autograd.graph.increment_version(p)
+            if hasattr(p, "_mu_prep"):
+                p._mu_prep.clear()
 
     def broadcast_buffers(self, src: int = 0):
         """Copy rank ``src``'s buffers (BatchNorm running statistics / step counters) to every rank."""

@@ -17,7 +17,8 @@ attention keep-masks are whatever the modules hold at capture time (set_keep_mas
 With a maskunet_amd.DataParallel model the replica's step is captured (the graph holds no collective) and the gradient exchange runs
 eagerly after every replay: the same bucketed all-reduce on the comm stream, without overlap with the backward -- the hooks of
 DataParallel sit on the parameters' AccumulateGrad nodes, which the captured torch.autograd.grad on fresh leaves never runs.  The
-averaged gradients land in the graph's own gradient tensors (p.grad); `no_sync()` around a call skips the exchange as usual.
+averaged gradients land in the graph's own gradient tensors (p.grad).  Gradient accumulation is NOT available through a graph: a
+replay overwrites the graph's gradient tensors instead of adding to them, so a call inside `DataParallel.no_sync()` raises.
 """
 from __future__ import annotations
 
@@ -77,6 +78,9 @@ class GraphedStep:
         return loss.detach(), sem.detach()
 
     def __call__(self, inputs, labels):
+        if self.dp is not None and not self.dp._sync:
+            raise RuntimeError("GraphedStep inside DataParallel.no_sync(): a replay overwrites the gradients of the previous micro-batch "
+                               "instead of accumulating into them -- run accumulation steps eagerly")
         self.inputs.copy_(inputs, non_blocking=True)
         self.labels.copy_(labels, non_blocking=True)
         self.graph.replay()

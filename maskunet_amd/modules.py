@@ -91,27 +91,25 @@ class Mask2FormerAttention(_HipModule):
         self.set_keep_mask(value == 0 if value.is_floating_point() else value)
 
     def set_keep_mask(self, keep):
-        """keep: [B,N], non-zero = key visible.  Builds the compacted kept-key index list on device."""
+        """keep: [B,N], non-zero = key visible.  The compacted kept-key index list is built on the device at the next forward."""
         keep = (keep != 0).to(torch.uint8)
         self._keep = keep
         self._kidx = self._kcnt = None
 
     def _compact(self, device):
         if self._kidx is None or self._kidx.device != device:
-            keep = self._keep.to(device)
-            self._keep = keep
-            # stable sort puts kept keys first, in ascending key order
-            self._kidx = torch.argsort(keep, dim=1, descending=True, stable=True).to(torch.int32).contiguous()
-            self._kcnt = keep.sum(dim=1, dtype=torch.int32).contiguous()
+            # visible keys first, ascending, then the masked ones (== a stable descending argsort): one HIP launch, no host sync
+            self._kidx, self._kcnt, self._keep = ops.compact_keys(self._keep.to(device))
         return self._kidx, self._kcnt
 
     def _mask_for(self, x_nhwc):
         B, H, W, _ = x_nhwc.shape
         N = H * W
         if self._keep is None or self._keep.shape[-1] != N or self.mask_mode == "resample":
-            # same draw as the reference (ade_semantic.py:178): randint(0,2,(B,H,W)) on the input's device
+            # same draw as the reference (ade_semantic.py:178): randint(0,2,(B,H,W)) on the input's device; the int64 draw goes
+            # straight into the compaction kernel (no uint8 copy, no torch.argsort: the per-step cost of mask_mode="resample")
             binary = torch.randint(0, 2, (B, H, W), device=x_nhwc.device)
-            self.set_keep_mask(binary.view(B, -1))
+            self._kidx, self._kcnt, self._keep = ops.compact_keys(binary.view(B, -1))
         kidx, kcnt = self._compact(x_nhwc.device)
         if kidx.shape[0] != B:
             if kidx.shape[0] == 1:      # reference: a cached batch-1 mask broadcasts
@@ -126,7 +124,8 @@ class Mask2FormerAttention(_HipModule):
         if x.shape[-1] != self.channels:
             raise ValueError("Input channel size does not match initialized channel size.")
         kidx, kcnt = self._mask_for(x)
-        return ops.mask_attention(x, self.query, self.key, self.value, self.norm, kidx, kcnt, scramble)
+        # kidx comes from ops.compact_keys: whole permutations, masked keys last -> the backward may skip the memset of dqkv
+        return ops.mask_attention(x, self.query, self.key, self.value, self.norm, kidx, kcnt, scramble, kidx_perm=True)
 
     def forward(self, x):
         batch_size, channels, height, width = x.size()
@@ -156,15 +155,16 @@ class ConvBlock(_HipModule):
             nn.BatchNorm2d(out_channels),
         )
 
-    def forward_nhwc(self, x, tail_bn=None):
+    def forward_nhwc(self, x, tail_bn=None, res_link=None):
         """tail_bn: the nn.BatchNorm2d DownSample / UpSample apply right behind this block (:219,240); in training mode it is
-        folded into the block's last BatchNorm (ops.bn_pair)."""
+        folded into the block's last BatchNorm (ops.bn_pair).  res_link: ops.GradLink shared with the op that produced x (residual
+        blocks only): the gradient of the `x +` branch (:208) is joined inside that op's backward kernel."""
         cb = self.conv_block
         y, st = ops.conv_stats(x, cb[0].weight, want=cb[1].training)   # BatchNorm statistics from the conv epilogue where it has one
         y = ops.bn_act(y, cb[1], ACT_GELU, stats=st)
         y, st = ops.conv_stats(y, cb[3].weight, want=cb[4].training)
         if self.residual:
-            y = ops.bn_act(y, cb[4], ACT_GELU, res=x, stats=st)         # gelu(x + BN(conv(...)))  (:208)
+            y = ops.bn_act(y, cb[4], ACT_GELU, res=x, stats=st, res_link=res_link)         # gelu(x + BN(conv(...)))  (:208)
             return y if tail_bn is None else ops.bn_act(y, tail_bn, ACT_NONE)
         if tail_bn is not None:
             return ops.bn_pair(y, cb[4], tail_bn, stats=st)
@@ -190,10 +190,12 @@ class DownSample(_HipModule):
         self.emb_layer = nn.Sequential(nn.SiLU(), nn.Linear(emb_dim, out_channels))
         self.out_channels = out_channels
 
-    def forward_nhwc(self, x):
+    def forward_nhwc(self, x, skip_link=None):
+        """skip_link: ops.GradLink shared with the UpSample that takes x as its skip tensor (UNet wiring, :292-309)."""
         mc = self.maxpool_conv
-        x = ops.maxpool2(x)
-        x = mc[1].forward_nhwc(x)
+        link = ops.grad_link(x)                           # residual branch of mc[1] -> the pool's backward
+        x = ops.maxpool2(x, link, skip_link)
+        x = mc[1].forward_nhwc(x, res_link=link)
         return mc[2].forward_nhwc(x, tail_bn=mc[3])       # ConvBlock + the BatchNorm behind it (:218-219)
 
     def forward(self, x):
@@ -215,10 +217,12 @@ class UpSample(_HipModule):
         )
         self.emb_layer = nn.Sequential(nn.SiLU(), nn.Linear(emb_dim, out_channels))
 
-    def forward_nhwc(self, x, skip_x, cx=None, cs=None):
-        """cx / cs: true channel counts of x / skip_x when they are not multiples of the 32-channel storage padding."""
-        x = ops.upcat(x, skip_x, cx, cs)         # cat([skip_x, up(x)], dim=1)  (:250-253)
-        x = self.conv[0].forward_nhwc(x)
+    def forward_nhwc(self, x, skip_x, cx=None, cs=None, skip_link=None):
+        """cx / cs: true channel counts of x / skip_x when they are not multiples of the 32-channel storage padding.
+        skip_link: ops.GradLink shared with the DownSample that also consumes skip_x (UNet wiring)."""
+        link = ops.grad_link(x, skip_x)          # residual branch of conv[0] -> the concat's backward
+        x = ops.upcat(x, skip_x, cx, cs, link, skip_link)         # cat([skip_x, up(x)], dim=1)  (:250-253)
+        x = self.conv[0].forward_nhwc(x, res_link=link)
         return self.conv[1].forward_nhwc(x, tail_bn=self.conv[2])      # ConvBlock + the BatchNorm behind it (:239-240)
 
     def forward(self, x, skip_x):
@@ -297,25 +301,30 @@ class UNet(_HipModule):
 
     def forward_nhwc(self, x):
         """x: NHWC [B,H,W,32] (3 real channels) -> tuple of NHWC head outputs (padded channels)."""
+        # x1, x2, x3 each feed a DownSample and, as skip tensors, an UpSample (:292-309): their two gradients are joined inside
+        # the pool's backward kernel (ops.GradLink) instead of by three autograd accumulation kernels
         x1 = self.initial_conv.forward_nhwc(x)
-        x2 = self.downsample1.forward_nhwc(x1)
+        l1 = ops.grad_link(x1)
+        x2 = self.downsample1.forward_nhwc(x1, skip_link=l1)
         x2 = self.self_attention1.forward_nhwc(x2)
-        x3 = self.downsample2.forward_nhwc(x2)
+        l2 = ops.grad_link(x2)
+        x3 = self.downsample2.forward_nhwc(x2, skip_link=l2)
         x3 = self.self_attention2.forward_nhwc(x3)
-        x4 = self.downsample3.forward_nhwc(x3)
+        l3 = ops.grad_link(x3)
+        x4 = self.downsample3.forward_nhwc(x3, skip_link=l3)
         x4 = self.self_attention3.forward_nhwc(x4)
 
         x4 = self.bottom1.forward_nhwc(x4)
         x4 = self.bottom2.forward_nhwc(x4)
         x4 = self.bottom3.forward_nhwc(x4)
 
-        y = self.upsample1.forward_nhwc(x4, x3)
+        y = self.upsample1.forward_nhwc(x4, x3, skip_link=l3)
         y = self._drop(y, 0)
         y = self.self_attention4.forward_nhwc(y)
-        y = self.upsample2.forward_nhwc(y, x2)
+        y = self.upsample2.forward_nhwc(y, x2, skip_link=l2)
         y = self._drop(y, 1)
         y = self.self_attention5.forward_nhwc(y)
-        y = self.upsample3.forward_nhwc(y, x1)
+        y = self.upsample3.forward_nhwc(y, x1, skip_link=l1)
         B, H, W, _ = y.shape
         # attention 6 feeds the per-sample LayerNorm, which works on the NCHW-flat memory == the
         # token-major buffer itself, so the scramble transpose is skipped here (:310-311)

@@ -29,6 +29,39 @@ def _pad_vec(v, n, fill):
     return F.pad(v, (0, n - v.numel()), value=fill)
 
 
+class GradLink:
+    """Side channel for ONE gradient tensor between two autograd nodes of one backward pass.
+
+    Where a tensor has two consumers (a residual ConvBlock reads its input twice, ade_semantic.py:208; a skip connection feeds
+    DownSample and UpSample, :292-309) autograd joins the two gradients with an elementwise kernel of its own (9 per step in the
+    UNet: 0.35 ms).  The consumer whose backward runs FIRST puts its gradient here and returns None to autograd; the backward of the
+    tensor's producer-side neighbour -- which data dependence orders later -- takes it and adds it inside its own kernel
+    (mu_maxpool2_bwd_acc / mu_upcat_bwd_acc).  Links are made per forward call by the modules that own both ends (DownSample,
+    UpSample, UNet); a link nobody fills is simply empty (take() -> None), and `armed` says a taker exists at all."""
+    __slots__ = ("t", "armed")
+
+    def __init__(self):
+        self.t = None
+        self.armed = False
+
+    def put(self, t):
+        self.t = t if self.t is None else self.t + t        # (two fills before a take: retain_graph re-runs; stays correct)
+
+    def take(self):
+        t, self.t = self.t, None
+        return t
+
+
+GRAD_LINKS = os.environ.get("MU_GRAD_LINKS", "1") != "0"      # debug switch: 0 = leave every gradient join to autograd
+
+
+def grad_link(*tensors):
+    """A fresh link when a backward pass can follow (grad mode on and one of `tensors` requires grad), else None."""
+    if not GRAD_LINKS or not torch.is_grad_enabled() or not any(t is not None and t.requires_grad for t in tensors):
+        return None
+    return GradLink()
+
+
 # ------------------------------------------------------------------------------------------------
 # layout conversion at the module boundary
 # ------------------------------------------------------------------------------------------------
@@ -121,7 +154,7 @@ def _cache_ok():
     return PREP_CACHE and not torch.is_grad_enabled()
 
 
-def _prep_cached(w, key, make, ok):
+def _prep_cached(w, key, make, ok, extra_tag=()):
     if not ok or torch.cuda.is_current_stream_capturing():
         return make()
     cache = getattr(w, "_mu_prep", None)
@@ -131,7 +164,7 @@ def _prep_cached(w, key, make, ok):
             w._mu_prep = cache
         except Exception:      # tensors that do not accept attributes
             return make()
-    tag = (w._version, w.data_ptr())
+    tag = (w._version, w.data_ptr()) + tuple(extra_tag)
     hit = cache.get(key)
     if hit is not None and hit[0] == tag:
         return hit[1]
@@ -355,8 +388,9 @@ class _BNAct(torch.autograd.Function):
     :285-286 (BN, ReLU).  Training uses batch statistics and updates the running buffers in place."""
 
     @staticmethod
-    def forward(ctx, x, res, gamma, beta, running_mean, running_var, training, momentum, eps, act, nbt=None, stats=None):
+    def forward(ctx, x, res, gamma, beta, running_mean, running_var, training, momentum, eps, act, nbt=None, stats=None, res_link=None):
         x = x.contiguous()
+        ctx.res_link = res_link if (res is not None and res_link is not None and res_link.armed) else None
         C = x.shape[-1]
         M = x.numel() // C
         cv = gamma.numel()
@@ -397,7 +431,10 @@ class _BNAct(torch.autograd.Function):
         ws = workspace(_lib.load().mu_bn_workspace_bytes(C), x.device)
         call("mu_bn_act_bwd", ptr(x), ptr(res), ptr(gy), ptr(dx), ptr(dres), M, C, C, ptr(mean), ptr(rstd), ptr(g_p), ptr(b_p),
              ctx.act, int(ctx.training), ptr(dgamma), ptr(dbeta), ptr(ws), ws.numel(), dt(x), stream())
-        return dx, dres, dgamma[:ctx.cv], dbeta[:ctx.cv], None, None, None, None, None, None, None, None
+        if ctx.res_link is not None:             # the residual-branch gradient travels to the backward of x's producer (GradLink)
+            ctx.res_link.put(dres)
+            dres = None
+        return dx, dres, dgamma[:ctx.cv], dbeta[:ctx.cv], None, None, None, None, None, None, None, None, None
 
 
 class _BNPair(torch.autograd.Function):
@@ -463,10 +500,11 @@ def bn_pair(x, bn1, bn2, stats=None):
                          bn1.momentum, bn1.eps, bn2.running_mean, bn2.running_var, bn2.num_batches_tracked, bn2.momentum, bn2.eps, stats)
 
 
-def bn_act(x, bn, act=ACT_NONE, res=None, stats=None):
+def bn_act(x, bn, act=ACT_NONE, res=None, stats=None, res_link=None):
     """Apply the BatchNorm2d parameter container `bn` (an nn.BatchNorm2d used only for its
     parameters/buffers/flags) followed by `act`, optionally adding `res` before the activation.
-    `stats`: statistics rows of x from conv_stats() (training mode only; ignored otherwise)."""
+    `stats`: statistics rows of x from conv_stats() (training mode only; ignored otherwise).
+    `res_link`: GradLink that carries d(res) to the backward of res's producer (maxpool2 / upcat) instead of through autograd."""
     training = bn.training or bn.running_mean is None
     # the step counter is bumped by the statistics kernel (one tiny torch kernel per BatchNorm otherwise: 39 per step)
     nbt = bn.num_batches_tracked if (bn.training and bn.num_batches_tracked is not None) else None
@@ -475,22 +513,30 @@ def bn_act(x, bn, act=ACT_NONE, res=None, stats=None):
         nbt = None
     momentum = 0.1 if bn.momentum is None else bn.momentum
     return _BNAct.apply(x, res, bn.weight, bn.bias, bn.running_mean, bn.running_var, training, momentum, bn.eps, act, nbt,
-                        stats if training else None)
+                        stats if training else None, res_link)
 
 
 # ------------------------------------------------------------------------------------------------
 # pooling / resampling / dropout
 # ------------------------------------------------------------------------------------------------
 class _MaxPool2(torch.autograd.Function):
-    """nn.MaxPool2d(2) (ade_semantic.py:216)."""
+    """nn.MaxPool2d(2) (ade_semantic.py:216).  res_link: GradLink filled by the residual ConvBlock behind the pool with a second
+    gradient of the pooled tensor; skip_link: GradLink filled by the UpSample that takes the pool's INPUT as its skip tensor with
+    that tensor's other gradient.  Both are joined inside mu_maxpool2_bwd_acc."""
 
     @staticmethod
-    def forward(ctx, x):
+    def forward(ctx, x, res_link=None, skip_link=None):
         x = x.contiguous()
         B, H, W, C = x.shape
         y = torch.empty((B, H // 2, W // 2, C), dtype=x.dtype, device=x.device)
         call("mu_maxpool2_fwd", ptr(x), ptr(y), B, H, W, C, dt(x), stream())
         ctx.save_for_backward(x)
+        ctx.res_link, ctx.skip_link = res_link, skip_link
+        if ctx.needs_input_grad[0]:              # a backward of this node will run: the fillers may route their gradients here
+            if res_link is not None:
+                res_link.armed = True
+            if skip_link is not None:
+                skip_link.armed = True
         return y
 
     @staticmethod
@@ -500,12 +546,17 @@ class _MaxPool2(torch.autograd.Function):
         gy = gy.contiguous()
         B, H, W, C = x.shape
         dx = torch.empty_like(x)
-        call("mu_maxpool2_bwd", ptr(x), ptr(gy), ptr(dx), B, H, W, C, dt(x), stream())
-        return dx
+        g2 = ctx.res_link.take() if ctx.res_link is not None else None
+        ga = ctx.skip_link.take() if ctx.skip_link is not None else None
+        if g2 is None and ga is None:
+            call("mu_maxpool2_bwd", ptr(x), ptr(gy), ptr(dx), B, H, W, C, dt(x), stream())
+        else:
+            call("mu_maxpool2_bwd_acc", ptr(x), ptr(gy), ptr(g2), ptr(ga), ptr(dx), B, H, W, C, dt(x), stream())
+        return dx, None, None
 
 
-def maxpool2(x):
-    return _MaxPool2.apply(x)
+def maxpool2(x, res_link=None, skip_link=None):
+    return _MaxPool2.apply(x, res_link, skip_link)
 
 
 class _UpCat(torch.autograd.Function):
@@ -513,7 +564,7 @@ class _UpCat(torch.autograd.Function):
     x / skip; where they are not the stored (32-padded) counts the concat compacts [skip valid | up valid | zero pad]."""
 
     @staticmethod
-    def forward(ctx, x, skip, cx, cs):
+    def forward(ctx, x, skip, cx, cs, res_link=None, skip_link=None):
         x, skip = x.contiguous(), skip.contiguous()
         B, h, w, Cx = x.shape
         Cs = skip.shape[-1]
@@ -527,6 +578,12 @@ class _UpCat(torch.autograd.Function):
         else:
             call("mu_upcat_fwd", ptr(x), ptr(skip), ptr(y), B, h, w, Cx, Cs, dt(x), stream())
         ctx.dims = (B, h, w, Cx, Cs, cx, cs, Ct)
+        # res_link (residual ConvBlock behind the concat -> this node): only the vector kernel joins a second gradient
+        ctx.res_link = res_link if not ctx.compact else None
+        if ctx.res_link is not None and (ctx.needs_input_grad[0] or ctx.needs_input_grad[1]):
+            ctx.res_link.armed = True
+        # skip_link (this node -> the maxpool that also consumes `skip`): used when that node armed it in its forward
+        ctx.skip_link = skip_link if (skip_link is not None and skip_link.armed and ctx.needs_input_grad[1]) else None
         return y
 
     @staticmethod
@@ -536,15 +593,21 @@ class _UpCat(torch.autograd.Function):
         gy = gy.contiguous()
         dx = torch.empty((B, h, w, Cx), dtype=gy.dtype, device=gy.device)
         dskip = torch.empty((B, 2 * h, 2 * w, Cs), dtype=gy.dtype, device=gy.device)
+        g2 = ctx.res_link.take() if ctx.res_link is not None else None
         if ctx.compact:
             call("mu_upcat_compact_bwd", ptr(gy), ptr(dx), ptr(dskip), B, h, w, Cx, cx, Cs, cs, Ct, dt(gy), stream())
+        elif g2 is not None:
+            call("mu_upcat_bwd_acc", ptr(gy), ptr(g2), ptr(dx), ptr(dskip), B, h, w, Cx, Cs, dt(gy), stream())
         else:
             call("mu_upcat_bwd", ptr(gy), ptr(dx), ptr(dskip), B, h, w, Cx, Cs, dt(gy), stream())
-        return dx, dskip, None, None
+        if ctx.skip_link is not None:            # d(skip) is added by the backward of the pool that shares the tensor (GradLink)
+            ctx.skip_link.put(dskip)
+            dskip = None
+        return dx, dskip, None, None, None, None
 
 
-def upcat(x, skip, cx=None, cs=None):
-    return _UpCat.apply(x, skip, x.shape[-1] if cx is None else int(cx), skip.shape[-1] if cs is None else int(cs))
+def upcat(x, skip, cx=None, cs=None, res_link=None, skip_link=None):
+    return _UpCat.apply(x, skip, x.shape[-1] if cx is None else int(cx), skip.shape[-1] if cs is None else int(cs), res_link, skip_link)
 
 
 SEED_STEP = None        # int64 device tensor [1] or None; set by maskunet_amd.graph.GraphedStep during capture
@@ -644,20 +707,26 @@ class _MaskAttention(torch.autograd.Function):
     consumer wants the NCHW-flat memory itself (the final LayerNorm, :311)."""
 
     @staticmethod
-    def forward(ctx, x, wq, bq, wk, bk, wv, bv, lnw, lnb, kidx, kcnt, eps, scramble, cache_ok=False):
+    def forward(ctx, x, wq, bq, wk, bk, wv, bv, lnw, lnb, kidx, kcnt, eps, scramble, cache_ok=False, kidx_perm=False):
         x = x.contiguous()
         B, H, W, C = x.shape
         N = H * W
-        def make_qkv():
-            wqkv_ = torch.cat([wq.detach(), wk.detach(), wv.detach()], 0).float().view(3 * C, C, 1, 1)
-            bqkv_ = torch.cat([bq.detach(), bk.detach(), bv.detach()], 0).float().contiguous()
-            return wqkv_, bqkv_, _prep_weight_raw(wqkv_, x.dtype, 3 * C, C, 2)
 
-        if cache_ok and isinstance(wq, torch.nn.Parameter):     # cached on the query weight, keyed on all six parameters' versions
+        def make_qkv():          # the three Linear layers as one [3C, C] 1x1 layer: forward + data-gradient layouts and the bias, one launch
+            wbuf = torch.empty((6 * C * C,), dtype=x.dtype, device=x.device)
+            bqkv_ = torch.empty((3 * C,), dtype=torch.float32, device=x.device)
+            src = [t.detach() if t.dtype == torch.float32 and t.is_contiguous() else t.detach().float().contiguous()
+                   for t in (wq, wk, wv, bq, bk, bv)]
+            call("mu_prep_qkv", *[ptr(t) for t in src], ptr(wbuf), ptr(bqkv_), dt(x), C, stream())
+            return bqkv_, (wbuf[:3 * C * C].view(1, 3 * C, C), wbuf[3 * C * C:].view(1, C, 3 * C))
+
+        if cache_ok and isinstance(wq, torch.nn.Parameter):
+            # cached on the query weight under ONE key per dtype; the tag carries all six parameters' versions, so a stale entry is
+            # overwritten in place (ADVICE r2: keying on the versions grew the dict by one entry per train/validate cycle)
             vers = tuple((t._version, t.data_ptr()) for t in (wk, wv, bq, bk, bv))
-            wqkv, bqkv, (wprep, wd_) = _prep_cached(wq, ("qkv", x.dtype, vers), make_qkv, True)
+            bqkv, (wprep, wd_) = _prep_cached(wq, ("qkv", x.dtype), make_qkv, True, extra_tag=vers)
         else:
-            wqkv, bqkv, (wprep, wd_) = make_qkv()
+            bqkv, (wprep, wd_) = make_qkv()
         ctx.wd = wd_ if ctx.needs_input_grad[0] else None
         qkv = _conv_raw(x, wprep, bqkv, 3 * C, 1)                      # [B,H,W,3C] == [B,N,3C]
         out = torch.empty((B, N, C), dtype=x.dtype, device=x.device)
@@ -667,8 +736,8 @@ class _MaskAttention(torch.autograd.Function):
         g, b_ = lnw.detach().float().contiguous(), lnb.detach().float().contiguous()
         call("mu_attn_fwd", ptr(qkv), ptr(x), ptr(kidx), ptr(kcnt), ptr(g), ptr(b_), ptr(out), ptr(oattn), ptr(lse2), ptr(mean),
              ptr(rstd), B, N, C, kidx.shape[1], float(eps), dt(x), stream())
-        ctx.save_for_backward(x, qkv, oattn, lse2, mean, rstd, g, wqkv, kidx, kcnt)
-        ctx.scramble, ctx.dims = scramble, (B, H, W, C)
+        ctx.save_for_backward(x, qkv, oattn, lse2, mean, rstd, g, kidx, kcnt)
+        ctx.scramble, ctx.dims, ctx.kidx_perm = scramble, (B, H, W, C), bool(kidx_perm) and kidx.shape[1] == N
         if scramble:
             return _transpose_tokens(out.view(B, C, N), C, N).view(B, H, W, C)
         return out
@@ -676,7 +745,7 @@ class _MaskAttention(torch.autograd.Function):
     @staticmethod
     @once_differentiable
     def backward(ctx, gout):
-        x, qkv, oattn, lse2, mean, rstd, g, wqkv, kidx, kcnt = ctx.saved_tensors
+        x, qkv, oattn, lse2, mean, rstd, g, kidx, kcnt = ctx.saved_tensors
         B, H, W, C = ctx.dims
         N = H * W
         gout = gout.contiguous()
@@ -688,9 +757,10 @@ class _MaskAttention(torch.autograd.Function):
         dg = torch.empty(C, dtype=torch.float32, device=x.device)
         db = torch.empty_like(dg)
         ws = workspace(_lib.load().mu_attn_bwd_workspace_bytes(B, N, C), x.device)
-        # kidx rows are stable descending argsorts of the keep masks (modules.Mask2FormerAttention._compact): whole permutations,
-        # masked keys last -> MU_ATTN_KIDX_PERMUTATION (8): the dK/dV sweep zeroes the masked rows, no memset of dqkv
-        perm = 8 if kidx.shape[1] == N else 0
+        # MU_ATTN_KIDX_PERMUTATION (8) is a promise the CALLER of mask_attention makes (kidx_perm=True: every kidx row is a whole
+        # permutation with the masked keys last, as mu_compact_keys / a stable descending argsort give): the dK/dV sweep then zeroes
+        # the masked rows itself.  Without the promise phase 1 memsets dqkv (kidx from outside may be padded behind kcnt).
+        perm = 8 if ctx.kidx_perm else 0
         for phase in (1, 2, 4):      # LayerNorm-backward prepass, dQ sweep, dK/dV sweep (separate calls: each can be timed)
             call("mu_attn_bwd_phases", ptr(qkv), ptr(x), ptr(oattn), ptr(gout), ptr(kidx), ptr(kcnt), ptr(lse2), ptr(mean), ptr(rstd),
                  ptr(g), ptr(dY), ptr(delta), ptr(dqkv), ptr(dg), ptr(db), B, N, C, kidx.shape[1], ptr(ws), ws.numel(), dt(x),
@@ -698,20 +768,47 @@ class _MaskAttention(torch.autograd.Function):
         dqkv4 = dqkv.view(B, H, W, 3 * C)
         gx = None
         if ctx.needs_input_grad[0]:
-            wd = ctx.wd if ctx.wd is not None else _prep_weight(wqkv, x.dtype, C, 3 * C, 1)
+            wd = ctx.wd
             ctx.wd = None
-            gx = _conv_raw(dqkv4, wd, None, C, 1)
-            call("mu_add", ptr(gx), ptr(dY), ptr(gx), gx.numel(), dt(gx), stream())
+            if ATTN_FUSED_ADD and _lib.load().mu_conv1x1_add_supported(3 * C, C, dt(x)):
+                # gx = dqkv @ Wqkv + dY: the residual branch (:187) joins the projection's data-gradient in its epilogue
+                gx = torch.empty((B, H, W, C), dtype=x.dtype, device=x.device)
+                call("mu_conv1x1_fwd_add", ptr(dqkv), ptr(wd), ptr(dY), ptr(gx), B * N, 3 * C, C, 3 * C, C, dt(x), stream())
+            else:
+                gx = _conv_raw(dqkv4, wd, None, C, 1)
+                call("mu_add", ptr(gx), ptr(dY), ptr(gx), gx.numel(), dt(gx), stream())
         both = _wgrad_bias_raw(x, dqkv4, (3 * C, C, 1, 1), 1)       # projection weight and bias gradients from one sweep over dqkv
         if both is not None:
             gw, gb = both[0].view(3 * C, C), both[1]
         else:
             gw = _wgrad_raw(x, dqkv4, (3 * C, C, 1, 1), 1).view(3 * C, C)
             gb = _colsum(dqkv4, 3 * C)
-        return (gx, gw[:C], gb[:C], gw[C:2 * C], gb[C:2 * C], gw[2 * C:], gb[2 * C:], dg, db, None, None, None, None, None)
+        return (gx, gw[:C], gb[:C], gw[C:2 * C], gb[C:2 * C], gw[2 * C:], gb[2 * C:], dg, db, None, None, None, None, None, None)
 
 
-def mask_attention(x, q, k, v, norm, kidx, kcnt, scramble=True):
-    """q,k,v: nn.Linear containers; norm: nn.LayerNorm([C]) container."""
+ATTN_FUSED_ADD = os.environ.get("MU_ATTN_FUSED_ADD", "1") != "0"      # debug switch: 0 = projection data-gradient + mu_add
+
+
+def mask_attention(x, q, k, v, norm, kidx, kcnt, scramble=True, kidx_perm=False):
+    """q,k,v: nn.Linear containers; norm: nn.LayerNorm([C]) container.  kidx [B, nkmax] int32 lists the visible keys of image b in
+    kidx[b, :kcnt[b]].  kidx_perm=True promises that nkmax == N and every row is a whole permutation of 0..N-1 with the masked keys
+    behind the visible ones (compact_keys() output); leave it False for index lists from anywhere else."""
     return _MaskAttention.apply(x, q.weight, q.bias, k.weight, k.bias, v.weight, v.bias, norm.weight, norm.bias, kidx, kcnt,
-                                norm.eps, scramble, _cache_ok())
+                                norm.eps, scramble, _cache_ok(), kidx_perm)
+
+
+def compact_keys(keep):
+    """keep [B, N] uint8 or int64 (non-zero = key visible) -> (kidx int32 [B, N], kcnt int32 [B], keep8 uint8 [B, N]): the visible
+    keys of every image in ascending order followed by the masked ones (== torch.argsort(keep, 1, descending=True, stable=True)),
+    on the current stream, no host sync."""
+    if keep.dim() != 2 or keep.dtype not in (torch.uint8, torch.int64, torch.bool):
+        raise RuntimeError("compact_keys expects a [B, N] uint8 / bool / int64 tensor")
+    keep = keep.contiguous()
+    if keep.dtype == torch.bool:
+        keep = keep.view(torch.uint8)
+    B, N = keep.shape
+    kidx = torch.empty((B, N), dtype=torch.int32, device=keep.device)
+    kcnt = torch.empty((B,), dtype=torch.int32, device=keep.device)
+    keep8 = torch.empty((B, N), dtype=torch.uint8, device=keep.device)
+    call("mu_compact_keys", ptr(keep), keep.element_size(), B, N, ptr(kidx), ptr(kcnt), ptr(keep8), stream())
+    return kidx, kcnt, keep8

@@ -733,3 +733,140 @@ def check_attention_bwd_masked_rows(dtype):
         res.append((f"attn bwd C={C} flag 8 == memset path", 0.0 if torch.equal(outs[0], outs[1]) else 1.0, 0.0))
         res.append((f"attn bwd C={C} finite", 0.0 if torch.isfinite(outs[1].float()).all() else 1.0, 0.0))
     return res
+
+
+# ------------------------------------------------------------------------------------------------
+# round 3: gradient joins inside kernels, key compaction, q/k/v weight prep
+# ------------------------------------------------------------------------------------------------
+def check_compact_keys():
+    """mu_compact_keys against torch.argsort(keep, descending=True, stable=True) (what the modules used before round 3): bit-exact
+    index lists for uint8 and int64 masks, ragged N, all keys kept / all masked / a single key."""
+    from maskunet_amd import ops
+    gen = torch.Generator().manual_seed(11)
+    out = []
+    for (B, N) in [(3, 256), (2, 1000), (64, 16384), (2, 65536), (5, 1), (4, 1025), (2, 3)]:
+        for kdt in (torch.uint8, torch.int64):
+            keep = torch.randint(0, 2, (B, N), generator=gen).to(kdt)
+            if B >= 3:
+                keep[0] = 1                       # every key visible
+                keep[1] = 0                       # no key visible (kcnt = 0: the index list is still the identity permutation)
+                keep[2] = 0
+                keep[2, N // 2] = 1
+            kd = keep.to(DEV)
+            kidx, kcnt, keep8 = ops.compact_keys(kd)
+            ref_idx = torch.argsort(keep.to(torch.uint8), dim=1, descending=True, stable=True).to(torch.int32)
+            ref_cnt = (keep != 0).sum(1).to(torch.int32)
+            ok = bool((kidx.cpu() == ref_idx).all()) and bool((kcnt.cpu() == ref_cnt).all()) and bool((keep8.cpu() == (keep != 0).to(torch.uint8)).all())
+            out.append((f"compact_keys{(B, N)} {str(kdt)[6:]}", 0.0 if ok else 1.0, 0.0))
+    return out
+
+
+def check_grad_joins(dtype):
+    """mu_maxpool2_bwd_acc / mu_upcat_bwd_acc / mu_conv1x1_fwd_add against the separate torch ops they replace."""
+    from maskunet_amd import _lib
+    gen = np.random.default_rng(21)
+    out = []
+    tol = TOL[dtype]
+    call, ptr, dt, st = _lib.call, _lib.ptr, _lib.dt, _lib.stream
+    for (B, H, W, C) in [(2, 12, 8, 64), (1, 32, 32, 128)]:
+        x = _rnd(gen, B, H, W, C).to(DEV, dtype)
+        g1, g2 = _rnd(gen, B, H // 2, W // 2, C).to(DEV, dtype), _rnd(gen, B, H // 2, W // 2, C).to(DEV, dtype)
+        ga = _rnd(gen, B, H, W, C).to(DEV, dtype)
+        xr = x.float().permute(0, 3, 1, 2).clone().requires_grad_(True)
+        F.max_pool2d(xr, 2).backward((g1.float() + g2.float()).permute(0, 3, 1, 2))
+        ref = xr.grad.permute(0, 2, 3, 1) + ga.float()
+        for (a2, aa, tag) in [(g2, ga, "dy2+dx_add"), (g2, None, "dy2"), (None, ga, "dx_add")]:
+            dx = torch.empty_like(x)
+            call("mu_maxpool2_bwd_acc", ptr(x), ptr(g1), ptr(a2), ptr(aa), ptr(dx), B, H, W, C, dt(x), st())
+            xr2 = x.float().permute(0, 3, 1, 2).clone().requires_grad_(True)
+            F.max_pool2d(xr2, 2).backward((g1.float() + (a2.float() if a2 is not None else 0)).permute(0, 3, 1, 2))
+            r = xr2.grad.permute(0, 2, 3, 1) + (aa.float() if aa is not None else 0)
+            out.append((f"maxpool_bwd_acc{(B, H, W, C)} {tag}", _rel_err(dx, r), tol))
+    for (B, Cx, Cs, h, w) in [(2, 32, 64, 5, 7), (1, 128, 128, 16, 16)]:
+        g1, g2 = _rnd(gen, B, 2 * h, 2 * w, Cs + Cx).to(DEV, dtype), _rnd(gen, B, 2 * h, 2 * w, Cs + Cx).to(DEV, dtype)
+        xr = torch.zeros(B, Cx, h, w, requires_grad=True)
+        sr = torch.zeros(B, Cs, 2 * h, 2 * w, requires_grad=True)
+        yr = torch.cat([sr, F.interpolate(xr, scale_factor=2, mode="bilinear", align_corners=True)], 1)
+        yr.backward((g1.float() + g2.float()).cpu().permute(0, 3, 1, 2))
+        dx = torch.empty(B, h, w, Cx, dtype=dtype, device=DEV)
+        ds = torch.empty(B, 2 * h, 2 * w, Cs, dtype=dtype, device=DEV)
+        call("mu_upcat_bwd_acc", ptr(g1), ptr(g2), ptr(dx), ptr(ds), B, h, w, Cx, Cs, dt(g1), st())
+        out += [(f"upcat_bwd_acc{(B, Cx, Cs, h, w)} dx", _rel_err(dx, xr.grad.permute(0, 2, 3, 1)), tol),
+                (f"upcat_bwd_acc{(B, Cx, Cs, h, w)} dskip", _rel_err(ds, sr.grad.permute(0, 2, 3, 1)), tol)]
+    lib = _lib.load()
+    for (M, Cin, Cout) in [(2 * 16 * 16, 192, 64), (1000, 384, 128), (300, 768, 256), (77, 64, 64)]:
+        if not lib.mu_conv1x1_add_supported(Cin, Cout, dt(dtype)):
+            out.append((f"conv1x1_add{(M, Cin, Cout)} supported", 1.0, 0.0))
+            continue
+        x = (_rnd(gen, M, Cin) * 0.5).to(DEV, dtype)
+        w = (_rnd(gen, Cout, Cin) / math.sqrt(Cin)).to(DEV, dtype)
+        a = _rnd(gen, M, Cout).to(DEV, dtype)
+        y = torch.full((M, Cout), 7.0, dtype=dtype, device=DEV)
+        call("mu_conv1x1_fwd_add", ptr(x), ptr(w), ptr(a), ptr(y), M, Cin, Cout, Cin, Cout, dt(x), st())
+        ref = x.double() @ w.double().t() + a.double()
+        out.append((f"conv1x1_add{(M, Cin, Cout)}", _err(y, ref.float()), tol))
+    out.append(("conv1x1_add unsupported shape -> MU_ERR_SHAPE", 0.0 if lib.mu_conv1x1_fwd_add(1, 1, 1, 1, 8, 32, 32, 32, 32, dt(dtype), None) == -2 else 1.0, 0.0))
+    return out
+
+
+def check_prep_qkv(dtype):
+    """mu_prep_qkv == mu_prep_weight(mode 2) of the concatenated [3C, C] weight + the concatenated bias, bit for bit."""
+    from maskunet_amd import _lib, ops
+    gen = np.random.default_rng(23)
+    out = []
+    for C in (32, 64, 256):
+        ws = [_rnd(gen, C, C).to(DEV) for _ in range(3)]
+        bs = [_rnd(gen, C).to(DEV) for _ in range(3)]
+        wbuf = torch.empty(6 * C * C, dtype=dtype, device=DEV)
+        bias = torch.empty(3 * C, dtype=torch.float32, device=DEV)
+        _lib.call("mu_prep_qkv", *[_lib.ptr(t) for t in ws + bs], _lib.ptr(wbuf), _lib.ptr(bias), _lib.dt(dtype), C, _lib.stream())
+        f, d = ops._prep_weight_raw(torch.cat(ws, 0).view(3 * C, C, 1, 1), dtype, 3 * C, C, 2)
+        same = bool((wbuf[:3 * C * C].view(3 * C, C) == f.view(3 * C, C)).all()) and bool((wbuf[3 * C * C:].view(C, 3 * C) == d.view(C, 3 * C)).all()) \
+            and bool((bias == torch.cat(bs)).all())
+        out.append((f"prep_qkv C={C}", 0.0 if same else 1.0, 0.0))
+    return out
+
+
+def check_grad_links_model(dtype, B=2):
+    """Whole UNet, training mode: parameter and input gradients with the in-kernel gradient joins (ops.GradLink: residual branches into
+    the pool / concat backward, skip connections into the pool backward, dY into the projection data-gradient) against the same model
+    with every join left to autograd (MU_GRAD_LINKS=0 semantics).  Same kernels otherwise, so fp32 agrees to rounding."""
+    import maskunet_amd
+    from maskunet_amd import ops
+    torch.manual_seed(7)
+    model = maskunet_amd.UNet(3, 19).to(DEV)
+    model.set_compute_dtype(dtype).train()
+    model.dropout.p = 0.0
+    gen = np.random.default_rng(31)
+    x = torch.from_numpy(gen.random((B, 3, 128, 128), dtype=np.float32)).to(DEV)
+    keeps = [torch.from_numpy(gen.integers(0, 2, (B, n)).astype(np.uint8)).to(DEV) for n in (4096, 1024, 256, 1024, 4096, 16384)]
+    labels = torch.from_numpy(gen.integers(0, 19, (B, 128, 128))).to(DEV)
+    scale = FP16_LOSS_SCALE if dtype == torch.float16 else 1.0
+    grads = []
+    saved = (ops.GRAD_LINKS, ops.ATTN_FUSED_ADD)
+    try:
+        for on in (True, False):
+            ops.GRAD_LINKS = ops.ATTN_FUSED_ADD = on
+            model.set_keep_masks(keeps)
+            for bn in [m for m in model.modules() if isinstance(m, torch.nn.BatchNorm2d)]:
+                bn.reset_running_stats()
+            xin = x.clone().requires_grad_(True)
+            out = model(xin)
+            (F.cross_entropy(out, labels) * scale).backward()
+            grads.append({"input": xin.grad.clone(), **{n: p.grad.clone() for n, p in model.named_parameters() if p.grad is not None}})
+            model.zero_grad(set_to_none=True)
+    finally:
+        ops.GRAD_LINKS, ops.ATTN_FUSED_ADD = saved
+    tol = 2e-5 if dtype == torch.float32 else 2e-2
+    # per-tensor max error relative to that tensor's own max, floored at 1e-3 of the largest gradient (the key biases' gradients are
+    # identically zero in exact arithmetic -- softmax does not see a per-query constant -- so what they hold is rounding noise)
+    gmax = max(float(v.abs().max()) for v in grads[1].values())
+
+    def rel(k):
+        a, b = grads[0][k].float(), grads[1][k].float()
+        if not torch.isfinite(a).all():
+            return float("inf")
+        return float((a - b).abs().max()) / max(float(b.abs().max()), 1e-3 * gmax)
+    worst = max(((rel(k), k) for k in grads[1]), key=lambda t: t[0])
+    return [(f"grad joins vs autograd sums: worst relative gradient difference ({worst[1]})", worst[0], tol),
+            ("grad joins: same set of gradients", 0.0 if set(grads[0]) == set(grads[1]) else 1.0, 0.0)]

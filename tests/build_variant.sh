@@ -9,7 +9,8 @@ SRC=${MU_SRC:-$ROOT/maskunet_amd/csrc}      # MU_SRC=<dir> builds another checko
 OUT=$ROOT/gpurun_variants
 mkdir -p $OUT/obj_$NAME
 for f in elementwise norm conv attn loss version; do
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -fPIC -std=c++17 -Wno-unused-value -Wno-pass-failed $EXTRA -c $SRC/$f.hip -o $OUT/obj_$NAME/$f.o &
+  FL=""; [ $f = attn ] && FL="-fno-slp-vectorize"      # as the Makefile builds attn.hip (FLAGS_attn)
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -fPIC -std=c++17 -Wno-unused-value -Wno-pass-failed $FL $EXTRA -c $SRC/$f.hip -o $OUT/obj_$NAME/$f.o &
 done
 wait
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC $OUT/obj_$NAME/*.o -o $OUT/libmu_$NAME.so

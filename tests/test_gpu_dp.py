@@ -256,6 +256,8 @@ def test_bench_starts_under_torchrun_world2_gloo():
     assert len(lines) == 1, r.stdout
     rec = json.loads(lines[0])
     assert rec["n_gpus"] == 2 and rec["config"]["global_batch"] == 4 and rec["value"] > 0
+    # N > 1 times the reference's multi-GPU semantics: nn.DataParallel discards its replicas, so every step draws fresh key masks
+    assert rec["config"]["mask_mode"] == "resample"
 
 
 @pytest.mark.parametrize("graph", [False, True])
@@ -274,6 +276,7 @@ def test_bench_multi_rank_path_over_rccl_one_rank(graph):
     assert len(lines) == 1, r.stdout
     rec = json.loads(lines[0])
     assert rec["n_gpus"] == 1 and rec["value"] > 0 and rec["roofline"]["frac"] > 0
+    assert rec["config"]["mask_mode"] == ("fixed" if graph else "resample")      # a captured step replays its masks
 
 
 def test_bench_refuses_gpus_without_launcher():

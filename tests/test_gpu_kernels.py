@@ -80,6 +80,23 @@ def test_attention_mask_semantics():
     _assert_all(G.check_attention_mask_semantics())
 
 
+def test_compact_keys_matches_stable_argsort():
+    from tests import _gpu_checks as G
+    _assert_all(G.check_compact_keys())
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_gradient_joins_and_qkv_prep(dtype):
+    from tests import _gpu_checks as G
+    _assert_all(G.check_grad_joins(dtype) + G.check_prep_qkv(dtype))
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_grad_links_whole_model(dtype):
+    from tests import _gpu_checks as G
+    _assert_all(G.check_grad_links_model(dtype))
+
+
 def test_error_codes_not_exceptions():
     """Bad arguments come back as negative status codes and surface as RuntimeError on the Python side."""
     from maskunet_amd import _lib

@@ -55,8 +55,9 @@ def test_mask_attribute_semantics_on_host():
     a.mask = add                                                     # the reference's own form (:180-181)
     assert tuple(a.mask.shape) == (2, 4, 4) and torch.equal(a.mask, add)
     assert a.mask.stride(1) == 0                                     # expand view: key-only mask
-    kidx, kcnt = a._compact(torch.device("cpu"))
-    assert kcnt.tolist() == [3, 1] and kidx[0, :3].tolist() == [0, 2, 3] and kidx[1, 0].item() == 2
+    assert a._keep.tolist() == keep.tolist() and a._kidx is None     # the index list is built lazily, on the device ...
+    with pytest.raises(RuntimeError, match="GPU"):
+        a._compact(torch.device("cpu"))                              # ... by mu_compact_keys: there is no host fallback (GPU test: check_compact_keys)
     a.mask = None
     assert a.mask is None and a._kidx is None
 
