@@ -250,6 +250,16 @@ int mu_inst_triplet_bwd(const float* feat, int B, int C, int H, int W, const voi
  * index) with chunks of mu_adamw_chunk() elements.  grad_scale_inv un-scales loss-scaled gradients. */
 /* f4: uint8 HWC image bytes [npix, C] -> [0,1] floats in the NHWC compute layout [npix, Cp] (ToTensor, ade_semantic.py:85) */
 int mu_u8_to_nhwc(const unsigned char* src, void* dst, long npix, int C, int Cp, int dtype, void* stream);
+/* f4, resize half: the sample preparation of the reference datasets on the device.  src: decoded image bytes [B][Hs][Ws][C] (C <= 4, as
+ * cv2.imread leaves them) of any size -> cv2.resize(.., (Wd, Hd), interpolation=cv2.INTER_LINEAR) (ade_semantic.py:72; OpenCV 4.10's
+ * 8-bit fixed-point algorithm incl. its 2x2 INTER_AREA shortcut, restated: cv2 is not vendored by the reference), channels 0 and 2
+ * swapped when swap_rb != 0 (cv2.COLOR_BGR2RGB, :65), then ToTensor (:85): dst [B][Hd][Wd][Cp] = byte / 255 in the NHWC compute layout,
+ * zero channel padding.  u8_out (may be NULL) receives the resized bytes [B][Hd][Wd][C] themselves. */
+int mu_resize_u8_nhwc(const unsigned char* src, int B, int Hs, int Ws, int C, int swap_rb, void* dst, unsigned char* u8_out, int Hd, int Wd,
+                      int Cp, int dtype, void* stream);
+/* the label map: uint8 [B][Hs][Ws] -> int64 [B][Hd][Wd] = torch.from_numpy(cv2.resize(mask, (Wd, Hd), interpolation=cv2.INTER_NEAREST)).long()
+ * (:73,78): source index min(floor(d * scale), n - 1) */
+int mu_resize_nearest_u8(const unsigned char* src, int B, int Hs, int Ws, long* dst, int Hd, int Wd, void* stream);
 int mu_adamw_chunk(void);
 int mu_adamw_multi(const void* table, const int* block_tensor, const int* block_chunk, int nblocks, float lr, float beta1, float beta2,
                    float eps, float weight_decay, float grad_scale_inv, void* stream);

@@ -8,10 +8,12 @@ from .modules import (ConvBlock, DoubleConv, Down, DownSample, InstanceUNet, Mas
                       UNet, Up, UpSample, set_default_compute_dtype)
 from .dp import DataParallel, shard_batch
 from .losses import CrossEntropyLoss, InstanceContrastiveLoss, cross_entropy, mean_iou, pixel_cross_entropy_nhwc
+from .ops import resize_labels_u8, resize_u8_to_nhwc
 from .optim import FusedAdamW
 from .graph import GraphedStep
 
 __all__ = ["ConvBlock", "DownSample", "UpSample", "Mask2FormerAttention", "UNet", "InstanceUNet", "DoubleConv", "Down", "Up",
            "MaskAttention", "OutConv", "set_default_compute_dtype", "DataParallel", "shard_batch", "pixel_cross_entropy_nhwc",
-           "mean_iou", "InstanceContrastiveLoss", "FusedAdamW", "CrossEntropyLoss", "cross_entropy", "GraphedStep"]
+           "mean_iou", "InstanceContrastiveLoss", "FusedAdamW", "CrossEntropyLoss", "cross_entropy", "GraphedStep",
+           "resize_u8_to_nhwc", "resize_labels_u8"]
 __version__ = "0.1.0"

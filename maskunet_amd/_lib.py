@@ -77,6 +77,8 @@ SIGNATURES = {
     "mu_maxpool2_bwd_acc": (I, [P, P, P, P, P, I, I, I, I, I, P]),
     "mu_upcat_bwd_acc": (I, [P, P, P, P, I, I, I, I, I, I, P]),
     "mu_compact_keys": (I, [P, I, I, I, P, P, P, P]),
+    "mu_resize_u8_nhwc": (I, [P, I, I, I, I, I, P, P, I, I, I, I, P]),
+    "mu_resize_nearest_u8": (I, [P, I, I, I, P, I, I, P]),
     "mu_attn_bwd_phases": (I, [P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, I, I, I, I, P, L, I, I, P]),
 }
 

@@ -749,3 +749,106 @@ extern "C" int mu_prep_qkv(const float* wq, const float* wk, const float* wv, co
     MU_CHECK_LAUNCH();
     return MU_OK;
 }
+
+// ------------------------------------------------------------------------------------------
+// SURVEY 8-f4, resize half: decoded image bytes of ANY size -> the network input, and the label map.
+// The reference datasets run cv2.resize(image, (128,128), INTER_LINEAR) / cv2.resize(mask, (128,128), INTER_NEAREST) on the host
+// (ade_semantic.py:72-73; opencv-python-headless 4.10, requirement.txt:168) after cv2.COLOR_BGR2RGB (:65), then ToTensor (:85).
+// These kernels restate OpenCV's 8-bit algorithms (modules/imgproc/src/resize.cpp; cv2 itself is not vendored by the reference):
+//   INTER_LINEAR, CV_8U: 11-bit fixed-point coefficients, horizontal pass in int, vertical pass
+//       uchar((((b0 * (D0 >> 4)) >> 16) + ((b1 * (D1 >> 4)) >> 16) + 2) >> 2);
+//       columns whose taps leave the image collapse to the edge pixel with weight 2048, rows are clamped with their weights kept;
+//       exactly-2x downscale in both directions takes cv::resize's INTER_AREA shortcut (a + b + c + d + 2) >> 2;
+//   INTER_NEAREST: source index = min(floor(d * scale), n - 1), no half-pixel offset.
+// The resized bytes are produced bit-exactly (u8_out, optional) and leave as [0,1] activations in the NHWC compute layout
+// (x / 255, channel-padded with zeros), optionally with channels 0 and 2 swapped (BGR -> RGB).
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ void cv_lin_coef(int d, double scale, int sn, bool clamp_taps, int& s, int& c0, int& c1) {
+    // two separately rounded double operations, as the host code this restates runs them (no fused multiply-add contraction)
+    float f = (float)__dadd_rn(__dmul_rn((double)d + 0.5, scale), -0.5);
+    int si = (int)floorf(f);
+    f -= (float)si;
+    if (clamp_taps) {
+        if (si < 0) { f = 0.f; si = 0; }
+        if (si + 1 >= sn) { f = 0.f; si = sn - 1; }
+    }
+    s = si;
+    c0 = __float2int_rn((1.0f - f) * 2048.0f);               // cvRound: round half to even
+    c1 = __float2int_rn(f * 2048.0f);
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void resize_linear_u8_kernel(const uint8_t* __restrict__ src, int B, int Hs, int Ws, int C, int swap_rb,
+                                                               double scale_x, double scale_y, T* __restrict__ dst, uint8_t* __restrict__ u8_out,
+                                                               int Hd, int Wd, int Cp) {
+    constexpr int N = Vec16<T>::N;
+    const long total = (long)B * Hd * Wd;
+    const bool area2 = Ws == 2 * Wd && Hs == 2 * Hd;
+    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+        const int dx = (int)(idx % Wd), dy = (int)((idx / Wd) % Hd), b = (int)(idx / ((long)Wd * Hd));
+        const uint8_t* img = src + (long)b * Hs * Ws * C;
+        int v[4] = {0, 0, 0, 0};
+        if (area2) {
+            const uint8_t* p0 = img + ((long)(2 * dy) * Ws + 2 * dx) * C;
+            const uint8_t* p1 = p0 + (long)Ws * C;
+            for (int c = 0; c < C && c < 4; ++c) v[c] = ((int)p0[c] + (int)p0[C + c] + (int)p1[c] + (int)p1[C + c] + 2) >> 2;
+        } else {
+            int sx, a0, a1, sy, b0, b1;
+            cv_lin_coef(dx, scale_x, Ws, true, sx, a0, a1);
+            cv_lin_coef(dy, scale_y, Hs, false, sy, b0, b1);
+            const int sx1 = sx + 1 < Ws ? sx + 1 : Ws - 1;       // weight 0 there at the right edge
+            const int r0 = sy < 0 ? 0 : (sy < Hs ? sy : Hs - 1), r1 = sy + 1 < 0 ? 0 : (sy + 1 < Hs ? sy + 1 : Hs - 1);
+            const uint8_t *q00 = img + ((long)r0 * Ws + sx) * C, *q01 = img + ((long)r0 * Ws + sx1) * C;
+            const uint8_t *q10 = img + ((long)r1 * Ws + sx) * C, *q11 = img + ((long)r1 * Ws + sx1) * C;
+            for (int c = 0; c < C && c < 4; ++c) {
+                const int d0 = (int)q00[c] * a0 + (int)q01[c] * a1, d1 = (int)q10[c] * a0 + (int)q11[c] * a1;
+                v[c] = ((((b0 * (d0 >> 4)) >> 16) + ((b1 * (d1 >> 4)) >> 16) + 2) >> 2) & 0xFF;
+            }
+        }
+        if (swap_rb && C >= 3) { const int t = v[0]; v[0] = v[2]; v[2] = t; }
+        if (u8_out)
+            for (int c = 0; c < C && c < 4; ++c) u8_out[idx * C + c] = (uint8_t)v[c];
+        for (int c0 = 0; c0 < Cp; c0 += N) {
+            Vec16<T> o;
+#pragma unroll
+            for (int i = 0; i < N; ++i) o.set(i, (c0 + i < C && c0 + i < 4) ? (float)v[c0 + i] * (1.0f / 255.0f) : 0.f);
+            o.store(dst + idx * Cp + c0);
+        }
+    }
+}
+
+extern "C" int mu_resize_u8_nhwc(const unsigned char* src, int B, int Hs, int Ws, int C, int swap_rb, void* dst, unsigned char* u8_out, int Hd,
+                                 int Wd, int Cp, int dtype, void* stream) {
+    if (!src || !dst || B <= 0 || Hs <= 0 || Ws <= 0 || Hd <= 0 || Wd <= 0) return MU_ERR_ARG;
+    if (C <= 0 || C > 4 || Cp < C || Cp % 8) return MU_ERR_SHAPE;
+    // exactly what cv::resize derives from dsize: inv_scale = dsize / ssize, scale = 1 / inv_scale (doubles)
+    const double scale_x = 1.0 / ((double)Wd / (double)Ws), scale_y = 1.0 / ((double)Hd / (double)Hs);
+    hipStream_t st = (hipStream_t)stream;
+    const long total = (long)B * Hd * Wd;
+    if (dtype == MU_F32) resize_linear_u8_kernel<float><<<ew_grid(total), 256, 0, st>>>(src, B, Hs, Ws, C, swap_rb, scale_x, scale_y, (float*)dst, u8_out, Hd, Wd, Cp);
+    else if (dtype == MU_F16) resize_linear_u8_kernel<h16><<<ew_grid(total), 256, 0, st>>>(src, B, Hs, Ws, C, swap_rb, scale_x, scale_y, (h16*)dst, u8_out, Hd, Wd, Cp);
+    else return MU_ERR_ARG;
+    MU_CHECK_LAUNCH();
+    return MU_OK;
+}
+
+// label map: uint8 [B][Hs][Ws] -> int64 [B][Hd][Wd], cv2.INTER_NEAREST + torch.from_numpy(mask).long() (ade_semantic.py:73,78)
+__global__ __launch_bounds__(256) void resize_nearest_u8_kernel(const uint8_t* __restrict__ src, int B, int Hs, int Ws, double ifx, double ify,
+                                                                long* __restrict__ dst, int Hd, int Wd) {
+    const long total = (long)B * Hd * Wd;
+    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+        const int dx = (int)(idx % Wd), dy = (int)((idx / Wd) % Hd), b = (int)(idx / ((long)Wd * Hd));
+        int sx = (int)floor((double)dx * ifx), sy = (int)floor((double)dy * ify);
+        sx = sx < Ws - 1 ? sx : Ws - 1;
+        sy = sy < Hs - 1 ? sy : Hs - 1;
+        dst[idx] = (long)src[((long)b * Hs + sy) * Ws + sx];
+    }
+}
+
+extern "C" int mu_resize_nearest_u8(const unsigned char* src, int B, int Hs, int Ws, long* dst, int Hd, int Wd, void* stream) {
+    if (!src || !dst || B <= 0 || Hs <= 0 || Ws <= 0 || Hd <= 0 || Wd <= 0) return MU_ERR_ARG;
+    const double ifx = 1.0 / ((double)Wd / (double)Ws), ify = 1.0 / ((double)Hd / (double)Hs);
+    resize_nearest_u8_kernel<<<ew_grid((long)B * Hd * Wd), 256, 0, (hipStream_t)stream>>>(src, B, Hs, Ws, ifx, ify, dst, Hd, Wd);
+    MU_CHECK_LAUNCH();
+    return MU_OK;
+}

@@ -350,10 +350,18 @@ class UNet(_HipModule):
         self._check_device(x)
         return self.forward_nhwc(ops.to_nhwc(x, self.compute_dtype))[0]
 
-    def forward_u8(self, images_u8_hwc):
-        """Forward from decoded image bytes: uint8 [B,H,W,3] (HWC) -> same outputs as ``forward(ToTensor(images))``."""
+    def forward_u8(self, images_u8_hwc, bgr=False):
+        """Forward from decoded image bytes: uint8 [B,H,W,3] (HWC) of ANY size -> same outputs as the reference's pipeline
+        ``forward(ToTensor(cv2.resize(img, (hw, hw), interpolation=cv2.INTER_LINEAR)))`` (ade_semantic.py:72-76,85); ``bgr=True`` also
+        applies ``cv2.cvtColor(img, cv2.COLOR_BGR2RGB)`` (:65), i.e. takes what cv2.imread returns.  Images that already have the
+        network's size skip the resize (cv2.resize to the same size is the identity)."""
         self._check_device(images_u8_hwc)
-        return self._finish(self.forward_nhwc(ops.u8_hwc_to_nhwc(images_u8_hwc, self.compute_dtype)))
+        H, W = int(self.norm.normalized_shape[1]), int(self.norm.normalized_shape[2])
+        if tuple(images_u8_hwc.shape[1:3]) == (H, W) and not bgr:
+            x = ops.u8_hwc_to_nhwc(images_u8_hwc, self.compute_dtype)
+        else:
+            x = ops.resize_u8_to_nhwc(images_u8_hwc, (W, H), self.compute_dtype, bgr=bgr)
+        return self._finish(self.forward_nhwc(x))
 
     def forward(self, x):
         self._check_device(x)

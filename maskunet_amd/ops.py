@@ -128,6 +128,34 @@ def u8_hwc_to_nhwc(img_u8, dtype):
     return y
 
 
+def resize_u8_to_nhwc(img_u8, size, dtype, bgr=False, return_u8=False):
+    """Decoded image bytes uint8 [B,Hs,Ws,C] (HWC, any size) -> network input [B,Hd,Wd,pad32(C)] in the compute dtype: the dataset
+    pipeline of the reference on the device -- cv2.cvtColor(BGR2RGB) when bgr=True (ade_semantic.py:65), cv2.resize(.., size,
+    INTER_LINEAR) (:72, OpenCV's 8-bit fixed-point algorithm), ToTensor() (:85).  size = (width, height) like cv2.  No gradient."""
+    img_u8 = img_u8.contiguous()
+    if img_u8.dtype != torch.uint8 or img_u8.dim() != 4 or img_u8.shape[-1] > 4:
+        raise RuntimeError("resize_u8_to_nhwc expects a uint8 [B,H,W,C<=4] tensor")
+    B, Hs, Ws, C = img_u8.shape
+    Wd, Hd = int(size[0]), int(size[1])
+    y = torch.empty((B, Hd, Wd, pad32(C)), dtype=dtype, device=img_u8.device)
+    u8 = torch.empty((B, Hd, Wd, C), dtype=torch.uint8, device=img_u8.device) if return_u8 else None
+    call("mu_resize_u8_nhwc", ptr(img_u8), B, Hs, Ws, C, int(bool(bgr)), ptr(y), ptr(u8), Hd, Wd, pad32(C), dt(y), stream())
+    return (y, u8) if return_u8 else y
+
+
+def resize_labels_u8(mask_u8, size):
+    """Label map uint8 [B,Hs,Ws] -> int64 [B,Hd,Wd]: torch.from_numpy(cv2.resize(mask, size, interpolation=cv2.INTER_NEAREST)).long()
+    (ade_semantic.py:73,78) on the device; size = (width, height)."""
+    mask_u8 = mask_u8.contiguous()
+    if mask_u8.dtype != torch.uint8 or mask_u8.dim() != 3:
+        raise RuntimeError("resize_labels_u8 expects a uint8 [B,H,W] tensor")
+    B, Hs, Ws = mask_u8.shape
+    Wd, Hd = int(size[0]), int(size[1])
+    out = torch.empty((B, Hd, Wd), dtype=torch.int64, device=mask_u8.device)
+    call("mu_resize_nearest_u8", ptr(mask_u8), B, Hs, Ws, ptr(out), Hd, Wd, stream())
+    return out
+
+
 def to_nchw(x, C, out_dtype=torch.float32):
     """NHWC channel-padded -> NCHW [B,C,H,W] (the layout the reference's callers see).  The result remembers its NHWC source
     (`_mu_nhwc` = (source, C, version)): maskunet_amd.cross_entropy / mean_iou use the source when they are handed the untouched

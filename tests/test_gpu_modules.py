@@ -39,6 +39,35 @@ def test_unet_vs_oracle_with_dropout(dtype):
     _assert_all(G.check_unet_vs_oracle(dtype, B=2, c_out=150))
 
 
+def test_unet_fp32_gradients_within_3x_of_the_references_own_fp32_noise(capsys):
+    """fp32 HIP path vs the fp64 oracle, gated per parameter at 3x the fp32 oracle's own error against fp64 (VERDICT r2 #3): the
+    gate follows the measured noise floor of the reference arithmetic instead of a constant."""
+    from tests import _gpu_checks as G
+    res = G.check_unet_vs_oracle(torch.float32, B=2, c_out=150, with_dropout=False, seed=310, noise_floor=True)
+    with capsys.disabled():
+        for n, e, t in res:
+            print(f"  {n}: {e:.3e} (gate {t:.1e})")
+    _assert_all(res)
+
+
+def test_unet_b8_train_mode_vs_oracle():
+    """Training mode at B = 8 against the live CPU oracle (fp32): >= 8 images per XCD in the attention block order, the persistent
+    conv kernel, multi-round split-K plans -- the batch-dependent dispatch under a VALUE check, not a property (VERDICT r2 #3)."""
+    from tests import _gpu_checks as G
+    _assert_all(G.check_unet_vs_oracle(torch.float32, B=8, c_out=150, seed=320))
+
+
+def test_kernels_are_bitwise_deterministic_at_bench_shapes():
+    """tests/stress_determinism.py (race screen of the hand-placed vmcnt / barrier schedules) with 20 launches per kernel and shape;
+    profiles/ holds the log of a 300-launch run."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tests", "stress_determinism.py"), "20"], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and "all launches bit-identical" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
 def test_unet_3head_vs_oracle():
     from tests import _gpu_checks as G
     _assert_all(G.check_unet_vs_oracle(torch.float32, B=2, c_out=19, three_head=True, seed=400))

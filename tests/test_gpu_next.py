@@ -266,6 +266,14 @@ def test_u8_input_pipeline_matches_totensor():
     assert torch.allclose(a, b, atol=1e-5)
 
 
+def test_resize_pipeline_matches_cv2_restatement():
+    """8-f4, resize half: cv2.resize INTER_LINEAR (image, + BGR2RGB + ToTensor) and INTER_NEAREST (label map) on the device, bit for bit
+    against the numpy restatement of OpenCV 4.10's 8-bit algorithm and its committed fixture (ade_semantic.py:65,72-73,78,85)."""
+    from tests import _gpu_checks as G
+    bad = [(n, e, t) for n, e, t in G.check_resize_u8() if not (e <= t)]
+    assert not bad, bad
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("name", ["instloss_ade_small", "instloss_ade_sparse", "instloss_city_ignore", "instloss_none"])
 def test_instance_contrastive_loss_matches_reference_goldens(name):

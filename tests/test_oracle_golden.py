@@ -37,7 +37,7 @@ def _check(a, b, tol=TOL, what=""):
 
 
 MODULE_CASES = sorted(os.path.basename(p)[:-4] for p in glob.glob(
-    os.path.join(os.path.dirname(__file__), "golden", "*.npz")) if not os.path.basename(p).startswith(("unet", "instloss", "miou")))
+    os.path.join(os.path.dirname(__file__), "golden", "*.npz")) if not os.path.basename(p).startswith(("unet", "instloss", "miou", "resize")))
 
 
 def test_have_module_cases():
@@ -178,3 +178,56 @@ def test_oracle_instance_contrastive_loss(golden_dir, name):
     grad = feat.grad if feat.grad is not None else torch.zeros_like(feat)
     assert abs(float(loss) - float(g["loss"])) <= 1e-6
     assert float((grad - torch.from_numpy(g["dfeat"])).abs().max()) <= 1e-6
+
+
+# ------------------------------------------------------------------------------------------------
+# SURVEY 8-f4, resize half: oracle/cv2_resize_oracle.py restates OpenCV 4.10's 8-bit cv2.resize (cv2 is not installed here and not
+# vendored by the reference).  Pinned by values computed by hand from the published fixed-point formulas.
+# ------------------------------------------------------------------------------------------------
+def test_cv2_resize_linear_hand_computed():
+    from oracle import cv2_resize_oracle as R
+    src = np.array([[0, 100], [200, 255]], np.uint8)
+    # x: dx=0 -> sx=-1 -> (0, weight 2048); dx=1 -> fx=.25 -> (1536, 512); dx=2 -> fx=.75 -> (512, 1536); dx=3 -> right tap outside -> (1, 2048)
+    # y: dy=0 -> sy=-1, fy=.75 but both rows clamp to row 0; dy=1 -> (1536, 512); ...
+    # (1,1): D0 = 0*1536 + 100*512 = 51200, D1 = 200*1536 + 255*512 = 437760
+    #        ((1536*(51200>>4))>>16) + ((512*(437760>>4))>>16) + 2 >> 2 = (75 + 213 + 2) >> 2 = 72
+    # (1,2): D0 = 153600, D1 = 494080 -> (225 + 241 + 2) >> 2 = 117
+    want = np.array([[0, 25, 75, 100], [50, 72, 117, 139], [150, 167, 200, 216], [200, 214, 241, 255]], np.uint8)
+    assert np.array_equal(R.resize_linear_u8(src, (4, 4)), want)
+    # exact 2x downscale: cv::resize switches INTER_LINEAR to the INTER_AREA fast path, (a + b + c + d + 2) >> 2
+    a = (np.arange(16, dtype=np.uint8).reshape(4, 4) * 10)
+    assert np.array_equal(R.resize_linear_u8(a, (2, 2)), np.array([[25, 45], [105, 125]], np.uint8))
+    assert np.array_equal(R.resize_linear_u8(np.array([[1, 2], [2, 2]], np.uint8), (1, 1)), np.array([[2]], np.uint8))     # (7 + 2) >> 2
+    # same size: every fx = fy = 0 -> identity; channels are independent
+    rng = np.random.default_rng(3)
+    img = rng.integers(0, 256, (7, 5, 3), dtype=np.uint8)
+    assert np.array_equal(R.resize_linear_u8(img, (5, 7)), img)
+    assert np.array_equal(R.resize_linear_u8(img, (11, 13))[:, :, 1], R.resize_linear_u8(np.ascontiguousarray(img[:, :, 1]), (11, 13)))
+    # a constant image stays constant for every scale (a0 + a1 == 2048 wherever both taps are used ... up to the >>4 / >>16 floors:
+    # 255 -> D = 522240, (b0*(32640))>>16 + (b1*32640)>>16 + 2 >> 2 = 255 when b0 + b1 = 2048 and the two floors lose < 2 together)
+    assert int(R.resize_linear_u8(np.full((9, 14), 255, np.uint8), (31, 23)).min()) == 255
+
+
+def test_cv2_resize_nearest_hand_computed():
+    from oracle import cv2_resize_oracle as R
+    src = np.arange(12, dtype=np.uint8).reshape(3, 4)
+    # columns floor(dx * 4/6) = 0,0,1,2,2,3; rows floor(dy * 3/5) = 0,0,1,1,2
+    want = np.array([[0, 0, 1, 2, 2, 3], [0, 0, 1, 2, 2, 3], [4, 4, 5, 6, 6, 7], [4, 4, 5, 6, 6, 7], [8, 8, 9, 10, 10, 11]], np.uint8)
+    assert np.array_equal(R.resize_nearest(src, (6, 5)), want)
+    assert np.array_equal(R.resize_nearest(src, (2, 1)), np.array([[0, 2]], np.uint8))           # floor(dx * 2), row 0
+
+
+def test_cv2_resize_fixture_is_reproducible(golden_dir):
+    """tests/golden/resize_cases.npz is what tests/golden/make_golden_resize.py writes from the oracle (the GPU tests hold the HIP
+    kernels to it bit for bit)."""
+    from oracle import cv2_resize_oracle as R
+    z = np.load(os.path.join(golden_dir, "resize_cases.npz"))
+    n = len([k for k in z.files if k.endswith("_img")])
+    assert n >= 6
+    for i in range(n):
+        dw, dh = (int(v) for v in z[f"c{i}_dsize"])
+        assert np.array_equal(R.resize_linear_u8(z[f"c{i}_img"], (dw, dh)), z[f"c{i}_lin"])
+        assert np.array_equal(R.resize_nearest(z[f"c{i}_lab"], (dw, dh)), z[f"c{i}_near"])
+    img, lab = R.prepare_sample(z["c0_img"], z["c0_lab"], (128, 128))
+    assert img.shape == (3, 128, 128) and img.dtype == np.float32 and lab.dtype == np.int64 and float(img.max()) <= 1.0
+    assert np.array_equal((img * 255).round().astype(np.uint8).transpose(1, 2, 0), R.resize_linear_u8(np.ascontiguousarray(z["c0_img"][:, :, ::-1]), (128, 128)))
