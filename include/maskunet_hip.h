@@ -77,6 +77,12 @@ int mu_conv_fwd(const void* x, const void* w, const float* bias, void* y, int B,
 int mu_conv1x1_add_supported(int Cin, int Cout, int dtype);
 int mu_conv1x1_fwd_add(const void* x, const void* w, const void* addend, void* y, long M, int Cin, int Cout, long x_ld, long y_ld, int dtype,
                        void* stream);
+/* Inference epilogue: y = act(conv(x, w) * scale[co] + shift[co] + res) with per-channel fp32 scale / shift (either may be NULL = 1 / 0),
+ * res (may be NULL) a tensor with y's shape and row stride, act = MU_ACT_*.  One launch for Conv2d -> BatchNorm2d(eval) [-> BatchNorm2d(eval)]
+ * [-> + x] -> GELU / ReLU of ConvBlock and the heads (ade_semantic.py:199-208, 283-287; validation loop :443-471) with (scale, shift)
+ * from mu_bn_eval_fold; every shape mu_conv_fwd accepts. */
+int mu_conv_fwd_fused(const void* x, const void* w, const float* scale, const float* shift, const void* res, int act, void* y, int B, int H,
+                      int W, int Cin, int Cout, int taps, long x_ld, long y_ld, int dtype, void* stream);
 /* mu_conv_fwd that also leaves per-tile BatchNorm statistics of its (rounded) output: stat_part[rows][Cout][2] floats =
  * (sum, sum of squares) per output channel, rows = mu_conv_stats_rows(...) (0 = this shape has no statistics epilogue;
  * stat_part must then be NULL).  Feeds mu_bn_train_stats_rows and saves the separate statistics sweep of
@@ -114,6 +120,12 @@ int mu_bn_train_stats_rows(const float* stat_part, int rows, long M, int C, floa
 /* eval mode: mean/rstd from the running statistics */
 int mu_bn_eval_stats(const float* running_mean, const float* running_var, float eps, float* mean, float* rstd, int C, int c_valid,
                      void* stream);
+/* eval mode, folded: the affine map of one BatchNorm2d with running statistics, or of two applied back to back (DownSample / UpSample
+ * tails, :218-219, 239-240), behind a conv with optional bias: scale[c], shift[c] for mu_conv_fwd_fused; entries c >= c_valid are (0, 0).
+ * gamma / beta / conv_bias and the whole second layer may be NULL. */
+int mu_bn_eval_fold(const float* running_mean1, const float* running_var1, const float* gamma1, const float* beta1, float eps1,
+                    const float* running_mean2, const float* running_var2, const float* gamma2, const float* beta2, float eps2,
+                    const float* conv_bias, float* scale, float* shift, int C, int c_valid, void* stream);
 /* y = act( res + (x-mean)*rstd*gamma + beta ); res may be NULL.  ConvBlock's BN+GELU (:200-201), BN (+x, GELU)
  * (:204,208) and final_layer's BN+ReLU (:285-286). */
 int mu_bn_act_fwd(const void* x, const void* res, void* y, long M, int C, long ld, const float* mean, const float* rstd,

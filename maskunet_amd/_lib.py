@@ -79,6 +79,8 @@ SIGNATURES = {
     "mu_compact_keys": (I, [P, I, I, I, P, P, P, P]),
     "mu_resize_u8_nhwc": (I, [P, I, I, I, I, I, P, P, I, I, I, I, P]),
     "mu_resize_nearest_u8": (I, [P, I, I, I, P, I, I, P]),
+    "mu_conv_fwd_fused": (I, [P, P, P, P, P, I, P, I, I, I, I, I, I, L, L, I, P]),
+    "mu_bn_eval_fold": (I, [P, P, P, P, F, P, P, P, P, F, P, P, P, I, I, P]),
     "mu_attn_bwd_phases": (I, [P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, I, I, I, I, P, L, I, I, P]),
 }
 

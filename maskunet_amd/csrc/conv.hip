@@ -40,9 +40,17 @@ __device__ __forceinline__ int swz64(int row, int chunk) { return chunk ^ ((0x78
 // y[p][co] = bias[co] + sum_{tap,ci} x[p + shift(tap)][ci] * w[tap][co][ci]
 // block tile: (WR*TM*16) output channels x (WC*TN*16) pixels, 4 waves, D[co][pixel].
 // ------------------------------------------------------------------------------------------
-template <typename T, int TM, int TN, int WR, int TAPS>
+// FEPI (all forward kernels below): the inference epilogue y = act(conv * scale[co] + bias[co] + res) -- eval-mode BatchNorm folded
+// into per-channel (scale, shift), the residual add and GELU / ReLU of ConvBlock (ade_semantic.py:199-208, validation loop :443-471)
+// inside the conv epilogue instead of a separate read + write pass per BatchNorm.  Compile-time: the training instantiations
+// (FEPI = false) are unchanged.  res has y's row stride.
+template <typename T>
+__device__ __forceinline__ float epi_act(float v, int act) { return mu_act_t<sizeof(T) == 2>(v, act); }
+
+template <typename T, int TM, int TN, int WR, int TAPS, bool FEPI = false>
 __global__ __launch_bounds__(256) void conv_nt_kernel(const T* __restrict__ x, const T* __restrict__ w, const float* __restrict__ bias,
-                                                      T* __restrict__ y, int B, int H, int W, int Cin, int Cout, long x_ld, long y_ld) {
+                                                      T* __restrict__ y, int B, int H, int W, int Cin, int Cout, long x_ld, long y_ld,
+                                                      const float* __restrict__ scale = nullptr, const T* __restrict__ res = nullptr, int act = 0) {
     using M_ = Mma<T>;
     using Frag = typename M_::Frag;
     constexpr int VN = M_::VN, KC = 4 * VN;
@@ -162,7 +170,12 @@ __global__ __launch_bounds__(256) void conv_nt_kernel(const T* __restrict__ x, c
                 const int co = (wr * TM + i) * 16 + 4 * g;
                 float v[4];
 #pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] = acc[i][j][r] + (bias && co0 + co + r < Cout ? bias[co0 + co + r] : 0.f);
+                for (int r = 0; r < 4; ++r) {
+                    const bool in = co0 + co + r < Cout;
+                    v[r] = acc[i][j][r];
+                    if constexpr (FEPI) { if (scale && in) v[r] *= scale[co0 + co + r]; }
+                    v[r] += (bias && in ? bias[co0 + co + r] : 0.f);
+                }
                 h16x4 o = {(h16)v[0], (h16)v[1], (h16)v[2], (h16)v[3]};
                 *reinterpret_cast<h16x4*>(lds + px * OPITCH + co * 2) = o;
             }
@@ -172,8 +185,17 @@ __global__ __launch_bounds__(256) void conv_nt_kernel(const T* __restrict__ x, c
         for (int idx = tid; idx < BPX * CH; idx += 256) {
             const int px = idx / CH, ch8 = idx - px * CH;
             const long p = px0 + px;
-            if (p < Mtot && co0 + ch8 * 8 < Cout)
-                *reinterpret_cast<uint4*>(y + p * y_ld + co0 + ch8 * 8) = *reinterpret_cast<const uint4*>(lds + px * OPITCH + ch8 * 16);
+            if (p < Mtot && co0 + ch8 * 8 < Cout) {
+                uint4 o4 = *reinterpret_cast<const uint4*>(lds + px * OPITCH + ch8 * 16);
+                if constexpr (FEPI) {
+                    h16x8 ov = *reinterpret_cast<const h16x8*>(&o4), rv = (h16x8)(h16)0;
+                    if (res) rv = *reinterpret_cast<const h16x8*>(res + p * y_ld + co0 + ch8 * 8);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) ov[e] = (h16)epi_act<T>((float)ov[e] + (float)rv[e], act);
+                    o4 = *reinterpret_cast<const uint4*>(&ov);
+                }
+                *reinterpret_cast<uint4*>(y + p * y_ld + co0 + ch8 * 8) = o4;
+            }
         }
         return;
     }
@@ -188,7 +210,19 @@ __global__ __launch_bounds__(256) void conv_nt_kernel(const T* __restrict__ x, c
             if (co >= Cout) continue;
             float v[4];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) v[r] = acc[i][j][r] + (bias ? bias[co + r] : 0.f);
+            for (int r = 0; r < 4; ++r) v[r] = acc[i][j][r];
+            if constexpr (FEPI) {
+                if (scale) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] *= scale[co + r];
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] += (bias ? bias[co + r] : 0.f);
+            if constexpr (FEPI) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = epi_act<T>(v[r] + (res ? (float)res[p * y_ld + co + r] : 0.f), act);
+            }
             if constexpr (sizeof(T) == 2) {
                 h16x4 o = {(h16)v[0], (h16)v[1], (h16)v[2], (h16)v[3]};
                 *reinterpret_cast<h16x4*>(y + p * y_ld + co) = o;
@@ -242,10 +276,12 @@ __device__ __forceinline__ void glds16a(const void* gsrc, void* lds_wave_base) {
 #ifndef MU_NT2_SB
 #define MU_NT2_SB 1
 #endif
-template <typename T, int TM, int TN, int WR, int TAPS, bool SB = false>
+template <typename T, int TM, int TN, int WR, int TAPS, bool SB = false, bool FEPI = false>
 __global__ __launch_bounds__(256, SB ? MU_NT2_SB_OCC : MU_NT2_OCC) void conv_nt2_kernel(const T* __restrict__ x, const T* __restrict__ w, const float* __restrict__ bias,
                                                        T* __restrict__ y, int B, int H, int W, int Cin, int Cout, long x_ld, long y_ld,
-                                                       const T* __restrict__ addend = nullptr) {
+                                                       const T* __restrict__ addend = nullptr, const float* __restrict__ scale = nullptr,
+                                                       int act = 0) {
+    // FEPI: y = act(conv * scale[co] + bias[co] + addend); the training instantiations (FEPI = false) ignore the three arguments
     using M_ = Mma<T>;
     using Frag = typename M_::Frag;
     constexpr int VN = M_::VN, KC = 8 * VN;                 // elements per 128-byte stage row
@@ -355,7 +391,12 @@ __global__ __launch_bounds__(256, SB ? MU_NT2_SB_OCC : MU_NT2_OCC) void conv_nt2
                 const int co = (wr * TM + i) * 16 + 4 * g;
                 float v[4];
 #pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] = acc[i][j][r] + (bias && co0 + co + r < Cout ? bias[co0 + co + r] : 0.f);
+                for (int r = 0; r < 4; ++r) {
+                    const bool in = co0 + co + r < Cout;
+                    v[r] = acc[i][j][r];
+                    if constexpr (FEPI) { if (scale && in) v[r] *= scale[co0 + co + r]; }
+                    v[r] += (bias && in ? bias[co0 + co + r] : 0.f);
+                }
                 h16x4 o = {(h16)v[0], (h16)v[1], (h16)v[2], (h16)v[3]};
                 *reinterpret_cast<h16x4*>(lds + px * OPITCH + co * 2) = o;
             }
@@ -367,12 +408,13 @@ __global__ __launch_bounds__(256, SB ? MU_NT2_SB_OCC : MU_NT2_OCC) void conv_nt2
             const long p = px0 + px;
             if (p < Mtot && co0 + ch * 8 < Cout) {
                 uint4 o = *reinterpret_cast<const uint4*>(lds + px * OPITCH + ch * 16);
-                if (addend) {                   // y = conv(x) + addend (same row layout as y): the residual-branch gradient of the attention block
-                    const uint4 a4 = *reinterpret_cast<const uint4*>(addend + p * y_ld + co0 + ch * 8);
+                if constexpr (FEPI) {           // y = act(conv(x) + addend) (addend has y's row layout): the residual-branch gradient of
+                    uint4 a4 = make_uint4(0, 0, 0, 0);      // the attention block (act none), or an inference epilogue
+                    if (addend) a4 = *reinterpret_cast<const uint4*>(addend + p * y_ld + co0 + ch * 8);
                     const h16x8 ov = *reinterpret_cast<const h16x8*>(&o), av = *reinterpret_cast<const h16x8*>(&a4);
                     h16x8 r;
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) r[e] = (h16)((float)ov[e] + (float)av[e]);
+                    for (int e = 0; e < 8; ++e) r[e] = (h16)epi_act<T>((float)ov[e] + (float)av[e], act);
                     o = *reinterpret_cast<const uint4*>(&r);
                 }
                 *reinterpret_cast<uint4*>(y + p * y_ld + co0 + ch * 8) = o;
@@ -390,10 +432,11 @@ __global__ __launch_bounds__(256, SB ? MU_NT2_SB_OCC : MU_NT2_OCC) void conv_nt2
             if (co >= Cout) continue;
             float v[4];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) v[r] = acc[i][j][r] + (bias ? bias[co + r] : 0.f);
-            if (addend) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] += (float)addend[p * y_ld + co + r];
+            for (int r = 0; r < 4; ++r) {
+                v[r] = acc[i][j][r];
+                if constexpr (FEPI) { if (scale) v[r] *= scale[co + r]; }
+                v[r] += (bias ? bias[co + r] : 0.f);
+                if constexpr (FEPI) v[r] = epi_act<T>(v[r] + (addend ? (float)addend[p * y_ld + co + r] : 0.f), act);
             }
             if constexpr (sizeof(T) == 2) {
                 h16x4 o = {(h16)v[0], (h16)v[1], (h16)v[2], (h16)v[3]};
@@ -417,9 +460,10 @@ __global__ __launch_bounds__(256, SB ? MU_NT2_SB_OCC : MU_NT2_OCC) void conv_nt2
 #ifndef MU_NT3_RING
 #define MU_NT3_RING 1
 #endif
-template <typename T, int TM, int TN, int WR, int NWV = 4, bool RINGP = false>
-__global__ __launch_bounds__(NWV * 64, NWV == 4 ? 2 : 1) void conv_nt3_kernel(const T* __restrict__ x, const T* __restrict__ w, const float* __restrict__ bias,
-                                                       T* __restrict__ y, int B, int H, int W, int Cin, int Cout, long x_ld, long y_ld) {
+template <typename T, int TM, int TN, int WR, int NWV, bool RINGP, bool FEPI>
+__device__ __forceinline__ void conv_nt3_body(const T* __restrict__ x, const T* __restrict__ w, const float* __restrict__ bias,
+                                              T* __restrict__ y, int B, int H, int W, int Cin, int Cout, long x_ld, long y_ld,
+                                              const float* __restrict__ scale, const T* __restrict__ res, int act) {
     using M_ = Mma<T>;
     using Frag = typename M_::Frag;
     constexpr int VN = M_::VN, KC = 8 * VN;
@@ -590,7 +634,11 @@ __global__ __launch_bounds__(NWV * 64, NWV == 4 ? 2 : 1) void conv_nt3_kernel(co
                 const int co = i * 16 + 4 * g;
                 float v[4];
 #pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] = acc[i][j][r] + (bias ? bias[co0 + wr * 64 + co + r] : 0.f);
+                for (int r = 0; r < 4; ++r) {
+                    v[r] = acc[i][j][r];
+                    if constexpr (FEPI) { if (scale) v[r] *= scale[co0 + wr * 64 + co + r]; }
+                    v[r] += (bias ? bias[co0 + wr * 64 + co + r] : 0.f);
+                }
                 h16x4 o = {(h16)v[0], (h16)v[1], (h16)v[2], (h16)v[3]};
                 *reinterpret_cast<h16x4*>(Os + p * 128 + (((co >> 2) ^ (((p >> 1) & 7) << 1)) << 3)) = o;
             }
@@ -599,8 +647,14 @@ __global__ __launch_bounds__(NWV * 64, NWV == 4 ? 2 : 1) void conv_nt3_kernel(co
 #pragma unroll
         for (int it = 0; it < TN * 2; ++it) {
             const int p = it * 8 + (lane >> 3);
-            const h16x8 o = *reinterpret_cast<const h16x8*>(Os + p * 128 + ((q ^ ((p >> 1) & 7)) << 4));
+            h16x8 o = *reinterpret_cast<const h16x8*>(Os + p * 128 + ((q ^ ((p >> 1) & 7)) << 4));
             const long gp = ((long)bimg * H + h0 + wc * TN + (p >> 4)) * W + w0 + (p & 15);
+            if constexpr (FEPI) {
+                h16x8 rv = (h16x8)(h16)0;
+                if (res) rv = *reinterpret_cast<const h16x8*>(res + gp * y_ld + co0 + wr * 64 + q * 8);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) o[e] = (h16)epi_act<T>((float)o[e] + (float)rv[e], act);
+            }
             *reinterpret_cast<h16x8*>(y + gp * y_ld + co0 + wr * 64 + q * 8) = o;
         }
         return;
@@ -613,7 +667,12 @@ __global__ __launch_bounds__(NWV * 64, NWV == 4 ? 2 : 1) void conv_nt3_kernel(co
             const int co = co0 + (wr * TM + i) * 16 + 4 * g;
             float v[4];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) v[r] = acc[i][j][r] + (bias ? bias[co + r] : 0.f);
+            for (int r = 0; r < 4; ++r) {
+                v[r] = acc[i][j][r];
+                if constexpr (FEPI) { if (scale) v[r] *= scale[co + r]; }
+                v[r] += (bias ? bias[co + r] : 0.f);
+                if constexpr (FEPI) v[r] = epi_act<T>(v[r] + (res ? (float)res[p * y_ld + co + r] : 0.f), act);
+            }
             if constexpr (sizeof(T) == 2) {
                 h16x4 o = {(h16)v[0], (h16)v[1], (h16)v[2], (h16)v[3]};
                 *reinterpret_cast<h16x4*>(y + p * y_ld + co) = o;
@@ -624,6 +683,18 @@ __global__ __launch_bounds__(NWV * 64, NWV == 4 ? 2 : 1) void conv_nt3_kernel(co
     }
 }
 
+
+template <typename T, int TM, int TN, int WR, int NWV = 4, bool RINGP = false>
+__global__ __launch_bounds__(NWV * 64, NWV == 4 ? 2 : 1) void conv_nt3_kernel(const T* __restrict__ x, const T* __restrict__ w, const float* __restrict__ bias,
+                                                       T* __restrict__ y, int B, int H, int W, int Cin, int Cout, long x_ld, long y_ld) {
+    conv_nt3_body<T, TM, TN, WR, NWV, RINGP, false>(x, w, bias, y, B, H, W, Cin, Cout, x_ld, y_ld, nullptr, nullptr, 0);
+}
+template <typename T, int TM, int TN, int WR>
+__global__ __launch_bounds__(256, 2) void conv_nt3f_kernel(const T* __restrict__ x, const T* __restrict__ w, const float* __restrict__ bias,
+                                                           T* __restrict__ y, int B, int H, int W, int Cin, int Cout, long x_ld, long y_ld,
+                                                           const float* __restrict__ scale, const T* __restrict__ res, int act) {
+    conv_nt3_body<T, TM, TN, WR, 4, false, true>(x, w, bias, y, B, H, W, Cin, Cout, x_ld, y_ld, scale, res, act);
+}
 
 // ------------------------------------------------------------------------------------------
 // v3p: persistent form of the halo-tile kernel for layers with short K loops (Cin <= 256: 18-36 tap steps per tile).
@@ -850,9 +921,12 @@ __device__ __forceinline__ void tile_stats_store(float (&ssum)[8], float (&ssq)[
 #ifndef MU_CONV_WIDE1X1
 #define MU_CONV_WIDE1X1 1
 #endif
-__global__ __launch_bounds__(512, 1) void conv_nt4_kernel(const h16* __restrict__ x, const h16* __restrict__ w, const float* __restrict__ bias,
-                                                          h16* __restrict__ y, int B, int H, int W, int Cin, int Cout, long x_ld, long y_ld,
-                                                          float* __restrict__ stat_part) {
+// (body shared by the training kernel, whose signature and code are exactly what they were without the inference epilogue, and the
+//  FEPI kernel below: three more kernel arguments on the hot kernel shifted its code enough to cost 0.1 ms per training step)
+template <bool FEPI>
+__device__ __forceinline__ void conv_nt4_body(const h16* __restrict__ x, const h16* __restrict__ w, const float* __restrict__ bias,
+                                              h16* __restrict__ y, int B, int H, int W, int Cin, int Cout, long x_ld, long y_ld,
+                                              float* __restrict__ stat_part, const float* __restrict__ scale, const h16* __restrict__ res, int act) {
     using M_ = Mma<h16>;
     using Frag = M_::Frag;
     constexpr int VN = 8, KC = 64, TM = 4, TN = 4, WC = 4, NWV = 8, BCO = 128;
@@ -1012,7 +1086,11 @@ __global__ __launch_bounds__(512, 1) void conv_nt4_kernel(const h16* __restrict_
             const int co = i * 16 + 4 * g;
             float v[4];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) v[r] = acc[i][j][r] + (bias ? bias[co0 + wr * 64 + co + r] : 0.f);
+            for (int r = 0; r < 4; ++r) {
+                v[r] = acc[i][j][r];
+                if constexpr (FEPI) { if (scale) v[r] *= scale[co0 + wr * 64 + co + r]; }
+                v[r] += (bias ? bias[co0 + wr * 64 + co + r] : 0.f);
+            }
             h16x4 o = {(h16)v[0], (h16)v[1], (h16)v[2], (h16)v[3]};
             *reinterpret_cast<h16x4*>(Os + p * 128 + (((co >> 2) ^ (((p >> 1) & 7) << 1)) << 3)) = o;
         }
@@ -1022,8 +1100,14 @@ __global__ __launch_bounds__(512, 1) void conv_nt4_kernel(const h16* __restrict_
 #pragma unroll
     for (int it = 0; it < 8; ++it) {
         const int p = it * 8 + (lane >> 3);                 // pixel inside the wave tile: image row wc*4 + (p >> 4), column p & 15
-        const h16x8 o = *reinterpret_cast<const h16x8*>(Os + p * 128 + ((q ^ ((p >> 1) & 7)) << 4));
+        h16x8 o = *reinterpret_cast<const h16x8*>(Os + p * 128 + ((q ^ ((p >> 1) & 7)) << 4));
         const long gp = ((long)bimg * H + h0 + wc * TN + (p >> 4)) * W + w0 + (p & 15);
+        if constexpr (FEPI) {
+            h16x8 rv = (h16x8)(h16)0;
+            if (res) rv = *reinterpret_cast<const h16x8*>(res + gp * y_ld + co0 + wr * 64 + q * 8);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] = (h16)epi_act<h16>((float)o[e] + (float)rv[e], act);
+        }
 #ifdef MU_NT4_ABL_NOSTORE
         if (B < 0)
 #endif
@@ -1031,6 +1115,17 @@ __global__ __launch_bounds__(512, 1) void conv_nt4_kernel(const h16* __restrict_
         if (stat_part) tile_stats_accum(o, ssum, ssq);
     }
     if (stat_part) tile_stats_store(ssum, ssq, stat_part + ((long)tl * 4 + wc) * Cout * 2, co0 + wr * 64 + q * 8, lane);
+}
+
+__global__ __launch_bounds__(512, 1) void conv_nt4_kernel(const h16* __restrict__ x, const h16* __restrict__ w, const float* __restrict__ bias,
+                                                          h16* __restrict__ y, int B, int H, int W, int Cin, int Cout, long x_ld, long y_ld,
+                                                          float* __restrict__ stat_part) {
+    conv_nt4_body<false>(x, w, bias, y, B, H, W, Cin, Cout, x_ld, y_ld, stat_part, nullptr, nullptr, 0);
+}
+__global__ __launch_bounds__(512, 1) void conv_nt4f_kernel(const h16* __restrict__ x, const h16* __restrict__ w, const float* __restrict__ bias,
+                                                           h16* __restrict__ y, int B, int H, int W, int Cin, int Cout, long x_ld, long y_ld,
+                                                           const float* __restrict__ scale, const h16* __restrict__ res, int act) {
+    conv_nt4_body<true>(x, w, bias, y, B, H, W, Cin, Cout, x_ld, y_ld, nullptr, scale, res, act);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1248,6 +1343,48 @@ __global__ __launch_bounds__(512, 1) void conv_nt4p_kernel(const h16* __restrict
     }
 }
 
+// The same dispatch for the inference epilogue y = act(conv * scale + bias + res): FEPI instantiations of the non-persistent kernels
+// (the persistent ping-pong kernel counts its epilogue's memory operations in hand-placed vmcnt waits and takes no epilogue loads).
+template <typename T, int TAPS>
+static int conv_fwd_fused_launch(const T* x, const T* w, const float* scale, const float* bias, const T* res, int act, T* y, int B, int H, int W,
+                                 int Cin, int Cout, long x_ld, long y_ld, hipStream_t st) {
+    const long M = (long)B * H * W;
+    const int npb = (int)((M + 127) / 128);
+    if (TAPS == 9 && (Cin * (int)sizeof(T)) % 128 == 0 && W % 16 == 0) {
+        if constexpr (sizeof(T) == 2 && MU_CONV_NT4) {
+            if (Cout % 128 == 0 && H % 16 == 0 && Cin % 64 == 0) {
+                conv_nt4f_kernel<<<B * (H / 16) * (W / 16) * (Cout / 128), 512, 0, st>>>(x, w, bias, y, B, H, W, Cin, Cout, x_ld, y_ld, scale, res, act);
+                return MU_OK;
+            }
+        }
+        if (Cout % 128 == 0 && H % 8 == 0) {
+            conv_nt3f_kernel<T, 4, 4, 2><<<B * (H / 8) * (W / 16) * (Cout / 128), 256, 0, st>>>(x, w, bias, y, B, H, W, Cin, Cout, x_ld, y_ld, scale, res, act);
+            return MU_OK;
+        }
+        if (Cout % 64 == 0 && H % 8 == 0) {
+            conv_nt3f_kernel<T, 4, 2, 1><<<B * (H / 8) * (W / 16) * (Cout / 64), 256, 0, st>>>(x, w, bias, y, B, H, W, Cin, Cout, x_ld, y_ld, scale, res, act);
+            return MU_OK;
+        }
+    }
+    if constexpr (TAPS == 1 && sizeof(T) == 2) {
+        if ((Cin * 2) % 128 == 0 && Cout == 160) {                      // the 150-class head: one tile spans all output channels
+            conv_nt2_kernel<T, 5, 4, 2, 1, false, true><<<npb, 256, 0, st>>>(x, w, bias, y, B, H, W, Cin, Cout, x_ld, y_ld, res, scale, act);
+            return MU_OK;
+        }
+    }
+    if ((Cin * (int)sizeof(T)) % 128 == 0 && Cout % 64 == 0) {         // LDS-DMA version (run-time epilogue arguments)
+        if (Cout % 128 == 0)
+            conv_nt2_kernel<T, 4, 4, 2, TAPS, false, true><<<npb * (Cout / 128), 256, 0, st>>>(x, w, bias, y, B, H, W, Cin, Cout, x_ld, y_ld, res, scale, act);
+        else
+            conv_nt2_kernel<T, 4, 4, 1, TAPS, false, true><<<(int)((M + 255) / 256) * (Cout / 64), 256, 0, st>>>(x, w, bias, y, B, H, W, Cin, Cout, x_ld, y_ld, res, scale, act);
+        return MU_OK;
+    }
+    if (Cout % 128 == 0) conv_nt_kernel<T, 4, 4, 2, TAPS, true><<<npb * (Cout / 128), 256, 0, st>>>(x, w, bias, y, B, H, W, Cin, Cout, x_ld, y_ld, scale, res, act);
+    else if (Cout % 64 == 0) conv_nt_kernel<T, 4, 2, 1, TAPS, true><<<npb * (Cout / 64), 256, 0, st>>>(x, w, bias, y, B, H, W, Cin, Cout, x_ld, y_ld, scale, res, act);
+    else conv_nt_kernel<T, 2, 2, 1, TAPS, true><<<npb * (Cout / 32), 256, 0, st>>>(x, w, bias, y, B, H, W, Cin, Cout, x_ld, y_ld, scale, res, act);
+    return MU_OK;
+}
+
 template <typename T, int TAPS>
 static int conv_fwd_launch(const T* x, const T* w, const float* bias, T* y, int B, int H, int W, int Cin, int Cout, long x_ld,
                            long y_ld, hipStream_t st, float* stat_part = nullptr) {
@@ -1345,6 +1482,23 @@ extern "C" int mu_conv_fwd_stats(const void* x, const void* w, const float* bias
     return MU_OK;
 }
 
+extern "C" int mu_conv_fwd_fused(const void* x, const void* w, const float* scale, const float* bias, const void* res, int act, void* y, int B,
+                                 int H, int W, int Cin, int Cout, int taps, long x_ld, long y_ld, int dtype, void* stream) {
+    if (!x || !w || !y || B <= 0 || H <= 0 || W <= 0) return MU_ERR_ARG;
+    if (Cin <= 0 || Cout <= 0 || Cin % 32 || Cout % 32 || x_ld < Cin || y_ld < Cout || x_ld % 8 || y_ld % 8) return MU_ERR_SHAPE;
+    if ((taps != 1 && taps != 9) || act < MU_ACT_NONE || act > MU_ACT_RELU) return MU_ERR_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == MU_F16) {
+        if (taps == 9) conv_fwd_fused_launch<h16, 9>((const h16*)x, (const h16*)w, scale, bias, (const h16*)res, act, (h16*)y, B, H, W, Cin, Cout, x_ld, y_ld, st);
+        else conv_fwd_fused_launch<h16, 1>((const h16*)x, (const h16*)w, scale, bias, (const h16*)res, act, (h16*)y, B, H, W, Cin, Cout, x_ld, y_ld, st);
+    } else if (dtype == MU_F32) {
+        if (taps == 9) conv_fwd_fused_launch<float, 9>((const float*)x, (const float*)w, scale, bias, (const float*)res, act, (float*)y, B, H, W, Cin, Cout, x_ld, y_ld, st);
+        else conv_fwd_fused_launch<float, 1>((const float*)x, (const float*)w, scale, bias, (const float*)res, act, (float*)y, B, H, W, Cin, Cout, x_ld, y_ld, st);
+    } else return MU_ERR_ARG;
+    MU_CHECK_LAUNCH();
+    return MU_OK;
+}
+
 extern "C" int mu_conv_fwd(const void* x, const void* w, const float* bias, void* y, int B, int H, int W, int Cin, int Cout, int taps,
                            long x_ld, long y_ld, int dtype, void* stream) {
     if (!x || !w || !y || B <= 0 || H <= 0 || W <= 0) return MU_ERR_ARG;
@@ -1375,9 +1529,9 @@ template <typename T>
 static void conv1x1_add_launch(const T* x, const T* w, const T* addend, T* y, long M, int Cin, int Cout, long x_ld, long y_ld, hipStream_t st) {
     const int npb = (int)((M + 127) / 128);
     if (Cout % 128 == 0)
-        conv_nt2_kernel<T, 4, 4, 2, 1><<<npb * (Cout / 128), 256, 0, st>>>(x, w, nullptr, y, 1, 1, (int)M, Cin, Cout, x_ld, y_ld, addend);
+        conv_nt2_kernel<T, 4, 4, 2, 1, false, true><<<npb * (Cout / 128), 256, 0, st>>>(x, w, nullptr, y, 1, 1, (int)M, Cin, Cout, x_ld, y_ld, addend);
     else
-        conv_nt2_kernel<T, 4, 4, 1, 1><<<(int)((M + 255) / 256) * (Cout / 64), 256, 0, st>>>(x, w, nullptr, y, 1, 1, (int)M, Cin, Cout, x_ld, y_ld, addend);
+        conv_nt2_kernel<T, 4, 4, 1, 1, false, true><<<(int)((M + 255) / 256) * (Cout / 64), 256, 0, st>>>(x, w, nullptr, y, 1, 1, (int)M, Cin, Cout, x_ld, y_ld, addend);
 }
 
 extern "C" int mu_conv1x1_fwd_add(const void* x, const void* w, const void* addend, void* y, long M, int Cin, int Cout, long x_ld, long y_ld,

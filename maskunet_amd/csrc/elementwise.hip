@@ -642,7 +642,7 @@ __global__ __launch_bounds__(256) void u8_to_nhwc_kernel(const uint8_t* __restri
         const int c0 = (int)(idx % cv) * N;
         Vec16<T> o;
 #pragma unroll
-        for (int i = 0; i < N; ++i) o.set(i, c0 + i < C ? (float)src[p * C + c0 + i] * (1.0f / 255.0f) : 0.f);
+        for (int i = 0; i < N; ++i) o.set(i, c0 + i < C ? (float)src[p * C + c0 + i] / 255.0f : 0.f);      // IEEE division, as ToTensor's .div(255) on the host
         o.store(dst + p * Cp + c0);
     }
 }
@@ -811,7 +811,7 @@ __global__ __launch_bounds__(256) void resize_linear_u8_kernel(const uint8_t* __
         for (int c0 = 0; c0 < Cp; c0 += N) {
             Vec16<T> o;
 #pragma unroll
-            for (int i = 0; i < N; ++i) o.set(i, (c0 + i < C && c0 + i < 4) ? (float)v[c0 + i] * (1.0f / 255.0f) : 0.f);
+            for (int i = 0; i < N; ++i) o.set(i, (c0 + i < C && c0 + i < 4) ? (float)v[c0 + i] / 255.0f : 0.f);       // IEEE division (ToTensor on the host)
             o.store(dst + idx * Cp + c0);
         }
     }

@@ -392,6 +392,39 @@ extern "C" int mu_bn_eval_stats(const float* running_mean, const float* running_
     return MU_OK;
 }
 
+// Inference: BatchNorm2d with running statistics is a per-channel affine map, and two of them back to back (DownSample / UpSample tails,
+// ade_semantic.py:218-219,239-240) compose into one.  (scale, shift) for the conv epilogue y = act(conv * scale + shift + res):
+//   a1 = gamma1 / sqrt(var1 + eps1), s1 = beta1 + (conv_bias - mean1) * a1;  second layer: a2 likewise, scale = a1 a2, shift = (s1 - mean2) a2 + beta2.
+// Padded channels get (0, 0) so they stay exact zeros.
+__global__ void bn_eval_fold_kernel(const float* __restrict__ rm1, const float* __restrict__ rv1, const float* __restrict__ g1,
+                                    const float* __restrict__ b1, float eps1, const float* __restrict__ rm2, const float* __restrict__ rv2,
+                                    const float* __restrict__ g2, const float* __restrict__ b2, float eps2, const float* __restrict__ conv_bias,
+                                    float* __restrict__ scale, float* __restrict__ shift, int C, int c_valid) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    if (c >= c_valid) { scale[c] = 0.f; shift[c] = 0.f; return; }
+    float a = (g1 ? g1[c] : 1.f) / sqrtf(rv1[c] + eps1);
+    float sh = (b1 ? b1[c] : 0.f) + ((conv_bias ? conv_bias[c] : 0.f) - rm1[c]) * a;
+    if (rm2) {
+        const float a2 = (g2 ? g2[c] : 1.f) / sqrtf(rv2[c] + eps2);
+        sh = (sh - rm2[c]) * a2 + (b2 ? b2[c] : 0.f);
+        a *= a2;
+    }
+    scale[c] = a;
+    shift[c] = sh;
+}
+
+extern "C" int mu_bn_eval_fold(const float* running_mean1, const float* running_var1, const float* gamma1, const float* beta1, float eps1,
+                               const float* running_mean2, const float* running_var2, const float* gamma2, const float* beta2, float eps2,
+                               const float* conv_bias, float* scale, float* shift, int C, int c_valid, void* stream) {
+    if (!running_mean1 || !running_var1 || !scale || !shift || C <= 0 || c_valid <= 0 || c_valid > C) return MU_ERR_ARG;
+    if ((running_mean2 != nullptr) != (running_var2 != nullptr)) return MU_ERR_ARG;
+    bn_eval_fold_kernel<<<mu_cdiv(C, 64), 64, 0, (hipStream_t)stream>>>(running_mean1, running_var1, gamma1, beta1, eps1, running_mean2, running_var2,
+                                                                       gamma2, beta2, eps2, conv_bias, scale, shift, C, c_valid);
+    MU_CHECK_LAUNCH();
+    return MU_OK;
+}
+
 extern "C" int mu_bn_act_fwd(const void* x, const void* res, void* y, long M, int C, long ld, const float* mean, const float* rstd,
                              const float* gamma, const float* beta, int act, int dtype, void* stream) {
     if (!x || !y || !mean || !rstd || !gamma || !beta || M <= 0 || C <= 0 || C % 8 || ld < C) return MU_ERR_ARG;

@@ -160,6 +160,13 @@ class ConvBlock(_HipModule):
         folded into the block's last BatchNorm (ops.bn_pair).  res_link: ops.GradLink shared with the op that produced x (residual
         blocks only): the gradient of the `x +` branch (:208) is joined inside that op's backward kernel."""
         cb = self.conv_block
+        if ops.eval_fusable(cb[1], cb[4], tail_bn):
+            # inference: every BatchNorm (+ residual add, + GELU) lives in the epilogue of the conv in front of it
+            y = ops.conv_bn_act_eval(x, cb[0].weight, None, cb[1], ACT_GELU)
+            if self.residual:
+                y = ops.conv_bn_act_eval(y, cb[3].weight, None, cb[4], ACT_GELU, res=x)
+                return y if tail_bn is None else ops.bn_act(y, tail_bn, ACT_NONE)
+            return ops.conv_bn_act_eval(y, cb[3].weight, None, cb[4], ACT_NONE, bn2=tail_bn)
         y, st = ops.conv_stats(x, cb[0].weight, want=cb[1].training)   # BatchNorm statistics from the conv epilogue where it has one
         y = ops.bn_act(y, cb[1], ACT_GELU, stats=st)
         y, st = ops.conv_stats(y, cb[3].weight, want=cb[4].training)
@@ -236,6 +243,8 @@ class _Head(nn.Sequential):
 
 
 def _head_1x1_bn_relu(seq, x):
+    if ops.eval_fusable(seq[1]):
+        return ops.conv_bn_act_eval(x, seq[0].weight, seq[0].bias, seq[1], ACT_RELU)
     y = ops.conv(x, seq[0].weight, seq[0].bias)
     return ops.bn_act(y, seq[1], ACT_RELU)
 
@@ -339,8 +348,11 @@ class UNet(_HipModule):
             return (sem,)
         emb = _head_1x1_bn_relu(self.embedding_head, y)
         bh = self.boundary_head
-        b = ops.conv(sem, bh[0].weight, bh[0].bias)
-        b = ops.bn_act(b, bh[1], ACT_RELU)
+        if ops.eval_fusable(bh[1]):
+            b = ops.conv_bn_act_eval(sem, bh[0].weight, bh[0].bias, bh[1], ACT_RELU)
+        else:
+            b = ops.conv(sem, bh[0].weight, bh[0].bias)
+            b = ops.bn_act(b, bh[1], ACT_RELU)
         b = ops.conv(b, bh[3].weight, bh[3].bias)
         return sem, b, emb
 

@@ -545,6 +545,49 @@ def bn_act(x, bn, act=ACT_NONE, res=None, stats=None, res_link=None):
 
 
 # ------------------------------------------------------------------------------------------------
+# inference: Conv2d -> BatchNorm2d(eval) [-> BatchNorm2d(eval)] [-> + res] -> activation in ONE launch
+# ------------------------------------------------------------------------------------------------
+EVAL_FUSE = os.environ.get("MU_EVAL_FUSE", "1") != "0"      # debug switch: 0 = conv, then a BatchNorm-apply pass per layer
+
+
+def eval_fusable(*bns):
+    """True when the BatchNorm containers `bns` (None entries ignored) can be folded into the producing conv's epilogue: no gradient is
+    being recorded (the validation loops of the reference run under torch.no_grad(), ade_semantic.py:443-447) and every layer
+    normalises with its running statistics."""
+    if not EVAL_FUSE or torch.is_grad_enabled():
+        return False
+    return all(bn is None or (not bn.training and bn.running_mean is not None and bn.running_var is not None) for bn in bns)
+
+
+def conv_bn_act_eval(x, weight, conv_bias, bn, act=ACT_NONE, res=None, bn2=None):
+    """act(res + bn2(bn(conv(x) + conv_bias))) with eval-mode BatchNorm layers, as one conv launch (mu_conv_fwd_fused): the layers'
+    running statistics and affine parameters become a per-channel (scale, shift) of the conv epilogue (mu_bn_eval_fold), the
+    residual add and GELU / ReLU follow in the same epilogue.  Removes one read + write pass per BatchNorm from the validation loop
+    (ade_semantic.py:443-471).  Only under eval_fusable(bn, bn2); no autograd."""
+    x = x.contiguous()
+    B, H, W, Cin_p = x.shape
+    O, I = weight.shape[0], weight.shape[1]
+    taps = weight.shape[2] * weight.shape[3]
+    Cout_p = pad32(O)
+    if pad32(I) != Cin_p:
+        raise RuntimeError(f"conv: input has {Cin_p} (padded) channels, weight expects {I}")
+    wprep = _prep_weight(weight, x.dtype, Cout_p, Cin_p, 0, True)
+    fold = torch.empty((2, Cout_p), dtype=torch.float32, device=x.device)
+    f = lambda t: None if t is None else t.detach().float().contiguous()      # noqa: E731  (fp32 parameters: no copy)
+    b2 = bn2 if bn2 is not None else None
+    call("mu_bn_eval_fold", ptr(f(bn.running_mean)), ptr(f(bn.running_var)), ptr(f(bn.weight)), ptr(f(bn.bias)), float(bn.eps),
+         ptr(f(b2.running_mean)) if b2 is not None else None, ptr(f(b2.running_var)) if b2 is not None else None,
+         ptr(f(b2.weight)) if b2 is not None else None, ptr(f(b2.bias)) if b2 is not None else None, float(b2.eps) if b2 is not None else 0.0,
+         ptr(f(conv_bias)), ptr(fold[0]), ptr(fold[1]), Cout_p, O, stream())
+    y = torch.empty((B, H, W, Cout_p), dtype=x.dtype, device=x.device)
+    if res is not None:
+        res = res.contiguous()
+    call("mu_conv_fwd_fused", ptr(x), ptr(wprep), ptr(fold[0]), ptr(fold[1]), ptr(res), act, ptr(y), B, H, W, Cin_p, Cout_p, taps, Cin_p, Cout_p,
+         dt(x), stream())
+    return y
+
+
+# ------------------------------------------------------------------------------------------------
 # pooling / resampling / dropout
 # ------------------------------------------------------------------------------------------------
 class _MaxPool2(torch.autograd.Function):

@@ -68,6 +68,12 @@ def test_kernels_are_bitwise_deterministic_at_bench_shapes():
     assert r.returncode == 0 and "all launches bit-identical" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float16])
+def test_eval_mode_batchnorm_folded_into_conv_epilogue(dtype):
+    from tests import _gpu_checks as G
+    _assert_all(G.check_eval_fused(dtype))
+
+
 def test_unet_3head_vs_oracle():
     from tests import _gpu_checks as G
     _assert_all(G.check_unet_vs_oracle(torch.float32, B=2, c_out=19, three_head=True, seed=400))

@@ -257,7 +257,7 @@ def test_u8_input_pipeline_matches_totensor():
     from maskunet_amd import ops
     img = torch.randint(0, 256, (2, 128, 128, 3), dtype=torch.uint8, device="cuda")
     y = ops.u8_hwc_to_nhwc(img, torch.float32)
-    ref = img.float() / 255.0
+    ref = (img.cpu().float() / 255.0).cuda()         # divided on the HOST like ToTensor (torch's GPU division by a scalar multiplies by the reciprocal)
     assert torch.equal(y[..., :3], ref) and float(y[..., 3:].abs().max()) == 0.0
     m = maskunet_amd.UNet(3, 5).cuda().eval()
     m.set_keep_masks([torch.ones(2, n, dtype=torch.uint8) for n in (4096, 1024, 256, 1024, 4096, 16384)])
