@@ -8,6 +8,7 @@
 // (exact fp32 FMA chain).  Both consume the same LDS image: rows of 64 bytes along K.
 #include "common.h"
 #include <stdlib.h>
+#include <type_traits>
 #include "../../include/maskunet_hip.h"
 
 template <typename T> struct Mma;
@@ -2217,10 +2218,19 @@ static inline void wgrad3_plan(long M, int Cin, int Cout, int tco, int tci, int*
 // Partial slab layout [block][tap][Cout][4] feeds the same deterministic reduce as the other kernels.
 // ------------------------------------------------------------------------------------------
 #define MU_RGB_MAXW 256
+// Round 3: the sweep was latency-bound (157 us against ~40 us of HBM time for the 200 MB of dy / x): every 4-pixel step loaded its dy
+// values and then ran 108 dependent FMAs, with two block barriers per image row around a scalar-load staging of the three input
+// rows.  Now a lane fetches the dy values of a whole 128-pixel chunk (8 steps) one chunk AHEAD of the FMAs that consume them, the
+// next image row's input pixels (one 8-byte load each) are in flight during the current row's arithmetic and land in the other
+// half of a double-buffered LDS image -- one barrier per image row.  Two blocks per CU (251 registers; at one wave per SIMD a lone wave
+// issues an FMA every 4 cycles instead of 2).  In-process A/B at B = 64: 141.8 -> 111.2 us, bit-identical sums.
 template <typename T>
-__global__ __launch_bounds__(256) void wgrad_rgb_kernel(const T* __restrict__ x, const T* __restrict__ dy, float* __restrict__ part,
+__global__ __launch_bounds__(256, 2) void wgrad_rgb_kernel(const T* __restrict__ x, const T* __restrict__ dy, float* __restrict__ part,
                                                         int B, int H, int W, int Cout, int cin_valid, long x_ld, long dy_ld) {
-    __shared__ float4 xs[3][MU_RGB_MAXW + 2];
+    constexpr int KU = 8;                                       // pixel steps per chunk: 8 x 16 pixels
+    constexpr int NX = (3 * (MU_RGB_MAXW + 2) + 255) / 256;     // input pixels a thread stages per image row
+    using DV = typename std::conditional<sizeof(T) == 2, h16x4, float4>::type;
+    __shared__ float4 xs[2][3][MU_RGB_MAXW + 2];
     __shared__ float red[4][27][64];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int pi = lane >> 4, cg = lane & 15;                 // pixel sub-index (4 per wave step), 4-channel group
@@ -2232,52 +2242,96 @@ __global__ __launch_bounds__(256) void wgrad_rgb_kernel(const T* __restrict__ x,
         for (int c = 0; c < 4; ++c) acc[t][c] = 0.f;
 
     const int rows = B * H;
-    for (int r = blockIdx.x; r < rows; r += gridDim.x) {
-        const int b = r / H, h = r - b * H;
-        __syncthreads();                                       // previous row's readers are done
-        for (int i = tid; i < 3 * (W + 2); i += 256) {
-            const int dh = i / (W + 2), wc = i - dh * (W + 2);
-            const int hh = h + dh - 1, ww = wc - 1;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (hh >= 0 && hh < H && ww >= 0 && ww < W) {
-                const T* px = x + (((long)b * H + hh) * W + ww) * x_ld;
-                v.x = (float)px[0];
-                if (cin_valid > 1) v.y = (float)px[1];
-                if (cin_valid > 2) v.z = (float)px[2];
-                if (cin_valid > 3) v.w = (float)px[3];
-            }
-            xs[dh][wc] = v;
-        }
-        __syncthreads();
+    const int nchunk = (W + 16 * KU - 1) / (16 * KU);
+    const int nstage = 3 * (W + 2);
+
+    auto load_dy = [&](int r, int chunk, DV (&d)[KU]) {
         const T* dyr = dy + ((long)r * W) * dy_ld + co0 + cg * 4;
-        for (int p0 = wave * 4; p0 < W; p0 += 16) {
-            const int p = p0 + pi;
-            float d[4] = {0.f, 0.f, 0.f, 0.f};
-            if (p < W) {
-                if constexpr (sizeof(T) == 2) {
-                    const h16x4 v = *reinterpret_cast<const h16x4*>(dyr + (long)p * dy_ld);
 #pragma unroll
-                    for (int c = 0; c < 4; ++c) d[c] = (float)v[c];
-                } else {
-                    const float4 v = *reinterpret_cast<const float4*>(dyr + (long)p * dy_ld);
-                    d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
-                }
+        for (int k = 0; k < KU; ++k) {
+            const int p = chunk * (16 * KU) + 16 * k + wave * 4 + pi;
+            if (p < W) d[k] = *reinterpret_cast<const DV*>(dyr + (long)p * dy_ld);
+            else d[k] = DV{};
+        }
+    };
+    auto load_x = [&](int r, DV (&xr)[NX]) {                    // 4 stored channels of each staged input pixel (channels >= cin_valid are zero padding)
+        const int b = r / H, h = r - b * H;
+#pragma unroll
+        for (int j = 0; j < NX; ++j) {
+            const int i = tid + j * 256;
+            xr[j] = DV{};
+            if (i < nstage) {
+                const int dh = i / (W + 2), wc = i - dh * (W + 2);
+                const int hh = h + dh - 1, ww = wc - 1;
+                if (hh >= 0 && hh < H && ww >= 0 && ww < W) xr[j] = *reinterpret_cast<const DV*>(x + (((long)b * H + hh) * W + ww) * x_ld);
             }
-            const int pc = p < W ? p : 0;
+        }
+    };
+    auto store_x = [&](int buf, const DV (&xr)[NX]) {
 #pragma unroll
-            for (int dh = 0; dh < 3; ++dh)
+        for (int j = 0; j < NX; ++j) {
+            const int i = tid + j * 256;
+            if (i < nstage) {
+                const int dh = i / (W + 2), wc = i - dh * (W + 2);
+                float4 v;
+                if constexpr (sizeof(T) == 2) v = make_float4((float)xr[j][0], (float)xr[j][1], (float)xr[j][2], (float)xr[j][3]);
+                else v = make_float4(xr[j].x, xr[j].y, xr[j].z, xr[j].w);
+                if (cin_valid < 4) v.w = 0.f;
+                if (cin_valid < 3) v.z = 0.f;
+                if (cin_valid < 2) v.y = 0.f;
+                xs[buf][dh][wc] = v;
+            }
+        }
+    };
+
+    int r = blockIdx.x, buf = 0;
+    DV xr[NX], dcur[KU], dnxt[KU];
+    if (r < rows) {
+        load_x(r, xr);
+        load_dy(r, 0, dcur);
+    }
+    while (r < rows) {
+        store_x(buf, xr);
+        __syncthreads();                                       // this row's input image is complete; the other buffer's readers are done
+        const int rn = r + gridDim.x;
+        if (rn < rows) load_x(rn, xr);
+        for (int chunk = 0; chunk < nchunk; ++chunk) {
+            if (chunk + 1 < nchunk) load_dy(r, chunk + 1, dnxt);
+            else if (rn < rows) load_dy(rn, 0, dnxt);
 #pragma unroll
-                for (int dw = 0; dw < 3; ++dw) {
-                    const float4 xv = xs[dh][pc + dw];
-                    const int t = (dh * 3 + dw) * 3;
+            for (int k = 0; k < KU; ++k) {
+                const int p = chunk * (16 * KU) + 16 * k + wave * 4 + pi;
+                const int pc = p < W ? p : 0;                    // (d is zero there)
+                float d[4];
+                if constexpr (sizeof(T) == 2) {
 #pragma unroll
                     for (int c = 0; c < 4; ++c) {
-                        acc[t + 0][c] = fmaf(d[c], xv.x, acc[t + 0][c]);
-                        acc[t + 1][c] = fmaf(d[c], xv.y, acc[t + 1][c]);
-                        acc[t + 2][c] = fmaf(d[c], xv.z, acc[t + 2][c]);
+                        d[c] = (float)dcur[k][c];
+                        asm volatile("" : "+v"(d[c]));          // one conversion per value: keeps the 27 FMAs on it plain v_fma_f32 (not v_fma_mix)
                     }
+                } else {
+                    d[0] = dcur[k].x; d[1] = dcur[k].y; d[2] = dcur[k].z; d[3] = dcur[k].w;
                 }
+#pragma unroll
+                for (int dh = 0; dh < 3; ++dh)
+#pragma unroll
+                    for (int dw = 0; dw < 3; ++dw) {
+                        const float4 xv = xs[buf][dh][pc + dw];
+                        const int t = (dh * 3 + dw) * 3;
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) {
+                            acc[t + 0][c] = fmaf(d[c], xv.x, acc[t + 0][c]);
+                            acc[t + 1][c] = fmaf(d[c], xv.y, acc[t + 1][c]);
+                            acc[t + 2][c] = fmaf(d[c], xv.z, acc[t + 2][c]);
+                        }
+                    }
+                __builtin_amdgcn_sched_barrier(0);               // keep the nine LDS reads of a step next to its FMAs (the scheduler otherwise
+            }                                                    // hoists all 72 of a chunk: 400 registers, spills)
+#pragma unroll
+            for (int k = 0; k < KU; ++k) dcur[k] = dnxt[k];
         }
+        r = rn;
+        buf ^= 1;
     }
     // (tap, ci) x 4 co per lane: fold the four pixel sub-indices (lanes 16 apart), then the four waves, in a fixed order
 #pragma unroll
