@@ -99,6 +99,8 @@ def load() -> ctypes.CDLL:
             "There is no CPU fallback.")
     lib = ctypes.CDLL(LIB_PATH)
     for name, (res, args) in SIGNATURES.items():
+        if os.environ.get("MU_LIB_PATH") and not hasattr(lib, name):
+            continue                     # debug builds of an older source tree (A/B profiling): entry points added since are simply absent
         fn = getattr(lib, name)          # AttributeError if a declared symbol is not exported
         fn.restype = res
         fn.argtypes = args

@@ -10,3 +10,5 @@ done
 cd $ROOT
 A=$(find gpurun_out/r03f_prof_pre -name '*kernel_stats.csv' | head -1); B=$(find gpurun_out/r03f_prof_cur -name '*kernel_stats.csv' | head -1)
 python tests/prof_diff.py $A $B 12 40 | tee gpurun_out/r03f_prof_diff.txt
+timeout 3000 python -m pytest tests -m gpu -q --timeout 1500 -p no:cacheprovider > gpurun_out/r03g_pytest.log 2>&1
+echo "pytest rc=$?"; tail -5 gpurun_out/r03g_pytest.log
