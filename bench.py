@@ -39,7 +39,8 @@ PEAK_MFMA_TFLOPS = {"fp16": 2500.0, "fp32": 157.3}      # dense, MI355X_MICROARC
 PEAK_HBM_GBS = 8000.0
 DOMINANT_KERNEL = "attn_bwd_dkv3_kernel"
 # PMC traffic of the dominant kernel per workload shape (key: b{batch}_c{c_out}_hw{hw}_{dtype}[_3head]); see profiles/README.md
-TRAFFIC_JSON = {"b64_c150_hw128_fp16": "r02_dkv_traffic.json"}
+TRAFFIC_JSON = {k: f"r03_dkv_traffic_{k}.json" for k in ("b64_c150_hw128_fp16", "b128_c133_hw128_fp16", "b64_c19_hw128_fp16_3head",
+                                                          "b32_c133_hw256_fp16", "b64_c150_hw128_fp32")}
 DATASET_BY_COUT = {150: "ADE20K-semantic", 151: "ADE20K-semantic", 133: "COCO-panoptic", 19: "Cityscapes", 81: "COCO-instance"}
 
 
