@@ -713,8 +713,16 @@ __global__ __launch_bounds__(256) void attn_ln_bwd_kernel(const T* __restrict__ 
 __global__ void attn_ln_bwd_final_kernel(const double* __restrict__ part, int nblk, int D, float* __restrict__ dgamma, float* __restrict__ dbeta) {
     const int c = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (c >= D) return;
+    double av[16], bv[16];           // nblk <= ATT_LN_MAXBLK = 1024: every load in flight before the first add (one L2 round trip, not 16)
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+        const int k = lane + 64 * u;
+        const double2 v = k < nblk ? *reinterpret_cast<const double2*>(part + ((long)k * D + c) * 2) : make_double2(0.0, 0.0);
+        av[u] = v.x; bv[u] = v.y;
+    }
     double a = 0.0, b = 0.0;
-    for (int k = lane; k < nblk; k += 64) { a += part[((long)k * D + c) * 2]; b += part[((long)k * D + c) * 2 + 1]; }
+#pragma unroll
+    for (int u = 0; u < 16; ++u) { a += av[u]; b += bv[u]; }
     a = wave_sum_d(a); b = wave_sum_d(b);
     if (lane) return;
     dgamma[c] = (float)a;
