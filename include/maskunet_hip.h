@@ -204,8 +204,8 @@ int mu_compact_keys(const void* keep, int keep_elem_bytes, int B, int N, int* ki
  * The {0,-inf} key mask is given as the compacted list of kept keys: kidx[b][0..kcnt[b]) (int32, row
  * stride nkmax).  Also returns what the backward needs: oattn (PV/l, pre-residual), lse2 (log2-domain
  * log-sum-exp of the scaled scores), LayerNorm mean/rstd per token.  C in {32,64,128,256}.
- * Every image must keep at least one key (kcnt[b] >= 1): with no visible key the reference yields NaN (softmax over -inf only),
- * here the outputs are undefined.  fp16: the sweep first runs without per-tile running-max tracking and verifies the row sums; a score
+ * An image without a visible key (kcnt[b] == 0) yields NaN in out / oattn and, in the backward, NaN dY and NaN dQ / dK / dV rows --
+ * what the reference's softmax over -inf only produces (:183-185).  fp16: the sweep first runs without per-tile running-max tracking and verifies the row sums; a score
  * that exceeds the first 64 kept keys' maximum by more than 16 (log2 units) makes the block repeat its sweep with exact tracking. */
 int mu_attn_fwd(const void* qkv, const void* x, const int* kidx, const int* kcnt, const float* gamma, const float* beta, void* out,
                 void* oattn, float* lse2, float* ln_mean, float* ln_rstd, int B, int N, int C, int nkmax, float eps, int dtype,

@@ -868,6 +868,14 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 && D <= 64 && sizeof(T) == 2) ? M
         const int qrow = q0 + t * 16 + r16;
         if (qrow >= N) continue;
         T* dst = dqkv + ((long)b * N + qrow) * 3 * D;
+        if (Nk == 0) {
+            // an image with NO visible key: the reference's softmax over -inf only is NaN for every query (ade_semantic.py:183-185), and so
+            // are all three gradients; this sweep visits every token row once, so it writes the NaN dQ, dK and dV of the row
+            const float nanv[4] = {__builtin_nanf(""), __builtin_nanf(""), __builtin_nanf(""), __builtin_nanf("")};
+#pragma unroll
+            for (int c = 0; c < 3 * NDT; ++c) store4<T>(dst + c * 16 + 4 * g, nanv);
+            continue;
+        }
 #pragma unroll
         for (int dt = 0; dt < NDT; ++dt) {
             float v[4] = {dq[dt][t][0], dq[dt][t][1], dq[dt][t][2], dq[dt][t][3]};
@@ -911,6 +919,7 @@ __global__ __launch_bounds__(NW * 64, NW >= 8 ? 1 : ((D <= 64 && sizeof(T) == 2 
     const int Nk = kcnt[b];
     const int kb0 = bx_ * (NW * NKT * 16);
     const int* kidx_b = kidx + (long)b * nkmax;
+    if (Nk == 0) return;                                      // no visible key at all: NaN gradients, written by the dQ sweep (see there)
     if (kb0 >= Nk) {
         // zero_masked (kidx rows are whole permutations, the masked keys listed after the kept ones): this block's keys are all
         // masked -- their dK / dV rows are exact zeros, written here instead of by a memset of the whole dqkv buffer

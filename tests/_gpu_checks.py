@@ -1048,3 +1048,38 @@ def check_eval_fused(dtype):
         if not three:
             res.append(("unet1_c150_b2_eval fused out0 slice vs reference", _err(outs[True][0][:, :, ::16, ::16], torch.from_numpy(rec["out0_slice"])), tol))
     return res
+
+
+def check_attention_no_visible_key(dtype):
+    """An image whose key mask hides EVERY key: the reference's softmax over -inf only is NaN for every query of that image
+    (ade_semantic.py:183-185) -- outputs and all gradients NaN; the other images of the batch are untouched (same values as without
+    the dead image in the batch)."""
+    import maskunet_amd
+    res = []
+    for C, hw in ((64, 16), (128, 8), (256, 8), (32, 8)):
+        torch.manual_seed(C)
+        m = maskunet_amd.Mask2FormerAttention(C, C).to(DEV).set_compute_dtype(dtype)
+        N = hw * hw
+        x = torch.randn(3, C, hw, hw, device=DEV)
+        keep = (torch.rand(3, N) > 0.5).to(torch.uint8)
+        keep[1] = 0
+        xa = x.clone().requires_grad_(True)
+        m.set_keep_mask(keep)
+        ya = m(xa)
+        g = torch.randn_like(ya)
+        ya.backward(g)
+        nan_out = bool(torch.isnan(ya[1]).all()) and bool(torch.isfinite(ya[0]).all()) and bool(torch.isfinite(ya[2]).all())
+        nan_gin = bool(torch.isnan(xa.grad[1]).all()) and bool(torch.isfinite(xa.grad[0]).all()) and bool(torch.isfinite(xa.grad[2]).all())
+        # sums over the batch: NaN like the reference's -- except LayerNorm's bias gradient, the plain sum of the incoming gradient
+        nan_gw = all(bool(torch.isnan(p.grad).all()) for n, p in m.named_parameters() if n != "norm.bias") and bool(torch.isfinite(m.norm.bias.grad).all())
+        m.zero_grad(set_to_none=True)
+        xb = x[[0, 2]].clone().requires_grad_(True)
+        m.set_keep_mask(keep[[0, 2]])
+        yb = m(xb)
+        yb.backward(g[[0, 2]])
+        same = _err(ya[[0, 2]], yb) + _rel_err(xa.grad[[0, 2]], xb.grad)
+        res += [(f"no visible key C={C}: outputs NaN for that image only", 0.0 if nan_out else 1.0, 0.0),
+                (f"no visible key C={C}: input gradient NaN for that image only", 0.0 if nan_gin else 1.0, 0.0),
+                (f"no visible key C={C}: parameter gradients NaN", 0.0 if nan_gw else 1.0, 0.0),
+                (f"no visible key C={C}: other images unchanged", same, 1e-6 if dtype == torch.float32 else 2e-3)]
+    return res

@@ -75,6 +75,12 @@ def test_attention_bwd_masked_rows_zeroed_by_sweep_or_memset(dtype):
     _assert_all(G.check_attention_bwd_masked_rows(dtype))
 
 
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_attention_image_without_visible_keys_is_nan_like_the_reference(dtype):
+    from tests import _gpu_checks as G
+    _assert_all(G.check_attention_no_visible_key(dtype))
+
+
 def test_attention_mask_semantics():
     from tests import _gpu_checks as G
     _assert_all(G.check_attention_mask_semantics())
