@@ -3,7 +3,28 @@
 import os, statistics, sys
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from tests.ab_bench import load, timeit
+import ctypes
+from maskunet_amd import _lib
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def load(name):
+    lib = ctypes.CDLL(os.path.join(ROOT, "gpurun_variants", f"libmu_{name}.so"))
+    for n, (res, args) in _lib.SIGNATURES.items():
+        f = getattr(lib, n, None)
+        if f is not None:
+            f.restype = res; f.argtypes = args
+    return lib
+
+
+def timeit(fn, reps=3):
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps): fn()
+    e1.record(); torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / reps
+
+
 names = sys.argv[1:]
 libs = {n: load(n) for n in names}
 B, H, Cin, Cout = 64, 128, 32, 64
