@@ -1152,265 +1152,6 @@ __global__ __launch_bounds__(NW * 64, NW >= 8 ? 1 : ((D <= 64 && sizeof(T) == 2 
 }
 
 // ------------------------------------------------------------------------------------------
-// dK/dV v4 (fp16, C = 64): the same sweep on v_mfma_f32_32x32x16_f16 with the softmax arithmetic of tile t issued INSIDE the matrix
-// section of tile t+1.  On this chip a wave's own VALU instructions hide behind its 32x32x16 MFMAs (16-20 issue cycles per MFMA,
-// tests/micro_gap.hip) but not behind another wave's, and hardly behind 16x16x32 ones (~4): v3 therefore runs at (MFMA cycles + VALU
-// cycles) = 512 + ~316 per 32-query tile.  Here a wave owns 32 keys and per tile
-//   G1(t+1): S = Q K^T - lse2 and dP = dO V^T - delta/sqrt(C) of the NEXT tile (8 MFMAs; K, V fragments live in registers as B operands,
-//            keys on the lanes; the row constants enter as the C operand)            || exp2 / multiply / fp16 packing of tile t's scores
-//   G2(t)  : dV^T += dO^T P and dK^T += Q^T dS of tile t (8 MFMAs): P / dS go from the accumulator registers straight into the B operand
-//            (registers 8s..8s+7 = the k-step-s fragment in the permuted query order q = 16s + 8(j>>2) + 4h + (j&3)); the A operands
-//            dO^T / Q^T are gathered in that same order by transposed LDS reads.
-// Ring, DMA accounting and block order are v3's; the 32-row tiles use a swizzle key that keeps both the 32-row ds_read_b128 fragment
-// reads and the transposed reads conflict-free (key32 below; derivation in DESIGN.md section 9a).
-// ------------------------------------------------------------------------------------------
-#ifndef MU_DKV4
-#define MU_DKV4 0                // measured slower than v3 (4.12 vs 3.61 ms at B 64, N 16384, half the keys kept): see DESIGN.md section 9a
-#endif
-#ifndef MU_DKV4_DBG
-#define MU_DKV4_DBG 0            // timing experiments only (wrong results): 1 = no exp2, 2 = no transposed gathers, 4 = no row-fragment reads
-#endif
-#ifndef MU_DKV4_SGB
-#define MU_DKV4_SGB 1            // 1 = pin the MFMA / VALU interleave of G1 with sched_group_barrier
-#endif
-#ifndef MU_DKV4_VPM
-#define MU_DKV4_VPM 6            // VALU instructions scheduled behind each MFMA of G1
-#endif
-__device__ __forceinline__ constexpr int key32(int row) { return (((row >> 1) & 1) << 2) | ((row >> 2) & 3); }
-__device__ __forceinline__ int off32(int row, int col) { return row * 64 + ((((col >> 3) ^ key32(row))) << 3) + (col & 7); }
-
-__global__ __launch_bounds__(256, 2) void attn_bwd_dkv4_kernel(const h16* __restrict__ qkv, const h16* __restrict__ dY, const int* __restrict__ kidx,
-                                                               const int* __restrict__ kcnt, const float* __restrict__ rowc,
-                                                               h16* __restrict__ dqkv, int N, int nkmax, float scale, float scale_log2,
-                                                               int zero_masked) {
-    constexpr int D = 64, QT = 32, NW = 4, RING = 4, STG = 2 * QT * D, OPS = 3;
-    __shared__ __attribute__((aligned(16))) h16 lds[RING * STG];
-    __shared__ __attribute__((aligned(16))) float rcs[RING * 256 + 256];
-
-    int bx_, b;
-    attn_block(bx_, b);
-    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int r32 = lane & 31, hh = lane >> 5;
-    const int Nk = kcnt[b];
-    const int kb0 = bx_ * (NW * 32);
-    const int* kidx_b = kidx + (long)b * nkmax;
-    if (Nk == 0) return;                                      // NaN gradients, written by the dQ sweep
-    if (kb0 >= Nk) {
-        if (zero_masked) {
-            constexpr int LPK = 2 * D * 2 / 16;
-            for (int i = threadIdx.x; i < NW * 32 * LPK; i += NW * 64) {
-                const int j = kb0 + i / LPK;
-                if (j < nkmax) {
-                    h16* dst = dqkv + ((long)b * N + kidx_b[j]) * 3 * D + D;
-                    reinterpret_cast<float4*>(dst)[i % LPK] = make_float4(0.f, 0.f, 0.f, 0.f);
-                }
-            }
-        }
-        return;
-    }
-    const h16* qkv_b = qkv + (long)b * N * 3 * D;
-    const h16* dY_b = dY + (long)b * N * D;
-    const int ntile = (N + QT - 1) / QT;
-    const float* rowc_b = rowc + (long)b * ntile * 64;
-
-    // ring fill: wave w moves rows 8w..8w+7 of Q and of dO (one 1-KiB LDS-DMA each) + the tile's 64 row constants
-    const int drow = wave * 8 + (lane >> 3);
-    const int dsc = (lane & 7) ^ key32(drow);
-    const int qlane = drow * 3 * D + dsc * 8, olane = drow * D + dsc * 8;
-    auto issue = [&](int tile) {
-        const int slot = tile & (RING - 1);
-        h16* Qt = lds + slot * STG;
-        h16* Ot = Qt + QT * D;
-        const h16* qb = qkv_b + (long)tile * QT * 3 * D;
-        const h16* ob = dY_b + (long)tile * QT * D;
-        glds16s(qb, (uint32_t)(qlane * 2), Qt + wave * 8 * D);          // (N % 32 == 0: every tile is whole; other N run v3)
-        glds16s(ob, (uint32_t)(olane * 2), Ot + wave * 8 * D);
-        glds16s(rowc_b + (long)tile * 64, (uint32_t)((lane & 15) * 16), rcs + (wave == 0 ? slot * 256 : RING * 256));
-    };
-    issue(0);
-    if (ntile > 1) issue(1);
-    if (ntile > 2) issue(2);
-
-    // this lane's key (lanes l and l + 32 share it) as B-operand fragments: K[key][16 ks + 8 h ..], pre-scaled
-    const int jk = kb0 + wave * 32 + r32;
-    const int keyrow = jk < Nk ? kidx_b[jk] : -1;
-    h16x8 kf[4], vf[4];
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
-        h16x8 fk = (h16x8)(h16)0, fv = (h16x8)(h16)0;
-        if (keyrow >= 0) {
-            fk = *reinterpret_cast<const h16x8*>(qkv_b + (long)keyrow * 3 * D + D + ks * 16 + hh * 8);
-            fv = *reinterpret_cast<const h16x8*>(qkv_b + (long)keyrow * 3 * D + 2 * D + ks * 16 + hh * 8);
-#pragma unroll
-            for (int e = 0; e < 8; ++e) { fk[e] = (h16)((float)fk[e] * scale_log2); fv[e] = (h16)((float)fv[e] * scale); }
-        }
-        kf[ks] = fk;
-        vf[ks] = fv;
-    }
-    f32x16 dv0, dv1, dk0, dk1;
-#pragma unroll
-    for (int i = 0; i < 16; ++i) { dv0[i] = 0.f; dv1[i] = 0.f; dk0[i] = 0.f; dk1[i] = 0.f; }
-
-    // per-lane LDS offsets (elements): row fragment reads (row r32, 16-byte chunk 2 ks + h) and the transposed gathers
-    int aoff[4];
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks) aoff[ks] = off32(r32, ks * 16 + hh * 8);
-    const int ti = lane & 15, tcb = (lane >> 4) & 1;
-    int toff[2][2][2];                                       // [k-step s][channel tile][lo / hi]
-#pragma unroll
-    for (int s_ = 0; s_ < 2; ++s_)
-#pragma unroll
-        for (int ct = 0; ct < 2; ++ct) {
-            toff[s_][ct][0] = off32(16 * s_ + 4 * hh + (ti >> 2), 32 * ct + 16 * tcb + 4 * (ti & 3));
-            toff[s_][ct][1] = off32(16 * s_ + 8 + 4 * hh + (ti >> 2), 32 * ct + 16 * tcb + 4 * (ti & 3));
-        }
-
-    auto wait_tile = [&](int t) {                            // this wave's DMAs of tile t have landed; newer issue groups stay in flight
-        const int issued = ntile < t + 2 ? ntile : (t == 0 ? (ntile < 3 ? ntile : 3) : t + 2);      // tiles issued so far (see call sites)
-        const int newer = issued - 1 - t;
-        if (newer >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * OPS) : "memory");
-        else if (newer == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(OPS) : "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    };
-    // G1 operands of a tile: the row constants (the C operand: S starts at -lse2, dP at -delta/sqrt(C)) and the Q / dO row fragments
-    auto g1_load = [&](int slot, f32x16& sa, f32x16& dpa, h16x8 (&qa)[4], h16x8 (&oa)[4]) {
-        const h16* Qt = lds + slot * STG;
-        const h16* Ot = Qt + QT * D;
-        const float* rc = rcs + slot * 256;
-#pragma unroll
-        for (int i4 = 0; i4 < 4; ++i4) {
-            const f32x4 a = *reinterpret_cast<const f32x4*>(rc + 8 * i4 + 4 * hh);
-            const f32x4 c = *reinterpret_cast<const f32x4*>(rc + 32 + 8 * i4 + 4 * hh);
-#pragma unroll
-            for (int r = 0; r < 4; ++r) { sa[4 * i4 + r] = a[r]; dpa[4 * i4 + r] = c[r]; }
-        }
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-            if (MU_DKV4_DBG & 4) { qa[ks] = vf[ks]; oa[ks] = kf[ks]; continue; }
-            qa[ks] = *reinterpret_cast<const h16x8*>(Qt + aoff[ks]);
-            oa[ks] = *reinterpret_cast<const h16x8*>(Ot + aoff[ks]);
-        }
-    };
-    // G2 A operand (dO^T for m even, Q^T for m odd) of k-step s_ = m >> 2, channel tile ct = (m >> 1) & 1, gathered by transposed reads
-    auto g2_load = [&](int slot, int m) -> h16x8 {
-        if (MU_DKV4_DBG & 2) return kf[m & 3];
-        const h16* base = lds + slot * STG + ((m & 1) ? 0 : QT * D);
-        auto lo = LDS_TR16(base + toff[m >> 2][(m >> 1) & 1][0]);
-        auto hi = LDS_TR16(base + toff[m >> 2][(m >> 1) & 1][1]);
-        return h16x8{(h16)lo[0], (h16)lo[1], (h16)lo[2], (h16)lo[3], (h16)hi[0], (h16)hi[1], (h16)hi[2], (h16)hi[3]};
-    };
-#define DKV4_SM(i)                                                                                                              \
-    {                                                                                                                           \
-        const float p_ = (MU_DKV4_DBG & 1) ? sc[i] : __builtin_amdgcn_exp2f(sc[i]);                                             \
-        sc[i] = p_;                                                                                                             \
-        dpc[i] *= p_;                                                                                                           \
-        if ((i) & 1) {                                                                                                          \
-            pb[(i) >> 3][((i) & 7) - 1] = (h16)sc[(i) - 1];                                                                     \
-            pb[(i) >> 3][(i) & 7] = (h16)sc[i];                                                                                 \
-            db[(i) >> 3][((i) & 7) - 1] = (h16)dpc[(i) - 1];                                                                    \
-            db[(i) >> 3][(i) & 7] = (h16)dpc[i];                                                                                \
-        }                                                                                                                       \
-    }
-#define DKV4_G2(m)                                                                                                              \
-    {                                                                                                                           \
-        if ((m) == 0 || (m) == 4) dv0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ga[m], pb[(m) >> 2], dv0, 0, 0, 0);              \
-        if ((m) == 1 || (m) == 5) dk0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ga[m], db[(m) >> 2], dk0, 0, 0, 0);              \
-        if ((m) == 2 || (m) == 6) dv1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ga[m], pb[(m) >> 2], dv1, 0, 0, 0);              \
-        if ((m) == 3 || (m) == 7) dk1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ga[m], db[(m) >> 2], dk1, 0, 0, 0);              \
-    }
-
-    // prologue: scores of tile 0
-    f32x16 sA, dpA, sB, dpB;
-    wait_tile(0);
-    __builtin_amdgcn_s_barrier();
-    {
-        h16x8 qa[4], oa[4];
-        g1_load(0, sA, dpA, qa, oa);
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-            sA = __builtin_amdgcn_mfma_f32_32x32x16_f16(qa[ks], kf[ks], sA, 0, 0, 0);
-            dpA = __builtin_amdgcn_mfma_f32_32x32x16_f16(oa[ks], vf[ks], dpA, 0, 0, 0);
-        }
-    }
-    // Steady state, one tile: the instruction order is pinned by hand (sched_barrier after every MFMA group), because the point of the
-    // kernel is WHICH vector instructions sit behind WHICH matrix instruction:
-    //   8 MFMAs of G1(tl+1), each followed by exp2 / multiply / pack of ONE score register of tile tl (registers 0..7 = k-step 0 of G2)
-    //                        and by two of the transposed LDS gathers of G2(tl) (the registers G1's own operands vacate)
-    //   4 MFMAs of G2(tl) k-step 0, each followed by two score registers of k-step 1 (registers 8..15)
-    //   4 MFMAs of G2(tl) k-step 1
-    auto step = [&](int tl, f32x16& sc, f32x16& dpc, f32x16& sn, f32x16& dpn) {       // requires tl + 1 < ntile
-        wait_tile(tl + 1);
-        __builtin_amdgcn_s_barrier();                        // tile tl+1 landed for everybody; everybody is done with tile tl-1's slot
-        h16x8 pb[2], db[2], qa[4], oa[4], ga[8];
-        const int slot = tl & (RING - 1);
-        g1_load((tl + 1) & (RING - 1), sn, dpn, qa, oa);
-        __builtin_amdgcn_sched_barrier(0);
-#define DKV4_G1(k)                                                                                                              \
-        if ((k) & 1) dpn = __builtin_amdgcn_mfma_f32_32x32x16_f16(oa[(k) >> 1], vf[(k) >> 1], dpn, 0, 0, 0);                    \
-        else sn = __builtin_amdgcn_mfma_f32_32x32x16_f16(qa[(k) >> 1], kf[(k) >> 1], sn, 0, 0, 0);                              \
-        DKV4_SM(k);                                                                                                             \
-        ga[k] = g2_load(slot, k);                                                                                               \
-        __builtin_amdgcn_sched_barrier(0);
-        DKV4_G1(0) DKV4_G1(1) DKV4_G1(2) DKV4_G1(3) DKV4_G1(4) DKV4_G1(5) DKV4_G1(6) DKV4_G1(7)
-#undef DKV4_G1
-#define DKV4_G2A(m)                                                                                                             \
-        DKV4_G2(m);                                                                                                             \
-        DKV4_SM(8 + 2 * (m));                                                                                                   \
-        DKV4_SM(9 + 2 * (m));                                                                                                   \
-        __builtin_amdgcn_sched_barrier(0);
-        DKV4_G2A(0) DKV4_G2A(1) DKV4_G2A(2) DKV4_G2A(3)
-#undef DKV4_G2A
-        DKV4_G2(4) DKV4_G2(5) DKV4_G2(6) DKV4_G2(7)
-        __builtin_amdgcn_sched_barrier(0);
-        if (tl + RING - 1 < ntile) issue(tl + RING - 1);     // refill the slot tile tl-1 vacated (last: LDS reads queue behind a DMA issue)
-    };
-    auto last = [&](int tl, f32x16& sc, f32x16& dpc) {       // the final tile: nothing left to multiply ahead
-        h16x8 pb[2], db[2], ga[8];
-#pragma unroll
-        for (int m = 0; m < 8; ++m) ga[m] = g2_load(tl & (RING - 1), m);
-        DKV4_SM(0) DKV4_SM(1) DKV4_SM(2) DKV4_SM(3) DKV4_SM(4) DKV4_SM(5) DKV4_SM(6) DKV4_SM(7)
-        DKV4_SM(8) DKV4_SM(9) DKV4_SM(10) DKV4_SM(11) DKV4_SM(12) DKV4_SM(13) DKV4_SM(14) DKV4_SM(15)
-        DKV4_G2(0) DKV4_G2(1) DKV4_G2(2) DKV4_G2(3) DKV4_G2(4) DKV4_G2(5) DKV4_G2(6) DKV4_G2(7)
-    };
-    int tl = 0;
-    for (; tl + 2 < ntile; tl += 2) {
-        step(tl, sA, dpA, sB, dpB);
-        step(tl + 1, sB, dpB, sA, dpA);
-    }
-    if (tl + 1 < ntile) {
-        step(tl, sA, dpA, sB, dpB);
-        last(tl + 1, sB, dpB);
-    } else {
-        last(tl, sA, dpA);
-    }
-#undef DKV4_SM
-#undef DKV4_G2
-
-    // dK^T / dV^T accumulators: lane = key, registers = channels 32 ct + (i & 3) + 8 (i >> 2) + 4 h
-    int row = keyrow;
-    const bool live = row >= 0;
-    if (!live) {
-        if (!zero_masked || jk >= nkmax) return;             // (no barrier follows)
-        row = kidx_b[jk];
-    }
-    h16* dst = dqkv + ((long)b * N + row) * 3 * D;
-#pragma unroll
-    for (int ct = 0; ct < 2; ++ct)
-#pragma unroll
-        for (int g4 = 0; g4 < 4; ++g4) {
-            float kv[4], vv[4];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                kv[r] = live ? (ct == 0 ? dk0[4 * g4 + r] : dk1[4 * g4 + r]) : 0.f;
-                vv[r] = live ? (ct == 0 ? dv0[4 * g4 + r] : dv1[4 * g4 + r]) : 0.f;
-            }
-            const int c = 32 * ct + 8 * g4 + 4 * hh;
-            store4<h16>(dst + D + c, kv);
-            store4<h16>(dst + 2 * D + c, vv);
-        }
-}
-
-// ------------------------------------------------------------------------------------------
 // host entry points
 // ------------------------------------------------------------------------------------------
 template <typename T>
@@ -1480,9 +1221,7 @@ static int attn_bwd_t(const T* qkv, const T* x, const T* oattn, const T* gout, c
     }                                                                                                                           \
     if (phases & 2) attn_bwd_dq2_kernel<T, DD, KTQ, 4><<<gq, 256, 0, st>>>(qkv, dY, kidx, kcnt, lse2, delta, dqkv, N, nkmax, scale, sl2); \
     if (phases & 4) {                                                                                                           \
-        if (sizeof(T) == 2 && DD == 64 && MU_DKV4 && N % 32 == 0)                                                               \
-            attn_bwd_dkv4_kernel<<<dim3(mu_cdiv(nkmax, 128), B), 256, 0, st>>>((const h16*)qkv, (const h16*)dY, kidx, kcnt, rowc, (h16*)dqkv, N, nkmax, scale, sl2, zero_masked); \
-        else if constexpr (sizeof(T) == 2 && DD == 64 && MU_DKV_NW64 != 4)                                                      \
+        if constexpr (sizeof(T) == 2 && DD == 64 && MU_DKV_NW64 != 4)                                                           \
             attn_bwd_dkv3_kernel<T, DD, NKT, MU_DKV_NW64><<<dim3(mu_cdiv(nkmax, 16 * MU_DKV_NW64 * NKT), B), 64 * MU_DKV_NW64, 0, st>>>(qkv, dY, kidx, kcnt, rowc, dqkv, N, nkmax, scale, sl2, zero_masked); \
         else if constexpr (sizeof(T) == 2 && DD == 128 && MU_DKV_NW128 != 4)                                                         \
             attn_bwd_dkv3_kernel<T, DD, NKT, MU_DKV_NW128><<<dim3(mu_cdiv(nkmax, 16 * MU_DKV_NW128 * NKT), B), 64 * MU_DKV_NW128, 0, st>>>(qkv, dY, kidx, kcnt, rowc, dqkv, N, nkmax, scale, sl2, zero_masked); \
