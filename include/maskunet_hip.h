@@ -58,6 +58,14 @@ int mu_cast(const void* src, int src_dtype, void* dst, int dst_dtype, long n, vo
 int mu_prep_weight(const float* w_oihw, void* dst, int dtype, int O, int I, int taps, int rows_pad, int cols_pad, int mode,
                    void* stream);
 
+/* mu_prep_weight for MANY layers in one launch (a training forward re-lays every conv weight of the model: nn.Conv2d keeps OIHW fp32
+ * masters, ade_semantic.py:199,202,284).  jobs = DEVICE array of njobs x 10 int64:
+ *   { address of the OIHW fp32 weight, dst offset in elements from dst_base, first_tile, O, I, taps, rows_pad, cols_pad, mode, 0 }
+ * a layer occupies the 32 x 32 tiles [first_tile, first_tile + rows_pad/32 * cols_pad/32) of the launch (rows = O, cols = I, both padded
+ * to multiples of 32; mode 0, 1 or 2 as above with rows/cols always meaning out/in); ntiles = the sum over layers.  njobs <= 128.
+ * Same values, bit for bit, as njobs mu_prep_weight calls. */
+int mu_prep_weights_multi(const void* jobs, int njobs, long ntiles, void* dst_base, int dtype, void* stream);
+
 /* The q/k/v projection of one attention block -- three nn.Linear(C, C) with bias (ade_semantic.py:157-159,170-172) -- as ONE [3C, C]
  * 1x1 layer: dst = the forward block [3C][C] followed by the data-gradient block [C][3C] (mu_prep_weight mode 2 of the concatenated
  * weight), bias[3C] = the concatenated fp32 biases.  C % 32 == 0. */

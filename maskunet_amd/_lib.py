@@ -72,6 +72,7 @@ SIGNATURES = {
     "mu_adamw_chunk": (I, []),
     "mu_adamw_multi": (I, [P, P, P, I, F, F, F, F, F, F, P]),
     "mu_prep_qkv": (I, [P, P, P, P, P, P, P, P, I, I, P]),
+    "mu_prep_weights_multi": (I, [P, I, L, P, I, P]),
     "mu_conv1x1_add_supported": (I, [I, I, I]),
     "mu_conv1x1_fwd_add": (I, [P, P, P, P, L, I, I, L, L, I, P]),
     "mu_maxpool2_bwd_acc": (I, [P, P, P, P, P, I, I, I, I, I, P]),

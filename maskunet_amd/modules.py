@@ -312,6 +312,22 @@ class UNet(_HipModule):
         """x: NHWC [B,H,W,32] (3 real channels) -> tuple of NHWC head outputs (padded channels)."""
         # x1, x2, x3 each feed a DownSample and, as skip tensors, an UpSample (:292-309): their two gradients are joined inside
         # the pool's backward kernel (ops.GradLink) instead of by three autograd accumulation kernels
+        if not (torch.is_grad_enabled() and self.training and ops.MULTI_PREP):
+            return self._forward_nhwc(x)
+        # training: every conv weight's compute layouts from ONE launch; each conv below consumes its one-shot entry, and whatever an
+        # exception leaves behind is dropped so that no later forward can pick up layouts of older weights
+        ws = self.__dict__.get("_conv_ws")
+        if ws is None:
+            ws = self.__dict__["_conv_ws"] = ([m.weight for m in self.modules() if isinstance(m, nn.Conv2d)], {})
+        first = self.initial_conv.conv_block[0].weight
+        ops.prep_conv_weights(ws[1], ws[0], x.dtype, fwd_only=() if x.requires_grad else (first,))
+        try:
+            return self._forward_nhwc(x)
+        finally:
+            for w in ws[0]:
+                w._mu_step = None
+
+    def _forward_nhwc(self, x):
         x1 = self.initial_conv.forward_nhwc(x)
         l1 = ops.grad_link(x1)
         x2 = self.downsample1.forward_nhwc(x1, skip_link=l1)

@@ -220,6 +220,60 @@ def _prep_weight_raw(w, dtype, rows_pad, cols_pad, mode):
     return dst.view(taps, rows_pad, cols_pad)
 
 
+# One launch for the layouts of ALL conv weights of a model at the start of a training forward (33 launches of 5-25 us otherwise; the
+# weights change every step, so a training forward cannot keep them).  Each weight gets a ONE-SHOT entry that the next _Conv.forward
+# on it consumes -- nothing survives the forward it was made for, so the no-stale-weights rule of the cache above holds here too.
+MULTI_PREP = os.environ.get("MU_MULTI_PREP", "1") != "0"
+
+
+def prep_conv_weights(holder, weights, dtype, fwd_only=()):
+    """weights: the conv Parameters (OIHW fp32) a forward is about to use, each once; fwd_only: those whose input needs no gradient
+    (forward layout only).  holder: a dict owned by the caller that keeps the device-side job table between calls."""
+    if not MULTI_PREP or not weights:
+        return
+    dev = weights[0].device
+    if dev.type != "cuda" or any(w.dtype != torch.float32 or not w.is_contiguous() or w.dim() != 4 for w in weights):
+        return
+    only = {id(w) for w in fwd_only}
+    key = (dtype, tuple(w.data_ptr() for w in weights), tuple(id(w) in only for w in weights))
+    plan = holder.get("plan")
+    if plan is None or plan[0] != key:
+        if torch.cuda.is_current_stream_capturing():
+            return                      # the table is an H2D copy: built by an eager forward (GraphedStep warms up eagerly)
+        rows, metas, off, chunk = [], [], 0, 0
+        for w in weights:
+            O, I, taps = w.shape[0], w.shape[1], w.shape[2] * w.shape[3]
+            rp, cp = pad32(O), pad32(I)
+            n = taps * rp * cp
+            mode = 0 if id(w) in only else 2
+            total = n if mode == 0 else 2 * n
+            rows.append([w.data_ptr(), off, chunk, O, I, taps, rp, cp, mode, 0])
+            metas.append((off, n, taps, rp, cp, mode))
+            off += total
+            chunk += (rp // 32) * (cp // 32)               # one block-iteration per 32 x 32 (out x in) tile
+        plan = holder["plan"] = (key, torch.tensor(rows, dtype=torch.int64, device=dev), metas, off, chunk)
+    _, table, metas, total, nchunks = plan
+    dst = torch.empty(total, dtype=dtype, device=dev)
+    call("mu_prep_weights_multi", ptr(table), len(weights), nchunks, ptr(dst), dt(dtype), stream())
+    for w, (off, n, taps, rp, cp, mode) in zip(weights, metas):
+        fwd = dst[off:off + n].view(taps, rp, cp)
+        wd = dst[off + n:off + 2 * n].view(taps, cp, rp) if mode == 2 else None
+        w._mu_step = (w._version, w.data_ptr(), dtype, fwd, wd)
+
+
+def _take_step_prep(w, dtype, taps, rows_pad, cols_pad, need_dgrad):
+    """The one-shot layouts prep_conv_weights made for this forward: (fwd, dgrad-or-None), or None."""
+    pre = getattr(w, "_mu_step", None)
+    if pre is None:
+        return None
+    w._mu_step = None
+    if pre[0] != w._version or pre[1] != w.data_ptr() or pre[2] != dtype or tuple(pre[3].shape) != (taps, rows_pad, cols_pad):
+        return None
+    if need_dgrad and pre[4] is None:
+        return None
+    return pre[3], pre[4]
+
+
 def _conv_raw(x, wprep, bias_p, Cout_p, taps, want_stats=False):
     """y = conv(x); with want_stats also the per-tile BatchNorm statistics rows of y ([rows, Cout_p, 2] floats) when the kernel
     serving this shape has a statistics epilogue (else None)."""
@@ -343,7 +397,10 @@ class _Conv(torch.autograd.Function):
             raise RuntimeError(f"conv: input has {Cin_p} (padded) channels, weight expects {I}")
         # the data-gradient layout is produced by the same launch when the backward will need it
         ctx.wd = None
-        if ctx.needs_input_grad[0]:
+        pre = _take_step_prep(weight, x.dtype, taps, Cout_p, Cin_p, ctx.needs_input_grad[0])
+        if pre is not None:
+            wprep, ctx.wd = pre[0], (pre[1] if ctx.needs_input_grad[0] else None)
+        elif ctx.needs_input_grad[0]:
             wprep, ctx.wd = _prep_weight(weight, x.dtype, Cout_p, Cin_p, 2)
         else:
             wprep = _prep_weight(weight, x.dtype, Cout_p, Cin_p, 0, cache_ok)

@@ -937,6 +937,77 @@ def check_grad_links_model(dtype, B=2):
             ("grad joins: same set of gradients", 0.0 if set(grads[0]) == set(grads[1]) else 1.0, 0.0)]
 
 
+def check_prep_weights_multi(dtype):
+    """mu_prep_weights_multi (one launch for many layers) == one mu_prep_weight call per layer, bit for bit; and a whole training step
+    with the one-launch path (ops.MULTI_PREP) gives bit-identical loss and gradients to the per-layer path."""
+    import maskunet_amd
+    from maskunet_amd import _lib, ops
+    gen = np.random.default_rng(5)
+    shapes = [(19, 3, 3), (64, 32, 3), (150, 64, 1), (96, 160, 3), (1, 32, 1), (512, 512, 3), (33, 65, 3)]
+    ws = [torch.nn.Parameter(_rnd(gen, O, I, k, k).to(DEV)) for (O, I, k) in shapes]
+    holder = {}
+    saved = ops.MULTI_PREP
+    out = []
+    try:
+        ops.MULTI_PREP = True
+        ops.prep_conv_weights(holder, ws, dtype, fwd_only=(ws[0], ws[4]))
+        bad = 0
+        for w, (O, I, k) in zip(ws, shapes):
+            taps, Op, Ip = k * k, (O + 31) // 32 * 32, (I + 31) // 32 * 32
+            need = w is not ws[0] and w is not ws[4]
+            pre = ops._take_step_prep(w, dtype, taps, Op, Ip, need)
+            if pre is None or (pre[1] is None) == need or getattr(w, "_mu_step", 1) is not None:
+                bad += 1
+                continue
+            ref = ops._prep_weight_raw(w, dtype, Op, Ip, 2)
+            if not torch.equal(pre[0], ref[0]) or (need and not torch.equal(pre[1], ref[1])):
+                bad += 1
+        out.append(("multi-layer weight prep == per-layer prep (layers that differ)", float(bad), 0.0))
+        # an entry is rejected when the weight changed after it was made, and when a data-gradient layout is needed but was not made
+        ops.prep_conv_weights(holder, ws, dtype, fwd_only=(ws[0], ws[4]))
+        with torch.no_grad():
+            ws[1].add_(1.0)
+        stale = ops._take_step_prep(ws[1], dtype, 9, 64, 32, True) is not None
+        nodg = ops._take_step_prep(ws[0], dtype, 9, 32, 32, True) is not None
+        out.append(("multi-layer prep: stale / insufficient entries rejected", float(stale) + float(nodg), 0.0))
+        for w in ws:
+            w._mu_step = None
+
+        torch.manual_seed(3)
+        model = maskunet_amd.UNet(3, 19, 16).to(DEV)
+        model.set_compute_dtype(dtype).train()
+        model.dropout.p = 0.0
+        B = 2
+        x = torch.from_numpy(gen.random((B, 3, 128, 128), dtype=np.float32)).to(DEV)
+        keeps = [torch.from_numpy(gen.integers(0, 2, (B, n)).astype(np.uint8)).to(DEV) for n in (4096, 1024, 256, 1024, 4096, 16384)]
+        labels = torch.from_numpy(gen.integers(0, 19, (B, 128, 128))).to(DEV)
+        res = []
+        for on in (True, False):
+            ops.MULTI_PREP = on
+            model.set_keep_masks(keeps)
+            for bn in [m for m in model.modules() if isinstance(m, torch.nn.BatchNorm2d)]:
+                bn.reset_running_stats()
+            calls = []
+            _lib.PROBE = {"pred": lambda name, a: (calls.append(name) or False) if name.startswith("mu_prep_weight") else False, "events": []}
+            try:
+                sem, bnd, emb = model(x)
+                loss = F.cross_entropy(sem, labels) + bnd.float().mean() + emb.float().square().mean()
+                loss.backward()
+            finally:
+                _lib.PROBE = None
+            res.append((loss.detach().clone(), {n: p.grad.clone() for n, p in model.named_parameters() if p.grad is not None}, calls))
+            model.zero_grad(set_to_none=True)
+        same = torch.equal(res[0][0], res[1][0]) and set(res[0][1]) == set(res[1][1]) and all(torch.equal(res[0][1][k], res[1][1][k]) for k in res[1][1])
+        out.append(("one-launch prep: loss and every gradient bit-identical to the per-layer path", 0.0 if same else 1.0, 0.0))
+        out.append(("one-launch prep: weight-layout launches in a 3-head training step (per-layer path: %d)" % len(res[1][2]),
+                    float(len(res[0][2])), 1.0))
+        left = sum(1 for m in model.modules() if isinstance(m, torch.nn.Conv2d) and getattr(m.weight, "_mu_step", None) is not None)
+        out.append(("one-launch prep: no entry survives the forward", float(left), 0.0))
+    finally:
+        ops.MULTI_PREP = saved
+    return out
+
+
 def check_resize_u8():
     """mu_resize_u8_nhwc / mu_resize_nearest_u8 against the committed fixture (tests/golden/resize_cases.npz) and the live numpy
     restatement of cv2.resize: the resized BYTES bit for bit, the [0,1] activations exactly byte/255, BGR->RGB, zero channel padding;

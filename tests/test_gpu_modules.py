@@ -74,6 +74,12 @@ def test_eval_mode_batchnorm_folded_into_conv_epilogue(dtype):
     _assert_all(G.check_eval_fused(dtype))
 
 
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_one_launch_weight_prep_is_bit_identical(dtype):
+    from tests import _gpu_checks as G
+    _assert_all(G.check_prep_weights_multi(dtype))
+
+
 def test_unet_3head_vs_oracle():
     from tests import _gpu_checks as G
     _assert_all(G.check_unet_vs_oracle(torch.float32, B=2, c_out=19, three_head=True, seed=400))
