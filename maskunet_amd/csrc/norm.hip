@@ -91,13 +91,21 @@ __global__ __launch_bounds__(256, MODE == 1 ? MU_BN_OCC1 : 1) void bn_partial_ke
                     const long rr = r + (long)u * rpi;
                     Vec16<T> dz;
 #pragma unroll
-                    for (int i = 0; i < N; ++i) {
-                        const float xh = (xv[u].get(i) - mu[i]) * rs[i];
-                        const float pre = fmaf(xh, ga[i], be[i]) + (res ? rv[u].get(i) : 0.f);
-                        dz.set(i, gv[u].get(i) * mu_act_grad_t<FAST>(pre, act));
-                        const float d = dz.get(i);       // the value the apply pass will re-read (rounded to T)
-                        f0[i] += d;
-                        f1[i] = fmaf(d, xh, f1[i]);
+                    for (int i = 0; i < N; i += 2) {
+                        float xh[2], pre[2], ag[2];
+#pragma unroll
+                        for (int e = 0; e < 2; ++e) {
+                            xh[e] = (xv[u].get(i + e) - mu[i + e]) * rs[i + e];
+                            pre[e] = fmaf(xh[e], ga[i + e], be[i + e]) + (res ? rv[u].get(i + e) : 0.f);
+                        }
+                        mu_act_grad2_t<FAST>(pre[0], pre[1], act, ag[0], ag[1]);
+#pragma unroll
+                        for (int e = 0; e < 2; ++e) {
+                            dz.set(i + e, gv[u].get(i + e) * ag[e]);
+                            const float d = dz.get(i + e);       // the value the apply pass will re-read (rounded to T)
+                            f0[i + e] += d;
+                            f1[i + e] = fmaf(d, xh[e], f1[i + e]);
+                        }
                     }
                     if (dzbuf && rr < r1) dz.store(dzbuf + rr * ld + c);
                 }
@@ -223,9 +231,13 @@ __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const T* __restrict__ x
             if (idx + u * stride < total) {
                 Vec16<T> o;
 #pragma unroll
-                for (int i = 0; i < N; ++i) {
-                    const float pre = fmaf(xv[u].get(i), a[i], b[i]) + (res ? rv[u].get(i) : 0.f);
-                    o.set(i, mu_act_t<FAST>(pre, act));
+                for (int i = 0; i < N; i += 2) {
+                    const float p0 = fmaf(xv[u].get(i), a[i], b[i]) + (res ? rv[u].get(i) : 0.f);
+                    const float p1 = fmaf(xv[u].get(i + 1), a[i + 1], b[i + 1]) + (res ? rv[u].get(i + 1) : 0.f);
+                    float o0, o1;
+                    mu_act2_t<FAST>(p0, p1, act, o0, o1);
+                    o.set(i, o0);
+                    o.set(i + 1, o1);
                 }
                 o.store(y + (r + u * rstep) * ld + c);
             }
@@ -276,15 +288,20 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
             if (idx + u * stride < total) {
                 Vec16<T> o;
 #pragma unroll
-                for (int i = 0; i < N; ++i) {
-                    float d = dz[u].get(i);
+                for (int i = 0; i < N; i += 2) {
+                    float d[2] = {dz[u].get(i), dz[u].get(i + 1)};
                     if (RECOMP) {
                         Vec16<T> t;                         // round dz to T exactly like the statistics sweep did
-                        const float xh = (xv[u].get(i) - mu[i]) * rsv[i];
-                        t.set(i, d * mu_act_grad_t<FAST>(fmaf(xh, ga[i], be[i]), act));
-                        d = t.get(i);
+                        const float xh0 = (xv[u].get(i) - mu[i]) * rsv[i], xh1 = (xv[u].get(i + 1) - mu[i + 1]) * rsv[i + 1];
+                        float ag[2];
+                        mu_act_grad2_t<FAST>(fmaf(xh0, ga[i], be[i]), fmaf(xh1, ga[i + 1], be[i + 1]), act, ag[0], ag[1]);
+                        t.set(i, d[0] * ag[0]);
+                        t.set(i + 1, d[1] * ag[1]);
+                        d[0] = t.get(i);
+                        d[1] = t.get(i + 1);
                     }
-                    o.set(i, fmaf(gr[i], d, fmaf(k1[i], xv[u].get(i), k0[i])));
+                    o.set(i, fmaf(gr[i], d[0], fmaf(k1[i], xv[u].get(i), k0[i])));
+                    o.set(i + 1, fmaf(gr[i + 1], d[1], fmaf(k1[i + 1], xv[u].get(i + 1), k0[i + 1])));
                 }
                 o.store(dx + (r + u * rstep) * ld + c);
             }
