@@ -11,6 +11,74 @@
 // backward: dlogits = (softmax - onehot) * gscale / count  (0 for ignored rows and for the channel padding).
 // ------------------------------------------------------------------------------------------
 #define CE_MAXBLK 1024
+#ifndef MU_CE_U2
+#define MU_CE_U2 4
+#endif
+
+// Rows of up to 3 * 128 channels are held in registers (one read of the logits; the two-pass form re-reads every row from L2 with a
+// single load in flight per lane and ran at 1.5 TB/s); several rows per lane group per iteration keep more loads in flight.  Branch-free:
+// padding channels enter as -inf (exp -> 0) and the target logit is fetched by address (the conditional per-element form compiled to an
+// exec-mask branch per element and ~60 VALU cycles per logit: 162 us for the 64 x 128 x 128 x 150 logits of the bench, 2 TB/s).
+template <typename T, int NV, int U>
+__device__ __forceinline__ void ce_rows_in_regs(const T* __restrict__ logits, const long* __restrict__ labels, long M, int Cp, int C,
+                                                long ignore_index, float* __restrict__ lse_out, double& loss, double& cnt, int l16, int rowl) {
+    constexpr int VN = Vec16<T>::N;
+    for (long r0 = (long)blockIdx.x * (16 * U); r0 < M; r0 += (long)gridDim.x * (16 * U)) {
+        Vec16<T> v[U][NV];
+        long lab[U];
+        bool ok[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const long r = r0 + u * 16 + rowl;
+            ok[u] = r < M;
+            const long rr = ok[u] ? r : M - 1;
+            lab[u] = labels[rr];
+#pragma unroll
+            for (int k = 0; k < NV; ++k) {
+                const int c = (k * 16 + l16) * VN;
+                if (k + 1 < NV || c < Cp) v[u][k].load(logits + rr * Cp + c);      // only the last vector of a row can lie past Cp
+                else v[u][k].zero();
+            }
+        }
+        // the target logit: one more (L2-resident, lane-group-uniform) load per row instead of a compare + select + add per element
+        float tgt[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const long r = r0 + u * 16 + rowl;
+            const long rr = r < M ? r : M - 1;
+            tgt[u] = (lab[u] >= 0 && lab[u] < C) ? (float)logits[rr * Cp + lab[u]] : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            float f[NV * VN];
+            float mx = -INFINITY;
+#pragma unroll
+            for (int k = 0; k < NV; ++k) {
+                const int c = (k * 16 + l16) * VN;
+                const bool whole = (k + 1) * 16 * VN <= C;                  // uniform: every lane's channels of this vector are real
+#pragma unroll
+                for (int i = 0; i < VN; ++i) {
+                    const float x = v[u][k].get(i);
+                    f[k * VN + i] = (whole || c + i < C) ? x : -INFINITY;    // channel padding: exp -> 0
+                    mx = fmaxf(mx, f[k * VN + i]);
+                }
+            }
+#pragma unroll
+            for (int o = 1; o < 16; o <<= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+            const float nmx = -mx * 1.4426950408889634f;
+            float se = 0.f;
+#pragma unroll
+            for (int j = 0; j < NV * VN; ++j) se += __builtin_amdgcn_exp2f(fmaf(f[j], 1.4426950408889634f, nmx));
+#pragma unroll
+            for (int o = 1; o < 16; o <<= 1) se += __shfl_xor(se, o);
+            const float lse = mx + __logf(se);
+            if (ok[u] && l16 == 0) {
+                lse_out[r0 + u * 16 + rowl] = lse;
+                if (lab[u] != ignore_index) { loss += (double)(lse - tgt[u]); cnt += 1.0; }
+            }
+        }
+    }
+}
 
 template <typename T>
 __global__ __launch_bounds__(256) void ce_fwd_kernel(const T* __restrict__ logits, const long* __restrict__ labels, long M, int Cp,
@@ -18,61 +86,12 @@ __global__ __launch_bounds__(256) void ce_fwd_kernel(const T* __restrict__ logit
     constexpr int VN = Vec16<T>::N;
     const int tid = threadIdx.x, l16 = tid & 15, rowl = tid >> 4;
     double loss = 0.0, cnt = 0.0;
-    // Rows of up to 3 * 128 channels are held in registers (one read of the logits; the two-pass form below re-read every row from
-    // L2 with a single load in flight per lane and ran at 1.5 TB/s); two rows per lane group per iteration keep more loads in flight.
-    constexpr int NVMAX = 3;
     const int nv = (Cp + 16 * VN - 1) / (16 * VN);
-    if (nv <= NVMAX) {
-        for (long r0 = (long)blockIdx.x * 32; r0 < M; r0 += (long)gridDim.x * 32) {
-            Vec16<T> v[2][NVMAX];
-            long lab[2];
-            bool ok[2];
-#pragma unroll
-            for (int u = 0; u < 2; ++u) {
-                const long r = r0 + u * 16 + rowl;
-                ok[u] = r < M;
-                const long rr = ok[u] ? r : M - 1;
-                lab[u] = labels[rr];
-#pragma unroll
-                for (int k = 0; k < NVMAX; ++k) {
-                    const int c = (k * 16 + l16) * VN;
-                    if (k < nv && c < Cp) v[u][k].load(logits + rr * Cp + c);
-                    else v[u][k].zero();
-                }
-            }
-#pragma unroll
-            for (int u = 0; u < 2; ++u) {
-                float mx = -INFINITY;
-#pragma unroll
-                for (int k = 0; k < NVMAX; ++k) {
-                    const int c = (k * 16 + l16) * VN;
-#pragma unroll
-                    for (int i = 0; i < VN; ++i) if (k < nv && c + i < C) mx = fmaxf(mx, v[u][k].get(i));
-                }
-#pragma unroll
-                for (int o = 1; o < 16; o <<= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
-                float se = 0.f, tgt = 0.f;
-#pragma unroll
-                for (int k = 0; k < NVMAX; ++k) {
-                    const int c = (k * 16 + l16) * VN;
-#pragma unroll
-                    for (int i = 0; i < VN; ++i) {
-                        if (k < nv && c + i < C) {
-                            se += __expf(v[u][k].get(i) - mx);
-                            if (c + i == lab[u]) tgt = v[u][k].get(i);
-                        }
-                    }
-                }
-#pragma unroll
-                for (int o = 1; o < 16; o <<= 1) { se += __shfl_xor(se, o); tgt += __shfl_xor(tgt, o); }
-                const float lse = mx + __logf(se);
-                if (ok[u] && l16 == 0) {
-                    lse_out[r0 + u * 16 + rowl] = lse;
-                    if (lab[u] != ignore_index) { loss += (double)(lse - tgt); cnt += 1.0; }
-                }
-            }
-        }
-    } else
+    // U rows per 16-lane group and iteration: the bytes in flight per wave (one exposed memory round trip per iteration)
+    if (nv == 1) ce_rows_in_regs<T, 1, 4>(logits, labels, M, Cp, C, ignore_index, lse_out, loss, cnt, l16, rowl);
+    else if (nv == 2) ce_rows_in_regs<T, 2, MU_CE_U2>(logits, labels, M, Cp, C, ignore_index, lse_out, loss, cnt, l16, rowl);
+    else if (nv == 3) ce_rows_in_regs<T, 3, 2>(logits, labels, M, Cp, C, ignore_index, lse_out, loss, cnt, l16, rowl);
+    else
     for (long r0 = (long)blockIdx.x * 16; r0 < M; r0 += (long)gridDim.x * 16) {
         const long r = r0 + rowl;
         const bool ok = r < M;
