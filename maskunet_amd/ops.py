@@ -235,7 +235,7 @@ def prep_conv_weights(holder, weights, dtype, fwd_only=()):
     if dev.type != "cuda" or any(w.dtype != torch.float32 or not w.is_contiguous() or w.dim() != 4 for w in weights):
         return
     only = {id(w) for w in fwd_only}
-    key = (dtype, tuple(w.data_ptr() for w in weights), tuple(id(w) in only for w in weights))
+    key = (dtype, tuple((w.data_ptr(), tuple(w.shape)) for w in weights), tuple(id(w) in only for w in weights))
     plan = holder.get("plan")
     if plan is None or plan[0] != key:
         if torch.cuda.is_current_stream_capturing():
