@@ -356,11 +356,19 @@ extern "C" int mu_maxpool2_bwd(const void* x, const void* dy, void* dx, int B, i
 // src = dst * (in-1)/(out-1)  (aten area_pixel_compute_source_index, align_corners branch)
 // ------------------------------------------------------------------------------------------
 __device__ __forceinline__ void lerp_axis(int d, float scale, int n_in, int& i0, int& i1, float& f) {
-    float s = scale * (float)d;
-    i0 = (int)s;
+#pragma clang fp contract(off)                                // rounded product, rounded difference: no FMA contraction, so that every
+    float s = scale * (float)d;                               // kernel of this op (and the CPU reference) sees the same weight
+    i0 = (int)s;                                              // (__fmul_rn / __fsub_rn are plain operators in HIP: they contract)
     if (i0 > n_in - 1) i0 = n_in - 1;
     i1 = i0 + (i0 < n_in - 1 ? 1 : 0);
     f = s - (float)i0;
+}
+
+__device__ __forceinline__ float lerp2(float a00, float a01, float a10, float a11, float fh, float fw) {
+#pragma clang fp contract(off)
+    const float r0 = a00 * (1.f - fh) + a10 * fh;
+    const float r1 = a01 * (1.f - fh) + a11 * fh;
+    return r0 * (1.f - fw) + r1 * fw;
 }
 
 template <typename T>
@@ -387,10 +395,9 @@ __global__ __launch_bounds__(256) void upcat_fwd_kernel(const T* __restrict__ x,
             a10.load(xb + ((long)h1 * w + w0) * Cx); a11.load(xb + ((long)h1 * w + w1) * Cx);
 #pragma unroll
             for (int i = 0; i < N; ++i) {
-                // same association as the oracle: rows first (over h), then columns
-                float r0 = a00.get(i) * (1.f - fh) + a10.get(i) * fh;
-                float r1 = a01.get(i) * (1.f - fh) + a11.get(i) * fh;
-                o.set(i, r0 * (1.f - fw) + r1 * fw);
+                // same association as the oracle: rows first (over h), then columns; products and sums rounded separately (no FMA
+                // contraction), as the reference's CPU kernel does -- and so that every kernel of this op gives the same bits
+                o.set(i, lerp2(a00.get(i), a01.get(i), a10.get(i), a11.get(i), fh, fw));
             }
         }
         o.store(y + p * Ct + c);
@@ -465,6 +472,166 @@ __global__ __launch_bounds__(256) void upcat_bwd_kernel(const T* __restrict__ dy
     }
 }
 
+// Row-per-block forms of the two kernels above (the UNet's shapes: 256 % (channels / vector) == 0).  The element-per-thread forms pay
+// three 64-bit divisions per 16-byte vector and keep ONE load per lane in flight (2.4 / 1.9 TB/s on the 128 x 128 decoder level, the
+// gradient gather walking its 6 x 6 candidate window with a divergent `continue` per tap).  Here a block owns one output row (forward, skip
+// gradient) or one input row (upsample gradient): the row interpolation is block-uniform, a lane's channel vector is fixed, pixels advance
+// by a constant, and every load of an iteration is issued before the first use.  Same arithmetic per element -> bit-identical results.
+#ifndef MU_UPCAT_ROWS
+#define MU_UPCAT_ROWS 1
+#endif
+template <typename T, int U>
+__global__ __launch_bounds__(256) void upcat_fwd_rows_kernel(const T* __restrict__ x, const T* __restrict__ skip, T* __restrict__ y,
+                                                             int B, int h, int w, int Cx, int Cs) {
+    constexpr int N = Vec16<T>::N;
+    const int Ho = 2 * h, Wo = 2 * w, Ct = Cx + Cs, cv = Ct / N;
+    const float sh = h > 1 ? (float)(h - 1) / (float)(Ho - 1) : 0.f, sw = w > 1 ? (float)(w - 1) / (float)(Wo - 1) : 0.f;
+    const int ppi = 256 / cv;                                  // pixels per block-iteration
+    const int vi = threadIdx.x % cv, pl = threadIdx.x / cv, c = vi * N;
+    for (int row = blockIdx.x; row < B * Ho; row += gridDim.x) {
+        const int ho = row % Ho, b = row / Ho;
+        int h0, h1; float fh;
+        lerp_axis(ho, sh, h, h0, h1, fh);
+        const T* srow = skip + (long)row * Wo * Cs + c;
+        const T* x0 = x + ((long)b * h + h0) * w * Cx + (c - Cs);
+        const T* x1 = x + ((long)b * h + h1) * w * Cx + (c - Cs);
+        T* yrow = y + (long)row * Wo * Ct + c;
+        for (int wb = pl; wb < Wo; wb += U * ppi) {
+            if (c < Cs) {
+                Vec16<T> v[U];
+#pragma unroll
+                for (int u = 0; u < U; ++u) if (wb + u * ppi < Wo) v[u].load(srow + (long)(wb + u * ppi) * Cs);
+#pragma unroll
+                for (int u = 0; u < U; ++u) if (wb + u * ppi < Wo) v[u].store(yrow + (long)(wb + u * ppi) * Ct);
+            } else {
+                Vec16<T> a00[U], a01[U], a10[U], a11[U];
+                float fw[U];
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const int wo = wb + u * ppi;
+                    if (wo < Wo) {
+                        int w0, w1;
+                        lerp_axis(wo, sw, w, w0, w1, fw[u]);
+                        a00[u].load(x0 + (long)w0 * Cx); a01[u].load(x0 + (long)w1 * Cx);
+                        a10[u].load(x1 + (long)w0 * Cx); a11[u].load(x1 + (long)w1 * Cx);
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const int wo = wb + u * ppi;
+                    if (wo < Wo) {
+                        Vec16<T> o;
+#pragma unroll
+                        for (int i = 0; i < N; ++i) {
+                            o.set(i, lerp2(a00[u].get(i), a01[u].get(i), a10[u].get(i), a11[u].get(i), fh, fw[u]));
+                        }
+                        o.store(yrow + (long)wo * Ct);
+                    }
+                }
+            }
+        }
+    }
+}
+
+// blocks [0, B*Ho): one output row of dskip each; blocks [B*Ho, B*Ho + B*h): one input row of dx each
+template <typename T>
+__global__ __launch_bounds__(256) void upcat_bwd_rows_kernel(const T* __restrict__ dy, const T* __restrict__ dy2, T* __restrict__ dx,
+                                                             T* __restrict__ dskip, int B, int h, int w, int Cx, int Cs) {
+    constexpr int N = Vec16<T>::N;
+    const int Ho = 2 * h, Wo = 2 * w, Ct = Cx + Cs;
+    const float sh = h > 1 ? (float)(h - 1) / (float)(Ho - 1) : 0.f, sw = w > 1 ? (float)(w - 1) / (float)(Wo - 1) : 0.f;
+    if ((int)blockIdx.x < B * Ho) {
+        constexpr int U = 4;
+        const int cvs = Cs / N, ppi = 256 / cvs;
+        const int c = (threadIdx.x % cvs) * N, pl = threadIdx.x / cvs;
+        const long row = blockIdx.x;
+        const T* g1 = dy + row * Wo * Ct + c;
+        const T* g2 = dy2 ? dy2 + row * Wo * Ct + c : nullptr;
+        T* o = dskip + row * Wo * Cs + c;
+        for (int wb = pl; wb < Wo; wb += U * ppi) {
+            Vec16<T> v[U], v2[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+                if (wb + u * ppi < Wo) {
+                    v[u].load(g1 + (long)(wb + u * ppi) * Ct);
+                    if (g2) v2[u].load(g2 + (long)(wb + u * ppi) * Ct);
+                }
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+                if (wb + u * ppi < Wo) {
+                    if (g2) {
+#pragma unroll
+                        for (int i = 0; i < N; ++i) v[u].set(i, v[u].get(i) + v2[u].get(i));
+                    }
+                    v[u].store(o + (long)(wb + u * ppi) * Cs);
+                }
+        }
+        return;
+    }
+    const int rowx = blockIdx.x - B * Ho;
+    const int hi = rowx % h, b = rowx / h;
+    const int cvx = Cx / N, ppi = 256 / cvx;
+    const int c = (threadIdx.x % cvx) * N, pl = threadIdx.x / cvx;
+    // destination rows whose source interval touches hi lie within [2hi-2, 2hi+3]: their weights are block-uniform
+    float wh[6];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+        const int ho = 2 * hi - 2 + k;
+        wh[k] = 0.f;
+        if (ho >= 0 && ho < Ho) {
+            int h0, h1; float fh;
+            lerp_axis(ho, sh, h, h0, h1, fh);
+            wh[k] = (h0 == hi ? 1.f - fh : 0.f) + (h1 == hi ? fh : 0.f);
+            if (h0 == hi && h1 == hi) wh[k] = 1.f;
+        }
+    }
+    for (int wi = pl; wi < w; wi += ppi) {
+        float ww[6];
+#pragma unroll
+        for (int k = 0; k < 6; ++k) {
+            const int wo = 2 * wi - 2 + k;
+            ww[k] = 0.f;
+            if (wo >= 0 && wo < Wo) {
+                int w0, w1; float fw;
+                lerp_axis(wo, sw, w, w0, w1, fw);
+                ww[k] = (w0 == wi ? 1.f - fw : 0.f) + (w1 == wi ? fw : 0.f);
+                if (w0 == wi && w1 == wi) ww[k] = 1.f;
+            }
+        }
+        float acc[N];
+#pragma unroll
+        for (int i = 0; i < N; ++i) acc[i] = 0.f;
+        for (int kr = 0; kr < 6; ++kr) {                      // (uniform) rows in ascending order, columns ascending: the order of the loops above
+            if (wh[kr] == 0.f) continue;
+            const int ho = 2 * hi - 2 + kr;
+            const long rbase = (((long)b * Ho + ho) * Wo) * Ct + Cs + c;
+            Vec16<T> g[6], g2v[6];
+#pragma unroll
+            for (int k = 0; k < 6; ++k)
+                if (ww[k] != 0.f) {
+                    g[k].load(dy + rbase + (long)(2 * wi - 2 + k) * Ct);
+                    if (dy2) g2v[k].load(dy2 + rbase + (long)(2 * wi - 2 + k) * Ct);
+                }
+#pragma unroll
+            for (int k = 0; k < 6; ++k)
+                if (ww[k] != 0.f) {
+                    const float wt = wh[kr] * ww[k];
+                    if (dy2) {
+#pragma unroll
+                        for (int i = 0; i < N; ++i) acc[i] += wt * (g[k].get(i) + g2v[k].get(i));
+                    } else {
+#pragma unroll
+                        for (int i = 0; i < N; ++i) acc[i] += wt * g[k].get(i);
+                    }
+                }
+        }
+        Vec16<T> o;
+#pragma unroll
+        for (int i = 0; i < N; ++i) o.set(i, acc[i]);
+        o.store(dx + (((long)b * h + hi) * w + wi) * Cx + c);
+    }
+}
+
 // Compacting variants for channel counts that are not multiples of the 32-channel padding (stand-alone UpSample with any
 // channel counts, ade_semantic.py:231-256): x has Cxv valid of Cxl stored channels, skip Csv of Csl; the output row is
 // [skip valid | up valid | zeros] with Ctl stored channels.  One element per thread (not a hot path: inside the UNet every
@@ -489,8 +656,7 @@ __global__ __launch_bounds__(256) void upcat_compact_fwd_kernel(const T* __restr
             const T* xb = x + (long)b * h * w * Cxl + (c - Csv);
             float a00 = (float)xb[((long)h0 * w + w0) * Cxl], a01 = (float)xb[((long)h0 * w + w1) * Cxl];
             float a10 = (float)xb[((long)h1 * w + w0) * Cxl], a11 = (float)xb[((long)h1 * w + w1) * Cxl];
-            float r0 = a00 * (1.f - fh) + a10 * fh, r1 = a01 * (1.f - fh) + a11 * fh;
-            o = r0 * (1.f - fw) + r1 * fw;
+            o = lerp2(a00, a01, a10, a11, fh, fw);
         }
         y[idx] = (T)o;
     }
@@ -577,7 +743,11 @@ extern "C" int mu_upcat_fwd(const void* x, const void* skip, void* y, int B, int
         upcat_fwd_kernel<float><<<ew_grid(total), 256, 0, st>>>((const float*)x, (const float*)skip, (float*)y, B, h, w, Cx, Cs);
     } else if (dtype == MU_F16) {
         long total = (long)B * 4 * h * w * ((Cx + Cs) / 8);
-        upcat_fwd_kernel<h16><<<ew_grid(total), 256, 0, st>>>((const h16*)x, (const h16*)skip, (h16*)y, B, h, w, Cx, Cs);
+        const int cv = (Cx + Cs) / 8;
+        if (MU_UPCAT_ROWS && cv <= 256 && 256 % cv == 0 && (long)B * 2 * h < (1 << 30))
+            upcat_fwd_rows_kernel<h16, 4><<<B * 2 * h < 16384 ? B * 2 * h : 16384, 256, 0, st>>>((const h16*)x, (const h16*)skip, (h16*)y, B, h, w, Cx, Cs);
+        else
+            upcat_fwd_kernel<h16><<<ew_grid(total), 256, 0, st>>>((const h16*)x, (const h16*)skip, (h16*)y, B, h, w, Cx, Cs);
     } else return MU_ERR_ARG;
     MU_CHECK_LAUNCH();
     return MU_OK;
@@ -592,7 +762,11 @@ extern "C" int mu_upcat_bwd_acc(const void* dy, const void* dy2, void* dx, void*
         upcat_bwd_kernel<float><<<ew_grid(total), 256, 0, st>>>((const float*)dy, (const float*)dy2, (float*)dx, (float*)dskip, B, h, w, Cx, Cs);
     } else if (dtype == MU_F16) {
         long total = (long)B * 4 * h * w * (Cs / 8) + (long)B * h * w * (Cx / 8);
-        upcat_bwd_kernel<h16><<<ew_grid(total), 256, 0, st>>>((const h16*)dy, (const h16*)dy2, (h16*)dx, (h16*)dskip, B, h, w, Cx, Cs);
+        const int cvs = Cs / 8, cvx = Cx / 8;
+        if (MU_UPCAT_ROWS && cvs <= 256 && 256 % cvs == 0 && cvx <= 256 && 256 % cvx == 0 && (long)B * 3 * h < (1 << 30))
+            upcat_bwd_rows_kernel<h16><<<B * 3 * h, 256, 0, st>>>((const h16*)dy, (const h16*)dy2, (h16*)dx, (h16*)dskip, B, h, w, Cx, Cs);
+        else
+            upcat_bwd_kernel<h16><<<ew_grid(total), 256, 0, st>>>((const h16*)dy, (const h16*)dy2, (h16*)dx, (h16*)dskip, B, h, w, Cx, Cs);
     } else return MU_ERR_ARG;
     MU_CHECK_LAUNCH();
     return MU_OK;
@@ -827,8 +1001,10 @@ extern "C" int mu_prep_qkv(const float* wq, const float* wk, const float* wv, co
 // (x / 255, channel-padded with zeros), optionally with channels 0 and 2 swapped (BGR -> RGB).
 // ------------------------------------------------------------------------------------------
 __device__ __forceinline__ void cv_lin_coef(int d, double scale, int sn, bool clamp_taps, int& s, int& c0, int& c1) {
-    // two separately rounded double operations, as the host code this restates runs them (no fused multiply-add contraction)
-    float f = (float)__dadd_rn(__dmul_rn((double)d + 0.5, scale), -0.5);
+    // two separately rounded double operations, as the host code this restates runs them: no fused multiply-add contraction (HIP's
+    // __dmul_rn / __dadd_rn are plain operators and would contract)
+#pragma clang fp contract(off)
+    float f = (float)(((double)d + 0.5) * scale - 0.5);
     int si = (int)floorf(f);
     f -= (float)si;
     if (clamp_taps) {
