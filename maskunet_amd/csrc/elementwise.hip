@@ -171,8 +171,9 @@ extern "C" int mu_prep_weight(const float* w_oihw, void* dst, int dtype, int O, 
 // each otherwise).  `jobs` is a device array of MU_PREP_JOB_FIELDS int64 per layer:
 //   { w (address of the OIHW fp32 weight), dst_off (elements from dst_base), first_tile, O, I, taps, rows_pad, cols_pad, mode, 0 }
 // A block moves one 32 (out) x 32 (in) x taps tile through LDS: the OIHW rows are read as contiguous 32*taps-float runs, both layouts
-// are written as 32-element runs (the per-layer kernel above gathers with a stride of `taps` floats: 156 us for the UNet's 36 layers
-// when simply batched into one launch).  Tiles [first_tile, first_tile + rows_pad/32 * cols_pad/32) belong to the layer.
+// are written as 16-byte vectors of 32-element runs (the per-layer kernel above gathers with a stride of `taps` floats and stores single
+// elements: 156 us for the UNet's 36 layers when simply batched into one launch, 120 us tiled with 2-byte stores, 77 us with 16-byte
+// stores).  Tiles [first_tile, first_tile + rows_pad/32 * cols_pad/32) belong to the layer.
 #define MU_PREP_JOB_FIELDS 10
 #define MU_PREP_MAX_JOBS 128
 template <typename T>
@@ -196,6 +197,7 @@ __global__ __launch_bounds__(256) void prep_weights_multi_kernel(const long* __r
         const int rel = (int)(tl - J[2]);
         const int o0 = (rel / tcols) * TS, i0 = (rel % tcols) * TS;
         const int run = TS * taps;                             // floats of one output channel's 32 input channels: contiguous in OIHW
+#pragma unroll 4
         for (int k = threadIdx.x; k < TS * run; k += 256) {
             const int ol = k / run, rem = k - ol * run;
             const int o = o0 + ol, i = i0 + rem / taps;
@@ -203,16 +205,23 @@ __global__ __launch_bounds__(256) void prep_weights_multi_kernel(const long* __r
         }
         __syncthreads();
         const long n = (long)taps * rows_pad * cols_pad;
+        constexpr int VN = 16 / (int)sizeof(T), VPR = TS / VN;  // 16-byte stores: VN elements, VPR vectors per 32-element run
         if (mode != 1)                                         // forward block [tap][out][in]
-            for (int k = threadIdx.x; k < taps * TS * TS; k += 256) {
-                const int il = k & 31, ol = (k >> 5) & 31, t = k >> 10;
-                dst[((long)t * rows_pad + o0 + ol) * cols_pad + i0 + il] = (T)tile[ol * LD + il * taps + t];
+            for (int k = threadIdx.x; k < taps * TS * VPR; k += 256) {
+                const int iv = k % VPR, ol = (k / VPR) & 31, t = k / (VPR * TS);
+                Vec16<T> v;
+#pragma unroll
+                for (int e = 0; e < VN; ++e) v.set(e, tile[ol * LD + (iv * VN + e) * taps + t]);
+                v.store(dst + ((long)t * rows_pad + o0 + ol) * cols_pad + i0 + iv * VN);
             }
         if (mode != 0) {                                       // data-gradient block [taps-1-tap][in][out]
             T* d1 = mode == 2 ? dst + n : dst;
-            for (int k = threadIdx.x; k < taps * TS * TS; k += 256) {
-                const int ol = k & 31, il = (k >> 5) & 31, t = k >> 10;
-                d1[((long)(taps - 1 - t) * cols_pad + i0 + il) * rows_pad + o0 + ol] = (T)tile[ol * LD + il * taps + t];
+            for (int k = threadIdx.x; k < taps * TS * VPR; k += 256) {
+                const int ov = k % VPR, il = (k / VPR) & 31, t = k / (VPR * TS);
+                Vec16<T> v;
+#pragma unroll
+                for (int e = 0; e < VN; ++e) v.set(e, tile[(ov * VN + e) * LD + il * taps + t]);
+                v.store(d1 + ((long)(taps - 1 - t) * cols_pad + i0 + il) * rows_pad + o0 + ov * VN);
             }
         }
         __syncthreads();
