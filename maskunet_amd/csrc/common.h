@@ -27,6 +27,8 @@ template <> struct Vec16<float> {
     float4 v;
     __device__ __forceinline__ void load(const float* p) { v = *reinterpret_cast<const float4*>(p); }
     __device__ __forceinline__ void store(float* p) const { *reinterpret_cast<float4*>(p) = v; }
+    __device__ __forceinline__ void load_nt(const float* p) { load(p); }
+    __device__ __forceinline__ void store_nt(float* p) const { store(p); }
     __device__ __forceinline__ float get(int i) const { return reinterpret_cast<const float*>(&v)[i]; }
     __device__ __forceinline__ void set(int i, float f) { reinterpret_cast<float*>(&v)[i] = f; }
     __device__ __forceinline__ void zero() { v = make_float4(0.f, 0.f, 0.f, 0.f); }
@@ -36,6 +38,8 @@ template <> struct Vec16<h16> {
     h16x8 v;
     __device__ __forceinline__ void load(const h16* p) { v = *reinterpret_cast<const h16x8*>(p); }
     __device__ __forceinline__ void store(h16* p) const { *reinterpret_cast<h16x8*>(p) = v; }
+    __device__ __forceinline__ void load_nt(const h16* p) { v = __builtin_nontemporal_load(reinterpret_cast<const h16x8*>(p)); }
+    __device__ __forceinline__ void store_nt(h16* p) const { __builtin_nontemporal_store(v, reinterpret_cast<h16x8*>(p)); }
     __device__ __forceinline__ float get(int i) const { return (float)v[i]; }
     __device__ __forceinline__ void set(int i, float f) { v[i] = (h16)f; }
     __device__ __forceinline__ void zero() { v = (h16x8)(h16)0; }

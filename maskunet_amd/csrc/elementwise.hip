@@ -3,6 +3,11 @@
 // nn.MaxPool2d(2) (:216), nn.Upsample(bilinear, align_corners=True) + torch.cat (:235,250-253),
 // nn.Dropout(0.3) (:273,304,307), and the OIHW<->tap-major weight re-layouts of this build.
 #include "common.h"
+// Nontemporal loads for operands a kernel reads exactly once (`nt`: past the CU's L1, L2-served): see norm.hip MU_BN_NT.
+#ifndef MU_EW_NT
+#define MU_EW_NT 1
+#endif
+#define EW_LD(vec, ptr_) do { if (MU_EW_NT) (vec).load_nt(ptr_); else (vec).load(ptr_); } while (0)
 #include "../../include/maskunet_hip.h"
 
 // ------------------------------------------------------------------------------------------
@@ -272,7 +277,7 @@ __global__ __launch_bounds__(256) void maxpool_fwd_kernel(const T* __restrict__ 
         int wo = p % Wo, ho = (p / Wo) % Ho, b = p / ((long)Wo * Ho);
         const T* base = x + (((long)b * H + 2 * ho) * W + 2 * wo) * C + c;
         Vec16<T> v00, v01, v10, v11, o;
-        v00.load(base); v01.load(base + C); v10.load(base + (long)W * C); v11.load(base + (long)W * C + C);
+        EW_LD(v00, base); EW_LD(v01, base + C); EW_LD(v10, base + (long)W * C); EW_LD(v11, base + (long)W * C + C);
 #pragma unroll
         for (int i = 0; i < N; ++i) o.set(i, fmaxf(fmaxf(v00.get(i), v01.get(i)), fmaxf(v10.get(i), v11.get(i))));
         o.store(y + p * C + c);
@@ -296,10 +301,10 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const T* __restrict__ 
         long off = (((long)b * H + 2 * ho) * W + 2 * wo) * C + c;
         const long offs[4] = {off, off + C, off + (long)W * C, off + (long)W * C + C};
         Vec16<T> v[4], g, g2, a[4], o[4];
-        v[0].load(x + offs[0]); v[1].load(x + offs[1]); v[2].load(x + offs[2]); v[3].load(x + offs[3]);
-        g.load(dy + p * C + c);
-        if (dy2) g2.load(dy2 + p * C + c);
-        if (dx_add) { a[0].load(dx_add + offs[0]); a[1].load(dx_add + offs[1]); a[2].load(dx_add + offs[2]); a[3].load(dx_add + offs[3]); }
+        EW_LD(v[0], x + offs[0]); EW_LD(v[1], x + offs[1]); EW_LD(v[2], x + offs[2]); EW_LD(v[3], x + offs[3]);
+        EW_LD(g, dy + p * C + c);
+        if (dy2) EW_LD(g2, dy2 + p * C + c);
+        if (dx_add) { EW_LD(a[0], dx_add + offs[0]); EW_LD(a[1], dx_add + offs[1]); EW_LD(a[2], dx_add + offs[2]); EW_LD(a[3], dx_add + offs[3]); }
 #pragma unroll
         for (int i = 0; i < N; ++i) {
             int best = 0;
@@ -509,7 +514,7 @@ __global__ __launch_bounds__(256) void upcat_fwd_rows_kernel(const T* __restrict
             if (c < Cs) {
                 Vec16<T> v[U];
 #pragma unroll
-                for (int u = 0; u < U; ++u) if (wb + u * ppi < Wo) v[u].load(srow + (long)(wb + u * ppi) * Cs);
+                for (int u = 0; u < U; ++u) if (wb + u * ppi < Wo) EW_LD(v[u], srow + (long)(wb + u * ppi) * Cs);
 #pragma unroll
                 for (int u = 0; u < U; ++u) if (wb + u * ppi < Wo) v[u].store(yrow + (long)(wb + u * ppi) * Ct);
             } else {
@@ -562,8 +567,8 @@ __global__ __launch_bounds__(256) void upcat_bwd_rows_kernel(const T* __restrict
 #pragma unroll
             for (int u = 0; u < U; ++u)
                 if (wb + u * ppi < Wo) {
-                    v[u].load(g1 + (long)(wb + u * ppi) * Ct);
-                    if (g2) v2[u].load(g2 + (long)(wb + u * ppi) * Ct);
+                    EW_LD(v[u], g1 + (long)(wb + u * ppi) * Ct);
+                    if (g2) EW_LD(v2[u], g2 + (long)(wb + u * ppi) * Ct);
                 }
 #pragma unroll
             for (int u = 0; u < U; ++u)
@@ -806,7 +811,7 @@ __global__ __launch_bounds__(256) void dropout_kernel(const T* __restrict__ x, T
     if (seed_step) seed ^= splitmix64(0x9E3779B97F4A7C15ull * (uint64_t)seed_step[0]);     // per-replay stream of a captured step
     for (long v = (long)blockIdx.x * 256 + threadIdx.x; v < nvec; v += (long)gridDim.x * 256) {
         Vec16<T> a, o;
-        a.load(x + v * N);
+        EW_LD(a, x + v * N);
         uint64_t r0 = 0, r1 = 0;
         if (!mask) {
             r0 = splitmix64(seed ^ (uint64_t)(2 * v) * 0xD6E8FEB86659FD93ull);
@@ -859,7 +864,7 @@ __global__ __launch_bounds__(256) void add_kernel(const T* __restrict__ a, const
     constexpr int N = Vec16<T>::N;
     for (long v = (long)blockIdx.x * 256 + threadIdx.x; v < nvec; v += (long)gridDim.x * 256) {
         Vec16<T> x, y, z;
-        x.load(a + v * N); y.load(b + v * N);
+        EW_LD(x, a + v * N); EW_LD(y, b + v * N);
 #pragma unroll
         for (int i = 0; i < N; ++i) z.set(i, x.get(i) + y.get(i));
         z.store(o + v * N);

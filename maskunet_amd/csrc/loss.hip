@@ -161,7 +161,7 @@ __global__ __launch_bounds__(256) void ce_bwd_kernel(const T* __restrict__ logit
         const int c = (int)(idx % cv) * VN;
         const long lab = labels[r];
         Vec16<T> v, o;
-        v.load(logits + r * Cp + c);
+        v.load_nt(logits + r * Cp + c);       // read once (norm.hip MU_BN_NT)
         const float l = lse[r];
 #pragma unroll
         for (int i = 0; i < VN; ++i) {
