@@ -172,7 +172,7 @@ class DataParallel(nn.Module):
             return
         b.flat, b.work = self._reduce(b.included)
 
-    def _write_back(self, params, flat, work):
+    def _write_back(self, params, flat, work, copy_back=False):
         dev = flat.device
         ctx = torch.cuda.stream(self._comm(dev)) if dev.type == "cuda" else contextlib.nullcontext()
         with ctx:
@@ -185,15 +185,24 @@ class DataParallel(nn.Module):
             for p in params:
                 g = p.grad
                 n = g.numel()
-                grads.append(g)
-                views.append(flat[off:off + n].view_as(g))
+                v = flat[off:off + n].view_as(g)
                 off += n
-            # one multi-tensor copy per bucket: ~330 separate copy launches cost ~1 ms of GPU time per step after the backward
-            torch._foreach_copy_(grads, views)
+                if copy_back or g.dtype != flat.dtype or not g.is_contiguous():
+                    grads.append(g)
+                    views.append(v)
+                else:
+                    # no copy: the averaged gradient IS the slice of the bucket (0.15 ms of multi-tensor copies per step otherwise)
+                    p.grad = v
+            if grads:
+                # one multi-tensor copy per bucket: ~330 separate copy launches cost ~1 ms of GPU time per step after the backward
+                torch._foreach_copy_(grads, views)
+        if dev.type == "cuda" and not copy_back:
+            flat.record_stream(torch.cuda.current_stream(dev))      # its slices live on as p.grad, read by the caller's stream
 
-    def finish_gradient_sync(self):
-        """Wait for the bucket all-reduces and write the averaged gradients back.  Buckets whose hooks did not
-        all fire (parameters without gradients this step) are reduced here with what they have."""
+    def finish_gradient_sync(self, copy_back=False):
+        """Wait for the bucket all-reduces and hand the averaged gradients back: ``p.grad`` becomes a slice of its bucket (no copy), or
+        with ``copy_back=True`` the existing ``p.grad`` tensors are overwritten (GraphedStep: its gradient tensors are the graph's).
+        Buckets whose hooks did not all fire (parameters without gradients this step) are reduced here with what they have."""
         if not self.multi or not self._sync:
             self._armed = False
             return
@@ -203,12 +212,12 @@ class DataParallel(nn.Module):
         late = []
         for b in self.buckets:
             if b.work is not None:
-                self._write_back(b.included, b.flat, b.work)
+                self._write_back(b.included, b.flat, b.work, copy_back)
             inc = {id(p) for p in b.included}
             late += [p for p in b.params if p.grad is not None and id(p) not in inc]
         if late:            # gradients that appeared after their bucket had been launched (a parameter that used to be dead)
             flat, work = self._reduce(late)
-            self._write_back(late, flat, work)
+            self._write_back(late, flat, work, copy_back)
         if self._comm_stream is not None:
             torch.cuda.current_stream(self._comm_stream.device).wait_stream(self._comm_stream)
         # the same autograd graph runs on every rank, so this set is identical everywhere

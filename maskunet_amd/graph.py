@@ -88,5 +88,5 @@ class GraphedStep:
             p.grad = g
         if self.dp is not None:                       # one exchange per step, after the replay (ade_semantic.py:373)
             self.dp._arm()
-            self.dp.finish_gradient_sync()
+            self.dp.finish_gradient_sync(copy_back=True)      # into the graph's own gradient tensors
         return self.loss.clone()                      # self.loss is overwritten by the next replay
