@@ -18,8 +18,9 @@ The collective backend is whatever ``torch.distributed`` was initialised with: "
 
 Stream order on GPUs (the part a blocking CPU backend cannot test): gradients are produced on the current (main)
 stream; the comm stream waits for the main stream, flattens the bucket and issues the all-reduce; ``Work.wait()`` is
-called WITH THE COMM STREAM CURRENT, so the divide and the copy back into ``p.grad`` (also on the comm stream) are
-ordered behind the collective; the main stream finally waits for the comm stream.
+called WITH THE COMM STREAM CURRENT, so the divide (and, with ``copy_back``, the copy into the existing ``p.grad``) are
+ordered behind the collective; ``p.grad`` otherwise becomes the parameter's slice of the reduced bucket; the main stream
+finally waits for the comm stream.
 """
 from __future__ import annotations
 
