@@ -26,6 +26,9 @@
 #ifndef MU_BN_UA
 #define MU_BN_UA 2
 #endif
+#ifndef MU_BN_STRIDED
+#define MU_BN_STRIDED 1            // whole step 28.80 -> 28.71 ms, the backward sweep 0.275 -> 0.268 ms on a 256 MiB tensor
+#endif
 #ifndef MU_BN_OCC1
 #define MU_BN_OCC1 1
 #endif
@@ -53,8 +56,16 @@ __global__ __launch_bounds__(256, MODE == 1 ? MU_BN_OCC1 : 1) void bn_partial_ke
     const int cv = C / N;
     const int rpi = 256 / cv;
     const int tc = threadIdx.x % cv, tr = threadIdx.x / cv;
+#if MU_BN_STRIDED
+    // chunks of U * rpi rows dealt round-robin: at any moment the resident blocks read ONE front of the tensor (as the grid-stride apply
+    // passes do) instead of gridDim.x separate sequential streams
+    const long r0 = (long)blockIdx.x * (U * rpi), r1 = M;
+    const long rstride = (long)gridDim.x * (U * rpi);
+#else
     const long rows_per_blk = (M + gridDim.x - 1) / gridDim.x;
     const long r0 = (long)blockIdx.x * rows_per_blk, r1 = (r0 + rows_per_blk < M ? r0 + rows_per_blk : M);
+    const long rstride = (long)U * rpi;
+#endif
     double s0[N], s1[N];
 #pragma unroll
     for (int i = 0; i < N; ++i) { s0[i] = 0.0; s1[i] = 0.0; }
@@ -65,7 +76,7 @@ __global__ __launch_bounds__(256, MODE == 1 ? MU_BN_OCC1 : 1) void bn_partial_ke
 #pragma unroll
             for (int i = 0; i < N; ++i) { mu[i] = mean[c + i]; rs[i] = rstd[c + i]; ga[i] = gamma[c + i]; be[i] = beta[c + i]; }
         }
-        for (long r = r0 + tr; r < r1; r += (long)U * rpi) {
+        for (long r = r0 + tr; r < r1; r += rstride) {
             Vec16<T> xv[U], gv[U], rv[U];
 #pragma unroll
             for (int u = 0; u < U; ++u) {
