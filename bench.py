@@ -38,6 +38,8 @@ sys.path.insert(0, ROOT)
 PEAK_MFMA_TFLOPS = {"fp16": 2500.0, "fp32": 157.3}      # dense, MI355X_MICROARCH.md
 PEAK_HBM_GBS = 8000.0
 DOMINANT_KERNEL = "attn_bwd_dkv3_kernel"
+REF_CLOCK_MHZ = 1900.0       # convention for `clock.ms_per_step_at_ref_clock` (about what the pool's boxes hold in the MFMA probe)
+MFMA_SHARE = 0.8             # share of the step spent in MFMA-bound kernels (attention, conv, weight-grad: 23.5 of 29.5 ms)
 # PMC traffic of the dominant kernel per workload shape (key: b{batch}_c{c_out}_hw{hw}_{dtype}[_3head]); see profiles/README.md
 TRAFFIC_JSON = {k: f"r03_dkv_traffic_{k}.json" for k in ("b64_c150_hw128_fp16", "b128_c133_hw128_fp16", "b64_c19_hw128_fp16_3head",
                                                           "b32_c133_hw256_fp16", "b64_c150_hw128_fp32")}
@@ -127,6 +129,137 @@ def cpu_baseline(c_out, hw, B=4, iters=3, budget_s=150.0):
                       f"median of {len(times) - 1} after 1 warm-up ({steady:.2f} s/iteration)"}
 
 
+class SmiSampler:
+    """sclk / board power of the benched GPU from sysfs, sampled by a helper thread over the timed region (context for the bench
+    line only: MI355X_MICROARCH.md warns that pp_dpm_sclk reads up to ~10 % above the in-kernel clock of an MFMA-dense loop, which
+    is what `clock_probe` below measures).  Every field is None where the box does not expose the file to an ordinary user."""
+
+    def __init__(self, index, period=0.05):
+        import glob
+        import threading
+        cards = sorted(d for d in glob.glob("/sys/class/drm/card[0-9]*/device") if os.path.exists(os.path.join(d, "pp_dpm_sclk")))
+        self.dev = cards[index] if index < len(cards) else (cards[0] if cards else None)
+        self.power_file = None
+        if self.dev:
+            import glob as g2
+            for name in ("power1_average", "power1_input"):
+                hits = g2.glob(os.path.join(self.dev, "hwmon", "hwmon*", name))
+                if hits:
+                    self.power_file = hits[0]
+                    break
+        self.period, self.sclk, self.power = period, [], []
+        self._stop = threading.Event()
+        self._th = threading.Thread(target=self._run, daemon=True)
+
+    def _run(self):
+        while not self._stop.is_set():
+            try:
+                for ln in open(os.path.join(self.dev, "pp_dpm_sclk")):
+                    if ln.rstrip().endswith("*"):
+                        self.sclk.append(float(ln.split(":")[1].strip().lower().split("mhz")[0]))
+            except (OSError, ValueError, IndexError):
+                pass
+            try:
+                if self.power_file:
+                    self.power.append(float(open(self.power_file).read()) * 1e-6)
+            except (OSError, ValueError):
+                pass
+            self._stop.wait(self.period)
+
+    def __enter__(self):
+        if self.dev:
+            self._th.start()
+        return self
+
+    def __exit__(self, *exc):
+        self._stop.set()
+        if self.dev:
+            self._th.join(timeout=1.0)
+
+    def summary(self):
+        def mean(v):
+            return round(sum(v) / len(v), 1) if v else None
+        return {"sclk_mhz_sysfs": mean(self.sclk), "power_w": mean(self.power), "samples": max(len(self.sclk), len(self.power)),
+                "source": self.dev}
+
+
+def clock_probe(dev, seconds=0.5, iters=16384):
+    """Clock the chip holds under a dense fp16 MFMA load, right after the timed region (the chip is warm): mu_clock_probe launched
+    back to back for `seconds`, median over the CUs of d(s_memtime) / d(s_memrealtime) of the last launches (the guide's check 6).
+    Also the matrix rate of that register-only loop -- the most this box gives a 16x16x32 fp16 MFMA stream on random operands."""
+    from maskunet_amd import _lib
+    ncu = torch.cuda.get_device_properties(dev).multi_processor_count
+    stamps = torch.zeros(ncu, 2, dtype=torch.int64, device=dev)
+    sink = torch.empty(ncu * 256, dtype=torch.float32, device=dev)
+    keep = []
+    t_end = time.perf_counter() + seconds
+    n = 0
+    while time.perf_counter() < t_end or n < 8:
+        _lib.call("mu_clock_probe", _lib.ptr(stamps), _lib.ptr(sink), ncu, iters, _lib.stream())
+        n += 1
+        if n % 4 == 0:
+            keep.append(stamps.clone())
+            torch.cuda.synchronize()
+    torch.cuda.synchronize()
+    st = torch.stack(keep[-4:]).double().cpu()              # [launch][cu][2]
+    clk = (st[..., 0] / st[..., 1].clamp(min=1) * 100.0).flatten().median().item()
+    t_loop = st[..., 1].flatten().median().item() * 1e-8    # seconds per launch (100 MHz ticks)
+    flops = ncu * 4 * iters * 16 * 16384.0                  # 4 waves per block, 16 MFMAs per iteration, 2*16*16*32 FLOP each
+    return {"clock_mhz": round(clk, 1), "probe_tflops": round(flops / t_loop / 1e12, 1), "launches": n,
+            "method": "mu_clock_probe: register-only v_mfma_f32_16x16x32_f16 loop on random operands, one 4-wave block per CU, "
+                      "100 MHz * d(s_memtime)/d(s_memrealtime), median over CUs of the last 4 sampled launches"}
+
+
+def parity_gate(args, dtype):
+    """The B = 2 whole-model golden (generated from the reference's own classes, tests/golden/make_golden.py) run once through the
+    timed dtype BEFORE the timed region: which parity gate the benched path passes, in the bench line itself.  Checker only."""
+    name = "unet3_c19_b2_train" if args.three_head else {150: "unet1_c150_b2_train", 133: "unet1_c133_b2_train"}.get(args.c_out)
+    if name is None or args.hw != 128 or (args.three_head and args.c_out != 19):
+        return {"fixture": None, "note": "no reference-generated whole-model golden for this shape (tests/golden/ holds c_out 150 / 133 / 3-head 19 at 128x128)"}
+    try:
+        from tests import _gpu_checks as G
+        res = G.check_unet_golden(name, dtype)
+    except Exception as e:                                   # the bench line must not depend on the checker
+        return {"fixture": f"tests/golden/{name}.npz", "error": repr(e)[:200]}
+    obs = {"out": max(e for n, e, t in res if " out" in n and "slice" in n),
+           "loss": max(e for n, e, t in res if n.endswith(" loss")),
+           "grad_maxnorm_worst_param": max(e for n, e, t in res if "worst grad" in n),
+           "running_stats": max([e for n, e, t in res if "running_" in n] or [0.0])}
+    gates = {"out": G.TOL[dtype], "loss": G.TOL[dtype], "grad_maxnorm_worst_param": max(t for n, e, t in res if "worst grad" in n),
+             "grad_1_minus_cos_per_param (tests/test_gpu_modules.py, vs the live oracle)": 1e-4 if dtype == torch.float32 else 2e-2}
+    return {"fixture": f"tests/golden/{name}.npz (outputs / loss / gradients of the reference's own UNet, B=2, train mode)",
+            "dtype": "f16" if dtype == torch.float16 else "f32", "gate": gates,
+            "observed": {k: float(f"{v:.3g}") for k, v in obs.items()}, "passed": all(e <= t for _, e, t in res),
+            "north_star_gate": "1e-3 (fp32 outputs): met by --dtype fp32 (observed ~1e-5), not by the fp16-storage path timed here"
+                               if dtype == torch.float16 else "1e-3 (fp32 outputs)"}
+
+
+def spawn_ranks(n):
+    """`python bench.py --gpus N` without a launcher: run `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr
+    127.0.0.1 --master-port <free> bench.py <same arguments>` as a child process and hand back its output and exit code."""
+    import socket
+    import subprocess
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")          # dmabuf IPC (RCCL across processes on this image)
+    env.setdefault("OMP_NUM_THREADS", "8")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    proc = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    line = None
+    for ln in proc.stdout.splitlines():
+        if ln.startswith("{") and '"metric"' in ln:
+            line = ln                                            # rank 0's JSON line
+        else:
+            print(ln, file=sys.stderr)
+    if line is not None:
+        print(line, flush=True)
+    if proc.returncode != 0 or line is None:
+        raise SystemExit(proc.returncode or 1)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -138,6 +271,8 @@ def main():
     ap.add_argument("--hw", type=int, default=128)
     ap.add_argument("--loss-scale", type=float, default=1024.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-parity-gate", action="store_true", help="skip the B=2 golden check that fills `parity_gate`")
+    ap.add_argument("--no-clock-probe", action="store_true", help="skip the MFMA-loop clock probe after the timed region")
     ap.add_argument("--three-head", action="store_true")
     ap.add_argument("--fused-loss", action="store_true",
                     help="SURVEY 8-f1 path: fused NHWC cross-entropy on the internal logits instead of module output + torch CE")
@@ -150,6 +285,11 @@ def main():
                          "redrawn + re-compacted on the device every step (what the reference does under multi-GPU nn.DataParallel, whose "
                          "replicas are discarded each step, :373); auto = fixed at N = 1, resample at N > 1")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # bare `python bench.py --gpus N`: start the N ranks ourselves (torch.distributed.run as a CHILD process, before anything in this
+        # process has touched the GPU -- never an exec of a process that has) and relay rank 0's JSON line and the exit code
+        return spawn_ranks(args.gpus)
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -167,10 +307,10 @@ def main():
             dist.init_process_group(backend)
             local = local % max(ndev, 1)
     if world != args.gpus:
-        # N > 1 is launched by `python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...` (one rank per GPU); a bare
-        # `bench.py --gpus N` must not silently bench one GPU
-        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: launch N>1 with torch.distributed.run "
-                         f"(--nproc-per-node {args.gpus}), which sets RANK/LOCAL_RANK/WORLD_SIZE")
+        # a launcher that set WORLD_SIZE to something else than --gpus: refuse instead of benching a different job than asked for
+        # (WORLD_SIZE unset and --gpus N > 1 never gets here: spawn_ranks above)
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: they must agree "
+                         f"(python -m torch.distributed.run --nproc-per-node {args.gpus} bench.py --gpus {args.gpus} ..., or no launcher at all)")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
 
@@ -242,6 +382,12 @@ def main():
         model.zero_grad(set_to_none=True)
         return loss
 
+    # which parity gate the timed dtype passes: the reference-generated B = 2 golden, once, outside the timed region
+    gate = None
+    if rank == 0 and not args.no_parity_gate:
+        gate = parity_gate(args, dtype)
+        torch.cuda.synchronize()
+
     fwd_events = None
     for _ in range(args.warmup):
         step()
@@ -250,17 +396,24 @@ def main():
     # mu_attn_bwd_phases(..., B, N, C, nkmax, ws, ws_bytes, dtype, phases, stream): args[16] = N, args[22] = phases
     N6 = args.hw * args.hw
     _lib.PROBE = {"pred": lambda name, a: name == "mu_attn_bwd_phases" and a[16] == N6 and (a[22] & 7) == 4, "events": []}
+    sampler = SmiSampler(local if rank == 0 else 1 << 30)      # sysfs sclk / power over the timed region (rank 0's GPU)
     if multi:
         dist.barrier()
     torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        loss = step()
-    if multi:
-        dist.barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
+    with sampler:
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            loss = step()
+        if multi:
+            dist.barrier()
+        torch.cuda.synchronize()
+        elapsed = time.perf_counter() - t0
     probe = _lib.PROBE
+    _lib.PROBE = None
+    clk = None
+    if rank == 0 and not args.no_clock_probe:
+        clk = clock_probe(dev)                                   # right behind the timed steps: the chip is still warm
+    _lib.PROBE = probe
     if graphed is not None:                     # a replayed graph makes no Python calls to probe: time the kernel in two eager steps
         graphed = None                          # after the timed region (on every rank: eager steps all-reduce)
         for _ in range(2):
@@ -329,7 +482,11 @@ def main():
                        "loss": "fused NHWC CE kernel" if args.fused_loss else ("torch CE on module output" if args.torch_loss else
                                                                                 "maskunet_amd.CrossEntropyLoss on module output"), "optimizer_in_step": bool(opt), "hip_graph": bool(args.graph)},
             "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
-                         "frac": round(achieved / peak, 4), "traffic": traffic, "traffic_source": traffic_source,
+                         "frac": round(achieved / peak, 4),
+                         # the same FLOPs against the matrix peak at the clock this chip holds under a dense MFMA load
+                         # (peak is quoted at 2400 MHz; `clock` below): what is left is the kernel's own issue efficiency
+                         "frac_at_measured_clock": round(achieved / (peak * clk["clock_mhz"] / 2400.0), 4) if clk else None,
+                         "traffic": traffic, "traffic_source": traffic_source,
                          "kernel": f"{DOMINANT_KERNEL} (self_attention6 dK/dV sweep, N={N6}, C=64)",
                          "ms_per_launch": round(tk * 1e3, 3), "launches_timed": len(durs),
                          "kept_keys": round(kept, 4), "flops_per_launch": flops_exec,
@@ -342,6 +499,12 @@ def main():
                                  "skipped exactly) / HIP-event time; algorithmic_* FLOPs = SURVEY 8-d4's full-key-set count 8*N*N*C; "
                                  "algorithmic_bytes = Q, dO, K, V read + dK, dV written once (6*N*C elements per image)"},
             "step_roofline": step,
+            "clock": dict(clk, **{"smi": sampler.summary(),
+                                  # box-to-box comparison: ~0.8 of the step is MFMA kernels whose time follows this clock, the rest
+                                  # HBM streams that do not (profiles/r03_kernel_time_split.txt); REF_CLOCK_MHZ is a convention
+                                  "ms_per_step_at_ref_clock": round(1e3 * t_step * (MFMA_SHARE * clk["clock_mhz"] / REF_CLOCK_MHZ + 1.0 - MFMA_SHARE), 3),
+                                  "ref_clock_mhz": REF_CLOCK_MHZ, "mfma_share_of_step": MFMA_SHARE}) if clk else {"smi": sampler.summary()},
+            "parity_gate": gate,
         }
         if world == 1 and not args.no_cpu_baseline:
             rec["cpu_baseline"] = cpu_baseline(args.c_out, args.hw)

@@ -224,6 +224,18 @@ long mu_attn_bwd_workspace_bytes(int B, int N, int C);
 int mu_attn_bwd(const void* qkv, const void* x, const void* oattn, const void* grad_out, const int* kidx, const int* kcnt,
                 const float* lse2, const float* ln_mean, const float* ln_rstd, const float* gamma, void* dY, float* delta, void* dqkv,
                 float* dgamma, float* dbeta, int B, int N, int C, int nkmax, void* workspace, long ws_bytes, int dtype, void* stream);
+/* Channel counts that are not one of the kernels' widths (32, 64, 128, 256) -- `Mask2FormerAttention(channels, size)` accepts any
+ * (ade_semantic.py:153-161) -- run zero-padded: C = the padded width every tensor here is stored with (qkv, x, out, ... and gamma /
+ * beta, all zero in the pad channels: zero-padded projection weights give zero Q/K/V pads), c_valid = the true channel count.  The
+ * scores are scaled by 1/sqrt(c_valid), the LayerNorm spans the first c_valid channels, pad channels of every output are zero.
+ * c_valid == C is exactly mu_attn_fwd / mu_attn_bwd_phases. */
+int mu_attn_fwd_padded(const void* qkv, const void* x, const int* kidx, const int* kcnt, const float* gamma, const float* beta, void* out,
+                       void* oattn, float* lse2, float* ln_mean, float* ln_rstd, int B, int N, int C, int c_valid, int nkmax, float eps,
+                       int dtype, void* stream);
+int mu_attn_bwd_phases_padded(const void* qkv, const void* x, const void* oattn, const void* grad_out, const int* kidx, const int* kcnt,
+                              const float* lse2, const float* ln_mean, const float* ln_rstd, const float* gamma, void* dY, float* delta,
+                              void* dqkv, float* dgamma, float* dbeta, int B, int N, int C, int c_valid, int nkmax, void* workspace,
+                              long ws_bytes, int dtype, int phases, void* stream);
 /* the same, one phase group at a time (bit mask): 1 = zero dqkv + LayerNorm backward / delta / dgamma,dbeta,
  * 2 = dQ sweep, 4 = dK/dV sweep.  Phases 2 and 4 need phase 1's dY, delta and workspace contents.
  * 8 (MU_ATTN_KIDX_PERMUTATION, OR-ed into every call of one backward) = a promise about kidx: nkmax == N and every row is a whole
@@ -264,10 +276,6 @@ int mu_inst_triplet_fwd(const float* feat, const long* mask, int B, int C, int H
                         const float* u, int id_cap, int max_inst, void* workspace, long ws_bytes, float* loss, void* stream);
 int mu_inst_triplet_bwd(const float* feat, int B, int C, int H, int W, const void* workspace, int id_cap, int max_inst,
                         const float* grad_out, float* dfeat, void* stream);
-/* f2: optim.AdamW step (ade_semantic.py:379,401) for every parameter in one launch.  table: device array of
- * {float* p; const float* g; float* m; float* v; long n; float bc1; float bc2_sqrt;} (48 bytes; g may be NULL; bc1 = 1-beta1^t,
- * bc2_sqrt = sqrt(1-beta2^t) for that tensor's own step count t); block_tensor/block_chunk: per-block (tensor index, chunk
- * index) with chunks of mu_adamw_chunk() elements.  grad_scale_inv un-scales loss-scaled gradients. */
 /* f4: uint8 HWC image bytes [npix, C] -> [0,1] floats in the NHWC compute layout [npix, Cp] (ToTensor, ade_semantic.py:85) */
 int mu_u8_to_nhwc(const unsigned char* src, void* dst, long npix, int C, int Cp, int dtype, void* stream);
 /* f4, resize half: the sample preparation of the reference datasets on the device.  src: decoded image bytes [B][Hs][Ws][C] (C <= 4, as
@@ -280,9 +288,28 @@ int mu_resize_u8_nhwc(const unsigned char* src, int B, int Hs, int Ws, int C, in
 /* the label map: uint8 [B][Hs][Ws] -> int64 [B][Hd][Wd] = torch.from_numpy(cv2.resize(mask, (Wd, Hd), interpolation=cv2.INTER_NEAREST)).long()
  * (:73,78): source index min(floor(d * scale), n - 1) */
 int mu_resize_nearest_u8(const unsigned char* src, int B, int Hs, int Ws, long* dst, int Hd, int Wd, void* stream);
+/* f2: optim.AdamW step (ade_semantic.py:379,401) for every parameter in one launch.  table: device array of `ntensors` entries
+ * {float* p; const float* g; float* m; float* v; long n; long step;} (48 bytes; g may be NULL = no gradient this step; step = that
+ * tensor's own count of attempted updates including this one, torch keeps one counter per parameter); block_tensor/block_chunk:
+ * per-block (tensor index, chunk index) with chunks of mu_adamw_chunk() elements.  Gradients are multiplied by grad_scale_inv, or by
+ * 1 / *grad_scale when grad_scale (a DEVICE float, torch.cuda.amp.GradScaler's scale) is given.
+ * Overflow protocol, all on the device (no host sync): found_inf (device float, may be NULL) != 0 makes the launch update NOTHING;
+ * with check_finite == 1 the entry point first sets *found_inf itself (0, then 1 if any gradient element is inf / NaN); check_finite == 2
+ * only ORs this table's gradients into *found_inf and updates nothing (several parameter groups: check all, then update all);
+ * skipped (device int[ntensors], may be NULL) counts the skipped steps per tensor and is subtracted from `step` in the bias
+ * corrections, so a skipped step leaves parameters, moments AND the effective step count untouched. */
 int mu_adamw_chunk(void);
-int mu_adamw_multi(const void* table, const int* block_tensor, const int* block_chunk, int nblocks, float lr, float beta1, float beta2,
-                   float eps, float weight_decay, float grad_scale_inv, void* stream);
+int mu_adamw_multi(const void* table, const int* block_tensor, const int* block_chunk, int nblocks, int ntensors, float lr, float beta1,
+                   float beta2, float eps, float weight_decay, float grad_scale_inv, const float* grad_scale, float* found_inf,
+                   int check_finite, int* skipped, void* stream);
+
+/* ---- measurement aid (bench.py; not on the model's path) ------------------------------------- */
+/* Clock / matrix-rate probe: one launch of `nblk` 256-thread blocks, every wave issuing iters * 16 register-only
+ * v_mfma_f32_16x16x32_f16 on random operands, stamped once around the loop.  stamps [nblk][2] uint64 = {d s_memtime (shader
+ * cycles), d s_memrealtime (100 MHz ticks)} -> clock the chip holds under a dense fp16 MFMA load = 100 MHz * [0]/[1]
+ * (MI355X_MICROARCH.md "DVFS give-back" item 6).  sink: nblk * 256 floats of scratch.  The reference has no counterpart: it is what
+ * makes two bench lines from two boxes of a pool comparable. */
+int mu_clock_probe(void* stamps, void* sink, int nblk, int iters, void* stream);
 
 #ifdef __cplusplus
 }

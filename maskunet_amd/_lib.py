@@ -70,7 +70,7 @@ SIGNATURES = {
     "mu_inst_triplet_bwd": (I, [P, I, I, I, I, P, I, I, P, P, P]),
     "mu_u8_to_nhwc": (I, [P, P, L, I, I, I, P]),
     "mu_adamw_chunk": (I, []),
-    "mu_adamw_multi": (I, [P, P, P, I, F, F, F, F, F, F, P]),
+    "mu_adamw_multi": (I, [P, P, P, I, I, F, F, F, F, F, F, P, P, I, P, P]),
     "mu_prep_qkv": (I, [P, P, P, P, P, P, P, P, I, I, P]),
     "mu_prep_weights_multi": (I, [P, I, L, P, I, P]),
     "mu_conv1x1_add_supported": (I, [I, I, I]),
@@ -83,6 +83,9 @@ SIGNATURES = {
     "mu_conv_fwd_fused": (I, [P, P, P, P, P, I, P, I, I, I, I, I, I, L, L, I, P]),
     "mu_bn_eval_fold": (I, [P, P, P, P, F, P, P, P, P, F, P, P, P, I, I, P]),
     "mu_attn_bwd_phases": (I, [P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, I, I, I, I, P, L, I, I, P]),
+    "mu_clock_probe": (I, [P, P, I, I, P]),
+    "mu_attn_fwd_padded": (I, [P, P, P, P, P, P, P, P, P, P, P, I, I, I, I, I, F, I, P]),
+    "mu_attn_bwd_phases_padded": (I, [P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, I, I, I, I, I, P, L, I, I, P]),
 }
 
 _lib = None

@@ -640,7 +640,8 @@ __global__ __launch_bounds__(256) void attn_ln_bwd_kernel(const T* __restrict__ 
                                                           const float* __restrict__ ln_mean, const float* __restrict__ ln_rstd,
                                                           const float* __restrict__ gamma, T* __restrict__ dY, float* __restrict__ delta,
                                                           double* __restrict__ part, long rows, const float* __restrict__ lse2,
-                                                          float* __restrict__ rowc, int N, float scale) {
+                                                          float* __restrict__ rowc, int N, float scale, int cv) {
+    // cv <= D: channels the LayerNorm really spans (channel counts that are not one of the kernels' widths run zero-padded to D)
     constexpr int VN = AT<T>::VN, LPR = D / VN, RPI = 256 / LPR;     // lanes per row, rows per block-iteration
     const int tid = threadIdx.x;
     const int lc = tid % LPR, lr = tid / LPR;
@@ -667,14 +668,15 @@ __global__ __launch_bounds__(256) void attn_ln_bwd_kernel(const T* __restrict__ 
         }
 #pragma unroll
         for (int o = 1; o < LPR; o <<= 1) { a += __shfl_xor(a, o); bsum += __shfl_xor(bsum, o); }
-        a *= (1.0f / D); bsum *= (1.0f / D);
+        const float icv = 1.0f / (float)cv;
+        a *= icv; bsum *= icv;
         float dl = 0.f;
 #pragma unroll
         for (int i = 0; i < VN; ++i) {
-            const float d = rs * (gg[i] - a - xh[i] * bsum);
+            const float d = (c + i < cv) ? rs * (gg[i] - a - xh[i] * bsum) : 0.f;
             dv.set(i, d);
             dl += dv.get(i) * ov.get(i);
-            if (ok) { dga[i] += gv.get(i) * xh[i]; dbe[i] += gv.get(i); }
+            if (ok && c + i < cv) { dga[i] += gv.get(i) * xh[i]; dbe[i] += gv.get(i); }
         }
 #pragma unroll
         for (int o = 1; o < LPR; o <<= 1) dl += __shfl_xor(dl, o);
@@ -707,6 +709,42 @@ __global__ __launch_bounds__(256) void attn_ln_bwd_kernel(const T* __restrict__ 
         }
         part[((long)blockIdx.x * D + cc) * 2] = sa;
         part[((long)blockIdx.x * D + cc) * 2 + 1] = sb;
+    }
+}
+
+// out = LayerNorm_{first cv channels}(oattn + x) * gamma + beta, pad channels 0: redoes the forward kernel's fused epilogue (which
+// normalises over all D channels) for channel counts that run zero-padded -- standalone Mask2FormerAttention(channels, ...) with a
+// width the UNet does not use (ade_semantic.py:153-161 accepts any); not on the model's path.
+template <typename T, int D>
+__global__ __launch_bounds__(256) void attn_ln_fwd_kernel(const T* __restrict__ oattn, const T* __restrict__ x, const float* __restrict__ gamma,
+                                                          const float* __restrict__ beta, T* __restrict__ out, float* __restrict__ ln_mean,
+                                                          float* __restrict__ ln_rstd, long rows, int cv, float eps) {
+    constexpr int VN = AT<T>::VN, LPR = D / VN, RPI = 256 / LPR;
+    const int lc = threadIdx.x % LPR, lr = threadIdx.x / LPR, c = lc * VN;
+    for (long rb = (long)blockIdx.x * RPI; rb < rows; rb += (long)gridDim.x * RPI) {
+        const long r = rb + lr;
+        const bool ok = r < rows;
+        const long rr = ok ? r : 0;
+        Vec16<T> ov, xv, yo;
+        ov.load(oattn + rr * D + c); xv.load(x + rr * D + c);
+        float y[VN], sum = 0.f;
+#pragma unroll
+        for (int i = 0; i < VN; ++i) { y[i] = (c + i < cv) ? ov.get(i) + xv.get(i) : 0.f; sum += y[i]; }
+#pragma unroll
+        for (int o = 1; o < LPR; o <<= 1) sum += __shfl_xor(sum, o);
+        const float mean = sum / (float)cv;
+        float sq = 0.f;
+#pragma unroll
+        for (int i = 0; i < VN; ++i) { const float d = (c + i < cv) ? y[i] - mean : 0.f; sq += d * d; }
+#pragma unroll
+        for (int o = 1; o < LPR; o <<= 1) sq += __shfl_xor(sq, o);
+        const float rstd = rsqrtf(sq / (float)cv + eps);
+#pragma unroll
+        for (int i = 0; i < VN; ++i) yo.set(i, (c + i < cv) ? (y[i] - mean) * rstd * gamma[c + i] + beta[c + i] : 0.f);
+        if (ok) {
+            yo.store(out + r * D + c);
+            if (lc == 0) { ln_mean[r] = mean; ln_rstd[r] = rstd; }
+        }
     }
 }
 
@@ -1156,8 +1194,8 @@ __global__ __launch_bounds__(NW * 64, NW >= 8 ? 1 : ((D <= 64 && sizeof(T) == 2 
 // ------------------------------------------------------------------------------------------
 template <typename T>
 static int attn_fwd_t(const T* qkv, const T* x, const int* kidx, const int* kcnt, const float* gamma, const float* beta, T* out,
-                      T* oattn, float* lse2, float* mean, float* rstd, int B, int N, int C, int nkmax, float eps, hipStream_t st) {
-    const float sl2 = (float)(1.4426950408889634 / sqrt((double)C));
+                      T* oattn, float* lse2, float* mean, float* rstd, int B, int N, int C, int cv, int nkmax, float eps, hipStream_t st) {
+    const float sl2 = (float)(1.4426950408889634 / sqrt((double)cv));      // 1/sqrt(channels) of the TRUE channel count (ade_semantic.py:174)
     // (measured and removed: 8-wave blocks sharing each K/V tile among 256 queries, -8 %; 64 queries per wave against 32-key tiles,
     //  -4 %; 128- / 32-key tiles and other occupancy bounds, +-0: the sweep is bound by MFMA + VALU issue time)
 #define LAUNCH_FWD(DD, KT) \
@@ -1176,22 +1214,38 @@ static int attn_fwd_t(const T* qkv, const T* x, const int* kidx, const int* kcnt
         default: return MU_ERR_SHAPE;
     }
 #undef LAUNCH_FWD
+    if (cv != C) {           // zero-padded channels: LayerNorm over the first cv channels only (re-does the fused epilogue's out / mean / rstd)
+        const long rows = (long)B * N;
+        const int nb = (int)(rows / 64 < 1 ? 1 : (rows / 64 > 4096 ? 4096 : rows / 64));
+        switch (C) {
+            case 32: attn_ln_fwd_kernel<T, 32><<<nb, 256, 0, st>>>(oattn, x, gamma, beta, out, mean, rstd, rows, cv, eps); break;
+            case 64: attn_ln_fwd_kernel<T, 64><<<nb, 256, 0, st>>>(oattn, x, gamma, beta, out, mean, rstd, rows, cv, eps); break;
+            case 128: attn_ln_fwd_kernel<T, 128><<<nb, 256, 0, st>>>(oattn, x, gamma, beta, out, mean, rstd, rows, cv, eps); break;
+            default: attn_ln_fwd_kernel<T, 256><<<nb, 256, 0, st>>>(oattn, x, gamma, beta, out, mean, rstd, rows, cv, eps); break;
+        }
+    }
+    return MU_OK;
+}
+
+extern "C" int mu_attn_fwd_padded(const void* qkv, const void* x, const int* kidx, const int* kcnt, const float* gamma, const float* beta,
+                                  void* out, void* oattn, float* lse2, float* ln_mean, float* ln_rstd, int B, int N, int C, int c_valid,
+                                  int nkmax, float eps, int dtype, void* stream) {
+    if (!qkv || !x || !kidx || !kcnt || !gamma || !beta || !out || !oattn || !lse2 || !ln_mean || !ln_rstd) return MU_ERR_ARG;
+    if (B <= 0 || N <= 0 || nkmax <= 0 || c_valid <= 0 || c_valid > C) return MU_ERR_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    int rc;
+    if (dtype == MU_F16) rc = attn_fwd_t<h16>((const h16*)qkv, (const h16*)x, kidx, kcnt, gamma, beta, (h16*)out, (h16*)oattn, lse2, ln_mean, ln_rstd, B, N, C, c_valid, nkmax, eps, st);
+    else if (dtype == MU_F32) rc = attn_fwd_t<float>((const float*)qkv, (const float*)x, kidx, kcnt, gamma, beta, (float*)out, (float*)oattn, lse2, ln_mean, ln_rstd, B, N, C, c_valid, nkmax, eps, st);
+    else return MU_ERR_ARG;
+    if (rc) return rc;
+    MU_CHECK_LAUNCH();
     return MU_OK;
 }
 
 extern "C" int mu_attn_fwd(const void* qkv, const void* x, const int* kidx, const int* kcnt, const float* gamma, const float* beta,
                            void* out, void* oattn, float* lse2, float* ln_mean, float* ln_rstd, int B, int N, int C, int nkmax,
                            float eps, int dtype, void* stream) {
-    if (!qkv || !x || !kidx || !kcnt || !gamma || !beta || !out || !oattn || !lse2 || !ln_mean || !ln_rstd) return MU_ERR_ARG;
-    if (B <= 0 || N <= 0 || nkmax <= 0) return MU_ERR_ARG;
-    hipStream_t st = (hipStream_t)stream;
-    int rc;
-    if (dtype == MU_F16) rc = attn_fwd_t<h16>((const h16*)qkv, (const h16*)x, kidx, kcnt, gamma, beta, (h16*)out, (h16*)oattn, lse2, ln_mean, ln_rstd, B, N, C, nkmax, eps, st);
-    else if (dtype == MU_F32) rc = attn_fwd_t<float>((const float*)qkv, (const float*)x, kidx, kcnt, gamma, beta, (float*)out, (float*)oattn, lse2, ln_mean, ln_rstd, B, N, C, nkmax, eps, st);
-    else return MU_ERR_ARG;
-    if (rc) return rc;
-    MU_CHECK_LAUNCH();
-    return MU_OK;
+    return mu_attn_fwd_padded(qkv, x, kidx, kcnt, gamma, beta, out, oattn, lse2, ln_mean, ln_rstd, B, N, C, C, nkmax, eps, dtype, stream);
 }
 
 #define ATT_LN_MAXBLK 1024
@@ -1203,12 +1257,12 @@ extern "C" long mu_attn_bwd_workspace_bytes(int B, int N, int C) {
 template <typename T>
 static int attn_bwd_t(const T* qkv, const T* x, const T* oattn, const T* gout, const int* kidx, const int* kcnt, const float* lse2,
                       const float* mean, const float* rstd, const float* gamma, T* dY, float* delta, T* dqkv, float* dgamma,
-                      float* dbeta, int B, int N, int C, int nkmax, void* ws, hipStream_t st, int phases) {
+                      float* dbeta, int B, int N, int C, int cv, int nkmax, void* ws, hipStream_t st, int phases) {
     const long rows = (long)B * N;
     float* rowc = (float*)((char*)ws + attn_ln_part_bytes(C));
     int nblk = (int)(rows / 64 < 1 ? 1 : (rows / 64 > ATT_LN_MAXBLK ? ATT_LN_MAXBLK : rows / 64));
-    const float scale = (float)(1.0 / sqrt((double)C));
-    const float sl2 = (float)(1.4426950408889634 / sqrt((double)C));
+    const float scale = (float)(1.0 / sqrt((double)cv));
+    const float sl2 = (float)(1.4426950408889634 / sqrt((double)cv));
     dim3 gq(mu_cdiv(N, 128), B);
     // phases & 8 (MU_ATTN_KIDX_PERMUTATION): every kidx row is a whole permutation of 0..N-1 with the masked keys after the kept
     // ones, so the dK/dV sweep writes the masked keys' zero rows itself (dQ parts are written for every row by the dQ sweep)
@@ -1216,7 +1270,7 @@ static int attn_bwd_t(const T* qkv, const T* x, const T* oattn, const T* gout, c
     if ((phases & 1) && !zero_masked && hipMemsetAsync(dqkv, 0, (size_t)rows * 3 * C * sizeof(T), st) != hipSuccess) return MU_ERR_LAUNCH;
 #define LAUNCH_BWD(DD, NKT)                                                                                                     \
     if (phases & 1) {                                                                                                           \
-        attn_ln_bwd_kernel<T, DD><<<nblk, 256, 0, st>>>(gout, oattn, x, mean, rstd, gamma, dY, delta, (double*)ws, rows, lse2, rowc, N, scale); \
+        attn_ln_bwd_kernel<T, DD><<<nblk, 256, 0, st>>>(gout, oattn, x, mean, rstd, gamma, dY, delta, (double*)ws, rows, lse2, rowc, N, scale, cv); \
         attn_ln_bwd_final_kernel<<<mu_cdiv(DD, 4), 256, 0, st>>>((const double*)ws, nblk, DD, dgamma, dbeta);                   \
     }                                                                                                                           \
     if (phases & 2) attn_bwd_dq2_kernel<T, DD, KTQ, 4><<<gq, 256, 0, st>>>(qkv, dY, kidx, kcnt, lse2, delta, dqkv, N, nkmax, scale, sl2); \
@@ -1242,25 +1296,33 @@ static int attn_bwd_t(const T* qkv, const T* x, const T* oattn, const T* gout, c
     return MU_OK;
 }
 
-extern "C" int mu_attn_bwd_phases(const void* qkv, const void* x, const void* oattn, const void* grad_out, const int* kidx, const int* kcnt,
+extern "C" int mu_attn_bwd_phases_padded(const void* qkv, const void* x, const void* oattn, const void* grad_out, const int* kidx, const int* kcnt,
                            const float* lse2, const float* ln_mean, const float* ln_rstd, const float* gamma, void* dY, float* delta,
-                           void* dqkv, float* dgamma, float* dbeta, int B, int N, int C, int nkmax, void* workspace, long ws_bytes,
+                           void* dqkv, float* dgamma, float* dbeta, int B, int N, int C, int c_valid, int nkmax, void* workspace, long ws_bytes,
                            int dtype, int phases, void* stream) {
     if (!qkv || !x || !oattn || !grad_out || !kidx || !kcnt || !lse2 || !ln_mean || !ln_rstd || !gamma || !dY || !delta || !dqkv ||
         !dgamma || !dbeta || !workspace)
         return MU_ERR_ARG;
-    if (B <= 0 || N <= 0 || nkmax <= 0) return MU_ERR_ARG;
+    if (B <= 0 || N <= 0 || nkmax <= 0 || c_valid <= 0 || c_valid > C) return MU_ERR_ARG;
     if (ws_bytes < mu_attn_bwd_workspace_bytes(B, N, C)) return MU_ERR_WORKSPACE;
     hipStream_t st = (hipStream_t)stream;
     int rc;
     if (dtype == MU_F16)
-        rc = attn_bwd_t<h16>((const h16*)qkv, (const h16*)x, (const h16*)oattn, (const h16*)grad_out, kidx, kcnt, lse2, ln_mean, ln_rstd, gamma, (h16*)dY, delta, (h16*)dqkv, dgamma, dbeta, B, N, C, nkmax, workspace, st, phases);
+        rc = attn_bwd_t<h16>((const h16*)qkv, (const h16*)x, (const h16*)oattn, (const h16*)grad_out, kidx, kcnt, lse2, ln_mean, ln_rstd, gamma, (h16*)dY, delta, (h16*)dqkv, dgamma, dbeta, B, N, C, c_valid, nkmax, workspace, st, phases);
     else if (dtype == MU_F32)
-        rc = attn_bwd_t<float>((const float*)qkv, (const float*)x, (const float*)oattn, (const float*)grad_out, kidx, kcnt, lse2, ln_mean, ln_rstd, gamma, (float*)dY, delta, (float*)dqkv, dgamma, dbeta, B, N, C, nkmax, workspace, st, phases);
+        rc = attn_bwd_t<float>((const float*)qkv, (const float*)x, (const float*)oattn, (const float*)grad_out, kidx, kcnt, lse2, ln_mean, ln_rstd, gamma, (float*)dY, delta, (float*)dqkv, dgamma, dbeta, B, N, C, c_valid, nkmax, workspace, st, phases);
     else return MU_ERR_ARG;
     if (rc) return rc;
     MU_CHECK_LAUNCH();
     return MU_OK;
+}
+
+extern "C" int mu_attn_bwd_phases(const void* qkv, const void* x, const void* oattn, const void* grad_out, const int* kidx, const int* kcnt,
+                           const float* lse2, const float* ln_mean, const float* ln_rstd, const float* gamma, void* dY, float* delta,
+                           void* dqkv, float* dgamma, float* dbeta, int B, int N, int C, int nkmax, void* workspace, long ws_bytes,
+                           int dtype, int phases, void* stream) {
+    return mu_attn_bwd_phases_padded(qkv, x, oattn, grad_out, kidx, kcnt, lse2, ln_mean, ln_rstd, gamma, dY, delta, dqkv, dgamma, dbeta, B, N, C, C,
+                                     nkmax, workspace, ws_bytes, dtype, phases, stream);
 }
 
 extern "C" int mu_attn_bwd(const void* qkv, const void* x, const void* oattn, const void* grad_out, const int* kidx, const int* kcnt,

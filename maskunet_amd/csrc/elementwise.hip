@@ -328,8 +328,30 @@ static inline int ew_grid(long total) {
     return (int)(g < 1 ? 1 : (g > 8192 ? 8192 : g));
 }
 
+// nn.MaxPool2d(2) floors odd sizes (ade_semantic.py:216): the last row / column of an odd H / W belongs to no window, so its
+// gradient is zero (plus dx_add where the tensor has a second consumer).  One thread per 16-byte vector of the uncovered pixels.
+template <typename T>
+__global__ __launch_bounds__(256) void maxpool_tail_kernel(const T* __restrict__ dx_add, T* __restrict__ dx, int B, int H, int W, int C) {
+    constexpr int N = Vec16<T>::N;
+    const int cv = C / N, He = H & ~1, We = W & ~1;
+    const int ntail = (H - He) * W + He * (W - We);            // uncovered pixels per image
+    const long total = (long)B * ntail * cv;
+    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+        const int c = (idx % cv) * N;
+        const long t = idx / cv;
+        const int k = (int)(t % ntail), b = (int)(t / ntail);
+        int h, w;
+        if (k < (H - He) * W) { h = He; w = k; }               // the odd last row
+        else { h = k - (H - He) * W; w = We; }                 // the odd last column of the covered rows
+        const long off = (((long)b * H + h) * W + w) * C + c;
+        Vec16<T> o;
+        if (dx_add) o.load(dx_add + off); else o.zero();
+        o.store(dx + off);
+    }
+}
+
 extern "C" int mu_maxpool2_fwd(const void* x, void* y, int B, int H, int W, int C, int dtype, void* stream) {
-    if (!x || !y || B <= 0 || (H & 1) || (W & 1) || C % 8) return MU_ERR_ARG;
+    if (!x || !y || B <= 0 || H < 2 || W < 2 || C % 8) return MU_ERR_ARG;
     hipStream_t st = (hipStream_t)stream;
     if (dtype == MU_F32) {
         long total = (long)B * (H / 2) * (W / 2) * (C / 4);
@@ -344,16 +366,19 @@ extern "C" int mu_maxpool2_fwd(const void* x, void* y, int B, int H, int W, int 
 
 extern "C" int mu_maxpool2_bwd_acc(const void* x, const void* dy, const void* dy2, const void* dx_add, void* dx, int B, int H, int W, int C,
                                    int dtype, void* stream) {
-    if (!x || !dy || !dx || B <= 0 || (H & 1) || (W & 1) || C % 8) return MU_ERR_ARG;
+    if (!x || !dy || !dx || B <= 0 || H < 2 || W < 2 || C % 8) return MU_ERR_ARG;
     hipStream_t st = (hipStream_t)stream;
+    const long tail = (long)B * ((H & 1) * W + (H & ~1) * (W & 1));
     if (dtype == MU_F32) {
         long total = (long)B * (H / 2) * (W / 2) * (C / 4);
         maxpool_bwd_kernel<float><<<ew_grid(total), 256, 0, st>>>((const float*)x, (const float*)dy, (const float*)dy2, (const float*)dx_add,
                                                                   (float*)dx, B, H, W, C);
+        if (tail) maxpool_tail_kernel<float><<<ew_grid(tail * (C / 4)), 256, 0, st>>>((const float*)dx_add, (float*)dx, B, H, W, C);
     } else if (dtype == MU_F16) {
         long total = (long)B * (H / 2) * (W / 2) * (C / 8);
         maxpool_bwd_kernel<h16><<<ew_grid(total), 256, 0, st>>>((const h16*)x, (const h16*)dy, (const h16*)dy2, (const h16*)dx_add, (h16*)dx,
                                                                 B, H, W, C);
+        if (tail) maxpool_tail_kernel<h16><<<ew_grid(tail * (C / 8)), 256, 0, st>>>((const h16*)dx_add, (h16*)dx, B, H, W, C);
     } else return MU_ERR_ARG;
     MU_CHECK_LAUNCH();
     return MU_OK;

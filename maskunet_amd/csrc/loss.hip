@@ -448,15 +448,29 @@ extern "C" int mu_mean_iou(const void* logits, const long* labels, long M, int C
 // bias-corrected moments).  One launch updates every parameter: a device table lists {p, g, m, v, n} per tensor and a
 // block map assigns (tensor, chunk) to each block.  grad_scale_inv un-scales fp16-loss-scaled gradients on the fly.
 // ------------------------------------------------------------------------------------------
-struct MuAdamEntry { float* p; const float* g; float* m; float* v; long n; float bc1; float bc2_sqrt; };   // 48 bytes
-// bc1 = 1 - beta1^t, bc2_sqrt = sqrt(1 - beta2^t) with the tensor's own step count t (torch keeps one counter per parameter)
+struct MuAdamEntry { float* p; const float* g; float* m; float* v; long n; long step; };   // 48 bytes
+// step = the tensor's own count of ATTEMPTED updates including this one (torch keeps one counter per parameter); the number of
+// those that were skipped for a non-finite gradient lives in skipped[tensor] on the device, so the bias corrections
+// bc1 = 1 - beta1^t, bc2 = 1 - beta2^t use t = step - skipped without the host ever reading the overflow flag.
 #define ADAM_CHUNK 4096
 
 __global__ __launch_bounds__(256) void adamw_kernel(const MuAdamEntry* __restrict__ table, const int* __restrict__ block_tensor,
                                                     const int* __restrict__ block_chunk, float lr, float beta1, float beta2, float eps,
-                                                    float wd, float ginv) {
-    const MuAdamEntry e = table[block_tensor[blockIdx.x]];
+                                                    float wd, float ginv, const float* __restrict__ grad_scale,
+                                                    const float* __restrict__ found_inf, const int* __restrict__ skipped) {
+    if (found_inf && *found_inf != 0.f) return;     // an overflowed step updates nothing (GradScaler semantics), decided on the device
+    const int ti = block_tensor[blockIdx.x];
+    const MuAdamEntry e = table[ti];
     if (!e.g) return;                               // parameter without a gradient this step
+    if (grad_scale) ginv = 1.0f / *grad_scale;      // GradScaler's device-side scale
+    __shared__ float sbc[2];
+    if (threadIdx.x == 0) {
+        const double t = (double)(e.step - (skipped ? skipped[ti] : 0));
+        sbc[0] = (float)(1.0 - pow((double)beta1, t));
+        sbc[1] = (float)sqrt(1.0 - pow((double)beta2, t));
+    }
+    __syncthreads();
+    const float bc1 = sbc[0], bc2_sqrt = sbc[1];
     const long base = (long)block_chunk[blockIdx.x] * ADAM_CHUNK;
     for (int i = threadIdx.x; i < ADAM_CHUNK; i += 256) {
         const long k = base + i;
@@ -468,24 +482,56 @@ __global__ __launch_bounds__(256) void adamw_kernel(const MuAdamEntry* __restric
         const float v = beta2 * e.v[k] + (1.f - beta2) * g * g;
         e.m[k] = m;
         e.v[k] = v;
-        const float denom = sqrtf(v) / e.bc2_sqrt + eps;
-        e.p[k] = p - (lr / e.bc1) * (m / denom);
+        const float denom = sqrtf(v) / bc2_sqrt + eps;
+        e.p[k] = p - (lr / bc1) * (m / denom);
     }
+}
+
+// found_inf[0] = 1 if any gradient element of the table is inf / NaN (the caller zeroes it first): one read of every gradient
+__global__ __launch_bounds__(256) void grads_nonfinite_kernel(const MuAdamEntry* __restrict__ table, const int* __restrict__ block_tensor,
+                                                              const int* __restrict__ block_chunk, float* __restrict__ found_inf) {
+    const MuAdamEntry e = table[block_tensor[blockIdx.x]];
+    if (!e.g) return;
+    const long base = (long)block_chunk[blockIdx.x] * ADAM_CHUNK;
+    bool bad = false;
+    for (int i = threadIdx.x; i < ADAM_CHUNK; i += 256) {
+        const long k = base + i;
+        if (k >= e.n) break;
+        const float g = e.g[k];
+        bad = bad || !(fabsf(g) <= 3.4028234e38f);     // false for inf and for NaN
+    }
+    if (__syncthreads_or(bad) && threadIdx.x == 0) *found_inf = 1.0f;
+}
+// after the (possibly skipped) update: count the skip for every tensor that had a gradient
+__global__ void adamw_skip_count_kernel(const MuAdamEntry* __restrict__ table, int ntensors, const float* __restrict__ found_inf,
+                                        int* __restrict__ skipped) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < ntensors && *found_inf != 0.f && table[i].g) skipped[i] += 1;
 }
 
 extern "C" int mu_adamw_chunk(void) { return ADAM_CHUNK; }
 
-extern "C" int mu_adamw_multi(const void* table, const int* block_tensor, const int* block_chunk, int nblocks, float lr, float beta1,
-                              float beta2, float eps, float weight_decay, float grad_scale_inv, void* stream) {
-    if (!table || !block_tensor || !block_chunk || nblocks <= 0) return MU_ERR_ARG;
-    adamw_kernel<<<nblocks, 256, 0, (hipStream_t)stream>>>((const MuAdamEntry*)table, block_tensor, block_chunk, lr, beta1, beta2, eps,
-                                                           weight_decay, grad_scale_inv);
+extern "C" int mu_adamw_multi(const void* table, const int* block_tensor, const int* block_chunk, int nblocks, int ntensors, float lr,
+                              float beta1, float beta2, float eps, float weight_decay, float grad_scale_inv, const float* grad_scale,
+                              float* found_inf, int check_finite, int* skipped, void* stream) {
+    if (!table || !block_tensor || !block_chunk || nblocks <= 0 || ntensors <= 0) return MU_ERR_ARG;
+    if (check_finite && !found_inf) return MU_ERR_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    if (check_finite == 1 && hipMemsetAsync(found_inf, 0, sizeof(float), st) != hipSuccess) return MU_ERR_LAUNCH;
+    if (check_finite) grads_nonfinite_kernel<<<nblocks, 256, 0, st>>>((const MuAdamEntry*)table, block_tensor, block_chunk, found_inf);
+    if (check_finite != 2) {
+        adamw_kernel<<<nblocks, 256, 0, st>>>((const MuAdamEntry*)table, block_tensor, block_chunk, lr, beta1, beta2, eps, weight_decay,
+                                              grad_scale_inv, grad_scale, found_inf, skipped);
+        if (found_inf && skipped)
+            adamw_skip_count_kernel<<<(ntensors + 255) / 256, 256, 0, st>>>((const MuAdamEntry*)table, ntensors, found_inf, skipped);
+    }
     MU_CHECK_LAUNCH();
     return MU_OK;
 }
 
 // ------------------------------------------------------------------------------------------
-// f1 (second half): InstanceContrastiveLoss (ade_panoptic.py:390-418; city_instance.py:279-307; coco_panoptic.py:482-521) without
+// f1 (second half): InstanceContrastiveLoss (ade_panoptic.py:390-418 and coco_panoptic.py:482-521, no ignore label; city_instance.py:279-307,
+// ignore label 255 -- ignore_label < 0 here means "none") without
 // torch.unique / nonzero host round trips.  Per instance id != 0 (and != ignore) with >= 2 pixels: triplet margin loss between the
 // feature columns addressed by the first two pixels of the instance and by the floor(u[k] n_neg)-th pixel outside it; mean over the
 // instances.  "Feature column of pixel (b,h,w)" is features[:, :, b, h] ([B*C] values) -- the reference indexes dims 2,3 with the

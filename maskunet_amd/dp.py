@@ -203,6 +203,12 @@ class DataParallel(nn.Module):
     def finish_gradient_sync(self, copy_back=False):
         """Wait for the bucket all-reduces and hand the averaged gradients back: ``p.grad`` becomes a slice of its bucket (no copy), or
         with ``copy_back=True`` the existing ``p.grad`` tensors are overwritten (GraphedStep: its gradient tensors are the graph's).
+
+        ALIASING (default, ``copy_back=False``): ``p.grad`` is REBOUND to a view of the bucket.  A reference taken to the previous
+        ``p.grad`` tensor before this call (a user-held gradient list, a flat-gradient optimiser's views, pre-allocated gradient
+        buffers) keeps the LOCAL, un-averaged gradient -- read gradients through ``p.grad`` after this call, or pass
+        ``copy_back=True`` to have the averaged values written into the tensors you already hold.  Each ``p.grad`` also keeps its
+        whole bucket (``bucket_mb``) alive until it is released (``zero_grad(set_to_none=True)``).
         Buckets whose hooks did not all fire (parameters without gradients this step) are reduced here with what they have."""
         if not self.multi or not self._sync:
             self._armed = False

@@ -121,7 +121,7 @@ class Mask2FormerAttention(_HipModule):
 
     # -- forward --------------------------------------------------------------------------------
     def forward_nhwc(self, x, scramble=True):
-        if x.shape[-1] != self.channels:
+        if x.shape[-1] != ops.attn_width(self.channels):
             raise ValueError("Input channel size does not match initialized channel size.")
         kidx, kcnt = self._mask_for(x)
         # kidx comes from ops.compact_keys: whole permutations, masked keys last -> the backward may skip the memset of dqkv
@@ -132,9 +132,12 @@ class Mask2FormerAttention(_HipModule):
         if channels != self.channels:
             raise ValueError("Input channel size does not match initialized channel size.")
         self._check_device(x)
-        if channels not in (32, 64, 128, 256):
-            raise RuntimeError("maskunet_amd: Mask2FormerAttention is built for 32, 64, 128 or 256 channels (INTEGRATION.md section 3)")
-        y = self.forward_nhwc(ops.to_nhwc(x, self.compute_dtype), scramble=False)    # [B,N,C] token-major
+        # any channel count up to 256 (the reference takes any, :153-161): widths the kernels are not built for run zero-padded to
+        # the next of 32 / 64 / 128 / 256 (scores scaled by the true 1/sqrt(C), LayerNorm over the true channels)
+        cw = ops.attn_width(channels)
+        y = self.forward_nhwc(ops.to_nhwc(x, self.compute_dtype, cw), scramble=False)    # [B,N,cw] token-major
+        if cw != channels:
+            y = y.view(batch_size, height * width, cw)[:, :, :channels].contiguous()
         # the reference returns this buffer re-viewed as [B,C,H,W] (ade_semantic.py:190)
         return y.view(batch_size, channels, height, width).to(x.dtype)
 

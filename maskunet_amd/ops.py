@@ -37,19 +37,34 @@ class GradLink:
     UNet: 0.35 ms).  The consumer whose backward runs FIRST puts its gradient here and returns None to autograd; the backward of the
     tensor's producer-side neighbour -- which data dependence orders later -- takes it and adds it inside its own kernel
     (mu_maxpool2_bwd_acc / mu_upcat_bwd_acc).  Links are made per forward call by the modules that own both ends (DownSample,
-    UpSample, UNet); a link nobody fills is simply empty (take() -> None), and `armed` says a taker exists at all."""
-    __slots__ = ("t", "armed")
+    UpSample, UNet); a link nobody fills is simply empty (take() -> None), and `armed` says a taker exists at all.
+
+    A fill belongs to the backward pass (autograd graph task) that made it: a partial backward over a retained graph
+    (`torch.autograd.grad(loss, late_params, retain_graph=True)`) can run the filler and prune the taker, and the gradient left
+    behind must not be added to the NEXT pass's -- put() and take() drop a fill that carries another pass's id.
+    Limitation (documented in INTEGRATION.md): the joined gradient bypasses autograd, so a tensor hook / retain_grad() on the linked
+    tensors (the pooled tensor, the skip tensors x1..x3) sees only the part that still flows through autograd; MU_GRAD_LINKS=0
+    restores autograd's own accumulation for such debugging."""
+    __slots__ = ("t", "armed", "task")
 
     def __init__(self):
         self.t = None
         self.armed = False
+        self.task = -1
 
     def put(self, t):
-        self.t = t if self.t is None else self.t + t        # (two fills before a take: retain_graph re-runs; stays correct)
+        task = _graph_task_id()
+        if self.t is not None and self.task == task:
+            self.t = self.t + t                              # two fills within one pass
+        else:
+            self.t, self.task = t, task                      # first fill of this pass (a stale fill of an earlier pass is dropped)
 
     def take(self):
         t, self.t = self.t, None
-        return t
+        return t if self.task == _graph_task_id() else None
+
+
+_graph_task_id = getattr(torch._C, "_current_graph_task_id", lambda: -1)     # id of the running backward pass (-1 outside one)
 
 
 GRAD_LINKS = os.environ.get("MU_GRAD_LINKS", "1") != "0"      # debug switch: 0 = leave every gradient join to autograd
@@ -69,10 +84,10 @@ class _ToNHWC(torch.autograd.Function):
     """NCHW fp32/fp16 [B,C,H,W] -> NHWC [B,H,W,pad32(C)] in the compute dtype (zero padded)."""
 
     @staticmethod
-    def forward(ctx, x, dtype):
+    def forward(ctx, x, dtype, cpad=None):
         B, C, H, W = x.shape
         x = x.contiguous()
-        Cp = pad32(C)
+        Cp = pad32(C) if cpad is None else int(cpad)
         y = torch.empty((B, H, W, Cp), dtype=dtype, device=x.device)
         call("mu_transpose_pad", ptr(x), dt(x), H * W, ptr(y), dt(y), Cp, B, C, H * W, Cp, stream())
         ctx.C, ctx.in_dtype = C, x.dtype
@@ -85,7 +100,7 @@ class _ToNHWC(torch.autograd.Function):
         B, H, W, Cp = g.shape
         gx = torch.empty((B, ctx.C, H, W), dtype=ctx.in_dtype, device=g.device)
         call("mu_transpose", ptr(g), dt(g), Cp, ptr(gx), dt(gx), H * W, B, H * W, ctx.C, stream())
-        return gx, None
+        return gx, None, None
 
 
 class _ToNCHW(torch.autograd.Function):
@@ -110,10 +125,11 @@ class _ToNCHW(torch.autograd.Function):
         return gx, None, None
 
 
-def to_nhwc(x, dtype):
+def to_nhwc(x, dtype, cpad=None):
+    """cpad: stored channel count (default pad32(C)); a wider zero padding for the ops that run on fixed widths (attn_width)."""
     if x.dtype not in (torch.float32, torch.float16):
         x = x.float()
-    return _ToNHWC.apply(x, dtype)
+    return _ToNHWC.apply(x, dtype, cpad)
 
 
 def u8_hwc_to_nhwc(img_u8, dtype):
@@ -224,6 +240,7 @@ def _prep_weight_raw(w, dtype, rows_pad, cols_pad, mode):
 # weights change every step, so a training forward cannot keep them).  Each weight gets a ONE-SHOT entry that the next _Conv.forward
 # on it consumes -- nothing survives the forward it was made for, so the no-stale-weights rule of the cache above holds here too.
 MULTI_PREP = os.environ.get("MU_MULTI_PREP", "1") != "0"
+MULTI_PREP_MAX_JOBS = 128       # MU_PREP_MAX_JOBS of the kernel's shared job table
 
 
 def prep_conv_weights(holder, weights, dtype, fwd_only=()):
@@ -234,11 +251,20 @@ def prep_conv_weights(holder, weights, dtype, fwd_only=()):
     dev = weights[0].device
     if dev.type != "cuda" or any(w.dtype != torch.float32 or not w.is_contiguous() or w.dim() != 4 for w in weights):
         return
+    if len(weights) > MULTI_PREP_MAX_JOBS or any(w.shape[2] * w.shape[3] not in (1, 9) for w in weights):
+        return                          # outside the kernel's job table / LDS tile (MU_PREP_MAX_JOBS, MAXT = 9): the per-layer path serves them
     only = {id(w) for w in fwd_only}
     key = (dtype, tuple((w.data_ptr(), tuple(w.shape)) for w in weights), tuple(id(w) in only for w in weights))
-    plan = holder.get("plan")
-    if plan is None or plan[0] != key:
-        if torch.cuda.is_current_stream_capturing():
+    # one device job table per distinct key, kept: a captured graph (GraphedStep) holds the raw address of the table its forward used,
+    # and a later eager forward under another key (compute dtype, requires_grad of the input) must not free it under the graph.
+    # Tables seen during a capture are pinned for the holder's lifetime; the others are bounded (oldest dropped beyond 8).
+    plans = holder.setdefault("plans", {})
+    plan = plans.get(key)
+    capturing = torch.cuda.is_current_stream_capturing()
+    if plan is not None and capturing:
+        holder.setdefault("pinned", {})[key] = plan
+    if plan is None:
+        if capturing:
             return                      # the table is an H2D copy: built by an eager forward (GraphedStep warms up eagerly)
         rows, metas, off, chunk = [], [], 0, 0
         for w in weights:
@@ -251,7 +277,10 @@ def prep_conv_weights(holder, weights, dtype, fwd_only=()):
             metas.append((off, n, taps, rp, cp, mode))
             off += total
             chunk += (rp // 32) * (cp // 32)               # one block-iteration per 32 x 32 (out x in) tile
-        plan = holder["plan"] = (key, torch.tensor(rows, dtype=torch.int64, device=dev), metas, off, chunk)
+        plan = plans[key] = (key, torch.tensor(rows, dtype=torch.int64, device=dev), metas, off, chunk)
+        pinned = holder.get("pinned", {})
+        for old in [k for k in plans if k != key and k not in pinned][:max(0, len(plans) - len(pinned) - 8)]:
+            del plans[old]
     _, table, metas, total, nchunks = plan
     dst = torch.empty(total, dtype=dtype, device=dev)
     call("mu_prep_weights_multi", ptr(table), len(weights), nchunks, ptr(dst), dt(dtype), stream())
@@ -839,6 +868,17 @@ class _MaskAttention(torch.autograd.Function):
         x = x.contiguous()
         B, H, W, C = x.shape
         N = H * W
+        cv = wq.shape[0]                          # true channel count; C = the width x is stored with (attn_width(cv))
+        ctx.cv = cv
+        if cv != C:
+            # a channel count the kernels have no width for: every parameter zero-padded to C (slow path, torch pads; standalone
+            # Mask2FormerAttention only -- the UNet's blocks are 64 / 128 / 256 wide)
+            if scramble:
+                raise RuntimeError("mask_attention: the re-viewed (scrambled) output needs an unpadded channel count")
+            pw = lambda w: F.pad(w.detach().float(), (0, C - cv, 0, C - cv))      # noqa: E731
+            pv = lambda v: F.pad(v.detach().float(), (0, C - cv))                # noqa: E731
+            wq, wk, wv, bq, bk, bv, lnw, lnb = pw(wq), pw(wk), pw(wv), pv(bq), pv(bk), pv(bv), pv(lnw), pv(lnb)
+            cache_ok = False
 
         def make_qkv():          # the three Linear layers as one [3C, C] 1x1 layer: forward + data-gradient layouts and the bias, one launch
             wbuf = torch.empty((6 * C * C,), dtype=x.dtype, device=x.device)
@@ -862,8 +902,12 @@ class _MaskAttention(torch.autograd.Function):
         lse2 = torch.empty((B, N), dtype=torch.float32, device=x.device)
         mean, rstd = torch.empty_like(lse2), torch.empty_like(lse2)
         g, b_ = lnw.detach().float().contiguous(), lnb.detach().float().contiguous()
-        call("mu_attn_fwd", ptr(qkv), ptr(x), ptr(kidx), ptr(kcnt), ptr(g), ptr(b_), ptr(out), ptr(oattn), ptr(lse2), ptr(mean),
-             ptr(rstd), B, N, C, kidx.shape[1], float(eps), dt(x), stream())
+        if cv == C:
+            call("mu_attn_fwd", ptr(qkv), ptr(x), ptr(kidx), ptr(kcnt), ptr(g), ptr(b_), ptr(out), ptr(oattn), ptr(lse2), ptr(mean),
+                 ptr(rstd), B, N, C, kidx.shape[1], float(eps), dt(x), stream())
+        else:
+            call("mu_attn_fwd_padded", ptr(qkv), ptr(x), ptr(kidx), ptr(kcnt), ptr(g), ptr(b_), ptr(out), ptr(oattn), ptr(lse2), ptr(mean),
+                 ptr(rstd), B, N, C, cv, kidx.shape[1], float(eps), dt(x), stream())
         ctx.save_for_backward(x, qkv, oattn, lse2, mean, rstd, g, kidx, kcnt)
         ctx.scramble, ctx.dims, ctx.kidx_perm = scramble, (B, H, W, C), bool(kidx_perm) and kidx.shape[1] == N
         if scramble:
@@ -889,15 +933,20 @@ class _MaskAttention(torch.autograd.Function):
         # permutation with the masked keys last, as mu_compact_keys / a stable descending argsort give): the dK/dV sweep then zeroes
         # the masked rows itself.  Without the promise phase 1 memsets dqkv (kidx from outside may be padded behind kcnt).
         perm = 8 if ctx.kidx_perm else 0
+        cv = ctx.cv
         for phase in (1, 2, 4):      # LayerNorm-backward prepass, dQ sweep, dK/dV sweep (separate calls: each can be timed)
-            call("mu_attn_bwd_phases", ptr(qkv), ptr(x), ptr(oattn), ptr(gout), ptr(kidx), ptr(kcnt), ptr(lse2), ptr(mean), ptr(rstd),
-                 ptr(g), ptr(dY), ptr(delta), ptr(dqkv), ptr(dg), ptr(db), B, N, C, kidx.shape[1], ptr(ws), ws.numel(), dt(x),
-                 phase | perm, stream())
+            if cv == C:
+                call("mu_attn_bwd_phases", ptr(qkv), ptr(x), ptr(oattn), ptr(gout), ptr(kidx), ptr(kcnt), ptr(lse2), ptr(mean), ptr(rstd),
+                     ptr(g), ptr(dY), ptr(delta), ptr(dqkv), ptr(dg), ptr(db), B, N, C, kidx.shape[1], ptr(ws), ws.numel(), dt(x),
+                     phase | perm, stream())
+            else:
+                call("mu_attn_bwd_phases_padded", ptr(qkv), ptr(x), ptr(oattn), ptr(gout), ptr(kidx), ptr(kcnt), ptr(lse2), ptr(mean),
+                     ptr(rstd), ptr(g), ptr(dY), ptr(delta), ptr(dqkv), ptr(dg), ptr(db), B, N, C, cv, kidx.shape[1], ptr(ws), ws.numel(),
+                     dt(x), phase | perm, stream())
         dqkv4 = dqkv.view(B, H, W, 3 * C)
         gx = None
         if ctx.needs_input_grad[0]:
-            wd = ctx.wd
-            ctx.wd = None
+            wd = ctx.wd                          # kept on ctx (views of one small buffer): a second backward over a retained graph needs it again
             if ATTN_FUSED_ADD and _lib.load().mu_conv1x1_add_supported(3 * C, C, dt(x)):
                 # gx = dqkv @ Wqkv + dY: the residual branch (:187) joins the projection's data-gradient in its epilogue
                 gx = torch.empty((B, H, W, C), dtype=x.dtype, device=x.device)
@@ -911,10 +960,25 @@ class _MaskAttention(torch.autograd.Function):
         else:
             gw = _wgrad_raw(x, dqkv4, (3 * C, C, 1, 1), 1).view(3 * C, C)
             gb = _colsum(dqkv4, 3 * C)
+        if cv != C:                  # gradients of the real (unpadded) parameters
+            return (gx, gw[:cv, :cv], gb[:cv], gw[C:C + cv, :cv], gb[C:C + cv], gw[2 * C:2 * C + cv, :cv], gb[2 * C:2 * C + cv],
+                    dg[:cv], db[:cv], None, None, None, None, None, None)
         return (gx, gw[:C], gb[:C], gw[C:2 * C], gb[C:2 * C], gw[2 * C:], gb[2 * C:], dg, db, None, None, None, None, None, None)
 
 
 ATTN_FUSED_ADD = os.environ.get("MU_ATTN_FUSED_ADD", "1") != "0"      # debug switch: 0 = projection data-gradient + mu_add
+
+
+ATTN_WIDTHS = (32, 64, 128, 256)
+
+
+def attn_width(channels: int) -> int:
+    """Stored (zero-padded) width the attention kernels run a block of `channels` channels at."""
+    for w in ATTN_WIDTHS:
+        if channels <= w:
+            return w
+    raise RuntimeError(f"maskunet_amd: Mask2FormerAttention supports up to {ATTN_WIDTHS[-1]} channels, got {channels} "
+                       "(INTEGRATION.md section 3)")
 
 
 def mask_attention(x, q, k, v, norm, kidx, kcnt, scramble=True, kidx_perm=False):

@@ -246,8 +246,8 @@ def mean_iou(y_pred, y_true, num_classes, smooth=1e-6):
 
 
 def instance_contrastive_loss(features, instance_mask, u, margin: float = 1.0, ignore_index=None):
-    """InstanceContrastiveLoss (ade_panoptic.py:390-418; with `ignore_index=255` city_instance.py:279-307 and
-    coco_panoptic.py:482-521): for every instance id != 0 with at least two pixels, a triplet margin loss between the feature
+    """InstanceContrastiveLoss (ade_panoptic.py:390-418 and coco_panoptic.py:482-521: every id of the mask, `ignore_index=None`;
+    city_instance.py:279-307: `valid_mask = instance_mask != 255`, i.e. `ignore_index=255`): for every instance id != 0 with at least two pixels, a triplet margin loss between the feature
     columns addressed by the FIRST two pixels of the instance and by one random pixel outside it, averaged over instances.
 
     Faithful to the reference's indexing: `nonzero(as_tuple=True)` of the [B,H,W] mask yields (batch, row, col) index

@@ -303,6 +303,17 @@ def check_pool_up(dtype):
     y = ops.to_nchw(ops.maxpool2(ops.to_nhwc(xd, dtype)), 64, torch.float32)
     y.backward(g.to(DEV))
     out += [("maxpool y", _err(y, yr), tol), ("maxpool dx", _rel_err(xd.grad, xr.grad), tol)]
+    # odd sizes: nn.MaxPool2d(2) floors (ade_semantic.py:216); the uncovered last row / column gets a zero gradient
+    for (H, W) in [(13, 8), (12, 9), (7, 5), (3, 2)]:
+        x = _rnd(gen, 2, 32, H, W)
+        g = _rnd(gen, 2, 32, H // 2, W // 2)
+        xr = x.to(dtype).float().clone().requires_grad_(True)
+        yr = F.max_pool2d(xr, 2)
+        yr.backward(g.to(dtype).float())
+        xd = x.to(DEV).requires_grad_(True)
+        y = ops.to_nchw(ops.maxpool2(ops.to_nhwc(xd, dtype)), 32, torch.float32)
+        y.backward(g.to(DEV))
+        out += [(f"maxpool{(H, W)} y", _err(y, yr), tol), (f"maxpool{(H, W)} dx", _rel_err(xd.grad, xr.grad), tol)]
     for (B, Cx, Cs, h, w) in [(2, 32, 64, 5, 7), (1, 256, 256, 16, 16), (2, 64, 32, 1, 3)]:
         x = _rnd(gen, B, Cx, h, w)
         s = _rnd(gen, B, Cs, 2 * h, 2 * w)

@@ -246,3 +246,86 @@ def test_three_head_batch64_training_step():
     assert any(n.startswith("embedding_head") for n in names) and any(n.startswith("final_layer") for n in names)
     assert not any(n.startswith("boundary_head") for n in names) and not any("emb_layer" in n for n in names)
     assert tuple(sem.shape) == (B, 19, 128, 128) and tuple(bnd.shape) == (B, 1, 128, 128) and tuple(emb.shape) == (B, 16, 128, 128)
+
+
+@pytest.mark.parametrize("c_out,hw,B", [(133, 128, 128), (133, 256, 32)])
+def test_full_size_configs_training_step_and_batch_invariance(c_out, hw, B):
+    """configs[2] at its full batch (COCO panoptic shape, c_out 133, B = 128) and configs[4] at its per-GPU batch (256x256, B = 32):
+    the batch-dependent dispatch (persistent tile walk, split-K plans, XCD image order, 64-bit offsets -- the 256x256 tensors are
+    671 MB) under the same property set as the B = 64 tests: a fp16 training step is finite and bit-reproducible, its loss equals a
+    recomputation of the criterion on its own output, and in eval mode images 0..1 of the big batch equal the B = 2 run bit for bit
+    (the B = 2 run is what the reference goldens / the live oracle pin at these shapes: test_unet_golden[unet1_c133_b2_train],
+    test_unet_c133_vs_oracle, test_unet_256_forward_vs_blockwise_oracle)."""
+    import maskunet_amd
+    model, params, keeps, x, labels = _build(c_out, hw, 7000 + hw + B, torch.float16, True, B)
+    xd, yd = x.cuda(), labels.cuda()
+    crit = maskunet_amd.CrossEntropyLoss()
+    runs = []
+    for _ in range(2):
+        model.load_state_dict(params)
+        model.zero_grad(set_to_none=True)
+        out = model(xd)
+        loss = crit(out, yd)
+        (loss * 1024.0).backward()
+        runs.append((out.detach().clone(), loss.item(), {n: p.grad.clone() for n, p in model.named_parameters() if p.grad is not None}))
+        del out, loss
+    assert runs[0][1] == runs[1][1] and torch.equal(runs[0][0], runs[1][0])
+    assert all(torch.equal(runs[0][2][n], runs[1][2][n]) for n in runs[0][2])
+    assert all(torch.isfinite(v).all() for v in runs[0][2].values()) and len(runs[0][2]) > 300
+    ref_loss = F.cross_entropy(runs[0][0].float(), yd).item()
+    assert abs(ref_loss - runs[0][1]) <= 1e-4 * max(1.0, abs(ref_loss))
+    # the gradient of the last image's logits is not zero: every image of the batch took part (a dropped tail of the batch would
+    # leave finite, reproducible, but wrong results)
+    gin = torch.autograd.grad(crit(model(xd.requires_grad_(True)), yd), xd)[0]
+    assert float(gin[-1].abs().max()) > 0 and float(gin[B // 2].abs().max()) > 0 and torch.isfinite(gin).all()
+    del runs, gin
+    model.zero_grad(set_to_none=True)
+    model.load_state_dict(params)
+    model.eval()
+    with torch.no_grad():
+        big = model(xd.detach())
+    model.set_keep_masks([k[:2] for k in keeps])
+    with torch.no_grad():
+        small = model(xd.detach()[:2])
+    assert torch.isfinite(big).all()
+    diff = float((big[:2] - small).abs().max())
+    assert diff == 0.0, f"B={B} and B=2 disagree on the same images: max abs diff {diff:.3e}"
+
+
+def test_attention_65536_tokens_batch32_offsets():
+    """self_attention6 of configs[4] at its per-GPU batch through the C ABI (fp16): qkv is 805 MB, so image 31 sits behind 32-bit
+    element offsets; its forward rows agree with a torch recomputation and its masked keys get exact-zero dK / dV."""
+    from maskunet_amd import _lib
+    B, N, C = 32, 256 * 256, 64
+    g_ = torch.Generator(device="cuda").manual_seed(9)
+    qkv = torch.randn(B, N, 3 * C, device="cuda", generator=g_).half()
+    x = torch.randn(B, N, C, device="cuda", generator=g_).half()
+    keep = torch.randint(0, 2, (B, N), device="cuda", generator=g_, dtype=torch.uint8)
+    kidx = torch.argsort(keep, dim=1, descending=True, stable=True).to(torch.int32).contiguous()
+    kcnt = keep.sum(1, dtype=torch.int32).contiguous()
+    g, b_ = torch.ones(C, device="cuda"), torch.zeros(C, device="cuda")
+    out, oattn = torch.empty_like(x), torch.empty_like(x)
+    lse = torch.empty(B, N, device="cuda")
+    mean, rstd, delta = torch.empty_like(lse), torch.empty_like(lse), torch.empty_like(lse)
+    dY, dqkv = torch.empty_like(x), torch.full_like(qkv, 7.0)
+    dg, db = torch.empty(C, device="cuda"), torch.empty(C, device="cuda")
+    gout = torch.randn(B, N, C, device="cuda", generator=g_).half()
+    ws = _lib.workspace(_lib.load().mu_attn_bwd_workspace_bytes(B, N, C), torch.device("cuda"))
+    st = _lib.stream()
+    _lib.call("mu_attn_fwd", qkv.data_ptr(), x.data_ptr(), kidx.data_ptr(), kcnt.data_ptr(), g.data_ptr(), b_.data_ptr(),
+              out.data_ptr(), oattn.data_ptr(), lse.data_ptr(), mean.data_ptr(), rstd.data_ptr(), B, N, C, N, 1e-5, _lib.dt(x), st)
+    _lib.call("mu_attn_bwd", qkv.data_ptr(), x.data_ptr(), oattn.data_ptr(), gout.data_ptr(), kidx.data_ptr(), kcnt.data_ptr(),
+              lse.data_ptr(), mean.data_ptr(), rstd.data_ptr(), g.data_ptr(), dY.data_ptr(), delta.data_ptr(), dqkv.data_ptr(),
+              dg.data_ptr(), db.data_ptr(), B, N, C, N, ws.data_ptr(), ws.numel(), _lib.dt(x), st)
+    assert torch.isfinite(dqkv).all()
+    for b in (0, 17, 31):
+        masked = keep[b] == 0
+        dk, dv = dqkv[b, :, C:2 * C], dqkv[b, :, 2 * C:]
+        assert float(dk[masked].abs().max()) == 0.0 and float(dv[masked].abs().max()) == 0.0 and float(dk[~masked].abs().max()) > 0
+        qs = torch.arange(0, N, N // 128, device="cuda")
+        q, k, v = (qkv[b, :, i * C:(i + 1) * C].double() for i in range(3))
+        s = (q[qs] @ k[~masked].T) / (C ** 0.5)
+        o = torch.softmax(s, dim=-1) @ v[~masked] + x[b, qs].double()
+        ref = F.layer_norm(o, (C,), eps=1e-5)
+        err = float((out[b, qs].double() - ref).abs().max()) / max(1.0, float(ref.abs().max()))
+        assert err <= 3e-2, (b, err)

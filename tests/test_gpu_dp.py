@@ -279,8 +279,41 @@ def test_bench_multi_rank_path_over_rccl_one_rank(graph):
     assert rec["config"]["mask_mode"] == ("fixed" if graph else "resample")      # a captured step replays its masks
 
 
-def test_bench_refuses_gpus_without_launcher():
+def test_bench_bare_gpus2_spawns_its_own_ranks():
+    """`python bench.py --gpus 2` with NO launcher (the shape of command a scaling driver may issue): bench.py starts the two ranks
+    itself as a child torch.distributed.run (before touching the GPU) and relays rank 0's JSON line and the exit code.  Two gloo ranks
+    share the one GPU here."""
+    import json
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env["MU_DIST_BACKEND"] = "gloo"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "2",
+                        "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["config"]["global_batch"] == 4 and rec["value"] > 0
+    assert rec["config"]["mask_mode"] == "resample" and rec["config"]["parallelism"] == "dp2"
+
+
+def test_bench_refuses_world_size_that_disagrees_with_gpus():
+    env = dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
-                       env={k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")},
-                       capture_output=True, text=True, timeout=300)
+                       env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode != 0 and "WORLD_SIZE" in (r.stdout + r.stderr)
+
+
+def test_bench_line_is_self_describing():
+    """The N = 1 line carries what a reader of BENCH alone needs: which parity gate the timed dtype passes (the reference-generated
+    B = 2 golden, run outside the timed region), the clock the chip holds under a dense MFMA load, and the roofline fraction at it."""
+    import json
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--batch", "4", "--no-cpu-baseline"],
+                       env={k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")},
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    rec = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])
+    g = rec["parity_gate"]
+    assert g["passed"] is True and g["dtype"] == "f16" and g["gate"]["out"] == 3e-2 and 0 < g["observed"]["out"] <= 3e-2
+    c = rec["clock"]
+    assert 800 < c["clock_mhz"] <= 2500 and c["probe_tflops"] > 200
+    assert rec["roofline"]["frac_at_measured_clock"] >= rec["roofline"]["frac"] > 0

@@ -195,3 +195,44 @@ def test_training_trajectory_matches_oracle():
     assert abs(ref_losses[-1] - ref_losses[0]) > 2e-2, ref_losses           # the steps do change the loss
     for a, b in zip(got, ref_losses):
         assert abs(a - b) <= 2e-3 * max(1.0, abs(b)), (got, ref_losses)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_attention_backward_twice_over_a_retained_graph(dtype):
+    """the projection's data-gradient layout stays on the autograd node, so a second backward over the same graph
+    (retain_graph=True, or two losses backpropagated separately) gives the same gradients instead of MU_ERR_ARG."""
+    import maskunet_amd
+    torch.manual_seed(5)
+    m = maskunet_amd.Mask2FormerAttention(64, 64).cuda().set_compute_dtype(dtype)
+    x = torch.randn(2, 64, 16, 16, device="cuda", requires_grad=True)
+    m.set_keep_mask(torch.randint(0, 2, (2, 256), dtype=torch.uint8))
+    y = m(x)
+    gy = torch.randn_like(y)
+    y.backward(gy, retain_graph=True)
+    g1 = [x.grad.clone()] + [p.grad.clone() for p in m.parameters()]
+    x.grad = None
+    m.zero_grad(set_to_none=True)
+    y.backward(gy)
+    g2 = [x.grad] + [p.grad for p in m.parameters()]
+    assert all(torch.equal(a, b) for a, b in zip(g1, g2))
+
+
+def test_partial_backward_does_not_leak_a_linked_gradient_into_the_next_pass():
+    """torch.autograd.grad towards LATE parameters over a retained graph runs the GradLink fillers (residual ConvBlock
+    / UpSample backward) and prunes the takers (max-pool backward); the gradient parked in the link belongs to THAT pass and must
+    not be added to the full backward that follows."""
+    import torch.nn.functional as F
+    from tests import _gpu_checks as G
+    model, params, keeps, x, labels = G.build_unet(150, False, 330, torch.float32, True, 2)
+    xd, ld = x.to("cuda"), labels.to("cuda")
+    F.cross_entropy(model(xd), ld).backward()
+    ref = {n: p.grad.clone() for n, p in model.named_parameters() if p.grad is not None}
+    model.zero_grad(set_to_none=True)
+    loss = F.cross_entropy(model(xd), ld)
+    late = [model.downsample1.maxpool_conv[1].conv_block[0].weight, model.upsample3.conv[0].conv_block[0].weight]
+    part = torch.autograd.grad(loss, late, retain_graph=True)          # fills links whose takers are pruned from this pass
+    assert torch.equal(part[0], ref["downsample1.maxpool_conv.1.conv_block.0.weight"])
+    loss.backward()
+    for n, p in model.named_parameters():
+        if n in ref:
+            assert torch.equal(p.grad, ref[n]), n

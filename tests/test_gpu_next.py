@@ -361,3 +361,66 @@ def test_weight_layout_cache_only_without_grad_and_invalidated_by_updates():
                 ops.PREP_CACHE = ops_cache
     finally:
         _lib.PROBE = None
+
+
+def test_fused_adamw_skips_an_overflowed_step_entirely():
+    """one inf / NaN gradient must not reach the fp32 master weights.  A step whose gradients hold a non-finite
+    value changes NOTHING (parameters, moments, effective step count) -- decided on the device, no host sync -- and the trajectory
+    afterwards equals torch.optim.AdamW's over the finite steps only."""
+    import maskunet_amd
+    torch.manual_seed(1)
+    shapes = [(64, 3, 3, 3), (150, 64, 1, 1), (5000,)]
+    ref_p = [torch.randn(s, device="cuda").requires_grad_(True) for s in shapes]
+    our_p = [p.detach().clone().requires_grad_(True) for p in ref_p]
+    ref = torch.optim.AdamW(ref_p, lr=5e-3, weight_decay=1e-1)
+    our = maskunet_amd.FusedAdamW(our_p, lr=5e-3, weight_decay=1e-1)
+    scale = 1024.0
+    for it in range(5):
+        grads = [torch.randn_like(a) for a in ref_p]
+        overflow = it in (1, 3)
+        for a, b, g in zip(ref_p, our_p, grads):
+            a.grad = g.clone()
+            b.grad = g * scale
+        if overflow:
+            our_p[1].grad.view(-1)[77] = float("inf") if it == 1 else float("nan")
+            before = [p.detach().clone() for p in our_p]
+            moments = [our.state[p]["exp_avg"].clone() for p in our_p]
+        else:
+            ref.step()
+        our.step(grad_scale=scale)
+        assert our.last_step_skipped() == overflow
+        if overflow:
+            assert all(torch.equal(a, b) for a, b in zip(before, our_p))
+            assert all(torch.equal(m, our.state[p]["exp_avg"]) for m, p in zip(moments, our_p))
+    for a, b in zip(ref_p, our_p):
+        assert torch.isfinite(b).all() and torch.allclose(a, b, rtol=2e-5, atol=2e-6), (a - b).abs().max()
+    assert our.effective_steps(our_p[0]) == 3
+    assert our.state_dict()["state"][0]["step"] == 3          # folded into the checkpointed counters
+
+
+def test_fused_adamw_under_torch_gradscaler():
+    """torch.cuda.amp.GradScaler.step(FusedAdamW): the scaler's device-side scale / found_inf drive the kernel (no .item() sync in
+    GradScaler for optimisers with _step_supports_amp_scaling); an overflowed step is skipped and the scale backs off."""
+    import maskunet_amd
+    torch.manual_seed(2)
+    w = torch.randn(4096, device="cuda").requires_grad_(True)
+    w_ref = w.detach().clone().requires_grad_(True)
+    our = maskunet_amd.FusedAdamW([w], lr=1e-2, weight_decay=0.0)
+    ref = torch.optim.AdamW([w_ref], lr=1e-2, weight_decay=0.0)
+    scaler = torch.amp.GradScaler("cuda", init_scale=2.0 ** 10, growth_interval=1000)
+    x = torch.randn(4096, device="cuda")
+    for it in range(4):
+        our.zero_grad(set_to_none=True)
+        loss = (w * x).square().mean()
+        scaler.scale(loss).backward()
+        if it == 2:
+            w.grad[5] = float("inf")                     # the overflow a too-large scale produces
+        else:
+            ref.zero_grad(set_to_none=True)
+            (w_ref * x).square().mean().backward()
+            ref.step()
+        s0 = scaler.get_scale()
+        scaler.step(our)
+        scaler.update()
+        assert (scaler.get_scale() < s0) == (it == 2)
+    assert torch.isfinite(w).all() and torch.allclose(w, w_ref, rtol=2e-5, atol=2e-6)
