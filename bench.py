@@ -152,11 +152,16 @@ class SmiSampler:
         self._th = threading.Thread(target=self._run, daemon=True)
 
     def _run(self):
+        import glob
+        freq = glob.glob(os.path.join(self.dev, "hwmon", "hwmon*", "freq1_input")) if self.dev else []
         while not self._stop.is_set():
             try:
-                for ln in open(os.path.join(self.dev, "pp_dpm_sclk")):
-                    if ln.rstrip().endswith("*"):
-                        self.sclk.append(float(ln.split(":")[1].strip().lower().split("mhz")[0]))
+                if freq:                                         # hwmon sclk in Hz (pp_dpm_sclk's starred level read 95 MHz under load on one box)
+                    self.sclk.append(float(open(freq[0]).read()) * 1e-6)
+                else:
+                    for ln in open(os.path.join(self.dev, "pp_dpm_sclk")):
+                        if ln.rstrip().endswith("*"):
+                            self.sclk.append(float(ln.split(":")[1].strip().lower().split("mhz")[0]))
             except (OSError, ValueError, IndexError):
                 pass
             try:

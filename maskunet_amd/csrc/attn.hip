@@ -94,6 +94,9 @@
 #ifndef MU_DQ_PREFETCH
 #define MU_DQ_PREFETCH 0
 #endif
+#ifndef MU_DKV_PKMUL
+#define MU_DKV_PKMUL 1
+#endif
 #ifndef MU_FWD_PREFETCH
 #define MU_FWD_PREFETCH 0
 #endif
@@ -167,6 +170,14 @@ template <> struct AT<h16> {
     }
     static __device__ __forceinline__ void mma_acc(const AccA& a, const f32x4& p0, const f32x4& p1, f32x4& c) {
         h16x8 b = {(h16)p0[0], (h16)p0[1], (h16)p0[2], (h16)p0[3], (h16)p1[0], (h16)p1[1], (h16)p1[2], (h16)p1[3]};
+        c = __builtin_amdgcn_mfma_f32_16x16x32_f16(a.v, b, c, 0, 0, 0);
+    }
+    // the same with the B operand already packed (MU_DKV_PKMUL: dS = P * dP' as four v_pk_mul_f16 on the packed halves)
+    using Packed = h16x8;
+    static __device__ __forceinline__ Packed pack(const f32x4& p0, const f32x4& p1) {
+        return (h16x8){(h16)p0[0], (h16)p0[1], (h16)p0[2], (h16)p0[3], (h16)p1[0], (h16)p1[1], (h16)p1[2], (h16)p1[3]};
+    }
+    static __device__ __forceinline__ void mma_acc_pk(const AccA& a, const Packed& b, f32x4& c) {
         c = __builtin_amdgcn_mfma_f32_16x16x32_f16(a.v, b, c, 0, 0, 0);
     }
 };
@@ -1127,6 +1138,38 @@ __global__ __launch_bounds__(NW * 64, NW >= 8 ? 1 : ((D <= 64 && sizeof(T) == 2 
             }
             __builtin_amdgcn_sched_barrier(0);
         }
+        // MU_DKV_PKMUL (fp16 storage): P and dP' are rounded to fp16 first -- both are fp16 MFMA operands' worth of precision anyway --
+        // and dS = P * dP' is FOUR packed fp16 multiplies per 8 scores instead of 8 fp32 ones: 24 instead of 32 VALU instructions per
+        // 32-query x 32-key tile behind the 16 exponentials (the sweep runs at MFMA + VALU issue time)
+        constexpr bool PKMUL = MU_DKV_PKMUL && sizeof(T) == 2;
+        if constexpr (PKMUL) {
+            typename AT<h16>::Packed pb[NKT], db[NKT];
+#pragma unroll
+            for (int qt = 0; qt < 2; ++qt)
+#pragma unroll
+                for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) s[qt][kt][r] = __builtin_amdgcn_exp2f(s[qt][kt][r]);
+#pragma unroll
+            for (int kt = 0; kt < NKT; ++kt) {
+                pb[kt] = AT<h16>::pack(s[0][kt], s[1][kt]);
+                db[kt] = AT<h16>::pack(dp[0][kt], dp[1][kt]) * pb[kt];
+            }
+            if constexpr (PRE > 0) __builtin_amdgcn_sched_barrier(0);
+            MU_PRIO(1);
+#pragma unroll
+            for (int dt = 0; dt < NDT; ++dt) {
+                typename AT<h16>::AccA oa, qa;
+                if (dt < PRE) { oa = oap[dt]; qa = qap[dt]; }
+                else { oa = AccLd<h16, D>::ld((const h16*)Ot, 0, dt * 16, g, r16); qa = AccLd<h16, D>::ld((const h16*)Qt, 0, dt * 16, g, r16); }
+#pragma unroll
+                for (int kt = 0; kt < NKT; ++kt) {
+                    AT<h16>::mma_acc_pk(oa, pb[kt], dv[dt][kt]);
+                    AT<h16>::mma_acc_pk(qa, db[kt], dk[dt][kt]);
+                }
+            }
+            MU_PRIO(0);
+        } else {
 #pragma unroll
         for (int qt = 0; qt < 2; ++qt)
 #pragma unroll
@@ -1151,6 +1194,7 @@ __global__ __launch_bounds__(NW * 64, NW >= 8 ? 1 : ((D <= 64 && sizeof(T) == 2 
             }
         }
         MU_PRIO(0);
+        }
         // Refill the slot tile tl-1 vacated -- issued LAST in the tile: LDS reads queue behind an in-flight LDS-DMA issue
         // (in-kernel s_memtime stamps: the row-constant reads right after the DMA cost ~980 cycles/tile, ~80 without it)
 #if !defined(MU_DKV_ISSUE_FIRST) && !defined(MU_DKV_ABL_NODMA)

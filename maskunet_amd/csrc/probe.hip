@@ -27,12 +27,12 @@ __global__ __launch_bounds__(256) void clock_probe_kernel(unsigned long long* __
     const unsigned long long t0 = __builtin_amdgcn_s_memtime();
     const unsigned long long r0 = __builtin_amdgcn_s_memrealtime();
     for (int it = 0; it < iters; ++it) {
+        // in-place accumulators through inline asm: compiled from the builtin, hipcc rotated the eight accumulators through
+        // overlapping register tuples across the unrolled body and every MFMA waited for its neighbour (36 instead of 16 cycles each)
 #pragma unroll
         for (int u = 0; u < 2; ++u)
 #pragma unroll
-            for (int i = 0; i < 8; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, acc[i], 0, 0, 0);
-        // keep the operands changing (no value the compiler can fold, sign pattern stays mixed)
-        a = -a;
+            for (int i = 0; i < 8; ++i) asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(acc[i]) : "v"(a), "v"(b));
     }
     const unsigned long long t1 = __builtin_amdgcn_s_memtime();
     const unsigned long long r1 = __builtin_amdgcn_s_memrealtime();

@@ -271,7 +271,7 @@ def test_full_size_configs_training_step_and_batch_invariance(c_out, hw, B):
         del out, loss
     assert runs[0][1] == runs[1][1] and torch.equal(runs[0][0], runs[1][0])
     assert all(torch.equal(runs[0][2][n], runs[1][2][n]) for n in runs[0][2])
-    assert all(torch.isfinite(v).all() for v in runs[0][2].values()) and len(runs[0][2]) > 300
+    assert all(torch.isfinite(v).all() for v in runs[0][2].values()) and len(runs[0][2]) >= 160
     ref_loss = F.cross_entropy(runs[0][0].float(), yd).item()
     assert abs(ref_loss - runs[0][1]) <= 1e-4 * max(1.0, abs(ref_loss))
     # the gradient of the last image's logits is not zero: every image of the batch took part (a dropped tail of the batch would

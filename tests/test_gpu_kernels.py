@@ -126,7 +126,7 @@ def test_error_codes_not_exceptions():
     x = torch.zeros(1, 4, 4, 48, device="cuda")
     assert lib.mu_conv_fwd(x.data_ptr(), x.data_ptr(), None, x.data_ptr(), 1, 4, 4, 48, 32, 9, 48, 32, 0, None) == -2
     with pytest.raises(RuntimeError, match="MU_ERR"):
-        _lib.call("mu_maxpool2_fwd", x.data_ptr(), x.data_ptr(), 1, 3, 4, 48, 0, None)
+        _lib.call("mu_maxpool2_fwd", x.data_ptr(), x.data_ptr(), 1, 1, 4, 48, 0, None)      # no 2 x 2 window fits a 1-row image
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
