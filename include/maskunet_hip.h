@@ -13,7 +13,8 @@
  *   - `stream` is a hipStream_t passed as void*; all work is enqueued on it (capturable);
  *   - activations are NHWC rows: a tensor [B,H,W,C] is M = B*H*W rows of C elements with row
  *     stride `ld` (elements); internal channel counts are multiples of 32 (callers zero-pad);
- *   - dtype: MU_F32 (0) = fp32 storage + exact-fp32 MFMA, MU_F16 (1) = fp16 storage + fp32 accumulate;
+ *   - dtype: MU_F32 (0) = fp32 storage + exact-fp32 MFMA, MU_F16 (1) = fp16 storage + fp32 accumulate, MU_F32X (2) = fp32 storage +
+ *     split-bf16 matrix products (matrix entry points only, see below);
  *     per-channel parameters, statistics and all parameter gradients are always fp32;
  *   - return value: 0 on success, <0 on error (MU_ERR_*); no exceptions cross the boundary.
  */
@@ -32,6 +33,10 @@ extern "C" {
 
 #define MU_F32 0
 #define MU_F16 1
+/* fp32 storage, matrix products as three bf16 MFMAs on (hi, lo) splits of the fp32 operands, fp32 accumulate (~1e-5 relative per
+ * product; torch's float32_matmul_precision "high").  Accepted by the matrix entry points (mu_conv_fwd*, mu_conv1x1_fwd_add,
+ * mu_conv_wgrad*, mu_attn_*); every other entry point takes MU_F32 for the same tensors. */
+#define MU_F32X 2
 
 #define MU_ACT_NONE 0
 #define MU_ACT_GELU 1 /* exact erf GELU, ade_semantic.py:201,208 */

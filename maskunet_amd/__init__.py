@@ -11,9 +11,10 @@ from .losses import CrossEntropyLoss, InstanceContrastiveLoss, cross_entropy, me
 from .ops import resize_labels_u8, resize_u8_to_nhwc
 from .optim import FusedAdamW
 from .graph import GraphedStep
+from ._lib import get_float32_matmul_precision, set_float32_matmul_precision
 
 __all__ = ["ConvBlock", "DownSample", "UpSample", "Mask2FormerAttention", "UNet", "InstanceUNet", "DoubleConv", "Down", "Up",
            "MaskAttention", "OutConv", "set_default_compute_dtype", "DataParallel", "shard_batch", "pixel_cross_entropy_nhwc",
            "mean_iou", "InstanceContrastiveLoss", "FusedAdamW", "CrossEntropyLoss", "cross_entropy", "GraphedStep",
-           "resize_u8_to_nhwc", "resize_labels_u8"]
+           "resize_u8_to_nhwc", "resize_labels_u8", "set_float32_matmul_precision", "get_float32_matmul_precision"]
 __version__ = "0.1.0"

@@ -15,7 +15,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("MU_LIB_PATH") or os.path.join(_HERE, "libmaskunet_hip.so")     # MU_LIB_PATH: debug builds (tests/build_attn_variant.sh)
 
-MU_F32, MU_F16 = 0, 1
+MU_F32, MU_F16, MU_F32X = 0, 1, 2
 ACT_NONE, ACT_GELU, ACT_RELU = 0, 1, 2
 _ERR = {-1: "MU_ERR_ARG", -2: "MU_ERR_SHAPE", -3: "MU_ERR_LAUNCH", -4: "MU_ERR_WORKSPACE"}
 
@@ -119,6 +119,31 @@ def dt(t_or_dtype) -> int:
     if d == torch.float16:
         return MU_F16
     raise TypeError(f"maskunet_amd supports float32 and float16 compute, got {d}")
+
+
+# fp32 compute: how the MATRIX products run (conv / Linear / attention; everything else is plain fp32 either way).
+#   "highest": exact-fp32 MFMA (v_mfma_f32_16x16x4_f32, 157 TF/s peak) -- bit-level fp32 FMA chains, the parity path;
+#   "high":    MU_F32X -- every fp32 operand split into bf16 hi + lo, three bf16 MFMAs per product, fp32 accumulate (~1e-5
+#              relative per product, unbiased): the scheme torch.set_float32_matmul_precision("high") names, ~2.5x faster.
+F32_MATMUL_PRECISION = os.environ.get("MU_F32_MATMUL", "highest")
+
+
+def set_float32_matmul_precision(precision: str):
+    """Process-wide, like torch.set_float32_matmul_precision: "highest" (default) or "high" (see above).  fp16 compute is unaffected."""
+    global F32_MATMUL_PRECISION
+    if precision not in ("highest", "high"):
+        raise ValueError('precision must be "highest" or "high"')
+    F32_MATMUL_PRECISION = precision
+
+
+def get_float32_matmul_precision() -> str:
+    return F32_MATMUL_PRECISION
+
+
+def mdt(t_or_dtype) -> int:
+    """dtype code for the matrix entry points (mu_conv_fwd*, mu_conv1x1_fwd_add, mu_conv_wgrad*, mu_attn_*)."""
+    d = dt(t_or_dtype)
+    return MU_F32X if (d == MU_F32 and F32_MATMUL_PRECISION == "high") else d
 
 
 def ptr(t):

@@ -151,6 +151,14 @@ template <> struct AT<h16> {
     static constexpr int VN = 8, KR = 32;
     using Frag = h16x8;
     struct AccA { h16x8 v; };
+    static __device__ __forceinline__ Frag ld(const h16* p) { return *reinterpret_cast<const Frag*>(p); }
+    static __device__ __forceinline__ Frag ld_scaled(const h16* p, float sc) {
+        Frag f = ld(p);
+#pragma unroll
+        for (int e = 0; e < VN; ++e) f[e] = (h16)((float)f[e] * sc);
+        return f;
+    }
+    static __device__ __forceinline__ Frag zero() { return (h16x8)(h16)0; }
     static __device__ __forceinline__ void mma_row(const Frag& a, const Frag& b, f32x4& c) {
         c = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
     }
@@ -185,6 +193,9 @@ template <> struct AT<float> {
     static constexpr int VN = 4, KR = 16;
     using Frag = f32x4;
     struct AccA { float v[8]; };
+    static __device__ __forceinline__ Frag ld(const float* p) { return *reinterpret_cast<const Frag*>(p); }
+    static __device__ __forceinline__ Frag ld_scaled(const float* p, float sc) { return ld(p) * sc; }
+    static __device__ __forceinline__ Frag zero() { return (f32x4){0.f, 0.f, 0.f, 0.f}; }
     static __device__ __forceinline__ void mma_row(const Frag& a, const Frag& b, f32x4& c) {
 #pragma unroll
         for (int s = 0; s < 4; ++s) c = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s], b[s], c, 0, 0, 0);
@@ -212,15 +223,27 @@ template <> struct AT<float> {
     }
 };
 
-template <typename T> __device__ __forceinline__ typename AT<T>::Frag ld16(const T* p) {
-    return *reinterpret_cast<const typename AT<T>::Frag*>(p);
-}
-template <typename T> __device__ __forceinline__ typename AT<T>::Frag zero_frag() {
-    typename AT<T>::Frag f;
-#pragma unroll
-    for (int i = 0; i < AT<T>::VN; ++i) f[i] = (T)0;
-    return f;
-}
+// fp32x (common.h): fp32 storage and the fp32 kernels' tiling, every operand split into bf16 (hi, lo) ONCE where it is loaded (row
+// fragments: four values -> v_mfma_f32_16x16x16_bf16; accumulator-operand products: eight values -> v_mfma_f32_16x16x32_bf16) and
+// three bf16 MFMAs per operand pair.  P / dS come out of the fp32 accumulators and are split the same way before they re-enter.
+template <> struct AT<xf32> {
+    static constexpr int VN = 4, KR = 16;
+    using Frag = SplitF4;
+    using AccA = SplitF8;
+    static __device__ __forceinline__ Frag ld(const xf32* p) { return mu_split4(*reinterpret_cast<const f32x4*>(p)); }
+    static __device__ __forceinline__ Frag ld_scaled(const xf32* p, float sc) { return mu_split4(*reinterpret_cast<const f32x4*>(p) * sc); }
+    static __device__ __forceinline__ Frag zero() { return mu_split4((f32x4){0.f, 0.f, 0.f, 0.f}); }
+    static __device__ __forceinline__ void mma_row(const Frag& a, const Frag& b, f32x4& c) { mu_mma_split(a, b, c); }
+    static __device__ __forceinline__ f32x4 mma_row_from(const Frag& a, const Frag& b, const f32x4& c0) {
+        f32x4 c = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a.lo, b.hi, c0, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a.hi, b.lo, c, 0, 0, 0);
+        return __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a.hi, b.hi, c, 0, 0, 0);
+    }
+    static __device__ __forceinline__ void mma_acc(const AccA& a, const f32x4& p0, const f32x4& p1, f32x4& c) {
+        const float pv[8] = {p0[0], p0[1], p0[2], p0[3], p1[0], p1[1], p1[2], p1[3]};
+        mu_mma_split(a, mu_split8(pv), c);
+    }
+};
 // reductions over the 4 lanes {r16 + 16g}: v_permlane16_swap / v_permlane32_swap exchange 16-/32-lane rows in
 // registers (no LDS round trip, unlike the ds_bpermute behind __shfl_xor).  swap(v, v) returns {own, partner} in
 // an order that depends on the row parity, so a symmetric combine needs no select.
@@ -245,12 +268,19 @@ template <> __device__ __forceinline__ void store4<h16>(h16* p, const float v[4]
 template <> __device__ __forceinline__ void store4<float>(float* p, const float v[4]) {
     *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
 }
+template <> __device__ __forceinline__ void store4<xf32>(xf32* p, const float v[4]) {
+    *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
+}
 template <typename T> __device__ __forceinline__ void load4(const T* p, float v[4]);
 template <> __device__ __forceinline__ void load4<h16>(const h16* p, float v[4]) {
     h16x4 o = *reinterpret_cast<const h16x4*>(p);
     v[0] = (float)o[0]; v[1] = (float)o[1]; v[2] = (float)o[2]; v[3] = (float)o[3];
 }
 template <> __device__ __forceinline__ void load4<float>(const float* p, float v[4]) {
+    float4 o = *reinterpret_cast<const float4*>(p);
+    v[0] = o.x; v[1] = o.y; v[2] = o.z; v[3] = o.w;
+}
+template <> __device__ __forceinline__ void load4<xf32>(const xf32* p, float v[4]) {
     float4 o = *reinterpret_cast<const float4*>(p);
     v[0] = o.x; v[1] = o.y; v[2] = o.z; v[3] = o.w;
 }
@@ -378,6 +408,23 @@ template <int D> struct AccLd<float, D> {
     }
 };
 
+template <int D> struct AccLd<xf32, D> {
+    static __device__ __forceinline__ SplitF8 ld(const xf32* tile, int r0, int col0, int g, int r16) {
+        using Z = SwzTile<xf32, D>;
+        float v[8];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            v[r] = tile[Z::off(r0 + 4 * g + r, col0 + r16)];
+            v[4 + r] = tile[Z::off(r0 + 16 + 4 * g + r, col0 + r16)];
+        }
+        return mu_split8(v);
+    }
+    static __device__ __forceinline__ SplitF8 ones() {
+        const float v[8] = {1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f};
+        return mu_split8(v);
+    }
+};
+
 template <typename T, int D, int KT, int NW, int OCC = 0, int NQ = 2>
 __global__ __launch_bounds__(NW * 64, OCC ? OCC : ((NW == 4 && D <= 64 && sizeof(T) == 2) ? MU_FWD_OCC : ((NW == 4 && D == 128 && sizeof(T) == 2) ? MU_FWD_OCC128 : ((NW == 4 && D == 256 && sizeof(T) == 2) ? MU_FWD_OCC256 : 1)))) void attn_fwd2_kernel(const T* __restrict__ qkv, const T* __restrict__ x, const int* __restrict__ kidx,
                                                         const int* __restrict__ kcnt, const float* __restrict__ gamma,
@@ -415,10 +462,7 @@ __global__ __launch_bounds__(NW * 64, OCC ? OCC : ((NW == 4 && D <= 64 && sizeof
         if (qrow > N - 1) qrow = N - 1;
 #pragma unroll
         for (int ks = 0; ks < NKS; ++ks) {
-            Frag f = ld16<T>(qkv_b + (long)qrow * 3 * D + ks * KR + g * VN);
-#pragma unroll
-            for (int e = 0; e < VN; ++e) f[e] = (T)((float)f[e] * scale_log2);
-            qf[t][ks] = f;
+            qf[t][ks] = A::ld_scaled(qkv_b + (long)qrow * 3 * D + ks * KR + g * VN, scale_log2);
         }
     }
     f32x4 o[NDT][NQ], lacc[NQ], negm[NQ];
@@ -458,7 +502,7 @@ __global__ __launch_bounds__(NW * 64, OCC ? OCC : ((NW == 4 && D <= 64 && sizeof
                 if (ks == 0)
                     for (int t = 0; t < NQ; ++t) { s[kt][t] = negm[t]; asm volatile("" : "+v"(s[kt][t])); }
 #else
-                Frag a = ld16<T>(Kt + Z::off(kt * 16 + r16, ks * KR + g * VN));
+                Frag a = A::ld(Kt + Z::off(kt * 16 + r16, ks * KR + g * VN));
 #pragma unroll
                 for (int t = 0; t < NQ; ++t) {
                     if (ks == 0) s[kt][t] = A::mma_row_from(a, qf[t][0], negm[t]);     // -m rides in as the C operand
@@ -820,12 +864,8 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 && D <= 64 && sizeof(T) == 2) ? M
         const long tok = (long)b * N + qrow;
 #pragma unroll
         for (int ks = 0; ks < NKS; ++ks) {
-            Frag fq = ld16<T>(qkv_b + (long)qrow * 3 * D + ks * KR + g * VN);
-            Frag fo = ld16<T>(dY + tok * D + ks * KR + g * VN);
-#pragma unroll
-            for (int e = 0; e < VN; ++e) { fq[e] = (T)((float)fq[e] * scale_log2); fo[e] = (T)((float)fo[e] * scale); }
-            qf[t][ks] = fq;
-            dof[t][ks] = fo;
+            qf[t][ks] = A::ld_scaled(qkv_b + (long)qrow * 3 * D + ks * KR + g * VN, scale_log2);
+            dof[t][ks] = A::ld_scaled(dY + tok * D + ks * KR + g * VN, scale);
         }
         const float l = -lse2[tok], d = -delta[tok] * scale;
         nlse[t] = (f32x4){l, l, l, l};
@@ -853,8 +893,8 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 && D <= 64 && sizeof(T) == 2) ? M
         for (int ks = 0; ks < NKS; ++ks)
 #pragma unroll
             for (int kt = 0; kt < NKT; ++kt) {
-                Frag ka = ld16<T>(Kt + Z::off(kt * 16 + r16, ks * KR + g * VN));
-                Frag va = ld16<T>(Vt + Z::off(kt * 16 + r16, ks * KR + g * VN));
+                Frag ka = A::ld(Kt + Z::off(kt * 16 + r16, ks * KR + g * VN));
+                Frag va = A::ld(Vt + Z::off(kt * 16 + r16, ks * KR + g * VN));
 #pragma unroll
                 for (int t = 0; t < 2; ++t) {
                     if (ks == 0) {                            // row constants as the C operand of the first k-step (no copies)
@@ -1050,12 +1090,10 @@ __global__ __launch_bounds__(NW * 64, NW >= 8 ? 1 : ((D <= 64 && sizeof(T) == 2 
         keyrow[kt] = j < Nk ? kidx_b[j] : -1;
 #pragma unroll
         for (int ks = 0; ks < NKS; ++ks) {
-            Frag fk = zero_frag<T>(), fv = zero_frag<T>();
+            Frag fk = A::zero(), fv = A::zero();
             if (keyrow[kt] >= 0) {
-                fk = ld16<T>(qkv_b + (long)keyrow[kt] * 3 * D + D + ks * KR + g * VN);
-                fv = ld16<T>(qkv_b + (long)keyrow[kt] * 3 * D + 2 * D + ks * KR + g * VN);
-#pragma unroll
-                for (int e = 0; e < VN; ++e) { fk[e] = (T)((float)fk[e] * scale_log2); fv[e] = (T)((float)fv[e] * scale); }
+                fk = A::ld_scaled(qkv_b + (long)keyrow[kt] * 3 * D + D + ks * KR + g * VN, scale_log2);
+                fv = A::ld_scaled(qkv_b + (long)keyrow[kt] * 3 * D + 2 * D + ks * KR + g * VN, scale);
             }
             kf[kt][ks] = fk;
             vf[kt][ks] = fv;
@@ -1100,8 +1138,8 @@ __global__ __launch_bounds__(NW * 64, NW >= 8 ? 1 : ((D <= 64 && sizeof(T) == 2 
         for (int ks = 0; ks < NKS; ++ks)
 #pragma unroll
             for (int qt = 0; qt < 2; ++qt) {
-                Frag qa = ld16<T>(Qt + Z::off(qt * 16 + r16, ks * KR + g * VN));
-                Frag oa = ld16<T>(Ot + Z::off(qt * 16 + r16, ks * KR + g * VN));
+                Frag qa = A::ld(Qt + Z::off(qt * 16 + r16, ks * KR + g * VN));
+                Frag oa = A::ld(Ot + Z::off(qt * 16 + r16, ks * KR + g * VN));
 #pragma unroll
                 for (int kt = 0; kt < NKT; ++kt) {
                     if (ks == 0) {                           // the row constants enter as the C operand of the first k-step
@@ -1259,13 +1297,16 @@ static int attn_fwd_t(const T* qkv, const T* x, const int* kidx, const int* kcnt
     }
 #undef LAUNCH_FWD
     if (cv != C) {           // zero-padded channels: LayerNorm over the first cv channels only (re-does the fused epilogue's out / mean / rstd)
+        using TS = typename std::conditional<std::is_same<T, xf32>::value, float, T>::type;      // storage type (no matrix product here)
+        const TS *oa = (const TS*)oattn, *xs = (const TS*)x;
+        TS* os = (TS*)out;
         const long rows = (long)B * N;
         const int nb = (int)(rows / 64 < 1 ? 1 : (rows / 64 > 4096 ? 4096 : rows / 64));
         switch (C) {
-            case 32: attn_ln_fwd_kernel<T, 32><<<nb, 256, 0, st>>>(oattn, x, gamma, beta, out, mean, rstd, rows, cv, eps); break;
-            case 64: attn_ln_fwd_kernel<T, 64><<<nb, 256, 0, st>>>(oattn, x, gamma, beta, out, mean, rstd, rows, cv, eps); break;
-            case 128: attn_ln_fwd_kernel<T, 128><<<nb, 256, 0, st>>>(oattn, x, gamma, beta, out, mean, rstd, rows, cv, eps); break;
-            default: attn_ln_fwd_kernel<T, 256><<<nb, 256, 0, st>>>(oattn, x, gamma, beta, out, mean, rstd, rows, cv, eps); break;
+            case 32: attn_ln_fwd_kernel<TS, 32><<<nb, 256, 0, st>>>(oa, xs, gamma, beta, os, mean, rstd, rows, cv, eps); break;
+            case 64: attn_ln_fwd_kernel<TS, 64><<<nb, 256, 0, st>>>(oa, xs, gamma, beta, os, mean, rstd, rows, cv, eps); break;
+            case 128: attn_ln_fwd_kernel<TS, 128><<<nb, 256, 0, st>>>(oa, xs, gamma, beta, os, mean, rstd, rows, cv, eps); break;
+            default: attn_ln_fwd_kernel<TS, 256><<<nb, 256, 0, st>>>(oa, xs, gamma, beta, os, mean, rstd, rows, cv, eps); break;
         }
     }
     return MU_OK;
@@ -1280,6 +1321,7 @@ extern "C" int mu_attn_fwd_padded(const void* qkv, const void* x, const int* kid
     int rc;
     if (dtype == MU_F16) rc = attn_fwd_t<h16>((const h16*)qkv, (const h16*)x, kidx, kcnt, gamma, beta, (h16*)out, (h16*)oattn, lse2, ln_mean, ln_rstd, B, N, C, c_valid, nkmax, eps, st);
     else if (dtype == MU_F32) rc = attn_fwd_t<float>((const float*)qkv, (const float*)x, kidx, kcnt, gamma, beta, (float*)out, (float*)oattn, lse2, ln_mean, ln_rstd, B, N, C, c_valid, nkmax, eps, st);
+    else if (dtype == MU_F32X) rc = attn_fwd_t<xf32>((const xf32*)qkv, (const xf32*)x, kidx, kcnt, gamma, beta, (xf32*)out, (xf32*)oattn, lse2, ln_mean, ln_rstd, B, N, C, c_valid, nkmax, eps, st);
     else return MU_ERR_ARG;
     if (rc) return rc;
     MU_CHECK_LAUNCH();
@@ -1302,6 +1344,7 @@ template <typename T>
 static int attn_bwd_t(const T* qkv, const T* x, const T* oattn, const T* gout, const int* kidx, const int* kcnt, const float* lse2,
                       const float* mean, const float* rstd, const float* gamma, T* dY, float* delta, T* dqkv, float* dgamma,
                       float* dbeta, int B, int N, int C, int cv, int nkmax, void* ws, hipStream_t st, int phases) {
+    using TS = typename std::conditional<std::is_same<T, xf32>::value, float, T>::type;      // storage type for the LayerNorm prepass
     const long rows = (long)B * N;
     float* rowc = (float*)((char*)ws + attn_ln_part_bytes(C));
     int nblk = (int)(rows / 64 < 1 ? 1 : (rows / 64 > ATT_LN_MAXBLK ? ATT_LN_MAXBLK : rows / 64));
@@ -1314,7 +1357,7 @@ static int attn_bwd_t(const T* qkv, const T* x, const T* oattn, const T* gout, c
     if ((phases & 1) && !zero_masked && hipMemsetAsync(dqkv, 0, (size_t)rows * 3 * C * sizeof(T), st) != hipSuccess) return MU_ERR_LAUNCH;
 #define LAUNCH_BWD(DD, NKT)                                                                                                     \
     if (phases & 1) {                                                                                                           \
-        attn_ln_bwd_kernel<T, DD><<<nblk, 256, 0, st>>>(gout, oattn, x, mean, rstd, gamma, dY, delta, (double*)ws, rows, lse2, rowc, N, scale, cv); \
+        attn_ln_bwd_kernel<TS, DD><<<nblk, 256, 0, st>>>((const TS*)gout, (const TS*)oattn, (const TS*)x, mean, rstd, gamma, (TS*)dY, delta, (double*)ws, rows, lse2, rowc, N, scale, cv); \
         attn_ln_bwd_final_kernel<<<mu_cdiv(DD, 4), 256, 0, st>>>((const double*)ws, nblk, DD, dgamma, dbeta);                   \
     }                                                                                                                           \
     if (phases & 2) attn_bwd_dq2_kernel<T, DD, KTQ, 4><<<gq, 256, 0, st>>>(qkv, dY, kidx, kcnt, lse2, delta, dqkv, N, nkmax, scale, sl2); \
@@ -1355,6 +1398,8 @@ extern "C" int mu_attn_bwd_phases_padded(const void* qkv, const void* x, const v
         rc = attn_bwd_t<h16>((const h16*)qkv, (const h16*)x, (const h16*)oattn, (const h16*)grad_out, kidx, kcnt, lse2, ln_mean, ln_rstd, gamma, (h16*)dY, delta, (h16*)dqkv, dgamma, dbeta, B, N, C, c_valid, nkmax, workspace, st, phases);
     else if (dtype == MU_F32)
         rc = attn_bwd_t<float>((const float*)qkv, (const float*)x, (const float*)oattn, (const float*)grad_out, kidx, kcnt, lse2, ln_mean, ln_rstd, gamma, (float*)dY, delta, (float*)dqkv, dgamma, dbeta, B, N, C, c_valid, nkmax, workspace, st, phases);
+    else if (dtype == MU_F32X)
+        rc = attn_bwd_t<xf32>((const xf32*)qkv, (const xf32*)x, (const xf32*)oattn, (const xf32*)grad_out, kidx, kcnt, lse2, ln_mean, ln_rstd, gamma, (xf32*)dY, delta, (xf32*)dqkv, dgamma, dbeta, B, N, C, c_valid, nkmax, workspace, st, phases);
     else return MU_ERR_ARG;
     if (rc) return rc;
     MU_CHECK_LAUNCH();

@@ -20,6 +20,69 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 static inline int mu_cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 
+// ------------------------------------------------------------------------------------------
+// MU_F32X ("fp32x"): fp32 STORAGE, matrix products on the bf16 matrix cores with every fp32 operand split into two bf16 parts,
+//     x = hi + lo,  hi = bf16_rne(x),  lo = bf16_rne(x - hi)          (|x - hi - lo| <= 2^-17 |x|)
+//     a * b ~= hi_a hi_b + hi_a lo_b + lo_a hi_b                       (the dropped lo_a lo_b is <= 2^-16 |a b|)
+// accumulated in the fp32 MFMA accumulator: ~1e-5 relative per product with random sign (the "bf16x3" scheme behind
+// torch.set_float32_matmul_precision("high")), against 2^-11 for one fp16 rounding -- and three 16-cycle bf16 MFMAs per K = 16
+// where the exact-fp32 MFMA (v_mfma_f32_16x16x4_f32, 1/16 of the bf16 rate) needs four 32-cycle ones.  The kernels are the fp32
+// instantiations: `xf32` is float storage under another name, so that the fragment traits (conv.hip Mma<T>, attn.hip AT<T>) can
+// pick the split arithmetic; everything that is not a matrix product treats MU_F32X as MU_F32.
+// ------------------------------------------------------------------------------------------
+struct xf32 {
+    float v;
+    __host__ __device__ xf32() = default;
+    __host__ __device__ xf32(float f) : v(f) {}
+    __host__ __device__ operator float() const { return v; }
+};
+static_assert(sizeof(xf32) == 4, "xf32 is float storage");
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+struct SplitF4 { s16x4 hi, lo; };          // four fp32 values as bf16 hi | bf16 lo: the A / B operand pair of v_mfma_f32_16x16x16_bf16
+struct SplitF8 { bf16x8 hi, lo; };         // eight: v_mfma_f32_16x16x32_bf16
+
+// (hi, lo) of two floats, packed: v_cvt_pk_bf16_f32, two bit ops, two subtracts, v_cvt_pk_bf16_f32
+__device__ __forceinline__ void mu_split2(float x0, float x1, uint32_t& hi, uint32_t& lo) {
+    const bf16x2 h = {(__bf16)x0, (__bf16)x1};
+    hi = __builtin_bit_cast(uint32_t, h);
+    const float h0 = __uint_as_float(hi << 16), h1 = __uint_as_float(hi & 0xffff0000u);
+    const bf16x2 l = {(__bf16)(x0 - h0), (__bf16)(x1 - h1)};
+    lo = __builtin_bit_cast(uint32_t, l);
+}
+__device__ __forceinline__ SplitF4 mu_split4(const f32x4& x) {
+    uint2 h, l;
+    mu_split2(x[0], x[1], h.x, l.x);
+    mu_split2(x[2], x[3], h.y, l.y);
+    SplitF4 r;
+    r.hi = __builtin_bit_cast(s16x4, h);
+    r.lo = __builtin_bit_cast(s16x4, l);
+    return r;
+}
+__device__ __forceinline__ SplitF8 mu_split8(const float (&x)[8]) {
+    uint4 h, l;
+    mu_split2(x[0], x[1], h.x, l.x);
+    mu_split2(x[2], x[3], h.y, l.y);
+    mu_split2(x[4], x[5], h.z, l.z);
+    mu_split2(x[6], x[7], h.w, l.w);
+    SplitF8 r;
+    r.hi = __builtin_bit_cast(bf16x8, h);
+    r.lo = __builtin_bit_cast(bf16x8, l);
+    return r;
+}
+// c += a * b over K = 16 / 32 with both operands split: smallest terms first
+__device__ __forceinline__ void mu_mma_split(const SplitF4& a, const SplitF4& b, f32x4& c) {
+    c = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a.lo, b.hi, c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a.hi, b.lo, c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a.hi, b.hi, c, 0, 0, 0);
+}
+__device__ __forceinline__ void mu_mma_split(const SplitF8& a, const SplitF8& b, f32x4& c) {
+    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.lo, b.hi, c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.hi, b.lo, c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.hi, b.hi, c, 0, 0, 0);
+}
+
 // 16-byte vector of T: 8 halves or 4 floats.
 template <typename T> struct Vec16;
 template <> struct Vec16<float> {

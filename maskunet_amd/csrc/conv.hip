@@ -15,13 +15,23 @@ template <typename T> struct Mma;
 template <> struct Mma<h16> {
     static constexpr int VN = 8;    // elements per 16-byte fragment
     using Frag = h16x8;
+    static __device__ __forceinline__ Frag ld(const void* p) { return *reinterpret_cast<const Frag*>(p); }
     static __device__ __forceinline__ void mma(const Frag& a, const Frag& b, f32x4& c) {
         c = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
     }
 };
+// fp32x (common.h): the fp32 kernels with every 16-byte fragment split into bf16 (hi, lo) as it leaves LDS -- once per fragment,
+// re-used by all the MFMAs it feeds -- and three v_mfma_f32_16x16x16_bf16 per fragment pair
+template <> struct Mma<xf32> {
+    static constexpr int VN = 4;
+    using Frag = SplitF4;
+    static __device__ __forceinline__ Frag ld(const void* p) { return mu_split4(*reinterpret_cast<const f32x4*>(p)); }
+    static __device__ __forceinline__ void mma(const Frag& a, const Frag& b, f32x4& c) { mu_mma_split(a, b, c); }
+};
 template <> struct Mma<float> {
     static constexpr int VN = 4;
     using Frag = f32x4;
+    static __device__ __forceinline__ Frag ld(const void* p) { return *reinterpret_cast<const Frag*>(p); }
     // lane group g holds k = 4g..4g+3; step s multiplies k = 4g+s of A with the same k of B
     static __device__ __forceinline__ void mma(const Frag& a, const Frag& b, f32x4& c) {
         c = __builtin_amdgcn_mfma_f32_16x16x4f32(a[0], b[0], c, 0, 0, 0);
@@ -145,12 +155,12 @@ __global__ __launch_bounds__(256) void conv_nt_kernel(const T* __restrict__ x, c
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
             const int row = (wr * TM + i) * 16 + r16;
-            a[i] = *reinterpret_cast<const Frag*>(As + buf * BCO * 64 + row * 64 + swz64(row, g) * 16);
+            a[i] = M_::ld(As + buf * BCO * 64 + row * 64 + swz64(row, g) * 16);
         }
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
             const int row = (wc * TN + j) * 16 + r16;
-            b[j] = *reinterpret_cast<const Frag*>(Bs + buf * BPX * 64 + row * 64 + swz64(row, g) * 16);
+            b[j] = M_::ld(Bs + buf * BPX * 64 + row * 64 + swz64(row, g) * 16);
         }
 #pragma unroll
         for (int i = 0; i < TM; ++i)
@@ -366,12 +376,12 @@ __global__ __launch_bounds__(256, SB ? MU_NT2_SB_OCC : MU_NT2_OCC) void conv_nt2
 #pragma unroll
             for (int i = 0; i < TM; ++i) {
                 const int row = (wr * TM + i) * 16 + r16;
-                a[i] = *reinterpret_cast<const Frag*>(Ab + row * 128 + (((kk * 4 + g) ^ (row & 7)) << 4));
+                a[i] = M_::ld(Ab + row * 128 + (((kk * 4 + g) ^ (row & 7)) << 4));
             }
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
                 const int row = (wc * TN + j) * 16 + r16;
-                b[j] = *reinterpret_cast<const Frag*>(Bb + row * 128 + (((kk * 4 + g) ^ (row & 7)) << 4));
+                b[j] = M_::ld(Bb + row * 128 + (((kk * 4 + g) ^ (row & 7)) << 4));
             }
 #pragma unroll
             for (int i = 0; i < TM; ++i)
@@ -593,9 +603,9 @@ __device__ __forceinline__ void conv_nt3_body(const T* __restrict__ x, const T* 
                     const char* wa = Wb + aoff[kk];
                     const char* hb = Hb + boff[dw][kk];
 #pragma unroll
-                    for (int i = 0; i < TM; ++i) a[i] = *reinterpret_cast<const Frag*>(wa + i * 2048);
+                    for (int i = 0; i < TM; ++i) a[i] = M_::ld(wa + i * 2048);
 #pragma unroll
-                    for (int j = 0; j < TN; ++j) b[j] = *reinterpret_cast<const Frag*>(hb + j * (HW_ * 128));
+                    for (int j = 0; j < TN; ++j) b[j] = M_::ld(hb + j * (HW_ * 128));
 #pragma unroll
                     for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -819,9 +829,9 @@ __global__ __launch_bounds__(256, 2) void conv_nt3p_kernel(const T* __restrict__
                         const char* wa = Wb + aoff[kk];
                         const char* hb = Hb + boff[dw][kk];
 #pragma unroll
-                        for (int i = 0; i < TM; ++i) a[i] = *reinterpret_cast<const Frag*>(wa + i * 2048);
+                        for (int i = 0; i < TM; ++i) a[i] = M_::ld(wa + i * 2048);
 #pragma unroll
-                        for (int j = 0; j < TN; ++j) b[j] = *reinterpret_cast<const Frag*>(hb + j * (HW_ * 128));
+                        for (int j = 0; j < TN; ++j) b[j] = M_::ld(hb + j * (HW_ * 128));
 #pragma unroll
                         for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -1039,9 +1049,9 @@ __device__ __forceinline__ void conv_nt4_body(const h16* __restrict__ x, const h
                 const char* wa = Wb + aoff[kk];
                 const char* hb = Hb + boff[dw][kk];
 #pragma unroll
-                for (int i = 0; i < TM; ++i) a[i] = *reinterpret_cast<const Frag*>(wa + i * 2048);
+                for (int i = 0; i < TM; ++i) a[i] = M_::ld(wa + i * 2048);
 #pragma unroll
-                for (int j = 0; j < TN; ++j) b[j] = *reinterpret_cast<const Frag*>(hb + j * (HW_ * 128));
+                for (int j = 0; j < TN; ++j) b[j] = M_::ld(hb + j * (HW_ * 128));
                 // exactly three DMAs per wave per tap: the halo piece in the first phase (tap 0: in the second -- the buffer it
                 // refills was read until the previous chunk's last phase), the two weight pieces in the second
                 if ((kk == 0) == (t != 0)) {
@@ -1263,9 +1273,9 @@ __global__ __launch_bounds__(512, 1) void conv_nt4p_kernel(const h16* __restrict
                     const char* wa = Wb + aoff[kk];
                     const char* hb = Hb + boff[dw][kk];
 #pragma unroll
-                    for (int i = 0; i < TM; ++i) a[i] = *reinterpret_cast<const Frag*>(wa + i * 2048);
+                    for (int i = 0; i < TM; ++i) a[i] = M_::ld(wa + i * 2048);
 #pragma unroll
-                    for (int j = 0; j < TN; ++j) b[j] = *reinterpret_cast<const Frag*>(hb + j * (HW_ * 128));
+                    for (int j = 0; j < TN; ++j) b[j] = M_::ld(hb + j * (HW_ * 128));
                     // exactly three DMAs per wave per tap: the halo piece in the first phase (tap 0: in the second, behind two more
                     // barriers -- its buffer was read until the previous chunk's last phase and staged the previous tile's output),
                     // the two weight pieces in the second
@@ -1495,6 +1505,9 @@ extern "C" int mu_conv_fwd_fused(const void* x, const void* w, const float* scal
     } else if (dtype == MU_F32) {
         if (taps == 9) conv_fwd_fused_launch<float, 9>((const float*)x, (const float*)w, scale, bias, (const float*)res, act, (float*)y, B, H, W, Cin, Cout, x_ld, y_ld, st);
         else conv_fwd_fused_launch<float, 1>((const float*)x, (const float*)w, scale, bias, (const float*)res, act, (float*)y, B, H, W, Cin, Cout, x_ld, y_ld, st);
+    } else if (dtype == MU_F32X) {
+        if (taps == 9) conv_fwd_fused_launch<xf32, 9>((const xf32*)x, (const xf32*)w, scale, bias, (const xf32*)res, act, (xf32*)y, B, H, W, Cin, Cout, x_ld, y_ld, st);
+        else conv_fwd_fused_launch<xf32, 1>((const xf32*)x, (const xf32*)w, scale, bias, (const xf32*)res, act, (xf32*)y, B, H, W, Cin, Cout, x_ld, y_ld, st);
     } else return MU_ERR_ARG;
     MU_CHECK_LAUNCH();
     return MU_OK;
@@ -1512,6 +1525,9 @@ extern "C" int mu_conv_fwd(const void* x, const void* w, const float* bias, void
     } else if (dtype == MU_F32) {
         if (taps == 9) conv_fwd_launch<float, 9>((const float*)x, (const float*)w, bias, (float*)y, B, H, W, Cin, Cout, x_ld, y_ld, st);
         else conv_fwd_launch<float, 1>((const float*)x, (const float*)w, bias, (float*)y, B, H, W, Cin, Cout, x_ld, y_ld, st);
+    } else if (dtype == MU_F32X) {
+        if (taps == 9) conv_fwd_launch<xf32, 9>((const xf32*)x, (const xf32*)w, bias, (xf32*)y, B, H, W, Cin, Cout, x_ld, y_ld, st);
+        else conv_fwd_launch<xf32, 1>((const xf32*)x, (const xf32*)w, bias, (xf32*)y, B, H, W, Cin, Cout, x_ld, y_ld, st);
     } else return MU_ERR_ARG;
     MU_CHECK_LAUNCH();
     return MU_OK;
@@ -1523,7 +1539,7 @@ extern "C" int mu_conv_fwd(const void* x, const void* w, const float* bias, void
 // Only shapes served by the LDS-DMA 1x1 kernel (Cin * elem_size % 128 == 0, Cout % 64 == 0); MU_ERR_SHAPE otherwise.
 extern "C" int mu_conv1x1_add_supported(int Cin, int Cout, int dtype) {
     const int es = dtype == MU_F16 ? 2 : 4;
-    return (dtype == MU_F16 || dtype == MU_F32) && Cin > 0 && Cout > 0 && (Cin * es) % 128 == 0 && Cout % 64 == 0 ? 1 : 0;
+    return (dtype == MU_F16 || dtype == MU_F32 || dtype == MU_F32X) && Cin > 0 && Cout > 0 && (Cin * es) % 128 == 0 && Cout % 64 == 0 ? 1 : 0;
 }
 
 template <typename T>
@@ -1541,6 +1557,7 @@ extern "C" int mu_conv1x1_fwd_add(const void* x, const void* w, const void* adde
     if (!mu_conv1x1_add_supported(Cin, Cout, dtype) || x_ld < Cin || y_ld < Cout || x_ld % 8 || y_ld % 8) return MU_ERR_SHAPE;
     hipStream_t st = (hipStream_t)stream;
     if (dtype == MU_F16) conv1x1_add_launch<h16>((const h16*)x, (const h16*)w, (const h16*)addend, (h16*)y, M, Cin, Cout, x_ld, y_ld, st);
+    else if (dtype == MU_F32X) conv1x1_add_launch<xf32>((const xf32*)x, (const xf32*)w, (const xf32*)addend, (xf32*)y, M, Cin, Cout, x_ld, y_ld, st);
     else conv1x1_add_launch<float>((const float*)x, (const float*)w, (const float*)addend, (float*)y, M, Cin, Cout, x_ld, y_ld, st);
     MU_CHECK_LAUNCH();
     return MU_OK;
@@ -1556,6 +1573,7 @@ template <typename T> struct WgTile;
 template <> struct WgTile<h16> { static constexpr int PAD = 0; static constexpr int KP = 32; };
 // fp32: row pad (elements) puts the g=0/1 pixel rows of a ds_read_b32 on different banks
 template <> struct WgTile<float> { static constexpr int PAD = 16; static constexpr int KP = 16; };
+template <> struct WgTile<xf32> { static constexpr int PAD = 16; static constexpr int KP = 16; };
 
 typedef __fp16 fp16x4v __attribute__((__vector_size__(4 * sizeof(__fp16))));
 
@@ -1678,6 +1696,25 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const T* __restrict__ x
                     for (int i = 0; i < TM; ++i) accb[i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[i], ones, accb[i], 0, 0, 0);
                 }
             }
+        } else if constexpr (std::is_same<T, xf32>::value) {
+            // fp32x: lane group g holds pixels {g, 4+g, 8+g, 12+g} of the 16-pixel stage for its column (the same k set on both
+            // operands), split once into bf16 (hi, lo): three v_mfma_f32_16x16x16_bf16 per tile pair instead of four fp32 MFMAs
+            static_assert(KP == 16, "one K = 16 MFMA triple per stage");
+            SplitF4 a[TM], b[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                const int col = (wr * TM + i) * 16 + r16;
+                a[i] = mu_split4((f32x4){(float)At[g * SA + col], (float)At[(4 + g) * SA + col], (float)At[(8 + g) * SA + col], (float)At[(12 + g) * SA + col]});
+            }
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int col = (wc * TN + j) * 16 + r16;
+                b[j] = mu_split4((f32x4){(float)Bt[g * SB + col], (float)Bt[(4 + g) * SB + col], (float)Bt[(8 + g) * SB + col], (float)Bt[(12 + g) * SB + col]});
+            }
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) mu_mma_split(a[i], b[j], acc[i][j]);
         } else {
 #pragma unroll
             for (int ks = 0; ks < KP / 4; ++ks) {
@@ -2429,7 +2466,8 @@ static int conv_wgrad_impl(const void* x, const void* dy, float* dw_oihw, float*
     wgrad_plan((long)B * H * W, Cin, Cout, taps, bco, bci, &nsplit, &pps);
     hipStream_t st = (hipStream_t)stream;
     float* part = (float*)workspace;
-    if (taps == 9 && cin_valid <= 3 && Cout % 64 == 0 && W <= MU_RGB_MAXW && (dtype == MU_F16 || dtype == MU_F32)) {
+    if (taps == 9 && cin_valid <= 3 && Cout % 64 == 0 && W <= MU_RGB_MAXW && (dtype == MU_F16 || dtype == MU_F32 || dtype == MU_F32X)) {
+        // (plain-FMA kernel: the fp32x mode runs it as fp32)
         long nb = ws_bytes / ((long)9 * Cout * 4 * (long)sizeof(float));
         if (nb > MU_RGB_MAXBLK) nb = MU_RGB_MAXBLK;
         if (nb > (long)B * H) nb = (long)B * H;
@@ -2485,6 +2523,9 @@ static int conv_wgrad_impl(const void* x, const void* dy, float* dw_oihw, float*
     } else if (dtype == MU_F32) {
         if (taps == 9) wgrad_launch<float, 9>((const float*)x, (const float*)dy, part, B, H, W, Cin, Cout, x_ld, dy_ld, bco, nsplit, pps, st);
         else wgrad_launch<float, 1>((const float*)x, (const float*)dy, part, B, H, W, Cin, Cout, x_ld, dy_ld, bco, nsplit, pps, st);
+    } else if (dtype == MU_F32X) {
+        if (taps == 9) wgrad_launch<xf32, 9>((const xf32*)x, (const xf32*)dy, part, B, H, W, Cin, Cout, x_ld, dy_ld, bco, nsplit, pps, st);
+        else wgrad_launch<xf32, 1>((const xf32*)x, (const xf32*)dy, part, B, H, W, Cin, Cout, x_ld, dy_ld, bco, nsplit, pps, st);
     } else return MU_ERR_ARG;
     const long n = (long)cout_valid * cin_valid * taps;
     if (nsplit >= 16) {

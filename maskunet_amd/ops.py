@@ -14,7 +14,7 @@ import torch.nn.functional as F
 from torch.autograd.function import once_differentiable
 
 from . import _lib
-from ._lib import ACT_GELU, ACT_NONE, ACT_RELU, call, dt, ptr, stream, workspace  # noqa: F401
+from ._lib import ACT_GELU, ACT_NONE, ACT_RELU, call, dt, mdt, ptr, stream, workspace  # noqa: F401
 
 
 def pad32(c: int) -> int:
@@ -315,9 +315,9 @@ def _conv_raw(x, wprep, bias_p, Cout_p, taps, want_stats=False):
             call("mu_conv_fwd_stats", ptr(x), ptr(wprep), ptr(bias_p), ptr(y), B, H, W, Cin_p, Cout_p, taps, Cin_p, Cout_p, dt(x),
                  ptr(part), stream())
             return y, part
-        call("mu_conv_fwd", ptr(x), ptr(wprep), ptr(bias_p), ptr(y), B, H, W, Cin_p, Cout_p, taps, Cin_p, Cout_p, dt(x), stream())
+        call("mu_conv_fwd", ptr(x), ptr(wprep), ptr(bias_p), ptr(y), B, H, W, Cin_p, Cout_p, taps, Cin_p, Cout_p, mdt(x), stream())
         return y, None
-    call("mu_conv_fwd", ptr(x), ptr(wprep), ptr(bias_p), ptr(y), B, H, W, Cin_p, Cout_p, taps, Cin_p, Cout_p, dt(x), stream())
+    call("mu_conv_fwd", ptr(x), ptr(wprep), ptr(bias_p), ptr(y), B, H, W, Cin_p, Cout_p, taps, Cin_p, Cout_p, mdt(x), stream())
     return y
 
 
@@ -329,7 +329,7 @@ def _wgrad_raw(x, gy, w_shape, taps, st=None, ws=None):
     if ws is None:
         ws = workspace(_lib.load().mu_conv_wgrad_workspace_bytes(B, H, W, Cin_p, Cout_p, taps), x.device)
     call("mu_conv_wgrad", ptr(x), ptr(gy), ptr(gw), B, H, W, Cin_p, Cout_p, taps, I, O, Cin_p, Cout_p, ptr(ws), ws.numel(),
-         dt(x), stream() if st is None else st)
+         mdt(x), stream() if st is None else st)
     return gw
 
 
@@ -669,7 +669,7 @@ def conv_bn_act_eval(x, weight, conv_bias, bn, act=ACT_NONE, res=None, bn2=None)
     if res is not None:
         res = res.contiguous()
     call("mu_conv_fwd_fused", ptr(x), ptr(wprep), ptr(fold[0]), ptr(fold[1]), ptr(res), act, ptr(y), B, H, W, Cin_p, Cout_p, taps, Cin_p, Cout_p,
-         dt(x), stream())
+         mdt(x), stream())
     return y
 
 
@@ -904,10 +904,10 @@ class _MaskAttention(torch.autograd.Function):
         g, b_ = lnw.detach().float().contiguous(), lnb.detach().float().contiguous()
         if cv == C:
             call("mu_attn_fwd", ptr(qkv), ptr(x), ptr(kidx), ptr(kcnt), ptr(g), ptr(b_), ptr(out), ptr(oattn), ptr(lse2), ptr(mean),
-                 ptr(rstd), B, N, C, kidx.shape[1], float(eps), dt(x), stream())
+                 ptr(rstd), B, N, C, kidx.shape[1], float(eps), mdt(x), stream())
         else:
             call("mu_attn_fwd_padded", ptr(qkv), ptr(x), ptr(kidx), ptr(kcnt), ptr(g), ptr(b_), ptr(out), ptr(oattn), ptr(lse2), ptr(mean),
-                 ptr(rstd), B, N, C, cv, kidx.shape[1], float(eps), dt(x), stream())
+                 ptr(rstd), B, N, C, cv, kidx.shape[1], float(eps), mdt(x), stream())
         ctx.save_for_backward(x, qkv, oattn, lse2, mean, rstd, g, kidx, kcnt)
         ctx.scramble, ctx.dims, ctx.kidx_perm = scramble, (B, H, W, C), bool(kidx_perm) and kidx.shape[1] == N
         if scramble:
@@ -937,20 +937,20 @@ class _MaskAttention(torch.autograd.Function):
         for phase in (1, 2, 4):      # LayerNorm-backward prepass, dQ sweep, dK/dV sweep (separate calls: each can be timed)
             if cv == C:
                 call("mu_attn_bwd_phases", ptr(qkv), ptr(x), ptr(oattn), ptr(gout), ptr(kidx), ptr(kcnt), ptr(lse2), ptr(mean), ptr(rstd),
-                     ptr(g), ptr(dY), ptr(delta), ptr(dqkv), ptr(dg), ptr(db), B, N, C, kidx.shape[1], ptr(ws), ws.numel(), dt(x),
+                     ptr(g), ptr(dY), ptr(delta), ptr(dqkv), ptr(dg), ptr(db), B, N, C, kidx.shape[1], ptr(ws), ws.numel(), mdt(x),
                      phase | perm, stream())
             else:
                 call("mu_attn_bwd_phases_padded", ptr(qkv), ptr(x), ptr(oattn), ptr(gout), ptr(kidx), ptr(kcnt), ptr(lse2), ptr(mean),
                      ptr(rstd), ptr(g), ptr(dY), ptr(delta), ptr(dqkv), ptr(dg), ptr(db), B, N, C, cv, kidx.shape[1], ptr(ws), ws.numel(),
-                     dt(x), phase | perm, stream())
+                     mdt(x), phase | perm, stream())
         dqkv4 = dqkv.view(B, H, W, 3 * C)
         gx = None
         if ctx.needs_input_grad[0]:
             wd = ctx.wd                          # kept on ctx (views of one small buffer): a second backward over a retained graph needs it again
-            if ATTN_FUSED_ADD and _lib.load().mu_conv1x1_add_supported(3 * C, C, dt(x)):
+            if ATTN_FUSED_ADD and _lib.load().mu_conv1x1_add_supported(3 * C, C, mdt(x)):
                 # gx = dqkv @ Wqkv + dY: the residual branch (:187) joins the projection's data-gradient in its epilogue
                 gx = torch.empty((B, H, W, C), dtype=x.dtype, device=x.device)
-                call("mu_conv1x1_fwd_add", ptr(dqkv), ptr(wd), ptr(dY), ptr(gx), B * N, 3 * C, C, 3 * C, C, dt(x), stream())
+                call("mu_conv1x1_fwd_add", ptr(dqkv), ptr(wd), ptr(dY), ptr(gx), B * N, 3 * C, C, 3 * C, C, mdt(x), stream())
             else:
                 gx = _conv_raw(dqkv4, wd, None, C, 1)
                 call("mu_add", ptr(gx), ptr(dY), ptr(gx), gx.numel(), dt(gx), stream())

@@ -136,3 +136,24 @@ def test_conv_persistent_tile_walk(dtype, monkeypatch):
     from tests import _gpu_checks as G
     monkeypatch.setenv("MU_CONV_PERSIST_BLOCKS", "3")
     _assert_all(G.check_conv(dtype, cases=[(2, 32, 32, 64, 128, 3), (1, 64, 48, 128, 128, 3), (3, 16, 16, 256, 256, 3), (2, 40, 16, 128, 256, 3)]))
+
+
+@pytest.fixture
+def fp32x():
+    import maskunet_amd
+    maskunet_amd.set_float32_matmul_precision("high")
+    yield
+    maskunet_amd.set_float32_matmul_precision("highest")
+
+
+def test_conv_fp32x(fp32x):
+    """Every conv / weight-gradient shape of the kernel suite in the split-bf16 mode, at the fp32 gate (1e-3)."""
+    from tests import _gpu_checks as G
+    _assert_all(G.check_conv(torch.float32))
+
+
+def test_attention_fp32x(fp32x):
+    from tests import _gpu_checks as G
+    _assert_all(G.check_attention(torch.float32))
+    _assert_all(G.check_attention(torch.float32, cases=[(2, 8, 12, 48), (1, 8, 8, 200)]))
+    _assert_all(G.check_attention_bwd_masked_rows(torch.float32))

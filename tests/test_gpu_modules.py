@@ -236,3 +236,57 @@ def test_partial_backward_does_not_leak_a_linked_gradient_into_the_next_pass():
     for n, p in model.named_parameters():
         if n in ref:
             assert torch.equal(p.grad, ref[n]), n
+
+
+# ------------------------------------------------------------------------------------------------
+# fp32x: fp32 storage, matrix products as three bf16 MFMAs on (hi, lo) operand splits
+# (maskunet_amd.set_float32_matmul_precision("high")) -- held to the SAME gates as the exact-fp32 path: north_star's 1e-3 on outputs,
+# the fp32 gradient gates of the whole-model goldens, per-parameter 1 - cos <= 1e-4 against the live oracle.
+# ------------------------------------------------------------------------------------------------
+@pytest.fixture
+def fp32x():
+    import maskunet_amd
+    maskunet_amd.set_float32_matmul_precision("high")
+    yield
+    maskunet_amd.set_float32_matmul_precision("highest")
+
+
+@pytest.mark.parametrize("name", ["unet1_c150_b2_eval", "unet1_c150_b2_train", "unet3_c19_b2_train", "unet1_c133_b2_train"])
+def test_unet_golden_fp32x(name, fp32x, capsys):
+    from tests import _gpu_checks as G
+    res = G.check_unet_golden(name, torch.float32)
+    with capsys.disabled():
+        print("  fp32x", name, "; ".join(f"{n.split(name)[-1].strip()}: {e:.2e}" for n, e, t in res[:4]))
+    _assert_all(res)
+
+
+@pytest.mark.parametrize("name", MODULE_CASES)
+def test_golden_module_fp32x(name, fp32x):
+    from tests import _gpu_checks as G
+    _assert_all(G.check_golden_module(name, torch.float32))
+
+
+def test_unet_vs_oracle_fp32x(fp32x):
+    from tests import _gpu_checks as G
+    _assert_all(G.check_unet_vs_oracle(torch.float32, B=2, c_out=150))
+
+
+def test_fp32x_is_really_the_split_path_and_fp32_is_untouched():
+    """The switch changes the matrix products (different bits from the exact-fp32 MFMA, error ~1e-5 against it) and switching back
+    restores the exact path bit for bit."""
+    import maskunet_amd
+    from maskunet_amd import ops
+    torch.manual_seed(0)
+    x = torch.randn(2, 16, 16, 64, device="cuda")
+    w = torch.randn(128, 64, 3, 3, device="cuda") * 0.05
+    exact = ops.conv(x, w)
+    maskunet_amd.set_float32_matmul_precision("high")
+    try:
+        assert maskunet_amd.get_float32_matmul_precision() == "high"
+        split = ops.conv(x, w)
+    finally:
+        maskunet_amd.set_float32_matmul_precision("highest")
+    again = ops.conv(x, w)
+    assert torch.equal(exact, again)
+    err = float((split - exact).abs().max()) / float(exact.abs().max())
+    assert 0 < err < 1e-4, err
