@@ -34,8 +34,13 @@ extern "C" {
 #define MU_F32 0
 #define MU_F16 1
 /* fp32 storage, matrix products as three bf16 MFMAs on (hi, lo) splits of the fp32 operands, fp32 accumulate (~1e-5 relative per
- * product; torch's float32_matmul_precision "high").  Accepted by the matrix entry points (mu_conv_fwd*, mu_conv1x1_fwd_add,
- * mu_conv_wgrad*, mu_attn_*); every other entry point takes MU_F32 for the same tensors. */
+ * product; torch's float32_matmul_precision "high").  Accepted by the matrix entry points (mu_conv_fwd, mu_conv_fwd_fused,
+ * mu_conv1x1_fwd_add, mu_conv_wgrad, mu_attn_*); every other entry point takes MU_F32 for the same tensors.
+ * With MU_F32X the MATRIX OPERANDS of those entry points -- x and w of the convolutions, x and dy of the weight gradient, qkv of
+ * the attention sweeps -- are passed CHUNK-ENCODED: every aligned 16-byte chunk of four fp32 values re-written as
+ * [4 x bf16 hi | 4 x bf16 lo] by mu_split_encode (same size, same strides; the split then costs one pass per tensor instead of
+ * VALU work per fragment per wave).  Outputs, biases, residual / addend tensors, x / oattn / grad_out / dY of the attention block
+ * are plain fp32. */
 #define MU_F32X 2
 
 #define MU_ACT_NONE 0
@@ -55,6 +60,9 @@ int mu_transpose(const void* src, int src_dtype, long src_ld, void* dst, int dst
  * layout). */
 int mu_transpose_pad(const void* src, int src_dtype, long src_ld, void* dst, int dst_dtype, long dst_ld, int batch, int R, int C,
                      int R_pad, void* stream);
+/* fp32x operand encoding (see MU_F32X): n_elems fp32 values (a multiple of 4, 16-byte aligned, contiguous rows) -> the chunk-encoded
+ * operand; dst may be src (in place). */
+int mu_split_encode(const void* src, void* dst, long n_elems, void* stream);
 /* elementwise dtype conversion of n elements */
 int mu_cast(const void* src, int src_dtype, void* dst, int dst_dtype, long n, void* stream);
 /* OIHW fp32 parameter -> tap-major compute layout [taps][rows_pad][cols_pad].

@@ -97,6 +97,14 @@
 #ifndef MU_DKV_PKMUL
 #define MU_DKV_PKMUL 1
 #endif
+// fp32x (chunk-encoded fp32 tiles): the 256-/512-byte-row swizzle of the fp16 tiles for the row fragment + transposed reads, and
+// the occupancy bound of the C <= 64 sweeps (the fp32 instantiations run one wave per SIMD)
+#ifndef MU_XF_SWZ256
+#define MU_XF_SWZ256 1
+#endif
+#ifndef MU_XF_OCC
+#define MU_XF_OCC 2
+#endif
 #ifndef MU_FWD_PREFETCH
 #define MU_FWD_PREFETCH 0
 #endif
@@ -152,6 +160,7 @@ template <> struct AT<h16> {
     using Frag = h16x8;
     struct AccA { h16x8 v; };
     static __device__ __forceinline__ Frag ld(const h16* p) { return *reinterpret_cast<const Frag*>(p); }
+    template <typename Z> static __device__ __forceinline__ Frag ldt(const h16* tile, int row, int col) { return ld(tile + Z::off(row, col)); }
     static __device__ __forceinline__ Frag ld_scaled(const h16* p, float sc) {
         Frag f = ld(p);
 #pragma unroll
@@ -194,6 +203,7 @@ template <> struct AT<float> {
     using Frag = f32x4;
     struct AccA { float v[8]; };
     static __device__ __forceinline__ Frag ld(const float* p) { return *reinterpret_cast<const Frag*>(p); }
+    template <typename Z> static __device__ __forceinline__ Frag ldt(const float* tile, int row, int col) { return ld(tile + Z::off(row, col)); }
     static __device__ __forceinline__ Frag ld_scaled(const float* p, float sc) { return ld(p) * sc; }
     static __device__ __forceinline__ Frag zero() { return (f32x4){0.f, 0.f, 0.f, 0.f}; }
     static __device__ __forceinline__ void mma_row(const Frag& a, const Frag& b, f32x4& c) {
@@ -223,21 +233,38 @@ template <> struct AT<float> {
     }
 };
 
-// fp32x (common.h): fp32 storage and the fp32 kernels' tiling, every operand split into bf16 (hi, lo) ONCE where it is loaded (row
-// fragments: four values -> v_mfma_f32_16x16x16_bf16; accumulator-operand products: eight values -> v_mfma_f32_16x16x32_bf16) and
-// three bf16 MFMAs per operand pair.  P / dS come out of the fp32 accumulators and are split the same way before they re-enter.
+// fp32x (common.h): fp32 storage and the fp32 kernels' tiling on CHUNK-ENCODED qkv / dY (16 bytes = [4 bf16 hi | 4 bf16 lo] of four
+// fp32 values): a row fragment load is the (hi, lo) operand pair of v_mfma_f32_16x16x16_bf16, the transposed operands of the
+// accumulator-operand products come from ds_read_b64_tr_b16 on the hi / lo halves (eight values -> v_mfma_f32_16x16x32_bf16), three
+// bf16 MFMAs per operand pair.  The resident, pre-scaled operands are decoded, scaled and re-split once outside the sweep; P / dS
+// come out of the fp32 accumulators and are split in registers before they re-enter.
 template <> struct AT<xf32> {
-    static constexpr int VN = 4, KR = 16;
-    using Frag = SplitF4;
+    // a row fragment = TWO chunks, 16 columns apart (lane group g: columns 32 ks + 4g.. and 32 ks + 16 + 4g..): their hi halves side
+    // by side are the eight-value operand of v_mfma_f32_16x16x32_bf16 -- half the MFMA instructions of the K = 16 form
+    static constexpr int VN = 4, KR = 32;
+    using Frag = SplitF8;
     using AccA = SplitF8;
-    static __device__ __forceinline__ Frag ld(const xf32* p) { return mu_split4(*reinterpret_cast<const f32x4*>(p)); }
-    static __device__ __forceinline__ Frag ld_scaled(const xf32* p, float sc) { return mu_split4(*reinterpret_cast<const f32x4*>(p) * sc); }
-    static __device__ __forceinline__ Frag zero() { return mu_split4((f32x4){0.f, 0.f, 0.f, 0.f}); }
+    static __device__ __forceinline__ Frag join(const uint4& e0, const uint4& e1) {
+        Frag r;
+        r.hi = __builtin_bit_cast(bf16x8, make_uint4(e0.x, e0.y, e1.x, e1.y));
+        r.lo = __builtin_bit_cast(bf16x8, make_uint4(e0.z, e0.w, e1.z, e1.w));
+        return r;
+    }
+    template <typename Z> static __device__ __forceinline__ Frag ldt(const xf32* tile, int row, int col) {
+        return join(*reinterpret_cast<const uint4*>(tile + Z::off(row, col)), *reinterpret_cast<const uint4*>(tile + Z::off(row, col + 16)));
+    }
+    // resident operands (global rows, contiguous): decode, scale, split again -- once per wave, outside the sweep
+    static __device__ __forceinline__ Frag ld_scaled(const xf32* p, float sc) {
+        const f32x4 a = mu_dec4(*reinterpret_cast<const uint4*>(p)) * sc, b = mu_dec4(*reinterpret_cast<const uint4*>(p + 16)) * sc;
+        const float v[8] = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+        return mu_split8(v);
+    }
+    static __device__ __forceinline__ Frag zero() { return join(make_uint4(0, 0, 0, 0), make_uint4(0, 0, 0, 0)); }
     static __device__ __forceinline__ void mma_row(const Frag& a, const Frag& b, f32x4& c) { mu_mma_split(a, b, c); }
     static __device__ __forceinline__ f32x4 mma_row_from(const Frag& a, const Frag& b, const f32x4& c0) {
-        f32x4 c = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a.lo, b.hi, c0, 0, 0, 0);
-        c = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a.hi, b.lo, c, 0, 0, 0);
-        return __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a.hi, b.hi, c, 0, 0, 0);
+        f32x4 c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.lo, b.hi, c0, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.hi, b.lo, c, 0, 0, 0);
+        return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.hi, b.hi, c, 0, 0, 0);
     }
     static __device__ __forceinline__ void mma_acc(const AccA& a, const f32x4& p0, const f32x4& p1, f32x4& c) {
         const float pv[8] = {p0[0], p0[1], p0[2], p0[3], p1[0], p1[1], p1[2], p1[3]};
@@ -312,7 +339,7 @@ template <typename T, int D> struct SwzTile {
     //    8 rows x 2 chunks of a transposed read on 8 slots.  (row & 7) << 1 puts each of 8 consecutive rows on its own even/odd slot
     //    PAIR (transposed reads touch {c, c+1} with c even) and makes row -> slot injective over the 16 rows of a b128 group.
     static __device__ __forceinline__ constexpr int key(int row) {
-        return (sizeof(T) == 2 && ROWB >= 256) ? ((row & 7) << 1) : (row & SW);
+        return ((sizeof(T) == 2 || MU_XF_SWZ256 && std::is_same<T, xf32>::value) && ROWB >= 256) ? ((row & 7) << 1) : (row & SW);
     }
     // element offset of (row, col) in the swizzled image
     static __device__ __forceinline__ int off(int row, int col) {
@@ -409,15 +436,19 @@ template <int D> struct AccLd<float, D> {
 };
 
 template <int D> struct AccLd<xf32, D> {
+    // chunk-encoded tile: lane (g, q = r16 >> 2, pc = r16 & 3) addresses row r0 + 4g + q (and + 16), chunk (col0 / 4 + pc); the
+    // transposing read hands lane r16 column col0 + r16 of rows 4g..4g+3 -- from the hi halves (bytes 0-7) and the lo halves (8-15)
     static __device__ __forceinline__ SplitF8 ld(const xf32* tile, int r0, int col0, int g, int r16) {
         using Z = SwzTile<xf32, D>;
-        float v[8];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            v[r] = tile[Z::off(r0 + 4 * g + r, col0 + r16)];
-            v[4 + r] = tile[Z::off(r0 + 16 + 4 * g + r, col0 + r16)];
-        }
-        return mu_split8(v);
+        const int q = r16 >> 2, pc = r16 & 3;
+        const char* a0 = reinterpret_cast<const char*>(tile + Z::off(r0 + 4 * g + q, col0 + 4 * pc));
+        const char* a1 = reinterpret_cast<const char*>(tile + Z::off(r0 + 16 + 4 * g + q, col0 + 4 * pc));
+        const uint2 h0 = __builtin_bit_cast(uint2, LDS_TR16(a0)), h1 = __builtin_bit_cast(uint2, LDS_TR16(a1));
+        const uint2 l0 = __builtin_bit_cast(uint2, LDS_TR16(a0 + 8)), l1 = __builtin_bit_cast(uint2, LDS_TR16(a1 + 8));
+        SplitF8 r;
+        r.hi = __builtin_bit_cast(bf16x8, make_uint4(h0.x, h0.y, h1.x, h1.y));
+        r.lo = __builtin_bit_cast(bf16x8, make_uint4(l0.x, l0.y, l1.x, l1.y));
+        return r;
     }
     static __device__ __forceinline__ SplitF8 ones() {
         const float v[8] = {1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f};
@@ -426,7 +457,7 @@ template <int D> struct AccLd<xf32, D> {
 };
 
 template <typename T, int D, int KT, int NW, int OCC = 0, int NQ = 2>
-__global__ __launch_bounds__(NW * 64, OCC ? OCC : ((NW == 4 && D <= 64 && sizeof(T) == 2) ? MU_FWD_OCC : ((NW == 4 && D == 128 && sizeof(T) == 2) ? MU_FWD_OCC128 : ((NW == 4 && D == 256 && sizeof(T) == 2) ? MU_FWD_OCC256 : 1)))) void attn_fwd2_kernel(const T* __restrict__ qkv, const T* __restrict__ x, const int* __restrict__ kidx,
+__global__ __launch_bounds__(NW * 64, OCC ? OCC : ((NW == 4 && D <= 64 && std::is_same<T, xf32>::value) ? MU_XF_OCC : (NW == 4 && D <= 64 && sizeof(T) == 2) ? MU_FWD_OCC : ((NW == 4 && D == 128 && sizeof(T) == 2) ? MU_FWD_OCC128 : ((NW == 4 && D == 256 && sizeof(T) == 2) ? MU_FWD_OCC256 : 1)))) void attn_fwd2_kernel(const T* __restrict__ qkv, const T* __restrict__ x, const int* __restrict__ kidx,
                                                         const int* __restrict__ kcnt, const float* __restrict__ gamma,
                                                         const float* __restrict__ beta, T* __restrict__ out, T* __restrict__ oattn,
                                                         float* __restrict__ lse2, float* __restrict__ ln_mean, float* __restrict__ ln_rstd,
@@ -502,7 +533,7 @@ __global__ __launch_bounds__(NW * 64, OCC ? OCC : ((NW == 4 && D <= 64 && sizeof
                 if (ks == 0)
                     for (int t = 0; t < NQ; ++t) { s[kt][t] = negm[t]; asm volatile("" : "+v"(s[kt][t])); }
 #else
-                Frag a = A::ld(Kt + Z::off(kt * 16 + r16, ks * KR + g * VN));
+                Frag a = A::template ldt<Z>(Kt, kt * 16 + r16, ks * KR + g * VN);
 #pragma unroll
                 for (int t = 0; t < NQ; ++t) {
                     if (ks == 0) s[kt][t] = A::mma_row_from(a, qf[t][0], negm[t]);     // -m rides in as the C operand
@@ -828,7 +859,7 @@ __global__ void attn_ln_bwd_final_kernel(const double* __restrict__ part, int nb
 // backward v2 kernels: LDS-DMA double-buffered tiles, swizzled images (see attn_fwd2_kernel)
 // ------------------------------------------------------------------------------------------
 template <typename T, int D, int KT, int NW>
-__global__ __launch_bounds__(NW * 64, (NW == 4 && D <= 64 && sizeof(T) == 2) ? MU_DQ_OCC : ((NW == 4 && D == 128 && sizeof(T) == 2) ? MU_DQ_OCC128 : ((NW == 4 && D == 256 && sizeof(T) == 2) ? MU_DQ_OCC256 : 1))) void attn_bwd_dq2_kernel(const T* __restrict__ qkv, const T* __restrict__ dY, const int* __restrict__ kidx,
+__global__ __launch_bounds__(NW * 64, (NW == 4 && D <= 64 && std::is_same<T, xf32>::value) ? MU_XF_OCC : (NW == 4 && D <= 64 && sizeof(T) == 2) ? MU_DQ_OCC : ((NW == 4 && D == 128 && sizeof(T) == 2) ? MU_DQ_OCC128 : ((NW == 4 && D == 256 && sizeof(T) == 2) ? MU_DQ_OCC256 : 1))) void attn_bwd_dq2_kernel(const T* __restrict__ qkv, const T* __restrict__ dY, const int* __restrict__ kidx,
                                                            const int* __restrict__ kcnt, const float* __restrict__ lse2,
                                                            const float* __restrict__ delta, T* __restrict__ dqkv, int N, int nkmax,
                                                            float scale, float scale_log2) {
@@ -893,8 +924,8 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 && D <= 64 && sizeof(T) == 2) ? M
         for (int ks = 0; ks < NKS; ++ks)
 #pragma unroll
             for (int kt = 0; kt < NKT; ++kt) {
-                Frag ka = A::ld(Kt + Z::off(kt * 16 + r16, ks * KR + g * VN));
-                Frag va = A::ld(Vt + Z::off(kt * 16 + r16, ks * KR + g * VN));
+                Frag ka = A::template ldt<Z>(Kt, kt * 16 + r16, ks * KR + g * VN);
+                Frag va = A::template ldt<Z>(Vt, kt * 16 + r16, ks * KR + g * VN);
 #pragma unroll
                 for (int t = 0; t < 2; ++t) {
                     if (ks == 0) {                            // row constants as the C operand of the first k-step (no copies)
@@ -985,7 +1016,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 && D <= 64 && sizeof(T) == 2) ? M
 // NW = waves per block (16 * NKT keys each).  The Q / dO stream a block pulls through L2 -> LDS is shared by NW * NKT * 16 keys: at
 // C = 128 with 4 waves of 16 keys every launch moved 4.2 GB in 0.7 ms (6 TB/s, the L2 -> LDS ceiling) -- 8 waves halve that.
 template <typename T, int D, int NKT, int NW = 4>
-__global__ __launch_bounds__(NW * 64, NW >= 8 ? 1 : ((D <= 64 && sizeof(T) == 2 && NKT <= 2) ? MU_DKV_OCC : ((D == 128 && sizeof(T) == 2 && NKT <= 2) ? MU_DKV_OCC128 : ((D == 256 && sizeof(T) == 2 && NKT == 1) ? MU_DKV_OCC256 : 1)))) void attn_bwd_dkv3_kernel(
+__global__ __launch_bounds__(NW * 64, NW >= 8 ? 1 : ((D <= 64 && std::is_same<T, xf32>::value) ? MU_XF_OCC : (D <= 64 && sizeof(T) == 2 && NKT <= 2) ? MU_DKV_OCC : ((D == 128 && sizeof(T) == 2 && NKT <= 2) ? MU_DKV_OCC128 : ((D == 256 && sizeof(T) == 2 && NKT == 1) ? MU_DKV_OCC256 : 1)))) void attn_bwd_dkv3_kernel(
     const T* __restrict__ qkv, const T* __restrict__ dY, const int* __restrict__ kidx, const int* __restrict__ kcnt,
     const float* __restrict__ rowc, T* __restrict__ dqkv, int N, int nkmax, float scale, float scale_log2, int zero_masked) {
     using A = AT<T>;
@@ -1138,8 +1169,8 @@ __global__ __launch_bounds__(NW * 64, NW >= 8 ? 1 : ((D <= 64 && sizeof(T) == 2 
         for (int ks = 0; ks < NKS; ++ks)
 #pragma unroll
             for (int qt = 0; qt < 2; ++qt) {
-                Frag qa = A::ld(Qt + Z::off(qt * 16 + r16, ks * KR + g * VN));
-                Frag oa = A::ld(Ot + Z::off(qt * 16 + r16, ks * KR + g * VN));
+                Frag qa = A::template ldt<Z>(Qt, qt * 16 + r16, ks * KR + g * VN);
+                Frag oa = A::template ldt<Z>(Ot, qt * 16 + r16, ks * KR + g * VN);
 #pragma unroll
                 for (int kt = 0; kt < NKT; ++kt) {
                     if (ks == 0) {                           // the row constants enter as the C operand of the first k-step
@@ -1336,8 +1367,10 @@ extern "C" int mu_attn_fwd(const void* qkv, const void* x, const int* kidx, cons
 
 #define ATT_LN_MAXBLK 1024
 static inline long attn_ln_part_bytes(int C) { return (long)ATT_LN_MAXBLK * C * 2 * sizeof(double); }
+static inline long attn_rowc_bytes(int B, int N) { return (long)B * ((N + 31) / 32) * 64 * sizeof(float); }
+// LayerNorm partials | row constants of the dK/dV sweep | (MU_F32X) the chunk-encoded copy of dY the two sweeps read
 extern "C" long mu_attn_bwd_workspace_bytes(int B, int N, int C) {
-    return attn_ln_part_bytes(C) + (long)B * ((N + 31) / 32) * 64 * sizeof(float);
+    return attn_ln_part_bytes(C) + attn_rowc_bytes(B, N) + (long)B * N * C * (long)sizeof(float);
 }
 
 template <typename T>
@@ -1355,21 +1388,26 @@ static int attn_bwd_t(const T* qkv, const T* x, const T* oattn, const T* gout, c
     // ones, so the dK/dV sweep writes the masked keys' zero rows itself (dQ parts are written for every row by the dQ sweep)
     const int zero_masked = ((phases & 8) && nkmax == N) ? 1 : 0;
     if ((phases & 1) && !zero_masked && hipMemsetAsync(dqkv, 0, (size_t)rows * 3 * C * sizeof(T), st) != hipSuccess) return MU_ERR_LAUNCH;
+    // fp32x: the sweeps take dY chunk-encoded like qkv (the caller encodes qkv; dY is produced here, by phase 1): its encoded copy
+    // lives in the workspace behind the row constants, and `dYs` is what the sweeps read
+    const T* dYs = dY;
+    if constexpr (std::is_same<T, xf32>::value) dYs = (const T*)((char*)ws + attn_ln_part_bytes(C) + attn_rowc_bytes(B, N));
 #define LAUNCH_BWD(DD, NKT)                                                                                                     \
     if (phases & 1) {                                                                                                           \
         attn_ln_bwd_kernel<TS, DD><<<nblk, 256, 0, st>>>((const TS*)gout, (const TS*)oattn, (const TS*)x, mean, rstd, gamma, (TS*)dY, delta, (double*)ws, rows, lse2, rowc, N, scale, cv); \
         attn_ln_bwd_final_kernel<<<mu_cdiv(DD, 4), 256, 0, st>>>((const double*)ws, nblk, DD, dgamma, dbeta);                   \
+        if (dYs != dY && mu_split_encode(dY, (void*)dYs, rows * DD, st) != MU_OK) return MU_ERR_LAUNCH;                          \
     }                                                                                                                           \
-    if (phases & 2) attn_bwd_dq2_kernel<T, DD, KTQ, 4><<<gq, 256, 0, st>>>(qkv, dY, kidx, kcnt, lse2, delta, dqkv, N, nkmax, scale, sl2); \
+    if (phases & 2) attn_bwd_dq2_kernel<T, DD, KTQ, 4><<<gq, 256, 0, st>>>(qkv, dYs, kidx, kcnt, lse2, delta, dqkv, N, nkmax, scale, sl2); \
     if (phases & 4) {                                                                                                           \
         if constexpr (sizeof(T) == 2 && DD == 64 && MU_DKV_NW64 != 4)                                                           \
-            attn_bwd_dkv3_kernel<T, DD, NKT, MU_DKV_NW64><<<dim3(mu_cdiv(nkmax, 16 * MU_DKV_NW64 * NKT), B), 64 * MU_DKV_NW64, 0, st>>>(qkv, dY, kidx, kcnt, rowc, dqkv, N, nkmax, scale, sl2, zero_masked); \
+            attn_bwd_dkv3_kernel<T, DD, NKT, MU_DKV_NW64><<<dim3(mu_cdiv(nkmax, 16 * MU_DKV_NW64 * NKT), B), 64 * MU_DKV_NW64, 0, st>>>(qkv, dYs, kidx, kcnt, rowc, dqkv, N, nkmax, scale, sl2, zero_masked); \
         else if constexpr (sizeof(T) == 2 && DD == 128 && MU_DKV_NW128 != 4)                                                         \
-            attn_bwd_dkv3_kernel<T, DD, NKT, MU_DKV_NW128><<<dim3(mu_cdiv(nkmax, 16 * MU_DKV_NW128 * NKT), B), 64 * MU_DKV_NW128, 0, st>>>(qkv, dY, kidx, kcnt, rowc, dqkv, N, nkmax, scale, sl2, zero_masked); \
+            attn_bwd_dkv3_kernel<T, DD, NKT, MU_DKV_NW128><<<dim3(mu_cdiv(nkmax, 16 * MU_DKV_NW128 * NKT), B), 64 * MU_DKV_NW128, 0, st>>>(qkv, dYs, kidx, kcnt, rowc, dqkv, N, nkmax, scale, sl2, zero_masked); \
         else if constexpr (sizeof(T) == 2 && DD == 256 && MU_DKV_NW256 == 8)                                                    \
-            attn_bwd_dkv3_kernel<T, DD, NKT, 8><<<dim3(mu_cdiv(nkmax, 128 * NKT), B), 512, 0, st>>>(qkv, dY, kidx, kcnt, rowc, dqkv, N, nkmax, scale, sl2, zero_masked); \
+            attn_bwd_dkv3_kernel<T, DD, NKT, 8><<<dim3(mu_cdiv(nkmax, 128 * NKT), B), 512, 0, st>>>(qkv, dYs, kidx, kcnt, rowc, dqkv, N, nkmax, scale, sl2, zero_masked); \
         else                                                                                                                    \
-            attn_bwd_dkv3_kernel<T, DD, NKT><<<dim3(mu_cdiv(nkmax, 64 * NKT), B), 256, 0, st>>>(qkv, dY, kidx, kcnt, rowc, dqkv, N, nkmax, scale, sl2, zero_masked); \
+            attn_bwd_dkv3_kernel<T, DD, NKT><<<dim3(mu_cdiv(nkmax, 64 * NKT), B), 256, 0, st>>>(qkv, dYs, kidx, kcnt, rowc, dqkv, N, nkmax, scale, sl2, zero_masked); \
     }
     if (N % 4) return MU_ERR_SHAPE;
     switch (C) {

@@ -71,6 +71,28 @@ __device__ __forceinline__ SplitF8 mu_split8(const float (&x)[8]) {
     r.lo = __builtin_bit_cast(bf16x8, l);
     return r;
 }
+// Chunk encoding of an fp32x MATRIX OPERAND in memory: every aligned 16-byte chunk of four fp32 values is stored as
+//     [hi0 hi1 hi2 hi3 | lo0 lo1 lo2 lo3]      (bf16 each: bytes 0-7 the hi parts, bytes 8-15 the lo parts)
+// -- the same 16 bytes, so strides, LDS-DMA pieces, swizzles and tile shapes of the fp32 kernels are untouched, but a 16-byte
+// fragment load IS the (hi, lo) operand pair (no VALU in the sweep) and ds_read_b64_tr_b16 transposes the hi / lo halves like an
+// fp16 tile.  Operands are encoded once per tensor by mu_split_encode (one read + one write), not once per fragment per wave.
+__device__ __forceinline__ uint4 mu_enc4(const f32x4& x) {
+    uint4 e;
+    mu_split2(x[0], x[1], e.x, e.z);
+    mu_split2(x[2], x[3], e.y, e.w);
+    return e;
+}
+__device__ __forceinline__ f32x4 mu_dec4(const uint4& e) {
+    return (f32x4){__uint_as_float(e.x << 16) + __uint_as_float(e.z << 16), __uint_as_float(e.x & 0xffff0000u) + __uint_as_float(e.z & 0xffff0000u),
+                   __uint_as_float(e.y << 16) + __uint_as_float(e.w << 16), __uint_as_float(e.y & 0xffff0000u) + __uint_as_float(e.w & 0xffff0000u)};
+}
+__device__ __forceinline__ SplitF4 mu_frag_enc(const uint4& e) {
+    SplitF4 r;
+    r.hi = __builtin_bit_cast(s16x4, make_uint2(e.x, e.y));
+    r.lo = __builtin_bit_cast(s16x4, make_uint2(e.z, e.w));
+    return r;
+}
+
 // c += a * b over K = 16 / 32 with both operands split: smallest terms first
 __device__ __forceinline__ void mu_mma_split(const SplitF4& a, const SplitF4& b, f32x4& c) {
     c = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a.lo, b.hi, c, 0, 0, 0);

@@ -19,19 +19,39 @@ template <> struct Mma<h16> {
     static __device__ __forceinline__ void mma(const Frag& a, const Frag& b, f32x4& c) {
         c = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
     }
+    static constexpr bool PAIR = false;      // (see Mma<xf32>)
+    using Frag2 = Frag;
+    static __device__ __forceinline__ Frag2 ld2(const void* p0, const void*) { return ld(p0); }
+    static __device__ __forceinline__ void mma2(const Frag2& a, const Frag2& b, f32x4& c) { mma(a, b, c); }
 };
-// fp32x (common.h): the fp32 kernels with every 16-byte fragment split into bf16 (hi, lo) as it leaves LDS -- once per fragment,
-// re-used by all the MFMAs it feeds -- and three v_mfma_f32_16x16x16_bf16 per fragment pair
+// fp32x (common.h): the fp32 kernels on CHUNK-ENCODED operands -- a 16-byte fragment is [4 bf16 hi | 4 bf16 lo] of four fp32 values,
+// i.e. the (hi, lo) operand pair itself -- and three v_mfma_f32_16x16x16_bf16 per fragment pair
 template <> struct Mma<xf32> {
     static constexpr int VN = 4;
     using Frag = SplitF4;
-    static __device__ __forceinline__ Frag ld(const void* p) { return mu_split4(*reinterpret_cast<const f32x4*>(p)); }
+    static __device__ __forceinline__ Frag ld(const void* p) { return mu_frag_enc(*reinterpret_cast<const uint4*>(p)); }
     static __device__ __forceinline__ void mma(const Frag& a, const Frag& b, f32x4& c) { mu_mma_split(a, b, c); }
+    // kernels whose K stage is 128 bytes (two chunks per lane group, kk = 0 / 1): the two chunks' hi halves side by side are the
+    // eight-value operand of v_mfma_f32_16x16x32_bf16 -- half the MFMA instructions of the K = 16 form
+    static constexpr bool PAIR = true;
+    using Frag2 = SplitF8;
+    static __device__ __forceinline__ Frag2 ld2(const void* p0, const void* p1) {
+        const uint4 e0 = *reinterpret_cast<const uint4*>(p0), e1 = *reinterpret_cast<const uint4*>(p1);
+        Frag2 r;
+        r.hi = __builtin_bit_cast(bf16x8, make_uint4(e0.x, e0.y, e1.x, e1.y));
+        r.lo = __builtin_bit_cast(bf16x8, make_uint4(e0.z, e0.w, e1.z, e1.w));
+        return r;
+    }
+    static __device__ __forceinline__ void mma2(const Frag2& a, const Frag2& b, f32x4& c) { mu_mma_split(a, b, c); }
 };
 template <> struct Mma<float> {
     static constexpr int VN = 4;
     using Frag = f32x4;
     static __device__ __forceinline__ Frag ld(const void* p) { return *reinterpret_cast<const Frag*>(p); }
+    static constexpr bool PAIR = false;
+    using Frag2 = Frag;
+    static __device__ __forceinline__ Frag2 ld2(const void* p0, const void*) { return ld(p0); }
+    static __device__ __forceinline__ void mma2(const Frag2& a, const Frag2& b, f32x4& c) { mma(a, b, c); }
     // lane group g holds k = 4g..4g+3; step s multiplies k = 4g+s of A with the same k of B
     static __device__ __forceinline__ void mma(const Frag& a, const Frag& b, f32x4& c) {
         c = __builtin_amdgcn_mfma_f32_16x16x4f32(a[0], b[0], c, 0, 0, 0);
@@ -370,6 +390,23 @@ __global__ __launch_bounds__(256, SB ? MU_NT2_SB_OCC : MU_NT2_OCC) void conv_nt2
         if (s + 1 < nsteps) stage(s + 1, buf ^ 1);
         const char* Ab = lds + buf * STAGE;
         const char* Bb = Ab + BCO * 128;
+        if constexpr (M_::PAIR) {
+            typename M_::Frag2 a[TM], b[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                const int row = (wr * TM + i) * 16 + r16;
+                a[i] = M_::ld2(Ab + row * 128 + ((g ^ (row & 7)) << 4), Ab + row * 128 + (((4 + g) ^ (row & 7)) << 4));
+            }
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int row = (wc * TN + j) * 16 + r16;
+                b[j] = M_::ld2(Bb + row * 128 + ((g ^ (row & 7)) << 4), Bb + row * 128 + (((4 + g) ^ (row & 7)) << 4));
+            }
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) M_::mma2(a[i], b[j], acc[i][j]);
+        } else {
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
             Frag a[TM], b[TN];
@@ -387,6 +424,7 @@ __global__ __launch_bounds__(256, SB ? MU_NT2_SB_OCC : MU_NT2_OCC) void conv_nt2
             for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int j = 0; j < TN; ++j) M_::mma(a[i], b[j], acc[i][j]);
+        }
         }
         __syncthreads();          // drains the LDS-DMA of stage s+1 (vmcnt(0)) and fences the reads of stage s
     }
@@ -597,6 +635,17 @@ __device__ __forceinline__ void conv_nt3_body(const T* __restrict__ x, const T* 
                 }
                 const char* Wb = Ws + (RING ? wslot : (s & 1)) * WBYTES;
                 const char* Hb = Hs + hbuf + dh * (HW_ * 128);
+                if constexpr (M_::PAIR) {
+                    typename M_::Frag2 a[TM], b[TN];
+#pragma unroll
+                    for (int i = 0; i < TM; ++i) a[i] = M_::ld2(Wb + aoff[0] + i * 2048, Wb + aoff[1] + i * 2048);
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) b[j] = M_::ld2(Hb + boff[dw][0] + j * (HW_ * 128), Hb + boff[dw][1] + j * (HW_ * 128));
+#pragma unroll
+                    for (int i = 0; i < TM; ++i)
+#pragma unroll
+                        for (int j = 0; j < TN; ++j) M_::mma2(a[i], b[j], acc[i][j]);
+                } else {
 #pragma unroll
                 for (int kk = 0; kk < 2; ++kk) {
                     Frag a[TM], b[TN];
@@ -610,6 +659,7 @@ __device__ __forceinline__ void conv_nt3_body(const T* __restrict__ x, const T* 
                     for (int i = 0; i < TM; ++i)
 #pragma unroll
                         for (int j = 0; j < TN; ++j) M_::mma(a[i], b[j], acc[i][j]);
+                }
                 }
                 if constexpr (RING) {
                     // all but this tap's PA + 1 DMAs have landed: W(s+1) (issued at tap s-1) and every older halo piece.  The MFMAs
@@ -823,6 +873,17 @@ __global__ __launch_bounds__(256, 2) void conv_nt3p_kernel(const T* __restrict__
                     }
                     const char* Wb = Ws + (s & 1) * WBYTES;
                     const char* Hb = Hs + hbuf + dh * (HW_ * 128);
+                    if constexpr (M_::PAIR) {
+                        typename M_::Frag2 a[TM], b[TN];
+#pragma unroll
+                        for (int i = 0; i < TM; ++i) a[i] = M_::ld2(Wb + aoff[0] + i * 2048, Wb + aoff[1] + i * 2048);
+#pragma unroll
+                        for (int j = 0; j < TN; ++j) b[j] = M_::ld2(Hb + boff[dw][0] + j * (HW_ * 128), Hb + boff[dw][1] + j * (HW_ * 128));
+#pragma unroll
+                        for (int i = 0; i < TM; ++i)
+#pragma unroll
+                            for (int j = 0; j < TN; ++j) M_::mma2(a[i], b[j], acc[i][j]);
+                    } else {
 #pragma unroll
                     for (int kk = 0; kk < 2; ++kk) {
                         Frag a[TM], b[TN];
@@ -836,6 +897,7 @@ __global__ __launch_bounds__(256, 2) void conv_nt3p_kernel(const T* __restrict__
                         for (int i = 0; i < TM; ++i)
 #pragma unroll
                             for (int j = 0; j < TN; ++j) M_::mma(a[i], b[j], acc[i][j]);
+                    }
                     }
                     __syncthreads();
                 }
@@ -1573,7 +1635,7 @@ template <typename T> struct WgTile;
 template <> struct WgTile<h16> { static constexpr int PAD = 0; static constexpr int KP = 32; };
 // fp32: row pad (elements) puts the g=0/1 pixel rows of a ds_read_b32 on different banks
 template <> struct WgTile<float> { static constexpr int PAD = 16; static constexpr int KP = 16; };
-template <> struct WgTile<xf32> { static constexpr int PAD = 16; static constexpr int KP = 16; };
+template <> struct WgTile<xf32> { static constexpr int PAD = 16; static constexpr int KP = 32; };     // K = 32 per stage: v_mfma_f32_16x16x32_bf16 triples
 
 typedef __fp16 fp16x4v __attribute__((__vector_size__(4 * sizeof(__fp16))));
 
@@ -1697,20 +1759,29 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const T* __restrict__ x
                 }
             }
         } else if constexpr (std::is_same<T, xf32>::value) {
-            // fp32x: lane group g holds pixels {g, 4+g, 8+g, 12+g} of the 16-pixel stage for its column (the same k set on both
-            // operands), split once into bf16 (hi, lo): three v_mfma_f32_16x16x16_bf16 per tile pair instead of four fp32 MFMAs
-            static_assert(KP == 16, "one K = 16 MFMA triple per stage");
-            SplitF4 a[TM], b[TN];
+            // fp32x, chunk-encoded tiles: the hi (bytes 0-7) and lo (bytes 8-15) halves of a chunk are four bf16 of four adjacent
+            // channels, so ds_read_b64_tr_b16 transposes them exactly as in the fp16 branch: lane (g, q = r16 >> 2, pc = r16 & 3) points
+            // at pixel rows 8g + q and 8g + 4 + q, channel chunk pc of its 16-channel tile and receives channel r16 of pixels
+            // 8g..8g+7 -- the same k set on both operands.  Three v_mfma_f32_16x16x32_bf16 per tile pair, no VALU.
+            static_assert(KP == 32, "one K = 32 MFMA triple per stage");
+            const int q = r16 >> 2, pc = r16 & 3;
+            auto frag = [&](const T* tile, int stride, int col) {
+                const char* r0 = reinterpret_cast<const char*>(tile + (8 * g + q) * stride + col + 4 * pc);
+                const char* r1 = reinterpret_cast<const char*>(tile + (8 * g + 4 + q) * stride + col + 4 * pc);
+                const uint2 h0 = __builtin_bit_cast(uint2, __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) fp16x4v*)(r0)));
+                const uint2 h1 = __builtin_bit_cast(uint2, __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) fp16x4v*)(r1)));
+                const uint2 l0 = __builtin_bit_cast(uint2, __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) fp16x4v*)(r0 + 8)));
+                const uint2 l1 = __builtin_bit_cast(uint2, __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) fp16x4v*)(r1 + 8)));
+                SplitF8 f;
+                f.hi = __builtin_bit_cast(bf16x8, make_uint4(h0.x, h0.y, h1.x, h1.y));
+                f.lo = __builtin_bit_cast(bf16x8, make_uint4(l0.x, l0.y, l1.x, l1.y));
+                return f;
+            };
+            SplitF8 a[TM], b[TN];
 #pragma unroll
-            for (int i = 0; i < TM; ++i) {
-                const int col = (wr * TM + i) * 16 + r16;
-                a[i] = mu_split4((f32x4){(float)At[g * SA + col], (float)At[(4 + g) * SA + col], (float)At[(8 + g) * SA + col], (float)At[(12 + g) * SA + col]});
-            }
+            for (int i = 0; i < TM; ++i) a[i] = frag(At, SA, (wr * TM + i) * 16);
 #pragma unroll
-            for (int j = 0; j < TN; ++j) {
-                const int col = (wc * TN + j) * 16 + r16;
-                b[j] = mu_split4((f32x4){(float)Bt[g * SB + col], (float)Bt[(4 + g) * SB + col], (float)Bt[(8 + g) * SB + col], (float)Bt[(12 + g) * SB + col]});
-            }
+            for (int j = 0; j < TN; ++j) b[j] = frag(Bt, SB, (wc * TN + j) * 16);
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll

@@ -263,6 +263,32 @@ extern "C" int mu_cast(const void* src, int src_dtype, void* dst, int dst_dtype,
 }
 
 // ------------------------------------------------------------------------------------------
+// fp32x operand encoding (common.h): n16 aligned 16-byte chunks of four fp32 values -> [4 x bf16 hi | 4 x bf16 lo].  In place or
+// out of place; contiguous rows only (a chunk never straddles a row: channel counts are multiples of 32).
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void split_encode_kernel(const f32x4* src, uint4* dst, long n16) {      // (may alias: no __restrict__)
+    const long stride = (long)gridDim.x * 256;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n16; i += 4 * stride) {
+        f32x4 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (i + u * stride < n16) v[u] = __builtin_nontemporal_load(src + i + u * stride);
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (i + u * stride < n16) dst[i + u * stride] = mu_enc4(v[u]);
+    }
+}
+extern "C" int mu_split_encode(const void* src, void* dst, long n_elems, void* stream) {
+    if (!src || !dst || n_elems <= 0 || n_elems % 4) return MU_ERR_ARG;
+    const long n16 = n_elems / 4;
+    long g = (n16 + 1023) / 1024;
+    g = g < 1 ? 1 : (g > 8192 ? 8192 : g);
+    split_encode_kernel<<<(int)g, 256, 0, (hipStream_t)stream>>>((const f32x4*)src, (uint4*)dst, n16);
+    MU_CHECK_LAUNCH();
+    return MU_OK;
+}
+
+// ------------------------------------------------------------------------------------------
 // MaxPool2d(2), NHWC.  Backward recomputes the arg-max from x (first maximum in (kh,kw) scan
 // order, the aten tie rule) so no index tensor is stored; windows are disjoint -> no atomics.
 // ------------------------------------------------------------------------------------------

@@ -29,6 +29,28 @@ def _pad_vec(v, n, fill):
     return F.pad(v, (0, n - v.numel()), value=fill)
 
 
+def _is_x(t_or_dtype) -> bool:
+    """fp32 compute with the split-bf16 matrix products (set_float32_matmul_precision("high")): matrix operands travel chunk-encoded."""
+    return mdt(t_or_dtype) == _lib.MU_F32X
+
+
+def _enc(t):
+    """Chunk-encoded copy of a matrix operand for the MU_F32X entry points (include/maskunet_hip.h); the tensor itself otherwise."""
+    if not _is_x(t):
+        return t
+    t = t.contiguous()
+    e = torch.empty_like(t)
+    call("mu_split_encode", ptr(t), ptr(e), t.numel(), stream())
+    return e
+
+
+def _enc_(t):
+    """The same in place (buffers nobody reads as plain fp32 afterwards: prepared weights, qkv)."""
+    if _is_x(t):
+        call("mu_split_encode", ptr(t), ptr(t), t.numel(), stream())
+    return t
+
+
 class GradLink:
     """Side channel for ONE gradient tensor between two autograd nodes of one backward pass.
 
@@ -220,7 +242,7 @@ def _prep_cached(w, key, make, ok, extra_tag=()):
 def _prep_weight(w, dtype, rows_pad, cols_pad, mode, cache_ok=False):
     """mode 0: forward layout; 1: data-gradient layout; 2: both from one launch -> (fwd, dgrad) views of one buffer."""
     if cache_ok and isinstance(w, torch.nn.Parameter):
-        return _prep_cached(w, (dtype, rows_pad, cols_pad, mode), lambda: _prep_weight_raw(w, dtype, rows_pad, cols_pad, mode), True)
+        return _prep_cached(w, (dtype, mdt(dtype), rows_pad, cols_pad, mode), lambda: _prep_weight_raw(w, dtype, rows_pad, cols_pad, mode), True)
     return _prep_weight_raw(w, dtype, rows_pad, cols_pad, mode)
 
 
@@ -231,6 +253,7 @@ def _prep_weight_raw(w, dtype, rows_pad, cols_pad, mode):
     dst = torch.empty((2 * n if mode == 2 else n,), dtype=dtype, device=w.device)
     wf = w.detach().float().contiguous()
     call("mu_prep_weight", ptr(wf), ptr(dst), dt(dtype), O, I, taps, rows_pad, cols_pad, mode, stream())
+    _enc_(dst)                          # fp32x: the compute layouts are matrix operands (rows of cols_pad % 32 == 0 elements: whole chunks)
     if mode == 2:
         return dst[:n].view(taps, rows_pad, cols_pad), dst[n:].view(taps, cols_pad, rows_pad)
     return dst.view(taps, rows_pad, cols_pad)
@@ -254,7 +277,7 @@ def prep_conv_weights(holder, weights, dtype, fwd_only=()):
     if len(weights) > MULTI_PREP_MAX_JOBS or any(w.shape[2] * w.shape[3] not in (1, 9) for w in weights):
         return                          # outside the kernel's job table / LDS tile (MU_PREP_MAX_JOBS, MAXT = 9): the per-layer path serves them
     only = {id(w) for w in fwd_only}
-    key = (dtype, tuple((w.data_ptr(), tuple(w.shape)) for w in weights), tuple(id(w) in only for w in weights))
+    key = (dtype, mdt(dtype), tuple((w.data_ptr(), tuple(w.shape)) for w in weights), tuple(id(w) in only for w in weights))
     # one device job table per distinct key, kept: a captured graph (GraphedStep) holds the raw address of the table its forward used,
     # and a later eager forward under another key (compute dtype, requires_grad of the input) must not free it under the graph.
     # Tables seen during a capture are pinned for the holder's lifetime; the others are bounded (oldest dropped beyond 8).
@@ -284,10 +307,12 @@ def prep_conv_weights(holder, weights, dtype, fwd_only=()):
     _, table, metas, total, nchunks = plan
     dst = torch.empty(total, dtype=dtype, device=dev)
     call("mu_prep_weights_multi", ptr(table), len(weights), nchunks, ptr(dst), dt(dtype), stream())
+    _enc_(dst)
+    tag = (dtype, mdt(dtype))
     for w, (off, n, taps, rp, cp, mode) in zip(weights, metas):
         fwd = dst[off:off + n].view(taps, rp, cp)
         wd = dst[off + n:off + 2 * n].view(taps, cp, rp) if mode == 2 else None
-        w._mu_step = (w._version, w.data_ptr(), dtype, fwd, wd)
+        w._mu_step = (w._version, w.data_ptr(), tag, fwd, wd)
 
 
 def _take_step_prep(w, dtype, taps, rows_pad, cols_pad, need_dgrad):
@@ -296,18 +321,20 @@ def _take_step_prep(w, dtype, taps, rows_pad, cols_pad, need_dgrad):
     if pre is None:
         return None
     w._mu_step = None
-    if pre[0] != w._version or pre[1] != w.data_ptr() or pre[2] != dtype or tuple(pre[3].shape) != (taps, rows_pad, cols_pad):
+    if pre[0] != w._version or pre[1] != w.data_ptr() or pre[2] != (dtype, mdt(dtype)) or tuple(pre[3].shape) != (taps, rows_pad, cols_pad):
         return None
     if need_dgrad and pre[4] is None:
         return None
     return pre[3], pre[4]
 
 
-def _conv_raw(x, wprep, bias_p, Cout_p, taps, want_stats=False):
+def _conv_raw(x, wprep, bias_p, Cout_p, taps, want_stats=False, x_encoded=False):
     """y = conv(x); with want_stats also the per-tile BatchNorm statistics rows of y ([rows, Cout_p, 2] floats) when the kernel
-    serving this shape has a statistics epilogue (else None)."""
+    serving this shape has a statistics epilogue (else None).  fp32x: x is chunk-encoded here unless the caller already did."""
     B, H, W, Cin_p = x.shape
     y = torch.empty((B, H, W, Cout_p), dtype=x.dtype, device=x.device)
+    if not x_encoded:
+        x = _enc(x)
     if want_stats:
         rows = _lib.load().mu_conv_stats_rows(B, H, W, Cin_p, Cout_p, taps, dt(x))
         if rows > 0:
@@ -321,15 +348,23 @@ def _conv_raw(x, wprep, bias_p, Cout_p, taps, want_stats=False):
     return y
 
 
-def _wgrad_raw(x, gy, w_shape, taps, st=None, ws=None):
+def _wgrad_raw(x, gy, w_shape, taps, st=None, ws=None, gy_encoded=False, x_encoded=False):
     B, H, W, Cin_p = x.shape
-    Cout_p = gy.shape[-1]
     O, I = w_shape[0], w_shape[1]
+    code = mdt(x)
+    if code == _lib.MU_F32X and taps == 9 and I <= 3 and not gy_encoded and not x_encoded:
+        code = _lib.MU_F32               # the first layer's weight gradient is a plain-FMA kernel (no matrix cores): plain fp32 operands
+    if code == _lib.MU_F32X:
+        if not x_encoded:
+            x = _enc(x)
+        if not gy_encoded:
+            gy = _enc(gy)
+    Cout_p = gy.shape[-1]
     gw = torch.empty(w_shape, dtype=torch.float32, device=x.device)
     if ws is None:
         ws = workspace(_lib.load().mu_conv_wgrad_workspace_bytes(B, H, W, Cin_p, Cout_p, taps), x.device)
     call("mu_conv_wgrad", ptr(x), ptr(gy), ptr(gw), B, H, W, Cin_p, Cout_p, taps, I, O, Cin_p, Cout_p, ptr(ws), ws.numel(),
-         mdt(x), stream() if st is None else st)
+         code, stream() if st is None else st)
     return gw
 
 
@@ -381,7 +416,7 @@ def _join_side(index):
     return cb
 
 
-def _wgrad_side(x, gy, w_shape, taps):
+def _wgrad_side(x, gy, w_shape, taps, x_encoded=False):
     dev = x.device
     side = _SIDE.get(dev.index)
     if side is None:
@@ -394,7 +429,7 @@ def _wgrad_side(x, gy, w_shape, taps):
         ws = _SIDE_WS.get(dev.index)
         if ws is None or ws.numel() < nbytes:
             ws = _SIDE_WS[dev.index] = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=dev)
-        gw = _wgrad_raw(x, gy, w_shape, taps, st=side.cuda_stream, ws=ws)
+        gw = _wgrad_raw(x, gy, w_shape, taps, st=side.cuda_stream, ws=ws, x_encoded=x_encoded)
     x.record_stream(side)
     gy.record_stream(side)
     gw.record_stream(main)
@@ -435,10 +470,15 @@ class _Conv(torch.autograd.Function):
             wprep = _prep_weight(weight, x.dtype, Cout_p, Cin_p, 0, cache_ok)
         bias_p = _pad_vec(bias, Cout_p, 0.0) if bias is not None else None
         part = None
+        # fp32x: the chunk-encoded input is what both the forward conv and the weight gradient read -- encode once, save THAT (the first
+        # layer's weight gradient is a plain-FMA kernel and keeps the plain tensor)
+        ctx.x_enc = _is_x(x) and not (taps == 9 and I <= 3)
+        if ctx.x_enc:
+            x = _enc(x)
         if want_stats:
-            y, part = _conv_raw(x, wprep, bias_p, Cout_p, taps, True)
+            y, part = _conv_raw(x, wprep, bias_p, Cout_p, taps, True, x_encoded=ctx.x_enc)
         else:
-            y = _conv_raw(x, wprep, bias_p, Cout_p, taps)
+            y = _conv_raw(x, wprep, bias_p, Cout_p, taps, x_encoded=ctx.x_enc)
         ctx.save_for_backward(x, weight)
         ctx.wparam = weight                      # the Parameter itself: backward looks at its .grad
         ctx.has_bias, ctx.taps = bias is not None, taps
@@ -461,19 +501,21 @@ class _Conv(torch.autograd.Function):
         gx = gw = gb = None
         side = ctx.needs_input_grad[1] and WGRAD_SIDE_STREAM and ctx.wparam.grad is None
         if side and os.environ.get("MU_WGRAD_SIDE_FIRST"):
-            gw = _wgrad_side(x, gy, tuple(weight.shape), ctx.taps)
+            gw = _wgrad_side(x, gy, tuple(weight.shape), ctx.taps, ctx.x_enc)
+        ge = _enc(gy) if (ctx.needs_input_grad[0] or (ctx.needs_input_grad[1] and not side)) else gy     # fp32x: one encoding of dy for both
         if ctx.needs_input_grad[0]:
             wd = ctx.wd if ctx.wd is not None else _prep_weight(weight, gy.dtype, x.shape[-1], gy.shape[-1], 1)
             ctx.wd = None
-            gx = _conv_raw(gy, wd, None, x.shape[-1], ctx.taps)
+            gx = _conv_raw(ge, wd, None, x.shape[-1], ctx.taps, x_encoded=True)
         if side and gw is None:                  # behind the data gradient (both want every CU's LDS): it then runs beside the
-            gw = _wgrad_side(x, gy, tuple(weight.shape), ctx.taps)      # HBM-bound kernels that follow on the main stream
+            gw = _wgrad_side(x, gy, tuple(weight.shape), ctx.taps, ctx.x_enc)      # HBM-bound kernels that follow on the main stream
         if ctx.needs_input_grad[1] and not side:
             both = _wgrad_bias_raw(x, gy, tuple(weight.shape), ctx.taps) if (ctx.has_bias and ctx.needs_input_grad[2]) else None
             if both is not None:
                 gw, gb = both
             else:
-                gw = _wgrad_raw(x, gy, tuple(weight.shape), ctx.taps)
+                first = not ctx.x_enc                                   # (the first layer's plain-FMA kernel: plain operands)
+                gw = _wgrad_raw(x, gy if first else ge, tuple(weight.shape), ctx.taps, gy_encoded=_is_x(gy) and not first, x_encoded=ctx.x_enc)
         if ctx.has_bias and ctx.needs_input_grad[2] and gb is None:
             gb = _colsum(gy, O)
         return gx, gw, gb, None, None
@@ -668,8 +710,8 @@ def conv_bn_act_eval(x, weight, conv_bias, bn, act=ACT_NONE, res=None, bn2=None)
     y = torch.empty((B, H, W, Cout_p), dtype=x.dtype, device=x.device)
     if res is not None:
         res = res.contiguous()
-    call("mu_conv_fwd_fused", ptr(x), ptr(wprep), ptr(fold[0]), ptr(fold[1]), ptr(res), act, ptr(y), B, H, W, Cin_p, Cout_p, taps, Cin_p, Cout_p,
-         mdt(x), stream())
+    call("mu_conv_fwd_fused", ptr(_enc(x)), ptr(wprep), ptr(fold[0]), ptr(fold[1]), ptr(res), act, ptr(y), B, H, W, Cin_p, Cout_p, taps, Cin_p,
+         Cout_p, mdt(x), stream())
     return y
 
 
@@ -886,17 +928,19 @@ class _MaskAttention(torch.autograd.Function):
             src = [t.detach() if t.dtype == torch.float32 and t.is_contiguous() else t.detach().float().contiguous()
                    for t in (wq, wk, wv, bq, bk, bv)]
             call("mu_prep_qkv", *[ptr(t) for t in src], ptr(wbuf), ptr(bqkv_), dt(x), C, stream())
+            _enc_(wbuf)
             return bqkv_, (wbuf[:3 * C * C].view(1, 3 * C, C), wbuf[3 * C * C:].view(1, C, 3 * C))
 
         if cache_ok and isinstance(wq, torch.nn.Parameter):
             # cached on the query weight under ONE key per dtype; the tag carries all six parameters' versions, so a stale entry is
             # overwritten in place (keying on the versions grew the dict by one entry per train/validate cycle)
             vers = tuple((t._version, t.data_ptr()) for t in (wk, wv, bq, bk, bv))
-            bqkv, (wprep, wd_) = _prep_cached(wq, ("qkv", x.dtype), make_qkv, True, extra_tag=vers)
+            bqkv, (wprep, wd_) = _prep_cached(wq, ("qkv", x.dtype, mdt(x)), make_qkv, True, extra_tag=vers)
         else:
             bqkv, (wprep, wd_) = make_qkv()
         ctx.wd = wd_ if ctx.needs_input_grad[0] else None
-        qkv = _conv_raw(x, wprep, bqkv, 3 * C, 1)                      # [B,H,W,3C] == [B,N,3C]
+        qkv = _enc_(_conv_raw(x, wprep, bqkv, 3 * C, 1))               # [B,H,W,3C] == [B,N,3C]; fp32x: chunk-encoded from here on (only the
+        # attention sweeps, forward and backward, ever read it)
         out = torch.empty((B, N, C), dtype=x.dtype, device=x.device)
         oattn = torch.empty_like(out)
         lse2 = torch.empty((B, N), dtype=torch.float32, device=x.device)
@@ -944,21 +988,22 @@ class _MaskAttention(torch.autograd.Function):
                      ptr(rstd), ptr(g), ptr(dY), ptr(delta), ptr(dqkv), ptr(dg), ptr(db), B, N, C, cv, kidx.shape[1], ptr(ws), ws.numel(),
                      mdt(x), phase | perm, stream())
         dqkv4 = dqkv.view(B, H, W, 3 * C)
+        dqkv_e = _enc(dqkv4)                     # fp32x: dqkv as a matrix operand (projection data- and weight-gradient); dqkv4 otherwise
         gx = None
         if ctx.needs_input_grad[0]:
             wd = ctx.wd                          # kept on ctx (views of one small buffer): a second backward over a retained graph needs it again
             if ATTN_FUSED_ADD and _lib.load().mu_conv1x1_add_supported(3 * C, C, mdt(x)):
                 # gx = dqkv @ Wqkv + dY: the residual branch (:187) joins the projection's data-gradient in its epilogue
                 gx = torch.empty((B, H, W, C), dtype=x.dtype, device=x.device)
-                call("mu_conv1x1_fwd_add", ptr(dqkv), ptr(wd), ptr(dY), ptr(gx), B * N, 3 * C, C, 3 * C, C, mdt(x), stream())
+                call("mu_conv1x1_fwd_add", ptr(dqkv_e), ptr(wd), ptr(dY), ptr(gx), B * N, 3 * C, C, 3 * C, C, mdt(x), stream())
             else:
-                gx = _conv_raw(dqkv4, wd, None, C, 1)
+                gx = _conv_raw(dqkv_e, wd, None, C, 1, x_encoded=True)
                 call("mu_add", ptr(gx), ptr(dY), ptr(gx), gx.numel(), dt(gx), stream())
         both = _wgrad_bias_raw(x, dqkv4, (3 * C, C, 1, 1), 1)       # projection weight and bias gradients from one sweep over dqkv
         if both is not None:
             gw, gb = both[0].view(3 * C, C), both[1]
         else:
-            gw = _wgrad_raw(x, dqkv4, (3 * C, C, 1, 1), 1).view(3 * C, C)
+            gw = _wgrad_raw(x, dqkv_e, (3 * C, C, 1, 1), 1, gy_encoded=True).view(3 * C, C)
             gb = _colsum(dqkv4, 3 * C)
         if cv != C:                  # gradients of the real (unpadded) parameters
             return (gx, gw[:cv, :cv], gb[:cv], gw[C:C + cv, :cv], gb[C:C + cv], gw[2 * C:2 * C + cv, :cv], gb[2 * C:2 * C + cv],
