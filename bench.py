@@ -42,8 +42,8 @@ DOMINANT_KERNEL = "attn_bwd_dkv3_kernel"
 REF_CLOCK_MHZ = 1900.0       # convention for `clock.ms_per_step_at_ref_clock` (about what the pool's boxes hold in the MFMA probe)
 MFMA_SHARE = 0.8             # share of the step spent in MFMA-bound kernels (attention, conv, weight-grad: 23.5 of 29.5 ms)
 # PMC traffic of the dominant kernel per workload shape (key: b{batch}_c{c_out}_hw{hw}_{dtype}[_3head]); see profiles/README.md
-TRAFFIC_JSON = {k: f"r03_dkv_traffic_{k}.json" for k in ("b64_c150_hw128_fp16", "b128_c133_hw128_fp16", "b64_c19_hw128_fp16_3head",
-                                                          "b32_c133_hw256_fp16", "b64_c150_hw128_fp32")}
+TRAFFIC_JSON = {k: f"r04_dkv_traffic_{k}.json" for k in ("b64_c150_hw128_fp16", "b128_c133_hw128_fp16", "b64_c19_hw128_fp16_3head",
+                                                          "b32_c133_hw256_fp16", "b64_c150_hw128_fp32", "b64_c150_hw128_fp32x")}
 DATASET_BY_COUT = {150: "ADE20K-semantic", 151: "ADE20K-semantic", 133: "COCO-panoptic", 19: "Cityscapes", 81: "COCO-instance"}
 
 
@@ -185,8 +185,9 @@ class SmiSampler:
     def summary(self):
         def mean(v):
             return round(sum(v) / len(v), 1) if v else None
-        return {"sclk_mhz_sysfs": mean(self.sclk), "power_w": mean(self.power), "samples": max(len(self.sclk), len(self.power)),
-                "source": self.dev}
+        # (the sysfs sclk files are not reported: on this pool pp_dpm_sclk / hwmon freq1_input read 95-2300 MHz for the same load --
+        # `clock_mhz` from the in-kernel stamps is the clock figure of the line)
+        return {"power_w": mean(self.power), "samples": len(self.power), "source": self.power_file}
 
 
 def clock_probe(dev, seconds=0.5, iters=16384):

@@ -12,6 +12,7 @@ run --three-head --c-out 19 --batch 64            # configs[3] per-GPU shape: Ci
 run --hw 256 --c-out 133 --batch 32               # configs[4] per-GPU shape: COCO semantic 256x256, B=32/GPU
 run --graph                                       # configs[1] replayed as one HIP graph
 run --optimizer --warmup 8                       # configs[1] + fused AdamW inside the step (one-time allocator / pinned-ring costs land in steps 4-7: longer warm-up)
-run --dtype fp32 --steps 4 --warmup 2             # fp32 parity path
+run --dtype fp32 --steps 4 --warmup 2             # fp32 parity path (exact-fp32 MFMA)
+run --dtype fp32x --steps 6 --warmup 2            # fp32 storage, split-bf16 matrix products (set_float32_matmul_precision("high"))
 run --batch 16
 cat $OUT | cut -c1-260
