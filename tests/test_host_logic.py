@@ -93,3 +93,73 @@ def test_compute_dtype_switch():
     assert m.downsample1.maxpool_conv[1].compute_dtype == torch.float16
     with pytest.raises(TypeError):
         m.set_compute_dtype(torch.bfloat16)
+
+
+def test_float32_matmul_precision_switch_maps_to_the_abi_dtype():
+    from maskunet_amd import _lib
+    assert maskunet_amd.get_float32_matmul_precision() == "highest"
+    assert _lib.mdt(torch.float32) == _lib.MU_F32 and _lib.mdt(torch.float16) == _lib.MU_F16
+    maskunet_amd.set_float32_matmul_precision("high")
+    try:
+        assert _lib.mdt(torch.float32) == _lib.MU_F32X          # the matrix entry points take the split-bf16 mode ...
+        assert _lib.dt(torch.float32) == _lib.MU_F32            # ... every other kernel sees plain fp32 storage
+        assert _lib.mdt(torch.float16) == _lib.MU_F16           # fp16 compute is unaffected
+    finally:
+        maskunet_amd.set_float32_matmul_precision("highest")
+    with pytest.raises(ValueError):
+        maskunet_amd.set_float32_matmul_precision("medium")
+
+
+def test_attention_width_table():
+    from maskunet_amd import ops
+    assert [ops.attn_width(c) for c in (1, 24, 32, 33, 64, 96, 128, 200, 256)] == [32, 32, 32, 64, 64, 128, 128, 256, 256]
+    with pytest.raises(RuntimeError, match="up to 256 channels"):
+        ops.attn_width(257)
+
+
+def test_grad_link_drops_a_fill_from_another_backward_pass(monkeypatch):
+    """ops.GradLink: a gradient parked by one backward pass (autograd graph task) is never handed to, or added into, another's."""
+    from maskunet_amd import ops
+    task = {"id": 7}
+    monkeypatch.setattr(ops, "_graph_task_id", lambda: task["id"])
+    link = ops.GradLink()
+    a, b = torch.ones(3), torch.full((3,), 2.0)
+    link.put(a)
+    link.put(b)                                  # two fills within one pass add up
+    assert torch.equal(link.take(), a + b) and link.take() is None
+    link.put(a)                                  # filled by pass 7, whose taker was pruned ...
+    task["id"] = 8
+    link.put(b)                                  # ... pass 8 starts from its own fill, not a + b
+    assert torch.equal(link.take(), b)
+    link.put(a)
+    task["id"] = 9
+    assert link.take() is None                   # a taker of pass 9 never sees pass 8's leftover
+
+
+def test_bench_spawns_a_child_launcher_for_bare_gpus(monkeypatch):
+    """bench.py --gpus N with WORLD_SIZE unset: the ranks are started as a CHILD `python -m torch.distributed.run` (never an exec of a
+    process that may have touched the GPU), with the same arguments, on 127.0.0.1; rank 0's JSON line and the exit code are relayed."""
+    import subprocess
+    import sys
+    import bench
+    seen = {}
+
+    class R:
+        returncode = 0
+        stdout = 'noise\n{"metric": "128x128 images/sec (fwd+bwd)", "n_gpus": 4}\n'
+
+    def fake_run(cmd, env=None, stdout=None, text=None):
+        seen["cmd"], seen["env"] = cmd, env
+        return R()
+
+    monkeypatch.setattr(subprocess, "run", fake_run)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "4", "--steps", "3"])
+    bench.spawn_ranks(4)
+    cmd = seen["cmd"]
+    assert cmd[:3] == [sys.executable, "-m", "torch.distributed.run"] and "--nproc-per-node=4" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[-4:] == ["--gpus", "4", "--steps", "3"]
+    assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+    R.returncode = 3
+    with pytest.raises(SystemExit) as e:
+        bench.spawn_ranks(4)
+    assert e.value.code == 3
