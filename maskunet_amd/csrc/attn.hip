@@ -97,6 +97,9 @@
 #ifndef MU_DKV_PKMUL
 #define MU_DKV_PKMUL 1
 #endif
+#ifndef MU_DKV_ROWC_ONE
+#define MU_DKV_ROWC_ONE 0
+#endif
 // fp32x (chunk-encoded fp32 tiles): the 256-/512-byte-row swizzle of the fp16 tiles for the row fragment + transposed reads, and
 // the occupancy bound of the C <= 64 sweeps (the fp32 instantiations run one wave per SIMD)
 #ifndef MU_XF_SWZ256
@@ -457,7 +460,7 @@ template <int D> struct AccLd<xf32, D> {
 };
 
 template <typename T, int D, int KT, int NW, int OCC = 0, int NQ = 2>
-__global__ __launch_bounds__(NW * 64, OCC ? OCC : ((NW == 4 && D <= 64 && std::is_same<T, xf32>::value) ? MU_XF_OCC : (NW == 4 && D <= 64 && sizeof(T) == 2) ? MU_FWD_OCC : ((NW == 4 && D == 128 && sizeof(T) == 2) ? MU_FWD_OCC128 : ((NW == 4 && D == 256 && sizeof(T) == 2) ? MU_FWD_OCC256 : 1)))) void attn_fwd2_kernel(const T* __restrict__ qkv, const T* __restrict__ x, const int* __restrict__ kidx,
+__global__ __launch_bounds__(NW * 64, OCC ? OCC : ((NW == 4 && D <= 128 && std::is_same<T, xf32>::value) ? MU_XF_OCC : (NW == 4 && D <= 64 && sizeof(T) == 2) ? MU_FWD_OCC : ((NW == 4 && D == 128 && sizeof(T) == 2) ? MU_FWD_OCC128 : ((NW == 4 && D == 256 && sizeof(T) == 2) ? MU_FWD_OCC256 : 1)))) void attn_fwd2_kernel(const T* __restrict__ qkv, const T* __restrict__ x, const int* __restrict__ kidx,
                                                         const int* __restrict__ kcnt, const float* __restrict__ gamma,
                                                         const float* __restrict__ beta, T* __restrict__ out, T* __restrict__ oattn,
                                                         float* __restrict__ lse2, float* __restrict__ ln_mean, float* __restrict__ ln_rstd,
@@ -1099,8 +1102,13 @@ __global__ __launch_bounds__(NW * 64, NW >= 8 ? 1 : ((D <= 64 && std::is_same<T,
         // row constants: 16 lanes x 16 B = the tile's 64 floats.  Every wave issues one DMA so that all waves count the same
         // number of vector-memory ops: wave 0's lanes >= 16 repeat the constants into the unused rest of the slot, waves 1-3
         // write theirs to a dump area
+#if MU_DKV_ROWC_ONE
+        // only wave 0 moves the row constants; the other waves count one DMA less per tile (wave-uniform branch on the waits below)
+        if (wave == 0) glds16s(rowc_b + (long)tile * 64, (uint32_t)((lane & 15) * 16), rcs + slot * 256);
+#else
         if (NW <= NI || wave < NI)
             glds16s(rowc_b + (long)tile * 64, (uint32_t)((lane & 15) * 16), rcs + (wave == 0 ? slot * 256 : DKV_RING * 256));
+#endif
     };
     constexpr int OPS = 2 * NPW + 1;
 
@@ -1145,8 +1153,18 @@ __global__ __launch_bounds__(NW * 64, NW >= 8 ? 1 : ((D <= 64 && std::is_same<T,
         if (tl == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         else
 #endif
+#if MU_DKV_ROWC_ONE
+        if (DKV_RING == 4 && newer >= 2) {
+            if (wave == 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * OPS) : "memory");
+            else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * (OPS - 1)) : "memory");
+        } else if (DKV_RING == 4 && newer == 1) {
+            if (wave == 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(OPS) : "memory");
+            else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(OPS - 1) : "memory");
+        }
+#else
         if (DKV_RING == 4 && newer >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * OPS) : "memory");
         else if (DKV_RING == 4 && newer == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(OPS) : "memory");
+#endif
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #ifndef MU_DKV_ABL_NOBAR
         __builtin_amdgcn_s_barrier();                        // everyone's share of tile tl landed; tile tl-1 fully consumed

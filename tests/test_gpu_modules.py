@@ -290,3 +290,31 @@ def test_fp32x_is_really_the_split_path_and_fp32_is_untouched():
     assert torch.equal(exact, again)
     err = float((split - exact).abs().max()) / float(exact.abs().max())
     assert 0 < err < 1e-4, err
+
+
+def test_eval_fused_and_one_launch_weight_prep_fp32x(fp32x):
+    """The inference epilogue (eval-mode BatchNorm folded into the conv) and the one-launch weight layouts in the split-bf16 mode: the
+    prepared weights are chunk-encoded behind both, keyed apart from the exact-fp32 layouts."""
+    from tests import _gpu_checks as G
+    _assert_all(G.check_eval_fused(torch.float32))
+    _assert_all(G.check_prep_weights_multi(torch.float32))
+
+
+def test_precision_modes_do_not_share_cached_weight_layouts():
+    """An eval forward under torch.no_grad() caches the prepared (compute-layout) weights on the parameters; switching the fp32 matmul
+    precision must not hand the exact-fp32 kernels chunk-encoded weights or vice versa."""
+    import maskunet_amd
+    from tests import _gpu_checks as G
+    model, params, keeps, x, labels = G.build_unet(150, False, 340, torch.float32, False, 2)
+    xd = x.cuda()
+    with torch.no_grad():
+        a = model(xd)
+        maskunet_amd.set_float32_matmul_precision("high")
+        try:
+            b = model(xd)
+        finally:
+            maskunet_amd.set_float32_matmul_precision("highest")
+        c = model(xd)
+    assert torch.equal(a, c)
+    err = float((a - b).abs().max()) / max(1.0, float(a.abs().max()))
+    assert 0 < err < 1e-3, err
