@@ -329,3 +329,30 @@ def test_attention_65536_tokens_batch32_offsets():
         ref = F.layer_norm(o, (C,), eps=1e-5)
         err = float((out[b, qs].double() - ref).abs().max()) / max(1.0, float(ref.abs().max()))
         assert err <= 3e-2, (b, err)
+
+
+def test_fp32x_batch64_training_step_is_reproducible_and_tracks_fp32():
+    """The fp32x mode (fp32 storage, split-bf16 matrix products on chunk-encoded operands) at the bench shape: a B = 64 training step is
+    finite and bit-reproducible (the xf32 instantiations of the ring / LDS-DMA kernels under the batch-dependent dispatch), and its
+    outputs / gradients agree with the exact-fp32 HIP path of the same step far inside the fp32 gates."""
+    import maskunet_amd
+    model, params, keeps, x, labels = _build(150, 128, 7640, torch.float32, True, 64)
+    xd, yd = x.cuda(), labels.cuda()
+
+    def run():
+        model.load_state_dict(params)
+        return _grads(model, xd, yd, 1.0)
+    o32, g32 = run()
+    maskunet_amd.set_float32_matmul_precision("high")
+    try:
+        ox, gx = run()
+        ox2, gx2 = run()
+    finally:
+        maskunet_amd.set_float32_matmul_precision("highest")
+    assert torch.equal(ox, ox2) and all(torch.equal(gx[n], gx2[n]) for n in gx), "fp32x step is not bit-reproducible"
+    assert set(gx) == set(g32) and all(torch.isfinite(v).all() for v in gx.values())
+    err_out = float((ox - o32).abs().max()) / max(1.0, float(o32.abs().max()))
+    worst = _worst_cos(gx, g32, 1.0, 1.0)
+    print(f"fp32x vs fp32 HIP at B=64: out err {err_out:.3e}, worst 1-cos {worst[0]:.3e} [{worst[1]}]")
+    assert err_out <= 1e-3, err_out
+    assert worst[0] <= 1e-4, worst
