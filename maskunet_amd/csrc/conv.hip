@@ -1202,171 +1202,6 @@ __global__ __launch_bounds__(512, 1) void conv_nt4f_kernel(const h16* __restrict
 }
 
 // ------------------------------------------------------------------------------------------
-// v5 (round 4, experiment behind MU_CONV_NT5=1): the same tile, LDS image, DMA stream and epilogue as v4, but LOCKSTEP with ONE barrier
-// per tap instead of two wave groups a phase apart with four.  tests/micro_feed.hip runs exactly this step shape (8 waves, pieces two
-// steps ahead, counted vmcnt, one barrier, 16 fragment reads feeding 32 MFMAs) at 1.52 PF/s where v4 delivers 1.0-1.3.
-//   tap s : s_barrier (every wave has finished tap s-1's reads and has seen W(s) land: its own vmcnt wait sits in front of the
-//           barrier) -> the 16 ds_read_b128 of both 32-channel halves -> the tap's three DMAs (halo piece of the next chunk, W(s+3) into
-//           the slot W(s-1) just vacated) -> 32 MFMAs, the compiler's own counted lgkmcnt waits letting the first ones start on the
-//           first fragments -> s_waitcnt vmcnt(6): all but the six youngest DMAs (this tap's and the previous tap's) have landed, i.e.
-//           W(s+1) and every halo piece issued two taps ago.
-// ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(512, 1) void conv_nt5_kernel(const h16* __restrict__ x, const h16* __restrict__ w, const float* __restrict__ bias,
-                                                          h16* __restrict__ y, int B, int H, int W, int Cin, int Cout, long x_ld, long y_ld,
-                                                          float* __restrict__ stat_part) {
-    using M_ = Mma<h16>;
-    using Frag = M_::Frag;
-    constexpr int VN = 8, KC = 64, TM = 4, TN = 4, NWV = 8, BCO = 128;
-    constexpr int TH = 16, TW = 16, HW_ = TW + 2, HROWS = (TH + 2) * HW_;
-    constexpr int HINST = (HROWS + 7) / 8;
-    constexpr int HPW = 7;
-    constexpr int HBYTES = HINST * 1024, WBYTES = BCO * 128, NWB = 4;
-
-    __shared__ __attribute__((aligned(16))) char lds[2 * HBYTES + NWB * WBYTES + 1024];
-    char* Hs = lds;
-    char* Ws = lds + 2 * HBYTES;
-    char* dump = lds + 2 * HBYTES + NWB * WBYTES;
-
-    const int tiles_w = W / TW, tiles_h = H / TH;
-    const int ntile = B * tiles_h * tiles_w, ncb = Cout / BCO;
-    const int L = xcd_remap(blockIdx.x, ntile * ncb);
-    const int cb = L % ncb, tl = L / ncb;
-    const int co0 = cb * BCO;
-    const int tw_ = tl % tiles_w, th_ = (tl / tiles_w) % tiles_h, bimg = tl / (tiles_w * tiles_h);
-    const int h0 = th_ * TH, w0 = tw_ * TW;
-
-    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wr = wave >> 2, wc = wave & 3;
-    const int r16 = lane & 15, g = lane >> 4;
-    const int srow = lane >> 3, sch = lane & 7;
-
-    const int kchunks = Cin / KC;
-    const int nsteps = 9 * kchunks;
-
-    int wl[2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int row = (i * NWV + wave) * 8 + srow;
-        wl[i] = (co0 + row) * Cin + (sch ^ (row & 7)) * VN;
-    }
-    int hl[HPW];
-#pragma unroll
-    for (int k = 0; k < HPW; ++k) {
-        const int hr = (k * NWV + wave) * 8 + srow;
-        const int hy = hr / HW_, hx = hr - hy * HW_;
-        const int hh = h0 - 1 + hy, ww = w0 - 1 + hx;
-        const bool ok = hr < HROWS && hh >= 0 && hh < H && ww >= 0 && ww < W;
-        hl[k] = ok ? (int)(((long)hh * W + ww) * x_ld) + (sch ^ (hx & 7)) * VN : -1;
-    }
-    const h16* xb = x + (long)bimg * H * W * x_ld;
-
-    auto stage_w = [&](int s) {
-        if (s < nsteps) {
-            const int tap = s % 9, ci0 = (s / 9) * KC;
-            const h16* wb = w + (long)tap * Cout * Cin + ci0;
-            char* Wb = Ws + (s & 3) * WBYTES;
-#pragma unroll
-            for (int i = 0; i < 2; ++i) glds16a(wb + wl[i], Wb + (i * NWV + wave) * 1024);
-        } else {
-            glds16a(mu_zero_page, dump);
-            glds16a(mu_zero_page, dump);
-        }
-    };
-    auto stage_h = [&](int k, int c) {
-        const int off = hl[k];
-        if (c < kchunks && k * NWV + wave < HINST) {
-            const void* src = off >= 0 ? (const void*)(xb + off + c * KC) : (const void*)mu_zero_page;
-            glds16a(src, Hs + (c & 1) * HBYTES + (k * NWV + wave) * 1024);
-        } else {
-            glds16a(mu_zero_page, dump);
-        }
-    };
-
-    f32x4 acc[TM][TN];
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-
-    int aoff[2], boff[3][2];
-#pragma unroll
-    for (int kk = 0; kk < 2; ++kk) {
-        aoff[kk] = (wr * TM * 16 + r16) * 128 + (((kk * 4 + g) ^ (r16 & 7)) << 4);
-#pragma unroll
-        for (int dw = 0; dw < 3; ++dw) boff[dw][kk] = (wc * TN * HW_ + r16 + dw) * 128 + (((kk * 4 + g) ^ ((r16 + dw) & 7)) << 4);
-    }
-
-#pragma unroll
-    for (int k = 0; k < HPW; ++k) stage_h(k, 0);
-    stage_w(0);
-    stage_w(1);
-    stage_w(2);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-
-    int s = 0;
-    for (int c = 0; c < kchunks; ++c) {
-        const int hbuf = (c & 1) * HBYTES;
-#pragma unroll
-        for (int t = 0; t < 9; ++t, ++s) {
-            const int dh = t / 3, dw = t % 3;
-            const char* Wb = Ws + (s & 3) * WBYTES;
-            const char* Hb = Hs + hbuf + dh * (HW_ * 128);
-            __builtin_amdgcn_s_barrier();
-            Frag a[2][TM], b[2][TN];
-#pragma unroll
-            for (int kk = 0; kk < 2; ++kk) {
-#pragma unroll
-                for (int i = 0; i < TM; ++i) a[kk][i] = M_::ld(Wb + aoff[kk] + i * 2048);
-#pragma unroll
-                for (int j = 0; j < TN; ++j) b[kk][j] = M_::ld(Hb + boff[dw][kk] + j * (HW_ * 128));
-            }
-            // three DMAs per wave per tap (dummies keep the vmcnt count uniform).  The halo piece refills the OTHER halo buffer (read
-            // again only from the next chunk on); W(s+3) goes to slot (s-1) & 3, whose readers all passed this tap's barrier
-            if (t < HPW) stage_h(t, c + 1); else glds16a(mu_zero_page, dump);
-            stage_w(s + 3);
-            __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-            for (int kk = 0; kk < 2; ++kk)
-#pragma unroll
-                for (int i = 0; i < TM; ++i)
-#pragma unroll
-                    for (int j = 0; j < TN; ++j) M_::mma(a[kk][i], b[kk][j], acc[i][j]);
-            __builtin_amdgcn_s_setprio(0);
-            asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-        }
-    }
-    __builtin_amdgcn_s_barrier();
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // (dummy DMAs to the dump slot: nothing may still be writing LDS when the epilogue reuses it)
-    __builtin_amdgcn_s_barrier();
-
-    char* Os = lds + wave * 8192;
-#pragma unroll
-    for (int j = 0; j < TN; ++j) {
-        const int p = j * 16 + r16;
-#pragma unroll
-        for (int i = 0; i < TM; ++i) {
-            const int co = i * 16 + 4 * g;
-            float v[4];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) v[r] = acc[i][j][r] + (bias ? bias[co0 + wr * 64 + co + r] : 0.f);
-            h16x4 o = {(h16)v[0], (h16)v[1], (h16)v[2], (h16)v[3]};
-            *reinterpret_cast<h16x4*>(Os + p * 128 + (((co >> 2) ^ (((p >> 1) & 7) << 1)) << 3)) = o;
-        }
-    }
-    const int q = lane & 7;
-    float ssum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, ssq[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int it = 0; it < 8; ++it) {
-        const int p = it * 8 + (lane >> 3);
-        h16x8 o = *reinterpret_cast<const h16x8*>(Os + p * 128 + ((q ^ ((p >> 1) & 7)) << 4));
-        const long gp = ((long)bimg * H + h0 + wc * TN + (p >> 4)) * W + w0 + (p & 15);
-        *reinterpret_cast<h16x8*>(y + gp * y_ld + co0 + wr * 64 + q * 8) = o;
-        if (stat_part) tile_stats_accum(o, ssum, ssq);
-    }
-    if (stat_part) tile_stats_store(ssum, ssq, stat_part + ((long)tl * 4 + wc) * Cout * 2, co0 + wr * 64 + q * 8, lane);
-}
-
-// ------------------------------------------------------------------------------------------
 // v4p: the ping-pong kernel as a PERSISTENT tile loop -- one block per CU walks the 16x16 tiles of its output-channel block.
 // Measured on v4 (in-process, 128->128 @128^2): every tile pays ~4.8 us of launch / index / prologue (halo + three weight
 // tiles behind a vmcnt(0)) / epilogue around 18 taps x 0.87 us.  Here the DMA stream simply runs on across the tile
@@ -1646,9 +1481,6 @@ static int conv_fwd_launch(const T* x, const T* w, const float* bias, T* y, int 
                     return MU_OK;
                 }
 #endif
-                static const bool nt5 = getenv("MU_CONV_NT5") != nullptr;      // round-4 experiment: the lockstep one-barrier-per-tap schedule
-                if (nt5) conv_nt5_kernel<<<B * (H / 16) * (W / 16) * (Cout / 128), 512, 0, st>>>(x, w, bias, y, B, H, W, Cin, Cout, x_ld, y_ld, stat_part);
-                else
                 conv_nt4_kernel<<<B * (H / 16) * (W / 16) * (Cout / 128), 512, 0, st>>>(x, w, bias, y, B, H, W, Cin, Cout, x_ld, y_ld, stat_part);
                 return MU_OK;
             }
