@@ -127,6 +127,23 @@ def module_cases(ns):
     run_module_case("attn_128_24x8", ns["Mask2FormerAttention"](128, 128), [rnd(1, 128, 24, 8)], True, keep=k3, weights_seed=18)
 
 
+def generality_cases(ns):
+    """Round 4: the reference's generality at the module boundary, from the reference itself -- Mask2FormerAttention(channels, size) with
+    channel counts that are none of the UNet's (ade_semantic.py:153-161 takes any), DownSample on an odd-sized map (nn.MaxPool2d(2)
+    floors, :216).  Own rng: the cases above keep their streams and stay bit-identical."""
+    r = np.random.default_rng(70)
+
+    def rnd(*s):
+        return torch.from_numpy(r.standard_normal(s).astype(np.float32))
+
+    ka = torch.from_numpy(r.integers(0, 2, size=(2, 8 * 12)).astype(np.uint8))
+    run_module_case("attn_48_8x12", ns["Mask2FormerAttention"](48, 48), [rnd(2, 48, 8, 12)], True, keep=ka, weights_seed=71)
+    kb = torch.from_numpy(r.integers(0, 2, size=(1, 64)).astype(np.uint8))
+    run_module_case("attn_200_8x8", ns["Mask2FormerAttention"](200, 200), [rnd(1, 200, 8, 8)], True, keep=kb, weights_seed=72)
+    for tr in (True, False):
+        run_module_case(f"down_16_32_odd13x9_{'train' if tr else 'eval'}", ns["DownSample"](16, 32), [rnd(2, 16, 13, 9)], tr, weights_seed=73)
+
+
 def unet_case(name, UNet, c_out, B, training, three_head, seed):
     torch.manual_seed(0)
     model = UNet(3, c_out, 16) if three_head else UNet(3, c_out)
@@ -178,7 +195,11 @@ def main():
     torch.set_num_threads(8)
     ns1 = load_reference(os.path.join(REF, "ade20k/ade_semantic.py"))
     ns3 = load_reference(os.path.join(REF, "cityscapes/city_instance.py"))
+    if "--generality-only" in sys.argv:        # (re)write only the round-4 cases
+        generality_cases(ns1)
+        return
     module_cases(ns1)
+    generality_cases(ns1)
     unet_case("unet1_c150_b2_train", ns1["UNet"], 150, 2, True, False, 100)
     unet_case("unet1_c150_b2_eval", ns1["UNet"], 150, 2, False, False, 100)
     # B=2, not 1: torch 2.10 CPU returns wrong BatchNorm grads at B=1 when grad_out arrives with
