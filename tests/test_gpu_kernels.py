@@ -157,3 +157,28 @@ def test_attention_fp32x(fp32x):
     _assert_all(G.check_attention(torch.float32))
     _assert_all(G.check_attention(torch.float32, cases=[(2, 8, 12, 48), (1, 8, 8, 200)]))
     _assert_all(G.check_attention_bwd_masked_rows(torch.float32))
+
+
+def test_split_encode_is_a_per_chunk_hi_lo_rewrite():
+    """mu_split_encode through the C ABI: every aligned 16-byte chunk of four fp32 values becomes [4 bf16 hi | 4 bf16 lo] with
+    hi = bf16_rne(x), lo = bf16_rne(x - hi); hi + lo reproduces x to 2^-16 relative (2^-17 bound + bf16 subnormal floor), in place too."""
+    from maskunet_amd import _lib
+    g = torch.Generator(device="cuda").manual_seed(3)
+    x = torch.randn(4096 + 8, device="cuda", generator=g) * torch.logspace(-6, 4, 4104, device="cuda")
+    x[:8] = torch.tensor([0.0, -0.0, 1.0, -1.0, 3.0e38, -3.0e38, 1e-30, 65504.0], device="cuda")
+    e = torch.empty_like(x)
+    _lib.call("mu_split_encode", x.data_ptr(), e.data_ptr(), x.numel(), _lib.stream())
+    w = e.view(torch.int32).view(-1, 4)                                  # dwords: hi(x0,x1) hi(x2,x3) lo(x0,x1) lo(x2,x3)
+    def halves(d):                                                       # a dword of two bf16 -> the two floats
+        return torch.stack([(d << 16).view(torch.float32), (d & -65536).view(torch.float32)], -1)
+    hi = torch.cat([halves(w[:, 0]), halves(w[:, 1])], -1).reshape(-1)
+    lo = torch.cat([halves(w[:, 2]), halves(w[:, 3])], -1).reshape(-1)
+    assert torch.equal(hi, x.bfloat16().float())                         # hi is the round-to-nearest-even bf16 of x
+    assert torch.equal(lo, (x - hi).bfloat16().float())
+    rel = ((hi.double() + lo.double() - x.double()).abs() / x.double().abs().clamp(min=1e-30)).max().item()
+    assert rel <= 2.0 ** -16, rel
+    y = x.clone()
+    _lib.call("mu_split_encode", y.data_ptr(), y.data_ptr(), y.numel(), _lib.stream())     # in place
+    assert torch.equal(y.view(torch.int32), e.view(torch.int32))
+    with pytest.raises(RuntimeError, match="MU_ERR_ARG"):
+        _lib.call("mu_split_encode", x.data_ptr(), e.data_ptr(), 6, _lib.stream())         # not whole chunks
