@@ -165,9 +165,20 @@ def test_training_step_is_bitwise_reproducible():
             assert torch.equal(grads[n], gref), f"gradient of {n} differs between identical runs"
 
 
-def test_training_trajectory_matches_oracle():
-    """Four optimisation steps (fp32 compute, FusedAdamW, maskunet_amd.CrossEntropyLoss) follow the CPU oracle trained with
-    torch.optim.AdamW on the same batch: the loss after every step agrees, and it moves by far more than the tolerance."""
+@pytest.mark.parametrize("precision", ["highest", "high"])
+def test_training_trajectory_matches_oracle(precision):
+    """Four optimisation steps (fp32 compute -- exact-fp32 MFMA and the fp32x split-bf16 mode --, FusedAdamW, maskunet_amd.CrossEntropyLoss)
+    follow the CPU oracle trained with torch.optim.AdamW on the same batch: the loss after every step agrees, and it moves by far more
+    than the tolerance."""
+    import maskunet_amd
+    maskunet_amd.set_float32_matmul_precision(precision)
+    try:
+        _trajectory()
+    finally:
+        maskunet_amd.set_float32_matmul_precision("highest")
+
+
+def _trajectory():
     import maskunet_amd
     from oracle import maskunet_oracle as O
     from tests import _gpu_checks as G
