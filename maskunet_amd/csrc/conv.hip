@@ -1202,193 +1202,6 @@ __global__ __launch_bounds__(512, 1) void conv_nt4f_kernel(const h16* __restrict
 }
 
 // ------------------------------------------------------------------------------------------
-// v6 (round 4, experiment behind MU_CONV_NT6=1): the v4 tile (128 output channels x 16 x 16 pixels, same LDS image, ring and DMA stream)
-// on FOUR waves, one per SIMD, each owning 64 channels x 8 image rows = 128 pixels (TM 4 x TN 8: 12 fragment reads per 32 MFMAs instead of
-// 16), software-pipelined inside the wave instead of ping-ponged across two: the fragments of the NEXT half-tap are in flight while the
-// current half-tap's 32 MFMAs issue, across the tap boundary too.  One barrier per tap, in the MIDDLE of it:
-//   tap s:  32 MFMAs on set0 (tap s, channels 0-31; read during tap s-1)  ||  reads of set1 (tap s, channels 32-63)
-//           s_waitcnt vmcnt(12): W(s+1) -- issued at tap s-2 -- and every older halo piece landed;  s_barrier
-//           the tap's six DMAs (W(s+3) into the slot W(s-1) vacated: its last reads were issued before this barrier by every wave;
-//           two pieces of the next chunk's halo or dummies)
-//           32 MFMAs on set1                                               ||  reads of set0' (tap s+1, channels 0-31: visible behind the barrier)
-// ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256, 1) void conv_nt6_kernel(const h16* __restrict__ x, const h16* __restrict__ w, const float* __restrict__ bias,
-                                                          h16* __restrict__ y, int B, int H, int W, int Cin, int Cout, long x_ld, long y_ld,
-                                                          float* __restrict__ stat_part) {
-    using M_ = Mma<h16>;
-    using Frag = M_::Frag;
-    constexpr int VN = 8, KC = 64, TM = 4, TN = 8, NWV = 4, BCO = 128;
-    constexpr int TH = 16, TW = 16, HW_ = TW + 2, HROWS = (TH + 2) * HW_;
-    constexpr int HINST = (HROWS + 7) / 8;                                       // 41 pieces of 8 halo rows
-    constexpr int HPW = 11;                                                      // halo pieces per wave and chunk (taps 0..5, two per tap)
-    static_assert(HPW * NWV >= HINST, "halo pieces");
-    constexpr int HBYTES = HINST * 1024, WBYTES = BCO * 128, NWB = 4;
-
-    __shared__ __attribute__((aligned(16))) char lds[2 * HBYTES + NWB * WBYTES + 1024];
-    char* Hs = lds;
-    char* Ws = lds + 2 * HBYTES;
-    char* dump = lds + 2 * HBYTES + NWB * WBYTES;
-
-    const int tiles_w = W / TW, tiles_h = H / TH;
-    const int ntile = B * tiles_h * tiles_w, ncb = Cout / BCO;
-    const int L = xcd_remap(blockIdx.x, ntile * ncb);
-    const int cb = L % ncb, tl = L / ncb;
-    const int co0 = cb * BCO;
-    const int tw_ = tl % tiles_w, th_ = (tl / tiles_w) % tiles_h, bimg = tl / (tiles_w * tiles_h);
-    const int h0 = th_ * TH, w0 = tw_ * TW;
-
-    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wr = wave >> 1, wc = wave & 1;                 // 64-channel half, 8-row half
-    const int r16 = lane & 15, g = lane >> 4;
-    const int srow = lane >> 3, sch = lane & 7;
-
-    const int kchunks = Cin / KC;
-    const int nsteps = 9 * kchunks;
-
-    int wl[4];                                               // this wave's four weight pieces per tap: rows (i*4 + wave)*8 + srow
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int row = (i * NWV + wave) * 8 + srow;
-        wl[i] = (co0 + row) * Cin + (sch ^ (row & 7)) * VN;
-    }
-    int hl[HPW];
-#pragma unroll
-    for (int k = 0; k < HPW; ++k) {
-        const int hr = (k * NWV + wave) * 8 + srow;
-        const int hy = hr / HW_, hx = hr - hy * HW_;
-        const int hh = h0 - 1 + hy, ww = w0 - 1 + hx;
-        const bool ok = hr < HROWS && hh >= 0 && hh < H && ww >= 0 && ww < W;
-        hl[k] = ok ? (int)(((long)hh * W + ww) * x_ld) + (sch ^ (hx & 7)) * VN : -1;
-    }
-    const h16* xb = x + (long)bimg * H * W * x_ld;
-
-    auto stage_w = [&](int s) {
-        if (s < nsteps) {
-            const int tap = s % 9, ci0 = (s / 9) * KC;
-            const h16* wb = w + (long)tap * Cout * Cin + ci0;
-            char* Wb = Ws + (s & 3) * WBYTES;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) glds16a(wb + wl[i], Wb + (i * NWV + wave) * 1024);
-        } else {
-#pragma unroll
-            for (int i = 0; i < 4; ++i) glds16a(mu_zero_page, dump);
-        }
-    };
-    auto stage_h = [&](int k, int c) {
-        const int off = hl[k < HPW ? k : 0];
-        if (k < HPW && c < kchunks && k * NWV + wave < HINST) {
-            const void* src = off >= 0 ? (const void*)(xb + off + c * KC) : (const void*)mu_zero_page;
-            glds16a(src, Hs + (c & 1) * HBYTES + (k * NWV + wave) * 1024);
-        } else {
-            glds16a(mu_zero_page, dump);
-        }
-    };
-
-    f32x4 acc[TM][TN];
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-
-    int aoff[2], boff[3][2];
-#pragma unroll
-    for (int kk = 0; kk < 2; ++kk) {
-        aoff[kk] = (wr * TM * 16 + r16) * 128 + (((kk * 4 + g) ^ (r16 & 7)) << 4);
-#pragma unroll
-        for (int dw = 0; dw < 3; ++dw) boff[dw][kk] = (wc * TN * HW_ + r16 + dw) * 128 + (((kk * 4 + g) ^ ((r16 + dw) & 7)) << 4);
-    }
-
-    Frag a0[TM], b0[TN], a1[TM], b1[TN];
-    auto load = [&](Frag (&a)[TM], Frag (&b)[TN], int s, int c, int t, int kk) {       // fragments of tap (s, chunk c, tap index t), half kk
-        const char* Wb = Ws + (s & 3) * WBYTES;
-        const char* Hb = Hs + (c & 1) * HBYTES + (t / 3) * (HW_ * 128);
-#pragma unroll
-        for (int i = 0; i < TM; ++i) a[i] = M_::ld(Wb + aoff[kk] + i * 2048);
-#pragma unroll
-        for (int j = 0; j < TN; ++j) b[j] = M_::ld(Hb + boff[t % 3][kk] + j * (HW_ * 128));
-    };
-    auto mfma = [&](const Frag (&a)[TM], const Frag (&b)[TN], int i0, int i1) {      // output-channel fragments i0..i1-1 x all 8 pixel rows
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-            if (i >= i0 && i < i1) {
-#pragma unroll
-                for (int j = 0; j < TN; ++j) M_::mma(a[i], b[j], acc[i][j]);
-            }
-    };
-
-    // prologue: halo of chunk 0, W(0..2); drained and visible; set0 of tap 0
-#pragma unroll
-    for (int k = 0; k < HPW; ++k) stage_h(k, 0);
-    stage_w(0);
-    stage_w(1);
-    stage_w(2);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    load(a0, b0, 0, 0, 0, 0);
-
-    int s = 0;
-    for (int c = 0; c < kchunks; ++c) {
-#pragma unroll
-        for (int t = 0; t < 9; ++t, ++s) {
-            // eight MFMAs on operands that landed a half-tap ago FIRST (the waits hipcc puts in front of them then cover no read of
-            // the next set), then the next set's 12 reads with 24 MFMAs to land behind
-            mfma(a0, b0, 0, 1);
-            __builtin_amdgcn_sched_barrier(0);
-            load(a1, b1, s, c, t, 1);                        // second half of this tap
-            __builtin_amdgcn_sched_barrier(0);
-            mfma(a0, b0, 1, 4);
-            asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
-            mfma(a1, b1, 0, 1);
-            __builtin_amdgcn_sched_barrier(0);
-            if (s + 1 < nsteps) {                            // first half of the next tap (next chunk's halo buffer when t == 8)
-                if (t < 8) load(a0, b0, s + 1, c, t + 1, 0);
-                else load(a0, b0, s + 1, c + 1, 0, 0);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-            mfma(a1, b1, 1, 2);
-            stage_w(s + 3);                                  // the tap's six DMAs, spread between the MFMA groups
-            mfma(a1, b1, 2, 3);
-            stage_h(2 * t, c + 1);
-            stage_h(2 * t + 1, c + 1);
-            mfma(a1, b1, 3, 4);
-        }
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // (dummy DMAs to the dump slot must not be in flight when the epilogue reuses LDS)
-    __builtin_amdgcn_s_barrier();
-
-    // epilogue: as v4, per wave two 64-pixel halves through its private 8 KB of LDS (whole 128-byte rows per store)
-    char* Os = lds + wave * 8192;
-    const int q = lane & 7;
-#pragma unroll
-    for (int hf = 0; hf < 2; ++hf) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int p = j * 16 + r16;
-#pragma unroll
-            for (int i = 0; i < TM; ++i) {
-                const int co = i * 16 + 4 * g;
-                float v[4];
-#pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] = acc[i][hf * 4 + j][r] + (bias ? bias[co0 + wr * 64 + co + r] : 0.f);
-                h16x4 o = {(h16)v[0], (h16)v[1], (h16)v[2], (h16)v[3]};
-                *reinterpret_cast<h16x4*>(Os + p * 128 + (((co >> 2) ^ (((p >> 1) & 7) << 1)) << 3)) = o;
-            }
-        }
-        float ssum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, ssq[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int it = 0; it < 8; ++it) {
-            const int p = it * 8 + (lane >> 3);
-            h16x8 o = *reinterpret_cast<const h16x8*>(Os + p * 128 + ((q ^ ((p >> 1) & 7)) << 4));
-            const long gp = ((long)bimg * H + h0 + wc * 8 + hf * 4 + (p >> 4)) * W + w0 + (p & 15);
-            *reinterpret_cast<h16x8*>(y + gp * y_ld + co0 + wr * 64 + q * 8) = o;
-            if (stat_part) tile_stats_accum(o, ssum, ssq);
-        }
-        if (stat_part) tile_stats_store(ssum, ssq, stat_part + ((long)tl * 4 + wc * 2 + hf) * Cout * 2, co0 + wr * 64 + q * 8, lane);
-    }
-}
-
-// ------------------------------------------------------------------------------------------
 // v4p: the ping-pong kernel as a PERSISTENT tile loop -- one block per CU walks the 16x16 tiles of its output-channel block.
 // Measured on v4 (in-process, 128->128 @128^2): every tile pays ~4.8 us of launch / index / prologue (halo + three weight
 // tiles behind a vmcnt(0)) / epilogue around 18 taps x 0.87 us.  Here the DMA stream simply runs on across the tile
@@ -1668,9 +1481,6 @@ static int conv_fwd_launch(const T* x, const T* w, const float* bias, T* y, int 
                     return MU_OK;
                 }
 #endif
-                static const bool nt6 = getenv("MU_CONV_NT6") != nullptr;      // round-4 experiment: four software-pipelined waves, 64 x 128 register tiles
-                if (nt6) conv_nt6_kernel<<<B * (H / 16) * (W / 16) * (Cout / 128), 256, 0, st>>>(x, w, bias, y, B, H, W, Cin, Cout, x_ld, y_ld, stat_part);
-                else
                 conv_nt4_kernel<<<B * (H / 16) * (W / 16) * (Cout / 128), 512, 0, st>>>(x, w, bias, y, B, H, W, Cin, Cout, x_ld, y_ld, stat_part);
                 return MU_OK;
             }
