@@ -317,3 +317,5 @@ def test_bench_line_is_self_describing():
     c = rec["clock"]
     assert 800 < c["clock_mhz"] <= 2500 and c["probe_tflops"] > 200
     assert rec["roofline"]["frac_at_measured_clock"] >= rec["roofline"]["frac"] > 0
+    pg = rec["parity_grade_path"]                      # the same workload in the fp32x mode, behind the timed region
+    assert pg["value"] > 0 and pg["finite"] and pg["parity_gate"]["passed"] is True and pg["parity_gate"]["observed"]["out"] <= 1e-3
