@@ -40,7 +40,9 @@ extern "C" {
  * the attention sweeps -- are passed CHUNK-ENCODED: every aligned 16-byte chunk of four fp32 values re-written as
  * [4 x bf16 hi | 4 x bf16 lo] by mu_split_encode (same size, same strides; the split then costs one pass per tensor instead of
  * VALU work per fragment per wave).  Outputs, biases, residual / addend tensors, x / oattn / grad_out / dY of the attention block
- * are plain fp32. */
+ * are plain fp32.  Two producers can write the encoded form directly and save the mu_split_encode pass: mu_bn_act_fwd with MU_F32X writes
+ * y encoded (for a y that only feeds a convolution), mu_bn_act_bwd / mu_bn_act_bwd_scaled with MU_F32X write dx encoded (dx of a BatchNorm
+ * is the dy of the convolution in front of it); their inputs, dres and all statistics stay plain fp32. */
 #define MU_F32X 2
 
 #define MU_ACT_NONE 0

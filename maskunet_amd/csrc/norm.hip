@@ -214,7 +214,9 @@ __global__ void bn_bwd_final_kernel(const double* __restrict__ part, int nblk, i
 
 // Elementwise passes: grid-stride over 16-byte vectors with a stride that is a multiple of the vectors per row (ew_grid),
 // so a thread's channel chunk -- and its per-channel constants -- never change; U vectors per operand in flight.
-template <typename T>
+// ENC (fp32 storage only, MU_F32X at the entry point): y feeds nothing but a convolution, so it is written as that convolution's chunk-encoded
+// matrix operand (common.h mu_enc4: a thread's 16-byte vector IS one chunk) -- the separate mu_split_encode pass (read + write) disappears.
+template <typename T, bool ENC = false>
 __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const T* __restrict__ x, const T* __restrict__ res, T* __restrict__ y, long M,
                                                          int C, long ld, const float* __restrict__ mean, const float* __restrict__ rstd,
                                                          const float* __restrict__ gamma, const float* __restrict__ beta, int act) {
@@ -256,11 +258,15 @@ __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const T* __restrict__ x
                     o.set(i, o0);
                     o.set(i + 1, o1);
                 }
+                if constexpr (ENC) {
+                    *reinterpret_cast<uint4*>(y + (r + u * rstep) * ld + c) = mu_enc4((f32x4){o.get(0), o.get(1), o.get(2), o.get(3)});
+                } else {
 #if MU_BN_NT & 2
                 o.store_nt(y + (r + u * rstep) * ld + c);
 #else
                 o.store(y + (r + u * rstep) * ld + c);
 #endif
+                }
             }
         }
     }
@@ -269,7 +275,7 @@ __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const T* __restrict__ x
 // dx = gamma*rstd*(dz - s1 - xhat*s2).  RECOMP = false: dz is read from dzbuf (may alias dx) -- the residual form, whose
 // d(residual) IS dz and has to be written anyway.  RECOMP = true (no residual): dz = g * act'(pre) is recomputed from x and
 // the incoming gradient, so the statistics sweep writes nothing: 5 tensor passes per BatchNorm backward instead of 6.
-template <typename T, bool RECOMP>
+template <typename T, bool RECOMP, bool ENC = false>
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__ x, const T* dzbuf, T* dx, long M, int C, long ld,
                                                            const float* __restrict__ mean, const float* __restrict__ rstd,
                                                            const float* __restrict__ gamma, const float* __restrict__ beta, int act,
@@ -324,7 +330,8 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
                     o.set(i, fmaf(gr[i], d[0], fmaf(k1[i], xv[u].get(i), k0[i])));
                     o.set(i + 1, fmaf(gr[i + 1], d[1], fmaf(k1[i + 1], xv[u].get(i + 1), k0[i + 1])));
                 }
-                o.store(dx + (r + u * rstep) * ld + c);
+                if constexpr (ENC) *reinterpret_cast<uint4*>(dx + (r + u * rstep) * ld + c) = mu_enc4((f32x4){o.get(0), o.get(1), o.get(2), o.get(3)});
+                else o.store(dx + (r + u * rstep) * ld + c);
             }
         }
     }
@@ -487,6 +494,8 @@ extern "C" int mu_bn_act_fwd(const void* x, const void* res, void* y, long M, in
     hipStream_t st = (hipStream_t)stream;
     if (dtype == MU_F32)
         bn_act_fwd_kernel<float><<<ew_grid(M * (C / 4), C / 4), 256, 0, st>>>((const float*)x, (const float*)res, (float*)y, M, C, ld, mean, rstd, gamma, beta, act);
+    else if (dtype == MU_F32X)      // fp32 storage, y written chunk-encoded (it only feeds a convolution in the fp32x mode)
+        bn_act_fwd_kernel<float, true><<<ew_grid(M * (C / 4), C / 4), 256, 0, st>>>((const float*)x, (const float*)res, (float*)y, M, C, ld, mean, rstd, gamma, beta, act);
     else if (dtype == MU_F16)
         bn_act_fwd_kernel<h16><<<ew_grid(M * (C / 8), C / 8), 256, 0, st>>>((const h16*)x, (const h16*)res, (h16*)y, M, C, ld, mean, rstd, gamma, beta, act);
     else return MU_ERR_ARG;
@@ -497,7 +506,7 @@ extern "C" int mu_bn_act_fwd(const void* x, const void* res, void* y, long M, in
 template <typename T>
 static int bn_act_bwd_t(const T* x, const T* res, const T* g, T* dx, T* dres, long M, int C, long ld, const float* mean,
                         const float* rstd, const float* gamma, const float* beta, int act, int training, float* dgamma,
-                        float* dbeta, void* ws, hipStream_t st, const float* xscale = nullptr) {
+                        float* dbeta, void* ws, hipStream_t st, const float* xscale = nullptr, bool enc = false) {
     constexpr int N = Vec16<T>::N;
     int cv = C / N;
     if (cv > 256) return MU_ERR_SHAPE;
@@ -513,10 +522,16 @@ static int bn_act_bwd_t(const T* x, const T* res, const T* g, T* dx, T* dres, lo
     if (res) {                      // d(residual) == dz exactly, so it doubles as the dz buffer
         bn_partial_kernel<T, 1><<<nblk, 256, lds, st>>>(x, g, res, dres, M, C, ld, mean, rstd, gamma, beta, act, part);
         bn_bwd_final_kernel<<<mu_cdiv(C, 4), 256, 0, st>>>(part, nblk, C, M, training, dgamma, dbeta, s1, s2, xscale);
+        if constexpr (sizeof(T) == 4) {
+            if (enc) { bn_bwd_apply_kernel<T, false, true><<<ew_grid(M * cv, cv), 256, 0, st>>>(x, dres, dx, M, C, ld, mean, rstd, gamma, beta, act, s1, s2); return MU_OK; }
+        }
         bn_bwd_apply_kernel<T, false><<<ew_grid(M * cv, cv), 256, 0, st>>>(x, dres, dx, M, C, ld, mean, rstd, gamma, beta, act, s1, s2);
     } else {                        // no residual: nothing is written by the statistics sweep, dz is recomputed in the apply pass
         bn_partial_kernel<T, 1><<<nblk, 256, lds, st>>>(x, g, nullptr, nullptr, M, C, ld, mean, rstd, gamma, beta, act, part);
         bn_bwd_final_kernel<<<mu_cdiv(C, 4), 256, 0, st>>>(part, nblk, C, M, training, dgamma, dbeta, s1, s2, xscale);
+        if constexpr (sizeof(T) == 4) {
+            if (enc) { bn_bwd_apply_kernel<T, true, true><<<ew_grid(M * cv, cv), 256, 0, st>>>(x, g, dx, M, C, ld, mean, rstd, gamma, beta, act, s1, s2); return MU_OK; }
+        }
         bn_bwd_apply_kernel<T, true><<<ew_grid(M * cv, cv), 256, 0, st>>>(x, g, dx, M, C, ld, mean, rstd, gamma, beta, act, s1, s2);
     }
     return MU_OK;
@@ -594,6 +609,8 @@ extern "C" int mu_bn_act_bwd_scaled(const void* x, const void* res, const void* 
     int rc;
     if (dtype == MU_F32)
         rc = bn_act_bwd_t<float>((const float*)x, (const float*)res, (const float*)grad_out, (float*)dx, (float*)dres, M, C, ld, mean, rstd, gamma, beta, act, training, dgamma, dbeta, workspace, st, xhat_scale);
+    else if (dtype == MU_F32X)      // fp32 storage; dx -- the dy of the convolution in front of this BatchNorm -- written chunk-encoded (dres stays plain)
+        rc = bn_act_bwd_t<float>((const float*)x, (const float*)res, (const float*)grad_out, (float*)dx, (float*)dres, M, C, ld, mean, rstd, gamma, beta, act, training, dgamma, dbeta, workspace, st, xhat_scale, true);
     else if (dtype == MU_F16)
         rc = bn_act_bwd_t<h16>((const h16*)x, (const h16*)res, (const h16*)grad_out, (h16*)dx, (h16*)dres, M, C, ld, mean, rstd, gamma, beta, act, training, dgamma, dbeta, workspace, st, xhat_scale);
     else return MU_ERR_ARG;

@@ -158,11 +158,17 @@ class ConvBlock(_HipModule):
             nn.BatchNorm2d(out_channels),
         )
 
-    def forward_nhwc(self, x, tail_bn=None, res_link=None):
+    def forward_nhwc(self, x, tail_bn=None, res_link=None, x_encoded=False, enc_out=False):
         """tail_bn: the nn.BatchNorm2d DownSample / UpSample apply right behind this block (:219,240); in training mode it is
         folded into the block's last BatchNorm (ops.bn_pair).  res_link: ops.GradLink shared with the op that produced x (residual
-        blocks only): the gradient of the `x +` branch (:208) is joined inside that op's backward kernel."""
+        blocks only): the gradient of the `x +` branch (:208) is joined inside that op's backward kernel.
+        fp32x mode only (ignored otherwise): x_encoded = x arrives as a chunk-encoded matrix operand (non-residual blocks: x feeds
+        nothing but the first conv); enc_out = the caller promises that the output feeds nothing but a conv, so the last
+        BatchNorm-apply pass writes it chunk-encoded.  Inside the block the BatchNorm outputs / gradients that only feed a conv are
+        written encoded by the BatchNorm kernels themselves (ops.EncLink)."""
         cb = self.conv_block
+        if x_encoded and self.residual:
+            raise RuntimeError("ConvBlock: a residual block adds its input and needs it plain")
         if ops.eval_fusable(cb[1], cb[4], tail_bn):
             # inference: every BatchNorm (+ residual add, + GELU) lives in the epilogue of the conv in front of it
             y = ops.conv_bn_act_eval(x, cb[0].weight, None, cb[1], ACT_GELU)
@@ -170,15 +176,21 @@ class ConvBlock(_HipModule):
                 y = ops.conv_bn_act_eval(y, cb[3].weight, None, cb[4], ACT_GELU, res=x)
                 return y if tail_bn is None else ops.bn_act(y, tail_bn, ACT_NONE)
             return ops.conv_bn_act_eval(y, cb[3].weight, None, cb[4], ACT_NONE, bn2=tail_bn)
-        y, st = ops.conv_stats(x, cb[0].weight, want=cb[1].training)   # BatchNorm statistics from the conv epilogue where it has one
-        y = ops.bn_act(y, cb[1], ACT_GELU, stats=st)
-        y, st = ops.conv_stats(y, cb[3].weight, want=cb[4].training)
+        # fp32x: the dy of a conv is the dx of the BatchNorm behind it (one link per pair); not for the 3-channel stem, whose weight
+        # gradient is a plain-FMA kernel.  mid: bn1's output feeds conv2 only.
+        l0 = ops.enc_link(x) if cb[0].weight.shape[1] > 3 else None
+        l1 = ops.enc_link(x)
+        fx = l1 is not None                                              # fp32x mode with a backward to come
+        y, st = ops.conv_stats(x, cb[0].weight, want=cb[1].training, x_encoded=x_encoded and ops._is_x(x), dy_link=l0)   # BatchNorm statistics from the conv epilogue where it has one
+        y = ops.bn_act(y, cb[1], ACT_GELU, stats=st, enc_out=fx, dx_link=l0)
+        y, st = ops.conv_stats(y, cb[3].weight, want=cb[4].training, x_encoded=fx, dy_link=l1)
         if self.residual:
-            y = ops.bn_act(y, cb[4], ACT_GELU, res=x, stats=st, res_link=res_link)         # gelu(x + BN(conv(...)))  (:208)
+            y = ops.bn_act(y, cb[4], ACT_GELU, res=x, stats=st, res_link=res_link, dx_link=l1,
+                           enc_out=enc_out and tail_bn is None and fx)            # gelu(x + BN(conv(...)))  (:208)
             return y if tail_bn is None else ops.bn_act(y, tail_bn, ACT_NONE)
         if tail_bn is not None:
-            return ops.bn_pair(y, cb[4], tail_bn, stats=st)
-        return ops.bn_act(y, cb[4], ACT_NONE, stats=st)
+            return ops.bn_pair(y, cb[4], tail_bn, stats=st, dx_link=l1)
+        return ops.bn_act(y, cb[4], ACT_NONE, stats=st, dx_link=l1, enc_out=enc_out and fx)
 
     def forward(self, x):
         self._check_device(x)
@@ -205,8 +217,9 @@ class DownSample(_HipModule):
         mc = self.maxpool_conv
         link = ops.grad_link(x)                           # residual branch of mc[1] -> the pool's backward
         x = ops.maxpool2(x, link, skip_link)
-        x = mc[1].forward_nhwc(x, res_link=link)
-        return mc[2].forward_nhwc(x, tail_bn=mc[3])       # ConvBlock + the BatchNorm behind it (:218-219)
+        fx = ops.enc_link(x) is not None                  # fp32x mode with a backward to come: mc[1]'s output goes to mc[2]'s first conv only
+        x = mc[1].forward_nhwc(x, res_link=link, enc_out=fx)
+        return mc[2].forward_nhwc(x, tail_bn=mc[3], x_encoded=fx)       # ConvBlock + the BatchNorm behind it (:218-219)
 
     def forward(self, x):
         self._check_device(x)
@@ -232,8 +245,9 @@ class UpSample(_HipModule):
         skip_link: ops.GradLink shared with the DownSample that also consumes skip_x (UNet wiring)."""
         link = ops.grad_link(x, skip_x)          # residual branch of conv[0] -> the concat's backward
         x = ops.upcat(x, skip_x, cx, cs, link, skip_link)         # cat([skip_x, up(x)], dim=1)  (:250-253)
-        x = self.conv[0].forward_nhwc(x, res_link=link)
-        return self.conv[1].forward_nhwc(x, tail_bn=self.conv[2])      # ConvBlock + the BatchNorm behind it (:239-240)
+        fx = ops.enc_link(x) is not None                  # (as in DownSample)
+        x = self.conv[0].forward_nhwc(x, res_link=link, enc_out=fx)
+        return self.conv[1].forward_nhwc(x, tail_bn=self.conv[2], x_encoded=fx)      # ConvBlock + the BatchNorm behind it (:239-240)
 
     def forward(self, x, skip_x):
         self._check_device(x)
@@ -342,9 +356,10 @@ class UNet(_HipModule):
         x4 = self.downsample3.forward_nhwc(x3, skip_link=l3)
         x4 = self.self_attention3.forward_nhwc(x4)
 
-        x4 = self.bottom1.forward_nhwc(x4)
-        x4 = self.bottom2.forward_nhwc(x4)
-        x4 = self.bottom3.forward_nhwc(x4)
+        fx = ops.enc_link(x4) is not None                # fp32x mode with a backward to come: the bottleneck blocks hand their outputs on chunk-encoded
+        x4 = self.bottom1.forward_nhwc(x4, enc_out=fx)
+        x4 = self.bottom2.forward_nhwc(x4, x_encoded=fx, enc_out=fx)
+        x4 = self.bottom3.forward_nhwc(x4, x_encoded=fx)
 
         y = self.upsample1.forward_nhwc(x4, x3, skip_link=l3)
         y = self._drop(y, 0)

@@ -89,6 +89,29 @@ class GradLink:
 _graph_task_id = getattr(torch._C, "_current_graph_task_id", lambda: -1)     # id of the running backward pass (-1 outside one)
 
 
+class EncLink:
+    """fp32x: tells a conv's backward that the dy it is handed was WRITTEN chunk-encoded by the backward of the BatchNorm behind that conv
+    (mu_bn_act_bwd with MU_F32X) -- the BatchNorm's dx is the conv's dy and has no other consumer (ConvBlock wiring), so the separate
+    encoding pass disappears.  One link per (conv, BatchNorm) pair and forward call; valid only within the backward pass that marked it."""
+    __slots__ = ("task",)
+
+    def __init__(self):
+        self.task = None
+
+    def mark(self):
+        self.task = _graph_task_id()
+
+    def take(self):
+        t, self.task = self.task, None
+        return t is not None and t == _graph_task_id()
+
+
+def enc_link(x):
+    """A fresh EncLink when x is an fp32 tensor in the fp32x mode and a backward can follow, else None."""
+    return EncLink() if (FUSED_ENCODE and torch.is_grad_enabled() and _is_x(x)) else None
+
+
+FUSED_ENCODE = os.environ.get("MU_FUSED_ENCODE", "1") != "0"     # debug switch: 0 = every operand through mu_split_encode
 GRAD_LINKS = os.environ.get("MU_GRAD_LINKS", "1") != "0"      # debug switch: 0 = leave every gradient join to autograd
 
 
@@ -452,8 +475,9 @@ class _Conv(torch.autograd.Function):
     """nn.Conv2d k=3/pad=1 or k=1, NHWC (ade_semantic.py:199,202,284; city_instance.py:243-249)."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, want_stats=False, cache_ok=False):
+    def forward(ctx, x, weight, bias, want_stats=False, cache_ok=False, x_encoded=False, dy_link=None):
         x = x.contiguous()
+        ctx.dy_link = dy_link
         O, I = weight.shape[0], weight.shape[1]
         taps = weight.shape[2] * weight.shape[3]
         Cin_p, Cout_p = x.shape[-1], pad32(O)
@@ -473,7 +497,9 @@ class _Conv(torch.autograd.Function):
         # fp32x: the chunk-encoded input is what both the forward conv and the weight gradient read -- encode once, save THAT (the first
         # layer's weight gradient is a plain-FMA kernel and keeps the plain tensor)
         ctx.x_enc = _is_x(x) and not (taps == 9 and I <= 3)
-        if ctx.x_enc:
+        if x_encoded and not ctx.x_enc:
+            raise RuntimeError("conv: a pre-encoded input needs the fp32x mode and a matrix-core layer")
+        if ctx.x_enc and not x_encoded:
             x = _enc(x)
         if want_stats:
             y, part = _conv_raw(x, wprep, bias_p, Cout_p, taps, True, x_encoded=ctx.x_enc)
@@ -494,15 +520,21 @@ class _Conv(torch.autograd.Function):
     @once_differentiable
     def backward(ctx, gy, gpart=None):
         if gy is None:
-            return None, None, None, None, None
+            return None, None, None, None, None, None, None
         x, weight = ctx.saved_tensors
         gy = gy.contiguous()
+        gy_pre = ctx.dy_link is not None and ctx.dy_link.take()      # fp32x: dy arrived chunk-encoded from the BatchNorm's backward
         O, I = weight.shape[0], weight.shape[1]
         gx = gw = gb = None
         side = ctx.needs_input_grad[1] and WGRAD_SIDE_STREAM and ctx.wparam.grad is None
         if side and os.environ.get("MU_WGRAD_SIDE_FIRST"):
             gw = _wgrad_side(x, gy, tuple(weight.shape), ctx.taps, ctx.x_enc)
-        ge = _enc(gy) if (ctx.needs_input_grad[0] or (ctx.needs_input_grad[1] and not side)) else gy     # fp32x: one encoding of dy for both
+        if gy_pre:
+            ge = gy
+            if side or not ctx.x_enc or (ctx.has_bias and ctx.needs_input_grad[2]):
+                raise RuntimeError("conv backward: an encoded dy reached a path that needs it plain")
+        else:
+            ge = _enc(gy) if (ctx.needs_input_grad[0] or (ctx.needs_input_grad[1] and not side)) else gy     # fp32x: one encoding of dy for both
         if ctx.needs_input_grad[0]:
             wd = ctx.wd if ctx.wd is not None else _prep_weight(weight, gy.dtype, x.shape[-1], gy.shape[-1], 1)
             ctx.wd = None
@@ -518,22 +550,23 @@ class _Conv(torch.autograd.Function):
                 gw = _wgrad_raw(x, gy if first else ge, tuple(weight.shape), ctx.taps, gy_encoded=_is_x(gy) and not first, x_encoded=ctx.x_enc)
         if ctx.has_bias and ctx.needs_input_grad[2] and gb is None:
             gb = _colsum(gy, O)
-        return gx, gw, gb, None, None
+        return gx, gw, gb, None, None, None, None
 
 
 def conv(x, weight, bias=None):
-    return _Conv.apply(x, weight, bias, False, _cache_ok())
+    return _Conv.apply(x, weight, bias, False, _cache_ok(), False, None)
 
 
 CONV_STATS = os.environ.get("MU_CONV_STATS", "1") != "0"      # debug switch: 0 = always the separate statistics sweep
 
 
-def conv_stats(x, weight, bias=None, want=True):
+def conv_stats(x, weight, bias=None, want=True, x_encoded=False, dy_link=None):
     """conv() that also returns the BatchNorm statistics rows of its output (an empty tensor when the kernel has none) --
-    pass them to bn_act(..., stats=rows) to skip the separate statistics sweep."""
+    pass them to bn_act(..., stats=rows) to skip the separate statistics sweep.  fp32x: x_encoded = x was written chunk-encoded by its
+    producer (bn_act(..., enc_out=True)); dy_link = EncLink shared with the BatchNorm behind this conv (see EncLink)."""
     if not want or not CONV_STATS:
-        return _Conv.apply(x, weight, bias, False, _cache_ok()), None
-    return _Conv.apply(x, weight, bias, True, _cache_ok())
+        return _Conv.apply(x, weight, bias, False, _cache_ok(), x_encoded, dy_link), None
+    return _Conv.apply(x, weight, bias, True, _cache_ok(), x_encoded, dy_link)
 
 
 # ------------------------------------------------------------------------------------------------
@@ -544,9 +577,12 @@ class _BNAct(torch.autograd.Function):
     :285-286 (BN, ReLU).  Training uses batch statistics and updates the running buffers in place."""
 
     @staticmethod
-    def forward(ctx, x, res, gamma, beta, running_mean, running_var, training, momentum, eps, act, nbt=None, stats=None, res_link=None):
+    def forward(ctx, x, res, gamma, beta, running_mean, running_var, training, momentum, eps, act, nbt=None, stats=None, res_link=None,
+                enc_out=False, dx_link=None):
         x = x.contiguous()
         ctx.res_link = res_link if (res is not None and res_link is not None and res_link.armed) else None
+        ctx.dx_link = dx_link if (dx_link is not None and _is_x(x)) else None
+        enc_out = bool(enc_out) and _is_x(x)
         C = x.shape[-1]
         M = x.numel() // C
         cv = gamma.numel()
@@ -568,7 +604,8 @@ class _BNAct(torch.autograd.Function):
         y = torch.empty_like(x)
         if res is not None:
             res = res.contiguous()
-        call("mu_bn_act_fwd", ptr(x), ptr(res), ptr(y), M, C, C, ptr(mean), ptr(rstd), ptr(g_p), ptr(b_p), act, dt(x), stream())
+        call("mu_bn_act_fwd", ptr(x), ptr(res), ptr(y), M, C, C, ptr(mean), ptr(rstd), ptr(g_p), ptr(b_p), act,
+             _lib.MU_F32X if enc_out else dt(x), stream())      # MU_F32X: y written as the next conv's chunk-encoded operand
         ctx.save_for_backward(x, res, mean, rstd, g_p, b_p)
         ctx.act, ctx.training, ctx.cv = act, bool(training), cv
         return y
@@ -585,12 +622,15 @@ class _BNAct(torch.autograd.Function):
         dgamma = torch.empty(C, dtype=torch.float32, device=x.device)
         dbeta = torch.empty_like(dgamma)
         ws = workspace(_lib.load().mu_bn_workspace_bytes(C), x.device)
+        enc = ctx.dx_link is not None            # fp32x: dx is the dy of the conv in front -- written chunk-encoded, the conv is told (EncLink)
         call("mu_bn_act_bwd", ptr(x), ptr(res), ptr(gy), ptr(dx), ptr(dres), M, C, C, ptr(mean), ptr(rstd), ptr(g_p), ptr(b_p),
-             ctx.act, int(ctx.training), ptr(dgamma), ptr(dbeta), ptr(ws), ws.numel(), dt(x), stream())
+             ctx.act, int(ctx.training), ptr(dgamma), ptr(dbeta), ptr(ws), ws.numel(), _lib.MU_F32X if enc else dt(x), stream())
+        if enc:
+            ctx.dx_link.mark()
         if ctx.res_link is not None:             # the residual-branch gradient travels to the backward of x's producer (GradLink)
             ctx.res_link.put(dres)
             dres = None
-        return dx, dres, dgamma[:ctx.cv], dbeta[:ctx.cv], None, None, None, None, None, None, None, None, None
+        return dx, dres, dgamma[:ctx.cv], dbeta[:ctx.cv], None, None, None, None, None, None, None, None, None, None, None
 
 
 class _BNPair(torch.autograd.Function):
@@ -598,8 +638,9 @@ class _BNPair(torch.autograd.Function):
     ConvBlock's last BatchNorm in DownSample / UpSample); see mu_bn_pair_compose in include/maskunet_hip.h for the algebra."""
 
     @staticmethod
-    def forward(ctx, x, g1, b1, g2, b2, rm1, rv1, nbt1, mom1, eps1, rm2, rv2, nbt2, mom2, eps2, stats):
+    def forward(ctx, x, g1, b1, g2, b2, rm1, rv1, nbt1, mom1, eps1, rm2, rv2, nbt2, mom2, eps2, stats, dx_link=None):
         x = x.contiguous()
+        ctx.dx_link = dx_link if (dx_link is not None and _is_x(x)) else None
         C = x.shape[-1]
         M = x.numel() // C
         cv = g1.numel()
@@ -634,29 +675,32 @@ class _BNPair(torch.autograd.Function):
         a = torch.empty(C, dtype=torch.float32, device=x.device)
         dbeta2 = torch.empty_like(a)
         ws = workspace(_lib.load().mu_bn_workspace_bytes(C), x.device)
+        enc = ctx.dx_link is not None
         call("mu_bn_act_bwd_scaled", ptr(x), None, ptr(gy), ptr(dx), None, M, C, C, ptr(mean), ptr(rstd), ptr(coef[0]), ptr(b2p), ACT_NONE, 1,
-             ptr(a), ptr(dbeta2), ptr(coef[1]), ptr(ws), ws.numel(), dt(x), stream())
+             ptr(a), ptr(dbeta2), ptr(coef[1]), ptr(ws), ws.numel(), _lib.MU_F32X if enc else dt(x), stream())
+        if enc:
+            ctx.dx_link.mark()
         dg = coef[2:4] * a                                   # rows: dgamma2, dgamma1
         cv = ctx.cv
-        return (dx, dg[1, :cv], torch.zeros(cv, dtype=torch.float32, device=x.device), dg[0, :cv], dbeta2[:cv]) + (None,) * 11
+        return (dx, dg[1, :cv], torch.zeros(cv, dtype=torch.float32, device=x.device), dg[0, :cv], dbeta2[:cv]) + (None,) * 12
 
 
 BN_PAIR = os.environ.get("MU_BN_PAIR", "1") != "0"          # debug switch: 0 = the two layers one after the other
 
 
-def bn_pair(x, bn1, bn2, stats=None):
+def bn_pair(x, bn1, bn2, stats=None, dx_link=None):
     """bn2(bn1(x)) for two nn.BatchNorm2d containers applied back to back (no activation, no residual in between)."""
     both_train = (bn1.training and bn2.training and bn1.running_mean is not None and bn2.running_mean is not None
                   and bn1.weight is not None and bn2.weight is not None)
     ok = both_train and BN_PAIR and all(t is not None and t.device == x.device and t.dtype == torch.int64
                                         for t in (bn1.num_batches_tracked, bn2.num_batches_tracked))
     if not ok or bn1.momentum is None or bn2.momentum is None:
-        return bn_act(bn_act(x, bn1, ACT_NONE, stats=stats), bn2, ACT_NONE)
+        return bn_act(bn_act(x, bn1, ACT_NONE, stats=stats, dx_link=dx_link), bn2, ACT_NONE)
     return _BNPair.apply(x, bn1.weight, bn1.bias, bn2.weight, bn2.bias, bn1.running_mean, bn1.running_var, bn1.num_batches_tracked,
-                         bn1.momentum, bn1.eps, bn2.running_mean, bn2.running_var, bn2.num_batches_tracked, bn2.momentum, bn2.eps, stats)
+                         bn1.momentum, bn1.eps, bn2.running_mean, bn2.running_var, bn2.num_batches_tracked, bn2.momentum, bn2.eps, stats, dx_link)
 
 
-def bn_act(x, bn, act=ACT_NONE, res=None, stats=None, res_link=None):
+def bn_act(x, bn, act=ACT_NONE, res=None, stats=None, res_link=None, enc_out=False, dx_link=None):
     """Apply the BatchNorm2d parameter container `bn` (an nn.BatchNorm2d used only for its
     parameters/buffers/flags) followed by `act`, optionally adding `res` before the activation.
     `stats`: statistics rows of x from conv_stats() (training mode only; ignored otherwise).
@@ -669,7 +713,7 @@ def bn_act(x, bn, act=ACT_NONE, res=None, stats=None, res_link=None):
         nbt = None
     momentum = 0.1 if bn.momentum is None else bn.momentum
     return _BNAct.apply(x, res, bn.weight, bn.bias, bn.running_mean, bn.running_var, training, momentum, bn.eps, act, nbt,
-                        stats if training else None, res_link)
+                        stats if training else None, res_link, enc_out, dx_link)
 
 
 # ------------------------------------------------------------------------------------------------
