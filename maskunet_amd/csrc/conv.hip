@@ -1636,6 +1636,9 @@ template <> struct WgTile<h16> { static constexpr int PAD = 0; static constexpr 
 // fp32: row pad (elements) puts the g=0/1 pixel rows of a ds_read_b32 on different banks
 template <> struct WgTile<float> { static constexpr int PAD = 16; static constexpr int KP = 16; };
 template <> struct WgTile<xf32> { static constexpr int PAD = 16; static constexpr int KP = 32; };     // K = 32 per stage: v_mfma_f32_16x16x32_bf16 triples
+#ifndef MU_WG_XSWAP
+#define MU_WG_XSWAP 1
+#endif
 
 typedef __fp16 fp16x4v __attribute__((__vector_size__(4 * sizeof(__fp16))));
 
@@ -1695,16 +1698,31 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const T* __restrict__ x
             else rb[i] = make_uint4(0, 0, 0, 0);
         }
     };
+    // fp32x (MU_WG_XSWAP): the transposed reads below fetch ONLY the hi (or only the lo) halves of the 16-byte chunks, i.e. banks
+    // = 0,1 (mod 4) -- a 32-lane group (pixel rows 8g + q, g in {0,1}) can then reach 32 of the 64 banks: 2-way conflicts whatever the
+    // row padding.  Rows with bit 3 set are therefore stored with their halves swapped ([lo | hi]): the two row quartets of a lane group
+    // use complementary banks.  Two 8-byte stores per chunk (as fast as one 16-byte store, MI355X_MICROARCH LDS table).
+    constexpr bool XSWAP = std::is_same<T, xf32>::value && MU_WG_XSWAP;
+    auto put = [&](T* dst, int row, const uint4& v) {
+        if constexpr (XSWAP) {
+            const int sw = ((row >> 3) & 1) * 8;
+            char* d = reinterpret_cast<char*>(dst);
+            *reinterpret_cast<uint2*>(d + sw) = make_uint2(v.x, v.y);
+            *reinterpret_cast<uint2*>(d + 8 - sw) = make_uint2(v.z, v.w);
+        } else {
+            *reinterpret_cast<uint4*>(dst) = v;
+        }
+    };
     auto lstore = [&](int buf) {
 #pragma unroll
         for (int i = 0; i < NA; ++i) {
             const int idx = tid + i * 256, row = idx / CA, c = (idx % CA) * VN;
-            if (idx < KP * CA) *reinterpret_cast<uint4*>(As + (buf * KP + row) * SA + c) = ra[i];
+            if (idx < KP * CA) put(As + (buf * KP + row) * SA + c, row, ra[i]);
         }
 #pragma unroll
         for (int i = 0; i < NB; ++i) {
             const int idx = tid + i * 256, row = idx / CB, c = (idx % CB) * VN;
-            if (idx < KP * CB) *reinterpret_cast<uint4*>(Bs + (buf * KP + row) * SB + c) = rb[i];
+            if (idx < KP * CB) put(Bs + (buf * KP + row) * SB + c, row, rb[i]);
         }
     };
 
@@ -1768,10 +1786,11 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const T* __restrict__ x
             auto frag = [&](const T* tile, int stride, int col) {
                 const char* r0 = reinterpret_cast<const char*>(tile + (8 * g + q) * stride + col + 4 * pc);
                 const char* r1 = reinterpret_cast<const char*>(tile + (8 * g + 4 + q) * stride + col + 4 * pc);
-                const uint2 h0 = __builtin_bit_cast(uint2, __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) fp16x4v*)(r0)));
-                const uint2 h1 = __builtin_bit_cast(uint2, __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) fp16x4v*)(r1)));
-                const uint2 l0 = __builtin_bit_cast(uint2, __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) fp16x4v*)(r0 + 8)));
-                const uint2 l1 = __builtin_bit_cast(uint2, __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) fp16x4v*)(r1 + 8)));
+                const int sw = XSWAP ? (g & 1) * 8 : 0;      // rows 8g + q and 8g + 4 + q: bit 3 = g & 1 (see `put`)
+                const uint2 h0 = __builtin_bit_cast(uint2, __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) fp16x4v*)(r0 + sw)));
+                const uint2 h1 = __builtin_bit_cast(uint2, __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) fp16x4v*)(r1 + sw)));
+                const uint2 l0 = __builtin_bit_cast(uint2, __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) fp16x4v*)(r0 + 8 - sw)));
+                const uint2 l1 = __builtin_bit_cast(uint2, __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) fp16x4v*)(r1 + 8 - sw)));
                 SplitF8 f;
                 f.hi = __builtin_bit_cast(bf16x8, make_uint4(h0.x, h0.y, h1.x, h1.y));
                 f.lo = __builtin_bit_cast(bf16x8, make_uint4(l0.x, l0.y, l1.x, l1.y));
@@ -1873,6 +1892,17 @@ __global__ __launch_bounds__(256) void wgrad_bias_reduce_kernel(const float* __r
 template <int BCH> __device__ __forceinline__ int wg_hash(int row) {
     return (BCH >= 128) ? ((row & 3) | (((row >> 3) & 1) << 2)) : (((row >> 1) & 1) | (((row >> 3) & 1) << 1));
 }
+// fp32x tiles (chunk-encoded, 4-byte elements): the swizzle granule is still 16 channels (64 bytes = the four 16-byte chunks one 16-lane
+// group of a transposed read touches in a row); rows are 256 or 512 bytes = whole bank lines, so the four consecutive rows of a lane group
+// (a .. a+3) must land on four different granules modulo 4: row bits 0-1.  Rows a and a+8 then share banks -- the reads fetch only the
+// hi (or only the lo) half of every chunk, i.e. half of the banks, so a 32-lane group is 2-way whatever the layout (SQ_LDS_BANK_CONFLICT
+// 33 % of the LDS cycles of every fp32x kernel with transposed reads); the stage's reads are hidden behind the partner wave's MFMAs instead.
+template <typename T, int BCH> __device__ __forceinline__ int wg_hash_t(int row) {
+    if constexpr (sizeof(T) == 2) return wg_hash<BCH>(row);
+    else return row & 3;
+}
+template <typename T> struct WgFrag { typedef h16x8 type; };
+template <> struct WgFrag<xf32> { typedef SplitF8 type; };
 
 template <int N> __device__ __forceinline__ void wait_vmcnt_c() {
     static_assert(N >= 0 && N < 64, "vmcnt is a 6-bit counter");
@@ -1908,6 +1938,9 @@ template <int N> __device__ __forceinline__ void wait_vmcnt_c() {
 #ifndef MU_WG_SPLIT_DMA
 #define MU_WG_SPLIT_DMA 1
 #endif
+#ifndef MU_WGX_STAGGER
+#define MU_WGX_STAGGER 1
+#endif
 // SPS = 32-pixel k-steps per DMA stage.  SPS = 2 (W % 64 == 0): one barrier / DMA batch / ring step per 64 pixels -- the two
 // waves of a SIMD run in lockstep behind the per-stage barrier, so the ~500 cycles of scalar + address work per ring step sit
 // in front of both waves' MFMA bursts (PMC: SQ_ACTIVE_INST_SCA 18 % of wave cycles, MFMA pipe 44 % busy at SPS = 1).
@@ -1915,15 +1948,24 @@ template <int N> __device__ __forceinline__ void wait_vmcnt_c() {
 // PP = ping-pong schedule (8 waves, SPS = 2): the two wave groups (wr = 0 / 1, one wave of each per SIMD) run one section apart,
 // a section being either a k-step's 24 MFMAs or its DMA issue + 20 transposed reads, so one group's matrix burst covers the
 // other group's scalar / address / LDS work instead of both doing each in lockstep.
-template <int TM, int TN, int WR, int NWV = 4, bool W16 = false, int SPS = 1, bool PP = false>
-__global__ __launch_bounds__(NWV * 64, 1) void conv_wgrad3_kernel(const h16* __restrict__ x, const h16* __restrict__ dy, float* __restrict__ part,
+// T = xf32 (fp32x, chunk-encoded operands; SPS = 1 only): the same ring and window logic on 4-byte elements, four stages of 33.8 KB (128 x 128
+// tiles) or 17.4 KB (64 x 64), fragments = transposed reads of the hi and of the lo halves, three v_mfma_f32_16x16x32_bf16 per tile pair.  The
+// fragments of a stage take 80 registers next to the 96 accumulators, so they are NOT double-buffered; instead the two wave groups of an
+// 8-wave block run half a stage apart (group 0: reads then MFMAs of stage s; group 1: MFMAs of stage s-1, then the reads of stage s), one
+// barrier per stage for both.
+template <typename T, int TM, int TN, int WR, int NWV = 4, bool W16 = false, int SPS = 1, bool PP = false>
+__global__ __launch_bounds__(NWV * 64, 1) void conv_wgrad3_kernel(const T* __restrict__ x, const T* __restrict__ dy, float* __restrict__ part,
                                                              int B, int H, int W, int Cin, int Cout, long x_ld, long dy_ld, int nsplit,
                                                              long pix_per_split) {
     constexpr int WC = NWV / WR;
     constexpr int BCO = WR * TM * 16, BCI = WC * TN * 16;
     // the dy tile (BCO wide) and the x window (BCI wide) may differ in width (128 x 64 tiles for the 64-channel layers): each has
     // its own row size, DMA lane mapping and swizzle hash
-    constexpr int CPRA = BCO / 8, RPWA = 1024 / (BCO * 2), CPRB = BCI / 8, RPWB = 1024 / (BCI * 2);
+    constexpr bool XF = std::is_same<T, xf32>::value;
+    static_assert(!XF || (SPS == 1 && !PP), "fp32x: one 32-pixel k-step per stage");
+    constexpr int VN = 16 / (int)sizeof(T);                 // elements per 16-byte chunk
+    constexpr int GS = XF ? 2 : 1;                          // log2(chunks per 16-channel swizzle granule)
+    constexpr int CPRA = BCO / VN, RPWA = 64 / CPRA, CPRB = BCI / VN, RPWB = 64 / CPRB;
     constexpr int KP = 32, SP = SPS * KP;                   // pixels per k-step (one MFMA K) and per DMA stage
     constexpr int RW = SP / 2;                              // two-row mode: image width
     constexpr int XR = ((W16 ? SP + 4 : SP + 2) + RPWB - 1) / RPWB * RPWB;   // x-window rows allocated (SP + 2, or 2 x (RW + 2))
@@ -1931,8 +1973,8 @@ __global__ __launch_bounds__(NWV * 64, 1) void conv_wgrad3_kernel(const h16* __r
     constexpr int STAGE = SP * BCO + XR * BCI;             // elements per stage
 
     static_assert(!PP || (SPS == 2 && NWV == 8 && WR == 2), "ping-pong needs two 4-wave groups and two k-steps per stage");
-    constexpr int NS = SPS == 1 ? MU_WG_NS : 4;
-    __shared__ __attribute__((aligned(16))) h16 lds[NS * STAGE];
+    constexpr int NS = XF ? 4 : (SPS == 1 ? MU_WG_NS : 4);
+    __shared__ __attribute__((aligned(16))) T lds[NS * STAGE];
 
     const long Mtot = (long)B * H * W;
     const int nco = Cout / BCO, nci = Cin / BCI;
@@ -1966,8 +2008,8 @@ __global__ __launch_bounds__(NWV * 64, 1) void conv_wgrad3_kernel(const h16* __r
 #pragma unroll
     for (int k = 0; k < NAW; ++k) {
         const int row = (wave + k * NWV) * RPWA + lrowA;
-        const int sc = (((c16A >> 1) ^ wg_hash<BCO>(row)) << 1) | (c16A & 1);
-        aoff[k] = row * (int)dy_ld + co0 + sc * 8;
+        const int sc = (((c16A >> GS) ^ wg_hash_t<T, BCO>(row)) << GS) | (c16A & ((1 << GS) - 1));
+        aoff[k] = row * (int)dy_ld + co0 + sc * VN;
     }
     // W == 16: a 32-pixel stage is two whole image rows; the window is two 18-row halves (columns -1 .. 16 of each image
     // row, the outer two always zero) instead of one 34-row run of the flat pixel index
@@ -1975,25 +2017,25 @@ __global__ __launch_bounds__(NWV * 64, 1) void conv_wgrad3_kernel(const h16* __r
 #pragma unroll
     for (int k = 0; k < NBW; ++k) {
         const int row = (wave + k * NWV) * RPWB + lrowB;    // window row: flat pixel pbase + dh*W - 1 + row
-        const int sc = (((c16B >> 1) ^ wg_hash<BCI>(row)) << 1) | (c16B & 1);
+        const int sc = (((c16B >> GS) ^ wg_hash_t<T, BCI>(row)) << GS) | (c16B & ((1 << GS) - 1));
         if (w16) {
             const int half = row >= RW + 2, kk = row - half * (RW + 2);
-            boff[k] = (half * RW + kk - 1) * (int)x_ld + ci0 + sc * 8;
+            boff[k] = (half * RW + kk - 1) * (int)x_ld + ci0 + sc * VN;
             bkind[k] = (kk == 0 || kk == RW + 1 || row >= 2 * (RW + 2)) ? 3 : (half ? 5 : 4);     // 4 / 5: plain row of the first / second image row
         } else {
-            boff[k] = (row - 1) * (int)x_ld + ci0 + sc * 8;
+            boff[k] = (row - 1) * (int)x_ld + ci0 + sc * VN;
             bkind[k] = row == 0 ? 1 : (row == SP + 1 ? 2 : (row > SP + 1 ? 3 : 0));
         }
     }
     long pis = p_begin;                                     // next stage to issue
     int wi = (int)(p_begin % W), hi = (int)((p_begin / W) % H);
-    const h16* dyp = dy + p_begin * dy_ld;
-    const h16* xp = x + (p_begin + (long)dh * W) * x_ld;
+    const T* dyp = dy + p_begin * dy_ld;
+    const T* xp = x + (p_begin + (long)dh * W) * x_ld;
 
     // (stage = stage_a + stage_b: the two-k-step kernels issue the dy pieces in front of the first k-step's MFMAs and the x pieces
     //  in front of the second's instead of all of them in one burst)
     auto stage_a = [&](int buf) {                // past p_end: an all-zero stage (keeps the per-wave DMA count uniform)
-        h16* At = lds + buf * STAGE;
+        T* At = lds + buf * STAGE;
         const bool live = pis < p_end;
 #pragma unroll
         for (int k = 0; k < NAW; ++k) {
@@ -2005,8 +2047,8 @@ __global__ __launch_bounds__(NWV * 64, 1) void conv_wgrad3_kernel(const h16* __r
         }
     };
     auto stage_b = [&](int buf) {
-        h16* At = lds + buf * STAGE;
-        h16* Bt = At + SP * BCO;
+        T* At = lds + buf * STAGE;
+        T* Bt = At + SP * BCO;
         const bool live = pis < p_end;
         const int hh = hi + dh;
         const bool rowok = live && hh >= 0 && hh < H, rowok1 = live && hh + 1 >= 0 && hh + 1 < H;
@@ -2047,31 +2089,48 @@ __global__ __launch_bounds__(NWV * 64, 1) void conv_wgrad3_kernel(const h16* __r
 
     // Register double-buffered fragments: the transposed LDS reads of stage s+1 are issued before the MFMAs of stage s, so
     // the LDS latency (8 + 12 dependent-free ds_read_tr per 24 MFMAs) no longer sits between the MFMA groups.
-    struct Frags { h16x8 a[TM]; h16x8 b[3][TN]; };
+    typedef typename WgFrag<T>::type Frag;
+    struct Frags { Frag a[TM]; Frag b[3][TN]; };
     const int wsh = (W16 && SPS == 1 && g >= 2) ? 2 : 0;     // W = 16: the second image row's window starts 18 rows in
+    auto rd_tr = [&](const T* tile, int stride, int r0, int col, int hash0, int hash1) -> Frag {
+        const T* p0 = tile + r0 * stride + ((((col >> 4) ^ hash0) << 4) | (col & 15));
+        const T* p1 = tile + (r0 + 4) * stride + ((((col >> 4) ^ hash1) << 4) | (col & 15));
+        if constexpr (XF) {
+            const char* c0 = reinterpret_cast<const char*>(p0);
+            const char* c1 = reinterpret_cast<const char*>(p1);
+            const uint2 h0 = __builtin_bit_cast(uint2, __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) fp16x4v*)(c0)));
+            const uint2 h1 = __builtin_bit_cast(uint2, __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) fp16x4v*)(c1)));
+            const uint2 l0 = __builtin_bit_cast(uint2, __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) fp16x4v*)(c0 + 8)));
+            const uint2 l1 = __builtin_bit_cast(uint2, __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) fp16x4v*)(c1 + 8)));
+            SplitF8 f;
+            f.hi = __builtin_bit_cast(bf16x8, make_uint4(h0.x, h0.y, h1.x, h1.y));
+            f.lo = __builtin_bit_cast(bf16x8, make_uint4(l0.x, l0.y, l1.x, l1.y));
+            return f;
+        } else {
+            auto lo = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) fp16x4v*)(p0));
+            auto hi = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) fp16x4v*)(p1));
+            return (h16x8){(h16)lo[0], (h16)lo[1], (h16)lo[2], (h16)lo[3], (h16)hi[0], (h16)hi[1], (h16)hi[2], (h16)hi[3]};
+        }
+    };
     auto load_frags = [&](int buf, int half, Frags& f) {     // k-step `half` of the stage in slot `buf`
-        const h16* At = lds + buf * STAGE;
-        const h16* Bt = At + SP * BCO;
+        const T* At = lds + buf * STAGE;
+        const T* Bt = At + SP * BCO;
         // absolute tile rows (the swizzle hash is a function of the row the DMA wrote): k-step `half` starts at dy row half*32
         // and at window row half*32 (flat) or half*34 (W = 32: one window per image row)
         const int ra = half * KP, rb = half * (W16 ? KP + 2 : KP);
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
-            const int col = (wr * TM + i) * 16 + 4 * pc;    // 4 halfs inside 32-byte chunk (col >> 4)
-            const int r0 = ra + 8 * g + q, r1 = r0 + 4;
-            auto lo = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) fp16x4v*)(At + r0 * BCO + ((((col >> 4) ^ wg_hash<BCO>(r0)) << 4) | (col & 15))));
-            auto hi = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) fp16x4v*)(At + r1 * BCO + ((((col >> 4) ^ wg_hash<BCO>(r1)) << 4) | (col & 15))));
-            f.a[i] = (h16x8){(h16)lo[0], (h16)lo[1], (h16)lo[2], (h16)lo[3], (h16)hi[0], (h16)hi[1], (h16)hi[2], (h16)hi[3]};
+            const int col = (wr * TM + i) * 16 + 4 * pc;    // 4 channels inside the 16-channel granule (col >> 4)
+            const int r0 = ra + 8 * g + q;
+            f.a[i] = rd_tr(At, BCO, r0, col, wg_hash_t<T, BCO>(r0), wg_hash_t<T, BCO>(r0 + 4));
         }
 #pragma unroll
         for (int t = 0; t < 3; ++t) {
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
                 const int col = (wc * TN + j) * 16 + 4 * pc;
-                const int r0 = rb + 8 * g + q + t + wsh, r1 = r0 + 4;
-                auto lo = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) fp16x4v*)(Bt + r0 * BCI + ((((col >> 4) ^ wg_hash<BCI>(r0)) << 4) | (col & 15))));
-                auto hi = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) fp16x4v*)(Bt + r1 * BCI + ((((col >> 4) ^ wg_hash<BCI>(r1)) << 4) | (col & 15))));
-                f.b[t][j] = (h16x8){(h16)lo[0], (h16)lo[1], (h16)lo[2], (h16)lo[3], (h16)hi[0], (h16)hi[1], (h16)hi[2], (h16)hi[3]};
+                const int r0 = rb + 8 * g + q + t + wsh;
+                f.b[t][j] = rd_tr(Bt, BCI, r0, col, wg_hash_t<T, BCI>(r0), wg_hash_t<T, BCI>(r0 + 4));
             }
         }
     };
@@ -2081,14 +2140,60 @@ __global__ __launch_bounds__(NWV * 64, 1) void conv_wgrad3_kernel(const h16* __r
 #pragma unroll
             for (int j = 0; j < TN; ++j)
 #pragma unroll
-                for (int i = 0; i < TM; ++i) acc[t][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(f.a[i], f.b[t][j], acc[t][i][j], 0, 0, 0);
+                for (int i = 0; i < TM; ++i) {
+                    if constexpr (XF) mu_mma_split(f.a[i], f.b[t][j], acc[t][i][j]);
+                    else acc[t][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(f.a[i], f.b[t][j], acc[t][i][j], 0, 0, 0);
+                }
     };
 
     // Ring protocol (one raw barrier per stage):
     //   top of step s : this wave's DMAs of stage s+1 have landed (vmcnt <= (NS-3) n_w); barrier -> everybody's have, and
     //                   everybody's reads of stage s-1 (issued in step s-2, consumed by the MFMAs of step s-1) are complete
     //   then          : DMA of stage s+NS-1 into the slot of stage s-1; fragment reads of stage s+1; MFMAs of stage s
-    if constexpr (PP) {
+    if constexpr (XF) {
+        constexpr int FULL = NAW + NBW;
+        auto wait_landed = [&]() {                           // the oldest outstanding stage of this wave has landed: NS-2 younger ones may fly
+            if (n_w == FULL) wait_vmcnt_c<(NS - 2) * FULL>();
+            else if (n_w == FULL - 1) wait_vmcnt_c<(NS - 2) * (FULL - 1)>();
+            else wait_vmcnt_c<(NS - 2) * (FULL > 2 ? FULL - 2 : 0)>();
+        };
+#pragma unroll 1
+        for (int k = 0; k < NS - 1; ++k) stage(k);
+        Frags f;
+        int buf = 0;
+        const bool late = NWV == 8 && MU_WGX_STAGGER && wr == 1;      // group 1 of an 8-wave block: MFMAs one stage behind its reads
+        // step s: stage s landed for everybody (counted wait + barrier), and everybody's reads of stage s-1 are complete (group 0 consumed
+        // them in its MFMAs, group 1 drained lgkmcnt before the barrier) -> stage s+NS-1 goes into the slot of stage s-1
+        if (!late) {
+#pragma unroll 1
+            for (int s = 0; s < nsteps; ++s) {
+                wait_landed();
+                __builtin_amdgcn_s_barrier();
+                stage(buf == 0 ? NS - 1 : buf - 1);
+                load_frags(buf, 0, f);
+                compute(f);
+                buf = buf + 1 == NS ? 0 : buf + 1;
+            }
+        } else if (nsteps > 0) {
+            wait_landed();
+            __builtin_amdgcn_s_barrier();
+            stage(NS - 1);
+            load_frags(0, 0, f);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            buf = 1;
+#pragma unroll 1
+            for (int s = 1; s < nsteps; ++s) {
+                wait_landed();
+                __builtin_amdgcn_s_barrier();
+                stage(buf == 0 ? NS - 1 : buf - 1);
+                compute(f);
+                load_frags(buf, 0, f);
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                buf = buf + 1 == NS ? 0 : buf + 1;
+            }
+            compute(f);
+        }
+    } else if constexpr (PP) {
         // Epochs: group A runs X(k) [DMA issue of stage S+2 when k opens stage S, then the k-step's fragment reads] at epoch 2k and
         // M(k) [its MFMAs, and when k opens a stage the wait for stage S+1] at 2k+1; group B one epoch later; one raw barrier per
         // epoch.  RAW: stage S+1 is first read in X(2S+2) (A: epoch 4S+4); both groups' waits sit in M(2S) (B: epoch 4S+2) and a
@@ -2297,11 +2402,14 @@ static inline void wgrad_tile(int Cin, int Cout, int* bco, int* bci, int taps = 
 #ifndef MU_WG_BLOCKS64
 #define MU_WG_BLOCKS64 512
 #endif
+#ifndef MU_WGX
+#define MU_WGX 1               // fp32x: the 3-taps-per-block ring kernel (0 = the generic register-staged kernel)
+#endif
 static inline bool wgrad3_choose(int H, int W, int Cin, int Cout, int taps, int dtype, int* tco, int* tci) {
-    if (dtype != MU_F16 || taps != 9 || !(W % 32 == 0 || (W == 16 && H % 2 == 0))) return false;
+    if ((dtype != MU_F16 && !(dtype == MU_F32X && MU_WGX)) || taps != 9 || !(W % 32 == 0 || (W == 16 && H % 2 == 0))) return false;
     const int a = Cout % 128 == 0 ? 128 : (Cout % 64 == 0 ? 64 : 0), b = Cin % 128 == 0 ? 128 : (Cin % 64 == 0 ? 64 : 0);
     if (!a || !b) return false;
-    if (a == b || MU_WG_MIXED) { *tco = a; *tci = b; }
+    if (a == b || (MU_WG_MIXED && dtype == MU_F16)) { *tco = a; *tci = b; }
     else { *tco = 64; *tci = 64; }
     return true;
 }
@@ -2558,9 +2666,13 @@ static int conv_wgrad_impl(const void* x, const void* dy, float* dw_oihw, float*
         if (ws_bytes < (long)nsplit * taps * Cout * Cin * (long)sizeof(float)) return MU_ERR_WORKSPACE;
         const int grid = 3 * (Cout / tco) * (Cin / tci) * nsplit;
         const h16 *xh = (const h16*)x, *dyh = (const h16*)dy;
-#define WG3(...) conv_wgrad3_kernel<__VA_ARGS__><<<grid, (tco == 128 && tci == 128) ? 512 : 256, 0, st>>>(xh, dyh, part, B, H, W, Cin, Cout, x_ld, dy_ld, nsplit, pps)
+#define WG3(...) conv_wgrad3_kernel<h16, __VA_ARGS__><<<grid, (tco == 128 && tci == 128) ? 512 : 256, 0, st>>>(xh, dyh, part, B, H, W, Cin, Cout, x_ld, dy_ld, nsplit, pps)
+#define WG3X(...) conv_wgrad3_kernel<xf32, __VA_ARGS__><<<grid, (tco == 128 && tci == 128) ? 512 : 256, 0, st>>>((const xf32*)x, (const xf32*)dy, part, B, H, W, Cin, Cout, x_ld, dy_ld, nsplit, pps)
         const bool two_row32 = W == 32 && H % 2 == 0, flat64 = W % 64 == 0;
-        if (tco == 128 && tci == 128) {   // 8 waves, 64x32 tile x 3 taps per wave (96 accumulators): 2 waves/SIMD
+        if (dtype == MU_F32X) {           // square tiles only, one 32-pixel k-step per stage
+            if (tco == 128) { if (W == 16) WG3X(4, 2, 2, 8, true); else WG3X(4, 2, 2, 8); }
+            else { if (W == 16) WG3X(2, 2, 2, 4, true); else WG3X(2, 2, 2, 4); }
+        } else if (tco == 128 && tci == 128) {   // 8 waves, 64x32 tile x 3 taps per wave (96 accumulators): 2 waves/SIMD
             if (W == 16) WG3(4, 2, 2, 8, true);
             else if (two_row32 && MU_WG_SPS2 && MU_WG_PP == 2) WG3(4, 2, 2, 8, true, 2, true);      // (W = 32: +2.6 % slower, opt-in)
             else if (two_row32 && MU_WG_SPS2) WG3(4, 2, 2, 8, true, 2);
@@ -2580,6 +2692,7 @@ static int conv_wgrad_impl(const void* x, const void* dy, float* dw_oihw, float*
             else WG3(2, 2, 2);
         }
 #undef WG3
+#undef WG3X
     } else if (ws_bytes < (long)nsplit * taps * Cout * Cin * (long)sizeof(float)) {
         return MU_ERR_WORKSPACE;
     } else if (dtype == MU_F16) {
