@@ -105,6 +105,11 @@
 #ifndef MU_XF_SWZ256
 #define MU_XF_SWZ256 1
 #endif
+// fp32x, C = 128 dK/dV: the 4-deep Q / dO ring takes 128 KB, so a 4-wave block is alone on its CU (one wave per SIMD: matrix pipe busy 25 %);
+// 8 waves share the ring (two per SIMD, 16 keys each)
+#ifndef MU_XF_DKV_NW128
+#define MU_XF_DKV_NW128 8
+#endif
 #ifndef MU_XF_OCC
 #define MU_XF_OCC 2
 #endif
@@ -1422,6 +1427,8 @@ static int attn_bwd_t(const T* qkv, const T* x, const T* oattn, const T* gout, c
             attn_bwd_dkv3_kernel<T, DD, NKT, MU_DKV_NW64><<<dim3(mu_cdiv(nkmax, 16 * MU_DKV_NW64 * NKT), B), 64 * MU_DKV_NW64, 0, st>>>(qkv, dYs, kidx, kcnt, rowc, dqkv, N, nkmax, scale, sl2, zero_masked); \
         else if constexpr (sizeof(T) == 2 && DD == 128 && MU_DKV_NW128 != 4)                                                         \
             attn_bwd_dkv3_kernel<T, DD, NKT, MU_DKV_NW128><<<dim3(mu_cdiv(nkmax, 16 * MU_DKV_NW128 * NKT), B), 64 * MU_DKV_NW128, 0, st>>>(qkv, dYs, kidx, kcnt, rowc, dqkv, N, nkmax, scale, sl2, zero_masked); \
+        else if constexpr (std::is_same<T, xf32>::value && DD == 128 && MU_XF_DKV_NW128 != 4)                                    \
+            attn_bwd_dkv3_kernel<T, DD, NKT, MU_XF_DKV_NW128><<<dim3(mu_cdiv(nkmax, 16 * MU_XF_DKV_NW128 * NKT), B), 64 * MU_XF_DKV_NW128, 0, st>>>(qkv, dYs, kidx, kcnt, rowc, dqkv, N, nkmax, scale, sl2, zero_masked); \
         else if constexpr (sizeof(T) == 2 && DD == 256 && MU_DKV_NW256 == 8)                                                    \
             attn_bwd_dkv3_kernel<T, DD, NKT, 8><<<dim3(mu_cdiv(nkmax, 128 * NKT), B), 512, 0, st>>>(qkv, dYs, kidx, kcnt, rowc, dqkv, N, nkmax, scale, sl2, zero_masked); \
         else                                                                                                                    \
