@@ -509,6 +509,9 @@ __global__ __launch_bounds__(256, SB ? MU_NT2_SB_OCC : MU_NT2_OCC) void conv_nt2
 #ifndef MU_NT3_RING
 #define MU_NT3_RING 1
 #endif
+#ifndef MU_XF_NT3_RING8
+#define MU_XF_NT3_RING8 1
+#endif
 template <typename T, int TM, int TN, int WR, int NWV, bool RINGP, bool FEPI>
 __device__ __forceinline__ void conv_nt3_body(const T* __restrict__ x, const T* __restrict__ w, const float* __restrict__ bias,
                                               T* __restrict__ y, int B, int H, int W, int Cin, int Cout, long x_ld, long y_ld,
@@ -530,7 +533,8 @@ __device__ __forceinline__ void conv_nt3_body(const T* __restrict__ x, const T* 
     // parked 48 %, MFMA pipe 26 % busy).  Exactly PA + 1 DMAs per wave per tap (dummies to a dump page keep the counts uniform).
     // In-process A/B: 128 -> 64 @128^2 0.226 -> 0.203 ms; with a single 64-channel chunk (9 taps per tile) the longer prologue
     // costs more than the waits it removes (64 -> 64 @128^2 0.110 -> 0.116 ms), so the launcher picks RINGP for Cin >= 128 only.
-    constexpr bool RING = RINGP && MU_NT3_RING && sizeof(T) == 2 && BCO == 64 && NWV == 4;
+    // (fp32x, MU_XF_NT3_RING8: the same ring on 8-wave blocks with 128 output channels x 16 x 16 pixels -- one block per CU, two waves per SIMD)
+    constexpr bool RING = RINGP && MU_NT3_RING && ((sizeof(T) == 2 && BCO == 64 && NWV == 4) || (std::is_same<T, xf32>::value && BCO == 128 && NWV == 8));
     constexpr int NWS = RING ? 3 : 2;
 
     __shared__ __attribute__((aligned(16))) char lds[2 * HBYTES + NWS * WBYTES + (RING ? 1024 : 0)];
@@ -1469,6 +1473,12 @@ static int conv_fwd_launch(const T* x, const T* w, const float* bias, T* y, int 
             // L2->LDS bytes per flop) yet the step time is unchanged (45.39 vs 45.29 ms): v3 is no longer L2->LDS bound
             conv_nt3_kernel<T, 4, 4, 2, 8><<<B * (H / 16) * (W / 16) * (Cout / 128), 512, 0, st>>>(x, w, bias, y, B, H, W, Cin, Cout, x_ld, y_ld);
             return MU_OK;
+        }
+        if constexpr (std::is_same<T, xf32>::value && MU_XF_NT3_RING8) {
+            if (Cout % 128 == 0 && H % 16 == 0) {
+                conv_nt3_kernel<T, 4, 4, 2, 8, true><<<B * (H / 16) * (W / 16) * (Cout / 128), 512, 0, st>>>(x, w, bias, y, B, H, W, Cin, Cout, x_ld, y_ld);
+                return MU_OK;
+            }
         }
         if constexpr (sizeof(T) == 2 && MU_CONV_NT4) {
             if (Cout % 128 == 0 && H % 16 == 0 && Cin % 64 == 0 && !getenv("MU_CONV_NO_NT4")) {
