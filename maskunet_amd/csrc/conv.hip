@@ -510,7 +510,7 @@ __global__ __launch_bounds__(256, SB ? MU_NT2_SB_OCC : MU_NT2_OCC) void conv_nt2
 #define MU_NT3_RING 1
 #endif
 #ifndef MU_XF_NT3_RING8
-#define MU_XF_NT3_RING8 1
+#define MU_XF_NT3_RING8 0       // measured: 14.45 vs 14.5 ms/step over the 51 launches (session r04s) -- neutral, the 4-wave two-block form stays
 #endif
 template <typename T, int TM, int TN, int WR, int NWV, bool RINGP, bool FEPI>
 __device__ __forceinline__ void conv_nt3_body(const T* __restrict__ x, const T* __restrict__ w, const float* __restrict__ bias,
