@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Per-layer table of the 3x3 conv kernels at the bench configuration (debug aid / profiles evidence):
-python tests/bench_layers.py [B] [--md]
+python tests/bench_layers.py [B] [--fp32x]
 Every 3x3 shape of UNet(3, c_out, hw=128) at batch B: forward, data-gradient (the same kernel family with Cin/Cout swapped) and
 weight-gradient, in-process HIP-event timings over 20 launches, algorithmic TFLOP/s = 2*B*H*W*Cin*Cout*9 / t."""
 import os, sys
@@ -28,7 +28,9 @@ def timeit(f, n=20):
 def main():
     args = [a for a in sys.argv[1:] if not a.startswith("--")]
     B = int(args[0]) if args else 64
-    dev, dt = "cuda", torch.float16
+    X = "--fp32x" in sys.argv                                # fp32 storage, chunk-encoded operands, split-bf16 products (MU_F32X)
+    dev, dt = "cuda", (torch.float32 if X else torch.float16)
+    code = 2 if X else 1
     st = _lib.stream()
     lib = _lib.load()
     tot = {"fwd": 0.0, "dgrad": 0.0, "wgrad": 0.0}; totfl = {"fwd": 0.0, "dgrad": 0.0, "wgrad": 0.0}
@@ -40,15 +42,18 @@ def main():
         w = (torch.randn(9, Cout, Cin, device=dev) * 0.05).to(dt)
         wt = (torch.randn(9, Cin, Cout, device=dev) * 0.05).to(dt)
         y = torch.empty(B, H, H, Cout, device=dev, dtype=dt)
+        if X:
+            for t in (x, dy, w, wt):
+                _lib.call("mu_split_encode", t.data_ptr(), t.data_ptr(), t.numel(), st)
         dx = torch.empty(B, H, H, Cin, device=dev, dtype=dt)
         cin_v = 3 if Cin == 32 else Cin
         gw = torch.empty(Cout, cin_v, 3, 3, device=dev)
         ws = _lib.workspace(lib.mu_conv_wgrad_workspace_bytes(B, H, H, Cin, Cout, 9), torch.device(dev))
         fl = 2.0 * B * H * H * Cin * Cout * 9
-        def fwd(): _lib.call("mu_conv_fwd", x.data_ptr(), w.data_ptr(), None, y.data_ptr(), B, H, H, Cin, Cout, 9, Cin, Cout, 1, st)
-        def dg(): _lib.call("mu_conv_fwd", dy.data_ptr(), wt.data_ptr(), None, dx.data_ptr(), B, H, H, Cout, Cin, 9, Cout, Cin, 1, st)
+        def fwd(): _lib.call("mu_conv_fwd", x.data_ptr(), w.data_ptr(), None, y.data_ptr(), B, H, H, Cin, Cout, 9, Cin, Cout, code, st)
+        def dg(): _lib.call("mu_conv_fwd", dy.data_ptr(), wt.data_ptr(), None, dx.data_ptr(), B, H, H, Cout, Cin, 9, Cout, Cin, code, st)
         def wg(): _lib.call("mu_conv_wgrad", x.data_ptr(), dy.data_ptr(), gw.data_ptr(), B, H, H, Cin, Cout, 9, cin_v, Cout, Cin, Cout,
-                            ws.data_ptr(), ws.numel(), 1, st)
+                            ws.data_ptr(), ws.numel(), code, st)
         row = []
         for name, f in (("fwd", fwd), ("dgrad", dg), ("wgrad", wg)):
             if name == "dgrad" and Cin == 32:
