@@ -15,4 +15,8 @@ run --optimizer --warmup 8                       # configs[1] + fused AdamW insi
 run --dtype fp32 --steps 4 --warmup 2             # fp32 parity path (exact-fp32 MFMA)
 run --dtype fp32x --steps 6 --warmup 2            # fp32 storage, split-bf16 matrix products (set_float32_matmul_precision("high"))
 run --batch 16
+# the other configuration shapes in the fp32x mode
+run --dtype fp32x --c-out 133 --batch 128 --steps 4 --warmup 2
+run --dtype fp32x --three-head --c-out 19 --batch 64 --steps 6 --warmup 2
+run --dtype fp32x --hw 256 --c-out 133 --batch 32 --steps 4 --warmup 2
 cat $OUT | cut -c1-260
