@@ -110,6 +110,9 @@
 #ifndef MU_XF_DKV_NW128
 #define MU_XF_DKV_NW128 8
 #endif
+#ifndef MU_XF_FWD_KT32
+#define MU_XF_FWD_KT32 1
+#endif
 #ifndef MU_XF_OCC
 #define MU_XF_OCC 2
 #endif
@@ -1338,7 +1341,11 @@ static int attn_fwd_t(const T* qkv, const T* x, const int* kidx, const int* kcnt
     attn_fwd2_kernel<T, DD, KT, 4><<<dim3(mu_cdiv(N, 128), B), 256, 0, st>>>(qkv, x, kidx, kcnt, gamma, beta, out, oattn, lse2, mean, rstd, N, nkmax, sl2, eps)
     switch (C) {
         case 32: LAUNCH_FWD(32, 64); break;
-        case 64: LAUNCH_FWD(64, 64); break;
+        case 64:
+            if constexpr (std::is_same<T, xf32>::value && MU_XF_FWD_KT32)       // 32-key tiles: 32 KB of LDS and <= 168 registers -> three waves per SIMD
+                attn_fwd2_kernel<T, 64, 32, 4, 3><<<dim3(mu_cdiv(N, 128), B), 256, 0, st>>>(qkv, x, kidx, kcnt, gamma, beta, out, oattn, lse2, mean, rstd, N, nkmax, sl2, eps);
+            else LAUNCH_FWD(64, 64);
+            break;
         case 128:
 #if MU_FWD_NW128 == 8
             attn_fwd2_kernel<T, 128, MU_FWD_KT128, 8, 1><<<dim3(mu_cdiv(N, 256), B), 512, 0, st>>>(qkv, x, kidx, kcnt, gamma, beta, out, oattn, lse2, mean, rstd, N, nkmax, sl2, eps);

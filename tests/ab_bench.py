@@ -29,6 +29,9 @@ def main():
     what, names = sys.argv[1], sys.argv[2:]
     libs = {n: load(n) for n in names}
     dev = "cuda"; dt = torch.float16; st = torch.cuda.current_stream().cuda_stream
+    XF = os.environ.get("MU_AB_FP32X") == "1"          # attn: fp32 storage, chunk-encoded qkv, split-bf16 products (dtype code 2)
+    if XF: dt = torch.float32
+    code = 2 if XF else 1
     if what == "attn":
         B, N, C = (int(v) for v in os.environ.get("MU_ATTN_SHAPE", "64,16384,64").split(","))
         qkv = torch.randn(B, N, 3 * C, device=dev, dtype=dt); x = torch.randn(B, N, C, device=dev, dtype=dt)
@@ -38,11 +41,12 @@ def main():
         out = torch.empty_like(x); oattn = torch.empty_like(x); lse = torch.empty(B, N, device=dev); mean = torch.empty_like(lse); rstd = torch.empty_like(lse)
         dY = torch.empty_like(x); dqkv = torch.empty_like(qkv); delta = torch.empty_like(lse); dg = torch.empty(C, device=dev); db = torch.empty(C, device=dev)
         gout = torch.randn_like(x)
+        if XF: _lib.call("mu_split_encode", qkv.data_ptr(), qkv.data_ptr(), qkv.numel(), st)
         ws = torch.empty(_lib.load().mu_attn_bwd_workspace_bytes(B, N, C), dtype=torch.uint8, device=dev)
         def mk(lib, phase):
             if phase == 0:
-                return lambda: lib.mu_attn_fwd(qkv.data_ptr(), x.data_ptr(), kidx.data_ptr(), kcnt.data_ptr(), g.data_ptr(), b_.data_ptr(), out.data_ptr(), oattn.data_ptr(), lse.data_ptr(), mean.data_ptr(), rstd.data_ptr(), B, N, C, N, 1e-5, 1, st)
-            return lambda: lib.mu_attn_bwd_phases(qkv.data_ptr(), x.data_ptr(), oattn.data_ptr(), gout.data_ptr(), kidx.data_ptr(), kcnt.data_ptr(), lse.data_ptr(), mean.data_ptr(), rstd.data_ptr(), g.data_ptr(), dY.data_ptr(), delta.data_ptr(), dqkv.data_ptr(), dg.data_ptr(), db.data_ptr(), B, N, C, N, ws.data_ptr(), ws.numel(), 1, phase, st)
+                return lambda: lib.mu_attn_fwd(qkv.data_ptr(), x.data_ptr(), kidx.data_ptr(), kcnt.data_ptr(), g.data_ptr(), b_.data_ptr(), out.data_ptr(), oattn.data_ptr(), lse.data_ptr(), mean.data_ptr(), rstd.data_ptr(), B, N, C, N, 1e-5, code, st)
+            return lambda: lib.mu_attn_bwd_phases(qkv.data_ptr(), x.data_ptr(), oattn.data_ptr(), gout.data_ptr(), kidx.data_ptr(), kcnt.data_ptr(), lse.data_ptr(), mean.data_ptr(), rstd.data_ptr(), g.data_ptr(), dY.data_ptr(), delta.data_ptr(), dqkv.data_ptr(), dg.data_ptr(), db.data_ptr(), B, N, C, N, ws.data_ptr(), ws.numel(), code, phase, st)
         cases = [("fwd", 0), ("dq", 2), ("dkv", 4)]
         first = libs[names[0]]; mk(first, 0)(); mk(first, 1)()
     elif what == "conv1":
