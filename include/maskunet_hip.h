@@ -33,14 +33,17 @@ extern "C" {
 
 #define MU_F32 0
 #define MU_F16 1
-/* fp32 storage, matrix products as three bf16 MFMAs on (hi, lo) splits of the fp32 operands, fp32 accumulate (~1e-5 relative per
+/* fp32 storage, matrix products as three 16-bit MFMAs on (hi, lo) splits of the fp32 operands, fp32 accumulate (~1e-5 relative per
  * product; torch's float32_matmul_precision "high").  Accepted by the matrix entry points (mu_conv_fwd, mu_conv_fwd_fused,
  * mu_conv1x1_fwd_add, mu_conv_wgrad, mu_attn_*); every other entry point takes MU_F32 for the same tensors.
- * With MU_F32X the MATRIX OPERANDS of those entry points -- x and w of the convolutions, x and dy of the weight gradient, qkv of
- * the attention sweeps -- are passed CHUNK-ENCODED: every aligned 16-byte chunk of four fp32 values re-written as
- * [4 x bf16 hi | 4 x bf16 lo] by mu_split_encode (same size, same strides; the split then costs one pass per tensor instead of
- * VALU work per fragment per wave).  Outputs, biases, residual / addend tensors, x / oattn / grad_out / dY of the attention block
- * are plain fp32.  Two producers can write the encoded form directly and save the mu_split_encode pass: mu_bn_act_fwd with MU_F32X writes
+ * With MU_F32X the MATRIX OPERANDS of those entry points are passed ENCODED (same size, same strides; the split then costs one pass per
+ * tensor instead of VALU work per fragment per wave):
+ *   - x and w of the convolutions, x and dy of the weight gradient: every aligned 16-byte chunk of four fp32 values re-written as
+ *     [4 x bf16 hi | 4 x bf16 lo] by mu_split_encode;
+ *   - qkv of the attention sweeps (mu_attn_*): every aligned 32-byte group of eight fp32 values re-written as
+ *     [8 x fp16 hi | 8 x fp16 lo] by mu_split_encode_h (|value| < 65504; the softmax probabilities and dS then enter the matrix core as
+ *     single fp16 operands: two MFMAs per P V / dS K / dS^T Q / P^T dO product, three for Q K^T and dO V^T).
+ * Outputs, biases, residual / addend tensors, x / oattn / grad_out / dY of the attention block are plain fp32.  Two producers can write the encoded form directly and save the mu_split_encode pass: mu_bn_act_fwd with MU_F32X writes
  * y encoded (for a y that only feeds a convolution), mu_bn_act_bwd / mu_bn_act_bwd_scaled with MU_F32X write dx encoded (dx of a BatchNorm
  * is the dy of the convolution in front of it); their inputs, dres and all statistics stay plain fp32. */
 #define MU_F32X 2
@@ -65,6 +68,9 @@ int mu_transpose_pad(const void* src, int src_dtype, long src_ld, void* dst, int
 /* fp32x operand encoding (see MU_F32X): n_elems fp32 values (a multiple of 4, 16-byte aligned, contiguous rows) -> the chunk-encoded
  * operand; dst may be src (in place). */
 int mu_split_encode(const void* src, void* dst, long n_elems, void* stream);
+/* fp32x ATTENTION operand encoding (see MU_F32X): n_elems fp32 values (a multiple of 8, 32-byte aligned) -> [8 fp16 hi | 8 fp16 lo] per
+ * group of eight, hi = fp16(x), lo = fp16(x - hi); dst may be src (in place).  qkv of mu_attn_fwd / mu_attn_bwd* with MU_F32X. */
+int mu_split_encode_h(const void* src, void* dst, long n_elems, void* stream);
 /* elementwise dtype conversion of n elements */
 int mu_cast(const void* src, int src_dtype, void* dst, int dst_dtype, long n, void* stream);
 /* OIHW fp32 parameter -> tap-major compute layout [taps][rows_pad][cols_pad].

@@ -27,6 +27,7 @@ SIGNATURES = {
     "mu_transpose_pad": (I, [P, I, L, P, I, L, I, I, I, I, P]),
     "mu_cast": (I, [P, I, P, I, L, P]),
     "mu_split_encode": (I, [P, P, L, P]),
+    "mu_split_encode_h": (I, [P, P, L, P]),
     "mu_prep_weight": (I, [P, P, I, I, I, I, I, I, I, P]),
     "mu_conv_fwd": (I, [P, P, P, P, I, I, I, I, I, I, L, L, I, P]),
     "mu_conv_stats_rows": (I, [I, I, I, I, I, I, I]),

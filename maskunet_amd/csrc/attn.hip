@@ -167,7 +167,10 @@ __device__ __forceinline__ void attn_block(int& bx, int& b) {
 
 template <typename T> struct AT;
 template <> struct AT<h16> {
-    static constexpr int VN = 8, KR = 32;
+    // VN: elements per 16-byte chunk; KR: contraction width of one row-product fragment; GS: column stride between the fragments of
+    // the four lane groups g; PK: P / dS enter the matrix core as one packed fp16 operand
+    static constexpr int VN = 8, KR = 32, GS = 8;
+    static constexpr bool PK = true;
     using Frag = h16x8;
     struct AccA { h16x8 v; };
     static __device__ __forceinline__ Frag ld(const h16* p) { return *reinterpret_cast<const Frag*>(p); }
@@ -200,6 +203,8 @@ template <> struct AT<h16> {
         h16x8 b = {(h16)p0[0], (h16)p0[1], (h16)p0[2], (h16)p0[3], (h16)p1[0], (h16)p1[1], (h16)p1[2], (h16)p1[3]};
         c = __builtin_amdgcn_mfma_f32_16x16x32_f16(a.v, b, c, 0, 0, 0);
     }
+    // the row-sum product (A = the constant-ones operand)
+    static __device__ __forceinline__ void mma_ones(const AccA& a, const f32x4& p0, const f32x4& p1, f32x4& c) { mma_acc(a, p0, p1, c); }
     // the same with the B operand already packed (MU_DKV_PKMUL: dS = P * dP' as four v_pk_mul_f16 on the packed halves)
     using Packed = h16x8;
     static __device__ __forceinline__ Packed pack(const f32x4& p0, const f32x4& p1) {
@@ -210,7 +215,8 @@ template <> struct AT<h16> {
     }
 };
 template <> struct AT<float> {
-    static constexpr int VN = 4, KR = 16;
+    static constexpr int VN = 4, KR = 16, GS = 4;
+    static constexpr bool PK = false;
     using Frag = f32x4;
     struct AccA { float v[8]; };
     static __device__ __forceinline__ Frag ld(const float* p) { return *reinterpret_cast<const Frag*>(p); }
@@ -242,44 +248,65 @@ template <> struct AT<float> {
 #pragma unroll
         for (int r = 0; r < 4; ++r) c = __builtin_amdgcn_mfma_f32_16x16x4f32(a.v[4 + r], p1[r], c, 0, 0, 0);
     }
+    static __device__ __forceinline__ void mma_ones(const AccA& a, const f32x4& p0, const f32x4& p1, f32x4& c) { mma_acc(a, p0, p1, c); }
 };
 
-// fp32x (common.h): fp32 storage and the fp32 kernels' tiling on CHUNK-ENCODED qkv / dY (16 bytes = [4 bf16 hi | 4 bf16 lo] of four
-// fp32 values): a row fragment load is the (hi, lo) operand pair of v_mfma_f32_16x16x16_bf16, the transposed operands of the
-// accumulator-operand products come from ds_read_b64_tr_b16 on the hi / lo halves (eight values -> v_mfma_f32_16x16x32_bf16), three
-// bf16 MFMAs per operand pair.  The resident, pre-scaled operands are decoded, scaled and re-split once outside the sweep; P / dS
-// come out of the fp32 accumulators and are split in registers before they re-enter.
+// fp32x (common.h): fp32 storage and the fp32 kernels' tiling on FP16-PAIR-ENCODED qkv / dY (32 bytes = [8 fp16 hi | 8 fp16 lo] of
+// eight fp32 values, two 16-byte chunks): a row fragment is the hi chunk + the lo chunk of one group (lane group g: columns
+// 32 ks + 8 g ..), three v_mfma_f32_16x16x32_f16 per row product (lo hi + hi lo + hi hi); the transposed operands of the
+// accumulator-operand products come from ds_read_b64_tr_b16 on the hi and on the lo chunks, and P / dS enter as ONE packed fp16
+// operand straight from the accumulators (two MFMAs per product, no register split).  The resident, pre-scaled operands are decoded,
+// scaled and re-split once outside the sweep.  Range management (the backward's power-of-two scales): see attn_bwd_t.
 template <> struct AT<xf32> {
-    // a row fragment = TWO chunks, 16 columns apart (lane group g: columns 32 ks + 4g.. and 32 ks + 16 + 4g..): their hi halves side
-    // by side are the eight-value operand of v_mfma_f32_16x16x32_bf16 -- half the MFMA instructions of the K = 16 form
-    static constexpr int VN = 4, KR = 32;
-    using Frag = SplitF8;
-    using AccA = SplitF8;
-    static __device__ __forceinline__ Frag join(const uint4& e0, const uint4& e1) {
-        Frag r;
-        r.hi = __builtin_bit_cast(bf16x8, make_uint4(e0.x, e0.y, e1.x, e1.y));
-        r.lo = __builtin_bit_cast(bf16x8, make_uint4(e0.z, e0.w, e1.z, e1.w));
-        return r;
-    }
+    static constexpr int VN = 4, KR = 32, GS = 8;
+    static constexpr bool PK = true;
+    using Frag = SplitH8;
+    using AccA = SplitH8;
+    using Packed = h16x8;
+    // col = 32 ks + 8 g: chunk col / 4 holds the group's hi parts, the next one its lo parts
     template <typename Z> static __device__ __forceinline__ Frag ldt(const xf32* tile, int row, int col) {
-        return join(*reinterpret_cast<const uint4*>(tile + Z::off(row, col)), *reinterpret_cast<const uint4*>(tile + Z::off(row, col + 16)));
+        Frag r;
+        r.hi = *reinterpret_cast<const h16x8*>(tile + Z::off(row, col));
+        r.lo = *reinterpret_cast<const h16x8*>(tile + Z::off(row, col + 4));
+        return r;
     }
     // resident operands (global rows, contiguous): decode, scale, split again -- once per wave, outside the sweep
     static __device__ __forceinline__ Frag ld_scaled(const xf32* p, float sc) {
-        const f32x4 a = mu_dec4(*reinterpret_cast<const uint4*>(p)) * sc, b = mu_dec4(*reinterpret_cast<const uint4*>(p + 16)) * sc;
-        const float v[8] = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
-        return mu_split8(v);
+        Frag e;
+        e.hi = *reinterpret_cast<const h16x8*>(p);
+        e.lo = *reinterpret_cast<const h16x8*>(p + 4);
+        float v[8];
+        mu_hdec8(e, v);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] *= sc;
+        return mu_hsplit8(v);
     }
-    static __device__ __forceinline__ Frag zero() { return join(make_uint4(0, 0, 0, 0), make_uint4(0, 0, 0, 0)); }
-    static __device__ __forceinline__ void mma_row(const Frag& a, const Frag& b, f32x4& c) { mu_mma_split(a, b, c); }
+    static __device__ __forceinline__ Frag zero() {
+        Frag r;
+        r.hi = (h16x8)(h16)0;
+        r.lo = (h16x8)(h16)0;
+        return r;
+    }
+    static __device__ __forceinline__ void mma_row(const Frag& a, const Frag& b, f32x4& c) {
+        c = __builtin_amdgcn_mfma_f32_16x16x32_f16(a.lo, b.hi, c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x32_f16(a.hi, b.lo, c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x32_f16(a.hi, b.hi, c, 0, 0, 0);
+    }
     static __device__ __forceinline__ f32x4 mma_row_from(const Frag& a, const Frag& b, const f32x4& c0) {
-        f32x4 c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.lo, b.hi, c0, 0, 0, 0);
-        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.hi, b.lo, c, 0, 0, 0);
-        return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.hi, b.hi, c, 0, 0, 0);
+        f32x4 c = __builtin_amdgcn_mfma_f32_16x16x32_f16(a.lo, b.hi, c0, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x32_f16(a.hi, b.lo, c, 0, 0, 0);
+        return __builtin_amdgcn_mfma_f32_16x16x32_f16(a.hi, b.hi, c, 0, 0, 0);
     }
-    static __device__ __forceinline__ void mma_acc(const AccA& a, const f32x4& p0, const f32x4& p1, f32x4& c) {
-        const float pv[8] = {p0[0], p0[1], p0[2], p0[3], p1[0], p1[1], p1[2], p1[3]};
-        mu_mma_split(a, mu_split8(pv), c);
+    static __device__ __forceinline__ Packed pack(const f32x4& p0, const f32x4& p1) {
+        return (h16x8){(h16)p0[0], (h16)p0[1], (h16)p0[2], (h16)p0[3], (h16)p1[0], (h16)p1[1], (h16)p1[2], (h16)p1[3]};
+    }
+    static __device__ __forceinline__ void mma_acc_pk(const AccA& a, const Packed& b, f32x4& c) {
+        c = __builtin_amdgcn_mfma_f32_16x16x32_f16(a.lo, b, c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x32_f16(a.hi, b, c, 0, 0, 0);
+    }
+    static __device__ __forceinline__ void mma_acc(const AccA& a, const f32x4& p0, const f32x4& p1, f32x4& c) { mma_acc_pk(a, pack(p0, p1), c); }
+    static __device__ __forceinline__ void mma_ones(const AccA& a, const f32x4& p0, const f32x4& p1, f32x4& c) {
+        c = __builtin_amdgcn_mfma_f32_16x16x32_f16(a.hi, pack(p0, p1), c, 0, 0, 0);          // (the ones operand has no lo part)
     }
 };
 // reductions over the 4 lanes {r16 + 16g}: v_permlane16_swap / v_permlane32_swap exchange 16-/32-lane rows in
@@ -349,8 +376,16 @@ template <typename T, int D> struct SwzTile {
     //    kernels): the 16 lanes of a b128 group (rows {0-3, 12-15} at chunk c, rows {4-11} at chunk c+1) fell on 8 slots, and the
     //    8 rows x 2 chunks of a transposed read on 8 slots.  (row & 7) << 1 puts each of 8 consecutive rows on its own even/odd slot
     //    PAIR (transposed reads touch {c, c+1} with c even) and makes row -> slot injective over the 16 rows of a b128 group.
+    //  * fp32x rows (fp16-pair encoded, 4-byte elements): a group's hi parts and lo parts are two ADJACENT 16-byte chunks (2s, 2s + 1).  A
+    //    transposed read of a 16-column block takes, per row, the whole chunks 4 dt and 4 dt + 2 (hi) or 4 dt + 1 and 4 dt + 3 (lo) of
+    //    8 consecutive rows in one 32-lane half; a ds_read_b128 group takes chunk c of 8 rows and chunk c ^ 2 of 8 other rows (lane
+    //    groups g, g + 1), all 8 residues mod 8 on both sides.  Both are conflict-free iff the 8 keys are distinct on bits {0, 2, 3}:
+    //    key = b0 | b1 << 2 | b2 << 3 of the row.  (The round-4 layout -- [4 hi | 4 lo] in every chunk, key (row & 7) << 1 -- left every
+    //    transposed read on half of the banks: 25-33 % of the LDS cycles were conflicts, profiles/r04_fp32x_lds_conflicts.md.)
+    //    128-byte rows (C = 32): two rows share a bank row, b1 and b2 of the row on key bits 0 and 2.
     static __device__ __forceinline__ constexpr int key(int row) {
-        return ((sizeof(T) == 2 || MU_XF_SWZ256 && std::is_same<T, xf32>::value) && ROWB >= 256) ? ((row & 7) << 1) : (row & SW);
+        if (std::is_same<T, xf32>::value) return ROWB >= 256 ? ((row & 1) | ((row & 6) << 1)) : (((row >> 1) & 1) | (((row >> 2) & 1) << 2));
+        return (sizeof(T) == 2 && ROWB >= 256) ? ((row & 7) << 1) : (row & SW);
     }
     // element offset of (row, col) in the swizzled image
     static __device__ __forceinline__ int off(int row, int col) {
@@ -447,23 +482,30 @@ template <int D> struct AccLd<float, D> {
 };
 
 template <int D> struct AccLd<xf32, D> {
-    // chunk-encoded tile: lane (g, q = r16 >> 2, pc = r16 & 3) addresses row r0 + 4g + q (and + 16), chunk (col0 / 4 + pc); the
-    // transposing read hands lane r16 column col0 + r16 of rows 4g..4g+3 -- from the hi halves (bytes 0-7) and the lo halves (8-15)
-    static __device__ __forceinline__ SplitF8 ld(const xf32* tile, int r0, int col0, int g, int r16) {
+    // fp16-pair tile: lane (g, q = r16 >> 2, pc = r16 & 3) addresses row r0 + 4g + q (and + 16), columns col0 + 4 pc .. + 3: half
+    // (pc & 1) of the hi chunk of group (col0 + 4 pc) / 8, and the same half of the lo chunk next to it; the transposing read hands
+    // lane r16 column col0 + r16 of rows 4g .. 4g + 3
+    static __device__ __forceinline__ SplitH8 ld(const xf32* tile, int r0, int col0, int g, int r16) {
         using Z = SwzTile<xf32, D>;
         const int q = r16 >> 2, pc = r16 & 3;
-        const char* a0 = reinterpret_cast<const char*>(tile + Z::off(r0 + 4 * g + q, col0 + 4 * pc));
-        const char* a1 = reinterpret_cast<const char*>(tile + Z::off(r0 + 16 + 4 * g + q, col0 + 4 * pc));
+        const int cg = (col0 + 4 * pc) & ~7, hb = (pc & 1) * 8;
+        const int ra = r0 + 4 * g + q, rb = ra + 16;
+        const char* a0 = reinterpret_cast<const char*>(tile + Z::off(ra, cg)) + hb;
+        const char* a1 = reinterpret_cast<const char*>(tile + Z::off(rb, cg)) + hb;
+        const char* l0 = reinterpret_cast<const char*>(tile + Z::off(ra, cg + 4)) + hb;
+        const char* l1 = reinterpret_cast<const char*>(tile + Z::off(rb, cg + 4)) + hb;
         const uint2 h0 = __builtin_bit_cast(uint2, LDS_TR16(a0)), h1 = __builtin_bit_cast(uint2, LDS_TR16(a1));
-        const uint2 l0 = __builtin_bit_cast(uint2, LDS_TR16(a0 + 8)), l1 = __builtin_bit_cast(uint2, LDS_TR16(a1 + 8));
-        SplitF8 r;
-        r.hi = __builtin_bit_cast(bf16x8, make_uint4(h0.x, h0.y, h1.x, h1.y));
-        r.lo = __builtin_bit_cast(bf16x8, make_uint4(l0.x, l0.y, l1.x, l1.y));
+        const uint2 w0 = __builtin_bit_cast(uint2, LDS_TR16(l0)), w1 = __builtin_bit_cast(uint2, LDS_TR16(l1));
+        SplitH8 r;
+        r.hi = __builtin_bit_cast(h16x8, make_uint4(h0.x, h0.y, h1.x, h1.y));
+        r.lo = __builtin_bit_cast(h16x8, make_uint4(w0.x, w0.y, w1.x, w1.y));
         return r;
     }
-    static __device__ __forceinline__ SplitF8 ones() {
-        const float v[8] = {1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f};
-        return mu_split8(v);
+    static __device__ __forceinline__ SplitH8 ones() {
+        SplitH8 r;
+        r.hi = (h16x8)(h16)1.0f;
+        r.lo = (h16x8)(h16)0;
+        return r;
     }
 };
 
@@ -504,7 +546,7 @@ __global__ __launch_bounds__(NW * 64, OCC ? OCC : ((NW == 4 && D <= 128 && std::
         if (qrow > N - 1) qrow = N - 1;
 #pragma unroll
         for (int ks = 0; ks < NKS; ++ks) {
-            qf[t][ks] = A::ld_scaled(qkv_b + (long)qrow * 3 * D + ks * KR + g * VN, scale_log2);
+            qf[t][ks] = A::ld_scaled(qkv_b + (long)qrow * 3 * D + ks * KR + g * A::GS, scale_log2);
         }
     }
     f32x4 o[NDT][NQ], lacc[NQ], negm[NQ];
@@ -544,7 +586,7 @@ __global__ __launch_bounds__(NW * 64, OCC ? OCC : ((NW == 4 && D <= 128 && std::
                 if (ks == 0)
                     for (int t = 0; t < NQ; ++t) { s[kt][t] = negm[t]; asm volatile("" : "+v"(s[kt][t])); }
 #else
-                Frag a = A::template ldt<Z>(Kt, kt * 16 + r16, ks * KR + g * VN);
+                Frag a = A::template ldt<Z>(Kt, kt * 16 + r16, ks * KR + g * A::GS);
 #pragma unroll
                 for (int t = 0; t < NQ; ++t) {
                     if (ks == 0) s[kt][t] = A::mma_row_from(a, qf[t][0], negm[t]);     // -m rides in as the C operand
@@ -621,7 +663,7 @@ __global__ __launch_bounds__(NW * 64, OCC ? OCC : ((NW == 4 && D <= 128 && std::
 #pragma unroll
         for (int h = 0; h < NH; ++h) {
 #pragma unroll
-            for (int t = 0; t < NQ; ++t) A::mma_acc(ones, s[2 * h][t], s[2 * h + 1][t], lacc[t]);
+            for (int t = 0; t < NQ; ++t) A::mma_ones(ones, s[2 * h][t], s[2 * h + 1][t], lacc[t]);
 #pragma unroll
             for (int dt = 0; dt < NDT; ++dt) {
                 typename A::AccA va;
@@ -639,11 +681,11 @@ __global__ __launch_bounds__(NW * 64, OCC ? OCC : ((NW == 4 && D <= 128 && std::
         MU_SYNC_DMA();        // tile j+1 landed (vmcnt(0)) and everyone is done reading tile j
 #endif
     };
-    // Optimistic sweep first (fp16 storage only): no per-tile running-max scan / cross-lane reduce / branch (13 % of the kernel at
+    // Optimistic sweep first (wherever P is an fp16 operand: fp16 storage and fp32x): no per-tile running-max scan / cross-lane reduce / branch (13 % of the kernel at
     // N = 16384, C = 64: a serial dependent chain between the score MFMAs and the exponentials).  A row whose later scores exceed the
     // first tile's maximum by more than 16 (log2 units) overflows fp16 and leaves an infinite row sum: the whole block then repeats
     // the sweep with exact tracking (wave-uniform decision through the barrier; never taken on the model's data, forced in the tests).
-    constexpr bool OPTIMISTIC = MU_FWD_OPTIMISTIC && sizeof(T) == 2;
+    constexpr bool OPTIMISTIC = MU_FWD_OPTIMISTIC && A::PK;
     bool redo = false;
     if (OPTIMISTIC) {
         for (int j0 = 0; j0 < Nk; j0 += 2 * KT) {
@@ -737,13 +779,16 @@ __global__ __launch_bounds__(256) void attn_ln_bwd_kernel(const T* __restrict__ 
                                                           const float* __restrict__ ln_mean, const float* __restrict__ ln_rstd,
                                                           const float* __restrict__ gamma, T* __restrict__ dY, float* __restrict__ delta,
                                                           double* __restrict__ part, long rows, const float* __restrict__ lse2,
-                                                          float* __restrict__ rowc, int N, float scale, int cv) {
+                                                          float* __restrict__ rowc, int N, float scale, int cv, float pshift,
+                                                          float* __restrict__ amax_part) {
+    // pshift / amax_part (fp32x only, 0 / NULL otherwise): the row constant -lse2 is stored as pshift - lse2 (the sweeps then compute
+    // 2^pshift P), and every block leaves max|dY| over its rows in amax_part[block] (-> the power-of-two scale of the encoded dY)
     // cv <= D: channels the LayerNorm really spans (channel counts that are not one of the kernels' widths run zero-padded to D)
     constexpr int VN = AT<T>::VN, LPR = D / VN, RPI = 256 / LPR;     // lanes per row, rows per block-iteration
     const int tid = threadIdx.x;
     const int lc = tid % LPR, lr = tid / LPR;
     const int c = lc * VN;
-    float ga[VN], dga[VN], dbe[VN];
+    float ga[VN], dga[VN], dbe[VN], am = 0.f;
 #pragma unroll
     for (int i = 0; i < VN; ++i) { ga[i] = gamma[c + i]; dga[i] = 0.f; dbe[i] = 0.f; }
     const long rows_per_blk = (rows + gridDim.x - 1) / gridDim.x;
@@ -773,6 +818,7 @@ __global__ __launch_bounds__(256) void attn_ln_bwd_kernel(const T* __restrict__ 
             const float d = (c + i < cv) ? rs * (gg[i] - a - xh[i] * bsum) : 0.f;
             dv.set(i, d);
             dl += dv.get(i) * ov.get(i);
+            if (ok) am = (d == d) ? fmaxf(am, fabsf(d)) : d;           // a NaN sticks (fmaxf would drop it)
             if (ok && c + i < cv) { dga[i] += gv.get(i) * xh[i]; dbe[i] += gv.get(i); }
         }
 #pragma unroll
@@ -786,7 +832,7 @@ __global__ __launch_bounds__(256) void attn_ln_bwd_kernel(const T* __restrict__ 
                 const int qn = (int)(r - bb * N);
                 const int ntile = (N + 31) >> 5;
                 float* rc = rowc + ((bb * ntile + (qn >> 5)) * 2) * 32 + (qn & 31);
-                rc[0] = -lse2[r];
+                rc[0] = pshift - lse2[r];
                 rc[32] = -dl * scale;
             }
         }
@@ -806,6 +852,19 @@ __global__ __launch_bounds__(256) void attn_ln_bwd_kernel(const T* __restrict__ 
         }
         part[((long)blockIdx.x * D + cc) * 2] = sa;
         part[((long)blockIdx.x * D + cc) * 2 + 1] = sb;
+    }
+    if (amax_part) {
+        __shared__ float wam[4];
+        const bool nan = __any(am != am);
+        am = nan ? __builtin_nanf("") : wave_max(am);
+        if ((tid & 63) == 0) wam[tid >> 6] = am;
+        __syncthreads();
+        if (tid == 0) {
+            float m = wam[0];
+#pragma unroll
+            for (int w = 1; w < 4; ++w) m = (m == m && wam[w] == wam[w]) ? fmaxf(m, wam[w]) : __builtin_nanf("");
+            amax_part[blockIdx.x] = m;
+        }
     }
 }
 
@@ -845,8 +904,26 @@ __global__ __launch_bounds__(256) void attn_ln_fwd_kernel(const T* __restrict__ 
     }
 }
 
-__global__ void attn_ln_bwd_final_kernel(const double* __restrict__ part, int nblk, int D, float* __restrict__ dgamma, float* __restrict__ dbeta) {
+// Power-of-two scale of the fp16-pair-encoded dY: gs * max|dY| in [2^-3, 2^-2).  Headroom: |dP'| = |gs (dO . V - delta) / sqrt(C)| <=
+// 2^-2 (sqrt(C) max|V| + ...), times 2^pshift P <= 2^12 -- dS overflows fp16 only where P ~ 1 meets |V| >~ 16 in every channel (and
+// then surfaces as inf / NaN gradients, never silently); typical values sit 10-20 binades above fp16's subnormal floor.
+__device__ __forceinline__ float attn_gscale_from_amax(float amax) {
+    if (!(amax == amax)) return amax;                        // NaN gradient: the scale is NaN and so is everything downstream
+    int e = (int)(__float_as_uint(amax) >> 23) - 127;        // floor(log2(amax)) for normal values; -127 for 0 / subnormals
+    e = e < -100 ? -100 : (e > 100 ? 100 : e);
+    return __uint_as_float((uint32_t)(127 - 3 - e) << 23);
+}
+__global__ void attn_ln_bwd_final_kernel(const double* __restrict__ part, int nblk, int D, float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                         const float* __restrict__ amax_part, float* __restrict__ gscale) {
     const int c = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (amax_part && c == 0) {                               // fp32x: max|dY| over the prepass blocks -> the scale of the encoded dY
+        float m = 0.f;
+        bool nan = false;
+        for (int k = lane; k < nblk; k += 64) { const float v = amax_part[k]; nan = nan || v != v; m = fmaxf(m, v); }
+        nan = __any(nan);
+        m = wave_max(m);
+        if (lane == 0) *gscale = attn_gscale_from_amax(nan ? __builtin_nanf("") : m);
+    }
     if (c >= D) return;
     double av[16], bv[16];           // nblk <= ATT_LN_MAXBLK = 1024: every load in flight before the first add (one L2 round trip, not 16)
 #pragma unroll
@@ -866,6 +943,54 @@ __global__ void attn_ln_bwd_final_kernel(const double* __restrict__ part, int nb
 
 
 
+// fp32x: dY -> the fp16-pair encoding of gs dY the two sweeps read (common.h), gs from attn_ln_bwd_final_kernel; the thread that owns a
+// row's first group also scales the row's -delta / sqrt(C) constant of the dK/dV sweep by gs (the dQ sweep scales delta itself).
+__global__ __launch_bounds__(256) void attn_dy_encode_kernel(const f32x4* __restrict__ dY, uint4* __restrict__ dYs, float* __restrict__ rowc,
+                                                             const float* __restrict__ gscale, long ngroups, int gpr, int N) {
+    const float gs = *gscale;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < ngroups; i += (long)gridDim.x * 256) {
+        const f32x4 a = __builtin_nontemporal_load(dY + 2 * i) * gs, b = __builtin_nontemporal_load(dY + 2 * i + 1) * gs;
+        const float v[8] = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+        const SplitH8 e = mu_hsplit8(v);
+        dYs[2 * i] = __builtin_bit_cast(uint4, e.hi);
+        dYs[2 * i + 1] = __builtin_bit_cast(uint4, e.lo);
+        if (i % gpr == 0) {
+            const long r = i / gpr, bb = r / N;
+            const int qn = (int)(r - bb * N), ntile = (N + 31) >> 5;
+            rowc[((bb * ntile + (qn >> 5)) * 2) * 32 + (qn & 31) + 32] *= gs;
+        }
+    }
+}
+
+// fp32x operand encoding of qkv (C ABI: mu_split_encode_h): n_elems fp32 values (a multiple of 8) -> [8 fp16 hi | 8 fp16 lo] per
+// aligned 32-byte group, in place or into dst
+__global__ __launch_bounds__(256) void split_encode_h_kernel(const f32x4* src, uint4* dst, long ngroups) {      // (may alias: no __restrict__)
+    const long stride = (long)gridDim.x * 256;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < ngroups; i += 2 * stride) {
+        f32x4 a[2], b[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+            if (i + u * stride < ngroups) { a[u] = __builtin_nontemporal_load(src + 2 * (i + u * stride)); b[u] = __builtin_nontemporal_load(src + 2 * (i + u * stride) + 1); }
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+            if (i + u * stride < ngroups) {
+                const float v[8] = {a[u][0], a[u][1], a[u][2], a[u][3], b[u][0], b[u][1], b[u][2], b[u][3]};
+                const SplitH8 e = mu_hsplit8(v);
+                dst[2 * (i + u * stride)] = __builtin_bit_cast(uint4, e.hi);
+                dst[2 * (i + u * stride) + 1] = __builtin_bit_cast(uint4, e.lo);
+            }
+    }
+}
+extern "C" int mu_split_encode_h(const void* src, void* dst, long n_elems, void* stream) {
+    if (!src || !dst || n_elems <= 0 || n_elems % 8) return MU_ERR_ARG;
+    const long ng = n_elems / 8;
+    long g = (ng + 511) / 512;
+    g = g < 1 ? 1 : (g > 8192 ? 8192 : g);
+    split_encode_h_kernel<<<(int)g, 256, 0, (hipStream_t)stream>>>((const f32x4*)src, (uint4*)dst, ng);
+    MU_CHECK_LAUNCH();
+    return MU_OK;
+}
+
 // ------------------------------------------------------------------------------------------
 // backward v2 kernels: LDS-DMA double-buffered tiles, swizzled images (see attn_fwd2_kernel)
 // ------------------------------------------------------------------------------------------
@@ -873,13 +998,21 @@ template <typename T, int D, int KT, int NW>
 __global__ __launch_bounds__(NW * 64, (NW == 4 && D <= 64 && std::is_same<T, xf32>::value) ? MU_XF_OCC : (NW == 4 && D <= 64 && sizeof(T) == 2) ? MU_DQ_OCC : ((NW == 4 && D == 128 && sizeof(T) == 2) ? MU_DQ_OCC128 : ((NW == 4 && D == 256 && sizeof(T) == 2) ? MU_DQ_OCC256 : 1))) void attn_bwd_dq2_kernel(const T* __restrict__ qkv, const T* __restrict__ dY, const int* __restrict__ kidx,
                                                            const int* __restrict__ kcnt, const float* __restrict__ lse2,
                                                            const float* __restrict__ delta, T* __restrict__ dqkv, int N, int nkmax,
-                                                           float scale, float scale_log2) {
+                                                           float scale, float scale_log2, const float* __restrict__ gsp, float pshift) {
     using A = AT<T>;
     using Frag = typename A::Frag;
     using Z = SwzTile<T, D>;
     constexpr int VN = A::VN, KR = A::KR, NKS = D / KR, NDT = D / 16, NKT = KT / 16, NH = KT / 32;
     constexpr bool MU_PRIO_BWD = true;
+    constexpr bool XF = std::is_same<T, xf32>::value;
     __shared__ __attribute__((aligned(16))) T lds[2 * 2 * KT * D];
+    // fp32x: dY arrives scaled by the power of two gs (attn_bwd_t), the probabilities are computed as 2^pshift P: dS -- ONE fp16 operand --
+    // then sits inside fp16's exponent range; the accumulators are un-scaled once, in the epilogue (exact: powers of two)
+    float gs = 1.0f, un = 1.0f;
+    if constexpr (XF) {
+        gs = *gsp;
+        un = 1.0f / (gs * exp2f(pshift));
+    }
 
     int bx_, b;
     attn_block(bx_, b);
@@ -906,10 +1039,10 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 && D <= 64 && std::is_same<T, xf3
         const long tok = (long)b * N + qrow;
 #pragma unroll
         for (int ks = 0; ks < NKS; ++ks) {
-            qf[t][ks] = A::ld_scaled(qkv_b + (long)qrow * 3 * D + ks * KR + g * VN, scale_log2);
-            dof[t][ks] = A::ld_scaled(dY + tok * D + ks * KR + g * VN, scale);
+            qf[t][ks] = A::ld_scaled(qkv_b + (long)qrow * 3 * D + ks * KR + g * A::GS, scale_log2);
+            dof[t][ks] = A::ld_scaled(dY + tok * D + ks * KR + g * A::GS, scale);
         }
-        const float l = -lse2[tok], d = -delta[tok] * scale;
+        const float l = (XF ? pshift : 0.f) - lse2[tok], d = -delta[tok] * scale * gs;
         nlse[t] = (f32x4){l, l, l, l};
         ndel[t] = (f32x4){d, d, d, d};
     }
@@ -935,8 +1068,8 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 && D <= 64 && std::is_same<T, xf3
         for (int ks = 0; ks < NKS; ++ks)
 #pragma unroll
             for (int kt = 0; kt < NKT; ++kt) {
-                Frag ka = A::template ldt<Z>(Kt, kt * 16 + r16, ks * KR + g * VN);
-                Frag va = A::template ldt<Z>(Vt, kt * 16 + r16, ks * KR + g * VN);
+                Frag ka = A::template ldt<Z>(Kt, kt * 16 + r16, ks * KR + g * A::GS);
+                Frag va = A::template ldt<Z>(Vt, kt * 16 + r16, ks * KR + g * A::GS);
 #pragma unroll
                 for (int t = 0; t < 2; ++t) {
                     if (ks == 0) {                            // row constants as the C operand of the first k-step (no copies)
@@ -1010,6 +1143,10 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 && D <= 64 && std::is_same<T, xf3
 #pragma unroll
         for (int dt = 0; dt < NDT; ++dt) {
             float v[4] = {dq[dt][t][0], dq[dt][t][1], dq[dt][t][2], dq[dt][t][3]};
+            if constexpr (XF) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] *= un;
+            }
             store4<T>(dst + dt * 16 + 4 * g, v);
         }
     }
@@ -1029,7 +1166,8 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 && D <= 64 && std::is_same<T, xf3
 template <typename T, int D, int NKT, int NW = 4>
 __global__ __launch_bounds__(NW * 64, NW >= 8 ? 1 : ((D <= 64 && std::is_same<T, xf32>::value) ? MU_XF_OCC : (D <= 64 && sizeof(T) == 2 && NKT <= 2) ? MU_DKV_OCC : ((D == 128 && sizeof(T) == 2 && NKT <= 2) ? MU_DKV_OCC128 : ((D == 256 && sizeof(T) == 2 && NKT == 1) ? MU_DKV_OCC256 : 1)))) void attn_bwd_dkv3_kernel(
     const T* __restrict__ qkv, const T* __restrict__ dY, const int* __restrict__ kidx, const int* __restrict__ kcnt,
-    const float* __restrict__ rowc, T* __restrict__ dqkv, int N, int nkmax, float scale, float scale_log2, int zero_masked) {
+    const float* __restrict__ rowc, T* __restrict__ dqkv, int N, int nkmax, float scale, float scale_log2, int zero_masked,
+    const float* __restrict__ gsp, float pshift) {
     using A = AT<T>;
     using Frag = typename A::Frag;
     using Z = SwzTile<T, D>;
@@ -1139,8 +1277,8 @@ __global__ __launch_bounds__(NW * 64, NW >= 8 ? 1 : ((D <= 64 && std::is_same<T,
         for (int ks = 0; ks < NKS; ++ks) {
             Frag fk = A::zero(), fv = A::zero();
             if (keyrow[kt] >= 0) {
-                fk = A::ld_scaled(qkv_b + (long)keyrow[kt] * 3 * D + D + ks * KR + g * VN, scale_log2);
-                fv = A::ld_scaled(qkv_b + (long)keyrow[kt] * 3 * D + 2 * D + ks * KR + g * VN, scale);
+                fk = A::ld_scaled(qkv_b + (long)keyrow[kt] * 3 * D + D + ks * KR + g * A::GS, scale_log2);
+                fv = A::ld_scaled(qkv_b + (long)keyrow[kt] * 3 * D + 2 * D + ks * KR + g * A::GS, scale);
             }
             kf[kt][ks] = fk;
             vf[kt][ks] = fv;
@@ -1151,6 +1289,11 @@ __global__ __launch_bounds__(NW * 64, NW >= 8 ? 1 : ((D <= 64 && std::is_same<T,
     for (int dt = 0; dt < NDT; ++dt)
 #pragma unroll
         for (int kt = 0; kt < NKT; ++kt) { dk[dt][kt] = (f32x4){0.f, 0.f, 0.f, 0.f}; dv[dt][kt] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+    float un = 1.0f;
+    if constexpr (std::is_same<T, xf32>::value) {
+        un = 1.0f / (*gsp * exp2f(pshift));
+        asm volatile("" : "+v"(un));                         // consumed HERE: no ordinary load may be pending under the counted waits below
+    }
     // the prologue's ordinary loads (kidx, K, V) are complete here: the frags were consumed by the scaling above
 
     auto tile = [&](auto SLOTC, int tl) {
@@ -1195,8 +1338,8 @@ __global__ __launch_bounds__(NW * 64, NW >= 8 ? 1 : ((D <= 64 && std::is_same<T,
         for (int ks = 0; ks < NKS; ++ks)
 #pragma unroll
             for (int qt = 0; qt < 2; ++qt) {
-                Frag qa = A::template ldt<Z>(Qt, qt * 16 + r16, ks * KR + g * VN);
-                Frag oa = A::template ldt<Z>(Ot, qt * 16 + r16, ks * KR + g * VN);
+                Frag qa = A::template ldt<Z>(Qt, qt * 16 + r16, ks * KR + g * A::GS);
+                Frag oa = A::template ldt<Z>(Ot, qt * 16 + r16, ks * KR + g * A::GS);
 #pragma unroll
                 for (int kt = 0; kt < NKT; ++kt) {
                     if (ks == 0) {                           // the row constants enter as the C operand of the first k-step
@@ -1236,9 +1379,10 @@ __global__ __launch_bounds__(NW * 64, NW >= 8 ? 1 : ((D <= 64 && std::is_same<T,
         // MU_DKV_PKMUL (fp16 storage): P and dP' are rounded to fp16 first -- both are fp16 MFMA operands' worth of precision anyway --
         // and dS = P * dP' is FOUR packed fp16 multiplies per 8 scores instead of 8 fp32 ones: 24 instead of 32 VALU instructions per
         // 32-query x 32-key tile behind the 16 exponentials (the sweep runs at MFMA + VALU issue time)
-        constexpr bool PKMUL = MU_DKV_PKMUL && sizeof(T) == 2;
+        // fp32x takes the same path (the row constants carry the power-of-two scales that keep P and dP' inside fp16's range: attn_bwd_t)
+        constexpr bool PKMUL = (MU_DKV_PKMUL && sizeof(T) == 2) || std::is_same<T, xf32>::value;
         if constexpr (PKMUL) {
-            typename AT<h16>::Packed pb[NKT], db[NKT];
+            typename A::Packed pb[NKT], db[NKT];
 #pragma unroll
             for (int qt = 0; qt < 2; ++qt)
 #pragma unroll
@@ -1247,20 +1391,20 @@ __global__ __launch_bounds__(NW * 64, NW >= 8 ? 1 : ((D <= 64 && std::is_same<T,
                     for (int r = 0; r < 4; ++r) s[qt][kt][r] = __builtin_amdgcn_exp2f(s[qt][kt][r]);
 #pragma unroll
             for (int kt = 0; kt < NKT; ++kt) {
-                pb[kt] = AT<h16>::pack(s[0][kt], s[1][kt]);
-                db[kt] = AT<h16>::pack(dp[0][kt], dp[1][kt]) * pb[kt];
+                pb[kt] = A::pack(s[0][kt], s[1][kt]);
+                db[kt] = A::pack(dp[0][kt], dp[1][kt]) * pb[kt];
             }
             if constexpr (PRE > 0) __builtin_amdgcn_sched_barrier(0);
             MU_PRIO(1);
 #pragma unroll
             for (int dt = 0; dt < NDT; ++dt) {
-                typename AT<h16>::AccA oa, qa;
+                typename A::AccA oa, qa;
                 if (dt < PRE) { oa = oap[dt]; qa = qap[dt]; }
-                else { oa = AccLd<h16, D>::ld((const h16*)Ot, 0, dt * 16, g, r16); qa = AccLd<h16, D>::ld((const h16*)Qt, 0, dt * 16, g, r16); }
+                else { oa = AccLd<T, D>::ld(Ot, 0, dt * 16, g, r16); qa = AccLd<T, D>::ld(Qt, 0, dt * 16, g, r16); }
 #pragma unroll
                 for (int kt = 0; kt < NKT; ++kt) {
-                    AT<h16>::mma_acc_pk(oa, pb[kt], dv[dt][kt]);
-                    AT<h16>::mma_acc_pk(qa, db[kt], dk[dt][kt]);
+                    A::mma_acc_pk(oa, pb[kt], dv[dt][kt]);
+                    A::mma_acc_pk(qa, db[kt], dk[dt][kt]);
                 }
             }
             MU_PRIO(0);
@@ -1318,6 +1462,10 @@ __global__ __launch_bounds__(NW * 64, NW >= 8 ? 1 : ((D <= 64 && std::is_same<T,
         for (int dt = 0; dt < NDT; ++dt) {
             float kv[4] = {dk[dt][kt][0], dk[dt][kt][1], dk[dt][kt][2], dk[dt][kt][3]};
             float vv[4] = {dv[dt][kt][0], dv[dt][kt][1], dv[dt][kt][2], dv[dt][kt][3]};
+            if constexpr (std::is_same<T, xf32>::value) {            // the sweep ran on gs dY and 2^pshift P (see attn_bwd_dq2_kernel)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { kv[r] *= un; vv[r] *= un; }
+            }
             if (!live) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) { kv[r] = 0.f; vv[r] = 0.f; }
@@ -1398,9 +1546,17 @@ extern "C" int mu_attn_fwd(const void* qkv, const void* x, const int* kidx, cons
 #define ATT_LN_MAXBLK 1024
 static inline long attn_ln_part_bytes(int C) { return (long)ATT_LN_MAXBLK * C * 2 * sizeof(double); }
 static inline long attn_rowc_bytes(int B, int N) { return (long)B * ((N + 31) / 32) * 64 * sizeof(float); }
-// LayerNorm partials | row constants of the dK/dV sweep | (MU_F32X) the chunk-encoded copy of dY the two sweeps read
+static inline long attn_amax_bytes() { return (long)(ATT_LN_MAXBLK + 64) * sizeof(float); }      // per-block max|dY| + the scale (fp32x)
+// the sweeps compute 2^pshift P (fp32x): typical probabilities ~1/N land near 1, P <= 1 stays below 2^12
+static inline float attn_pshift(int N) {
+    int j = 0;
+    while ((2 << j) <= N) ++j;                               // floor(log2(N))
+    j -= 2;
+    return (float)(j < 0 ? 0 : (j > 12 ? 12 : j));
+}
+// LayerNorm partials | max|dY| partials + scale | row constants of the dK/dV sweep | (MU_F32X) the fp16-pair-encoded copy of dY the two sweeps read
 extern "C" long mu_attn_bwd_workspace_bytes(int B, int N, int C) {
-    return attn_ln_part_bytes(C) + attn_rowc_bytes(B, N) + (long)B * N * C * (long)sizeof(float);
+    return attn_ln_part_bytes(C) + attn_amax_bytes() + attn_rowc_bytes(B, N) + (long)B * N * C * (long)sizeof(float);
 }
 
 template <typename T>
@@ -1409,7 +1565,11 @@ static int attn_bwd_t(const T* qkv, const T* x, const T* oattn, const T* gout, c
                       float* dbeta, int B, int N, int C, int cv, int nkmax, void* ws, hipStream_t st, int phases) {
     using TS = typename std::conditional<std::is_same<T, xf32>::value, float, T>::type;      // storage type for the LayerNorm prepass
     const long rows = (long)B * N;
-    float* rowc = (float*)((char*)ws + attn_ln_part_bytes(C));
+    float* amaxp = (float*)((char*)ws + attn_ln_part_bytes(C));
+    float* gsc = amaxp + ATT_LN_MAXBLK;
+    float* rowc = (float*)((char*)ws + attn_ln_part_bytes(C) + attn_amax_bytes());
+    constexpr bool XF = std::is_same<T, xf32>::value;
+    const float pshift = XF ? attn_pshift(N) : 0.f;
     int nblk = (int)(rows / 64 < 1 ? 1 : (rows / 64 > ATT_LN_MAXBLK ? ATT_LN_MAXBLK : rows / 64));
     const float scale = (float)(1.0 / sqrt((double)cv));
     const float sl2 = (float)(1.4426950408889634 / sqrt((double)cv));
@@ -1421,25 +1581,29 @@ static int attn_bwd_t(const T* qkv, const T* x, const T* oattn, const T* gout, c
     // fp32x: the sweeps take dY chunk-encoded like qkv (the caller encodes qkv; dY is produced here, by phase 1): its encoded copy
     // lives in the workspace behind the row constants, and `dYs` is what the sweeps read
     const T* dYs = dY;
-    if constexpr (std::is_same<T, xf32>::value) dYs = (const T*)((char*)ws + attn_ln_part_bytes(C) + attn_rowc_bytes(B, N));
+    if constexpr (XF) dYs = (const T*)((char*)ws + attn_ln_part_bytes(C) + attn_amax_bytes() + attn_rowc_bytes(B, N));
 #define LAUNCH_BWD(DD, NKT)                                                                                                     \
     if (phases & 1) {                                                                                                           \
-        attn_ln_bwd_kernel<TS, DD><<<nblk, 256, 0, st>>>((const TS*)gout, (const TS*)oattn, (const TS*)x, mean, rstd, gamma, (TS*)dY, delta, (double*)ws, rows, lse2, rowc, N, scale, cv); \
-        attn_ln_bwd_final_kernel<<<mu_cdiv(DD, 4), 256, 0, st>>>((const double*)ws, nblk, DD, dgamma, dbeta);                   \
-        if (dYs != dY && mu_split_encode(dY, (void*)dYs, rows * DD, st) != MU_OK) return MU_ERR_LAUNCH;                          \
+        attn_ln_bwd_kernel<TS, DD><<<nblk, 256, 0, st>>>((const TS*)gout, (const TS*)oattn, (const TS*)x, mean, rstd, gamma, (TS*)dY, delta, (double*)ws, rows, lse2, rowc, N, scale, cv, pshift, XF ? amaxp : nullptr); \
+        attn_ln_bwd_final_kernel<<<mu_cdiv(DD, 4), 256, 0, st>>>((const double*)ws, nblk, DD, dgamma, dbeta, XF ? amaxp : nullptr, gsc); \
+        if constexpr (XF) {                                                                                                     \
+            const long ng = rows * DD / 8;                                                                                      \
+            const long gr = (ng + 511) / 512;                                                                                   \
+            attn_dy_encode_kernel<<<(int)(gr < 1 ? 1 : (gr > 8192 ? 8192 : gr)), 256, 0, st>>>((const f32x4*)dY, (uint4*)dYs, rowc, gsc, ng, DD / 8, N); \
+        }                                                                                                                       \
     }                                                                                                                           \
-    if (phases & 2) attn_bwd_dq2_kernel<T, DD, KTQ, 4><<<gq, 256, 0, st>>>(qkv, dYs, kidx, kcnt, lse2, delta, dqkv, N, nkmax, scale, sl2); \
+    if (phases & 2) attn_bwd_dq2_kernel<T, DD, KTQ, 4><<<gq, 256, 0, st>>>(qkv, dYs, kidx, kcnt, lse2, delta, dqkv, N, nkmax, scale, sl2, gsc, pshift); \
     if (phases & 4) {                                                                                                           \
         if constexpr (sizeof(T) == 2 && DD == 64 && MU_DKV_NW64 != 4)                                                           \
-            attn_bwd_dkv3_kernel<T, DD, NKT, MU_DKV_NW64><<<dim3(mu_cdiv(nkmax, 16 * MU_DKV_NW64 * NKT), B), 64 * MU_DKV_NW64, 0, st>>>(qkv, dYs, kidx, kcnt, rowc, dqkv, N, nkmax, scale, sl2, zero_masked); \
+            attn_bwd_dkv3_kernel<T, DD, NKT, MU_DKV_NW64><<<dim3(mu_cdiv(nkmax, 16 * MU_DKV_NW64 * NKT), B), 64 * MU_DKV_NW64, 0, st>>>(qkv, dYs, kidx, kcnt, rowc, dqkv, N, nkmax, scale, sl2, zero_masked, gsc, pshift); \
         else if constexpr (sizeof(T) == 2 && DD == 128 && MU_DKV_NW128 != 4)                                                         \
-            attn_bwd_dkv3_kernel<T, DD, NKT, MU_DKV_NW128><<<dim3(mu_cdiv(nkmax, 16 * MU_DKV_NW128 * NKT), B), 64 * MU_DKV_NW128, 0, st>>>(qkv, dYs, kidx, kcnt, rowc, dqkv, N, nkmax, scale, sl2, zero_masked); \
+            attn_bwd_dkv3_kernel<T, DD, NKT, MU_DKV_NW128><<<dim3(mu_cdiv(nkmax, 16 * MU_DKV_NW128 * NKT), B), 64 * MU_DKV_NW128, 0, st>>>(qkv, dYs, kidx, kcnt, rowc, dqkv, N, nkmax, scale, sl2, zero_masked, gsc, pshift); \
         else if constexpr (std::is_same<T, xf32>::value && DD == 128 && MU_XF_DKV_NW128 != 4)                                    \
-            attn_bwd_dkv3_kernel<T, DD, NKT, MU_XF_DKV_NW128><<<dim3(mu_cdiv(nkmax, 16 * MU_XF_DKV_NW128 * NKT), B), 64 * MU_XF_DKV_NW128, 0, st>>>(qkv, dYs, kidx, kcnt, rowc, dqkv, N, nkmax, scale, sl2, zero_masked); \
+            attn_bwd_dkv3_kernel<T, DD, NKT, MU_XF_DKV_NW128><<<dim3(mu_cdiv(nkmax, 16 * MU_XF_DKV_NW128 * NKT), B), 64 * MU_XF_DKV_NW128, 0, st>>>(qkv, dYs, kidx, kcnt, rowc, dqkv, N, nkmax, scale, sl2, zero_masked, gsc, pshift); \
         else if constexpr (sizeof(T) == 2 && DD == 256 && MU_DKV_NW256 == 8)                                                    \
-            attn_bwd_dkv3_kernel<T, DD, NKT, 8><<<dim3(mu_cdiv(nkmax, 128 * NKT), B), 512, 0, st>>>(qkv, dYs, kidx, kcnt, rowc, dqkv, N, nkmax, scale, sl2, zero_masked); \
+            attn_bwd_dkv3_kernel<T, DD, NKT, 8><<<dim3(mu_cdiv(nkmax, 128 * NKT), B), 512, 0, st>>>(qkv, dYs, kidx, kcnt, rowc, dqkv, N, nkmax, scale, sl2, zero_masked, gsc, pshift); \
         else                                                                                                                    \
-            attn_bwd_dkv3_kernel<T, DD, NKT><<<dim3(mu_cdiv(nkmax, 64 * NKT), B), 256, 0, st>>>(qkv, dYs, kidx, kcnt, rowc, dqkv, N, nkmax, scale, sl2, zero_masked); \
+            attn_bwd_dkv3_kernel<T, DD, NKT><<<dim3(mu_cdiv(nkmax, 64 * NKT), B), 256, 0, st>>>(qkv, dYs, kidx, kcnt, rowc, dqkv, N, nkmax, scale, sl2, zero_masked, gsc, pshift); \
     }
     if (N % 4) return MU_ERR_SHAPE;
     switch (C) {

@@ -105,6 +105,43 @@ __device__ __forceinline__ void mu_mma_split(const SplitF8& a, const SplitF8& b,
     c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.hi, b.hi, c, 0, 0, 0);
 }
 
+// ------------------------------------------------------------------------------------------
+// fp16-pair encoding of the ATTENTION operands in the fp32x mode (round 5): every aligned 32-byte group of eight fp32 values is
+//     [hi0 .. hi7 | lo0 .. lo7]      (fp16 each: bytes 0-15 the hi parts, bytes 16-31 the lo parts)
+// with hi = fp16_rne(s x), lo = fp16_rne(s x - hi) and s a power of two (1 for qkv; chosen from max|dY| for the gradient so that
+// the tiny values of a backward pass sit inside fp16's exponent range).  hi + lo carries 22 mantissa bits (bf16 pairs: 16) down to
+// an absolute floor of 2^-25, and -- the point of it -- the softmax probabilities P and dS = P o (dP - delta) can then enter the
+// matrix core as ONE fp16 operand straight from the accumulators, as in the fp16 kernels: P V, dV = P^T dO, dK = dS^T Q and
+// dQ = dS K are two fp16 MFMAs per product (P x hi, P x lo) instead of three bf16 ones, and the ~50 VALU instructions per 32 x 32 tile
+// that split P / dS in registers are gone.  Q K^T and dO V^T keep three terms (lo x hi + hi x lo + hi x hi).  Sizing on the CPU
+// oracle (tools/numerics_attn_single_term.py, the reference's own golden unet1_c150_b2_train): outputs 2.0e-5, worst parameter
+// gradient 5.9e-3 against gates of 1e-3 / 5e-2.  |s x| must stay below 65504 (a larger value encodes as inf and surfaces as NaN).
+// A 32-byte group = two 16-byte LDS-DMA pieces, so strides, pieces and tile shapes of the fp32 kernels are untouched.
+// ------------------------------------------------------------------------------------------
+struct SplitH8 { h16x8 hi, lo; };
+typedef h16 h16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void mu_hsplit2(float x0, float x1, uint32_t& hi, uint32_t& lo) {
+    const h16x2 h = {(h16)x0, (h16)x1};
+    hi = __builtin_bit_cast(uint32_t, h);
+    const h16x2 l = {(h16)(x0 - (float)h[0]), (h16)(x1 - (float)h[1])};
+    lo = __builtin_bit_cast(uint32_t, l);
+}
+__device__ __forceinline__ SplitH8 mu_hsplit8(const float (&x)[8]) {
+    uint4 h, l;
+    mu_hsplit2(x[0], x[1], h.x, l.x);
+    mu_hsplit2(x[2], x[3], h.y, l.y);
+    mu_hsplit2(x[4], x[5], h.z, l.z);
+    mu_hsplit2(x[6], x[7], h.w, l.w);
+    SplitH8 r;
+    r.hi = __builtin_bit_cast(h16x8, h);
+    r.lo = __builtin_bit_cast(h16x8, l);
+    return r;
+}
+__device__ __forceinline__ void mu_hdec8(const SplitH8& e, float (&x)[8]) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) x[i] = (float)e.hi[i] + (float)e.lo[i];
+}
+
 // 16-byte vector of T: 8 halves or 4 floats.
 template <typename T> struct Vec16;
 template <> struct Vec16<float> {

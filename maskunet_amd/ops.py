@@ -51,6 +51,14 @@ def _enc_(t):
     return t
 
 
+def _enc_h_(t):
+    """fp32x: the ATTENTION operand encoding ([8 fp16 hi | 8 fp16 lo] per eight fp32 values, include/maskunet_hip.h), in place -- qkv,
+    which only the attention sweeps ever read."""
+    if _is_x(t):
+        call("mu_split_encode_h", ptr(t), ptr(t), t.numel(), stream())
+    return t
+
+
 class GradLink:
     """Side channel for ONE gradient tensor between two autograd nodes of one backward pass.
 
@@ -983,7 +991,7 @@ class _MaskAttention(torch.autograd.Function):
         else:
             bqkv, (wprep, wd_) = make_qkv()
         ctx.wd = wd_ if ctx.needs_input_grad[0] else None
-        qkv = _enc_(_conv_raw(x, wprep, bqkv, 3 * C, 1))               # [B,H,W,3C] == [B,N,3C]; fp32x: chunk-encoded from here on (only the
+        qkv = _enc_h_(_conv_raw(x, wprep, bqkv, 3 * C, 1))             # [B,H,W,3C] == [B,N,3C]; fp32x: fp16-pair-encoded from here on (only the
         # attention sweeps, forward and backward, ever read it)
         out = torch.empty((B, N, C), dtype=x.dtype, device=x.device)
         oattn = torch.empty_like(out)

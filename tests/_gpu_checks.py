@@ -421,11 +421,13 @@ def check_attention(dtype, cases=None):
     return out
 
 
-def check_attention_overflow_redo(dtype):
+def check_attention_overflow_redo(dtype, fp32x=False, hot=True, gout_scale=1.0):
     """The forward's optimistic sweep (no per-tile running-max tracking, attn.hip) must detect a late score that overflows fp16
     against the first tile's maximum and redo the block exactly (cdna guide rule 26: force the rare branch, full-tensor fp64
     reference).  A kept key far down the list is aligned with a few queries so that its score exceeds every earlier one by ~35 log2
-    units; forward (out, PV/l, lse2) and the backward that consumes lse2 are compared with fp64 torch."""
+    units; forward (out, PV/l, lse2) and the backward that consumes lse2 are compared with fp64 torch.
+    fp32x=True: the MU_F32X entry points on fp16-pair-encoded qkv (mu_split_encode_h); hot=False: no aligned key (plain C-ABI parity
+    run); gout_scale: magnitude of the incoming gradient."""
     from maskunet_amd import _lib
     B, N, C = 2, 1024, 64
     g_ = torch.Generator().manual_seed(77)
@@ -434,7 +436,7 @@ def check_attention_overflow_redo(dtype):
     keep = torch.randint(0, 2, (B, N), generator=g_, dtype=torch.uint8)
     keep[:, 900] = 1
     hot_q = [3, 200, 777]
-    for b in range(B):
+    for b in range(B if hot else 0):
         for i in hot_q:
             qkv[b, i, :C] = qkv[b, i, :C] * (8.0 / qkv[b, i, :C].norm())
         qkv[b, 900, C:2 * C] = 3.5 * qkv[b, 3, :C] + 3.5 * qkv[b, 200, :C] + 3.5 * qkv[b, 777, :C]     # key 900: late in the kept list
@@ -442,7 +444,7 @@ def check_attention_overflow_redo(dtype):
     x = x.to(dtype)
     gam = torch.rand(C, generator=g_) + 0.5
     bet = torch.randn(C, generator=g_) * 0.1
-    gout = torch.randn(B, N, C, generator=g_).to(dtype)
+    gout = (torch.randn(B, N, C, generator=g_) * gout_scale).to(dtype)
     # fp64 reference
     qr = qkv.double().clone().requires_grad_(True)
     xr = x.double().clone().requires_grad_(True)
@@ -462,21 +464,29 @@ def check_attention_overflow_redo(dtype):
     lse = torch.empty(B, N, device=d)
     mean, rstd, delta = torch.empty_like(lse), torch.empty_like(lse), torch.empty_like(lse)
     st = _lib.stream()
+    cdt = _lib.MU_F32X if fp32x else _lib.dt(xd)
+    if fp32x:
+        _lib.call("mu_split_encode_h", qd.data_ptr(), qd.data_ptr(), qd.numel(), st)
     _lib.call("mu_attn_fwd", qd.data_ptr(), xd.data_ptr(), kidx.data_ptr(), kcnt.data_ptr(), gd.data_ptr(), bd.data_ptr(), out.data_ptr(),
-              oattn.data_ptr(), lse.data_ptr(), mean.data_ptr(), rstd.data_ptr(), B, N, C, N, 1e-5, _lib.dt(xd), st)
+              oattn.data_ptr(), lse.data_ptr(), mean.data_ptr(), rstd.data_ptr(), B, N, C, N, 1e-5, cdt, st)
     dY, dqkv = torch.empty_like(xd), torch.empty_like(qd)
     dg, db = torch.empty(C, device=d), torch.empty(C, device=d)
     ws = _lib.workspace(_lib.load().mu_attn_bwd_workspace_bytes(B, N, C), torch.device(d))
     go = gout.to(d)
     _lib.call("mu_attn_bwd", qd.data_ptr(), xd.data_ptr(), oattn.data_ptr(), go.data_ptr(), kidx.data_ptr(), kcnt.data_ptr(), lse.data_ptr(),
               mean.data_ptr(), rstd.data_ptr(), gd.data_ptr(), dY.data_ptr(), delta.data_ptr(), dqkv.data_ptr(), dg.data_ptr(), db.data_ptr(),
-              B, N, C, N, ws.data_ptr(), ws.numel(), _lib.dt(xd), st)
+              B, N, C, N, ws.data_ptr(), ws.numel(), cdt, st)
     tol = TOL[dtype]
-    hot = float(sc[0, 3, 900].detach() * 1.4426950408889634 - lse_ref[0, 3].detach())      # ~0: key 900 dominates row 3
-    return [("attn overflow-redo out", _err(out, ref.detach()), tol), ("attn overflow-redo PV", _err(oattn, pv.detach()), tol),
-            ("attn overflow-redo lse2", _err(lse, lse_ref.detach()), tol),
-            ("attn overflow-redo hot key dominates", abs(hot), 0.5),
-            ("attn overflow-redo dqkv", _rel_err(dqkv, qr.grad), tol)]
+    res = [("attn overflow-redo out", _err(out, ref.detach()), tol), ("attn overflow-redo PV", _err(oattn, pv.detach()), tol),
+           ("attn overflow-redo lse2", _err(lse, lse_ref.detach()), tol),
+           ("attn overflow-redo dqkv", _rel_err(dqkv, qr.grad), tol),
+           ("attn overflow-redo dq", _rel_err(dqkv[..., :C], qr.grad[..., :C]), tol),
+           ("attn overflow-redo dk", _rel_err(dqkv[..., C:2 * C], qr.grad[..., C:2 * C]), tol),
+           ("attn overflow-redo dv", _rel_err(dqkv[..., 2 * C:], qr.grad[..., 2 * C:]), tol)]
+    if hot:
+        hotv = float(sc[0, 3, 900].detach() * 1.4426950408889634 - lse_ref[0, 3].detach())      # ~0: key 900 dominates row 3
+        res.append(("attn overflow-redo hot key dominates", abs(hotv), 0.5))
+    return res
 
 
 def check_attention_mask_semantics():

@@ -41,9 +41,14 @@ def main():
         out = torch.empty_like(x); oattn = torch.empty_like(x); lse = torch.empty(B, N, device=dev); mean = torch.empty_like(lse); rstd = torch.empty_like(lse)
         dY = torch.empty_like(x); dqkv = torch.empty_like(qkv); delta = torch.empty_like(lse); dg = torch.empty(C, device=dev); db = torch.empty(C, device=dev)
         gout = torch.randn_like(x)
-        if XF: _lib.call("mu_split_encode", qkv.data_ptr(), qkv.data_ptr(), qkv.numel(), st)
-        ws = torch.empty(_lib.load().mu_attn_bwd_workspace_bytes(B, N, C), dtype=torch.uint8, device=dev)
-        def mk(lib, phase):
+        qkv_h = qkv
+        if XF:          # round-5 libraries read qkv as fp16 pairs (mu_split_encode_h), round-4 ones as bf16 chunks (mu_split_encode)
+            qkv_h = qkv.clone()
+            _lib.call("mu_split_encode_h", qkv_h.data_ptr(), qkv_h.data_ptr(), qkv_h.numel(), st)
+            _lib.call("mu_split_encode", qkv.data_ptr(), qkv.data_ptr(), qkv.numel(), st)
+        ws = torch.empty(max(l.mu_attn_bwd_workspace_bytes(B, N, C) for l in libs.values()), dtype=torch.uint8, device=dev)
+        def mk(lib, phase, qkv_b=qkv):
+            qkv = qkv_h if hasattr(lib, "mu_split_encode_h") else qkv_b
             if phase == 0:
                 return lambda: lib.mu_attn_fwd(qkv.data_ptr(), x.data_ptr(), kidx.data_ptr(), kcnt.data_ptr(), g.data_ptr(), b_.data_ptr(), out.data_ptr(), oattn.data_ptr(), lse.data_ptr(), mean.data_ptr(), rstd.data_ptr(), B, N, C, N, 1e-5, code, st)
             return lambda: lib.mu_attn_bwd_phases(qkv.data_ptr(), x.data_ptr(), oattn.data_ptr(), gout.data_ptr(), kidx.data_ptr(), kcnt.data_ptr(), lse.data_ptr(), mean.data_ptr(), rstd.data_ptr(), g.data_ptr(), dY.data_ptr(), delta.data_ptr(), dqkv.data_ptr(), dg.data_ptr(), db.data_ptr(), B, N, C, N, ws.data_ptr(), ws.numel(), code, phase, st)

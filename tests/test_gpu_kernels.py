@@ -182,3 +182,42 @@ def test_split_encode_is_a_per_chunk_hi_lo_rewrite():
     assert torch.equal(y.view(torch.int32), e.view(torch.int32))
     with pytest.raises(RuntimeError, match="MU_ERR_ARG"):
         _lib.call("mu_split_encode", x.data_ptr(), e.data_ptr(), 6, _lib.stream())         # not whole chunks
+
+
+def test_split_encode_h_is_a_per_group_fp16_hi_lo_rewrite():
+    """mu_split_encode_h through the C ABI (the fp32x ATTENTION operand encoding): every aligned 32-byte group of eight fp32 values becomes
+    [8 fp16 hi | 8 fp16 lo] with hi = fp16_rne(x), lo = fp16_rne(x - hi); hi + lo reproduces x to 2^-21 relative or 2^-25 absolute (fp16's
+    subnormal floor), in place too."""
+    from maskunet_amd import _lib
+    g = torch.Generator(device="cuda").manual_seed(5)
+    x = torch.randn(8192, device="cuda", generator=g) * torch.logspace(-4, 3, 8192, device="cuda")
+    x[:8] = torch.tensor([0.0, -0.0, 1.0, -1.0, 65504.0, -65504.0, 1e-9, 2.0 ** -24], device="cuda")
+    e = torch.empty_like(x)
+    _lib.call("mu_split_encode_h", x.data_ptr(), e.data_ptr(), x.numel(), _lib.stream())
+    h = e.view(torch.float16).view(-1, 16)
+    hi, lo = h[:, :8].reshape(-1).float(), h[:, 8:].reshape(-1).float()
+    assert torch.equal(hi, x.half().float())
+    assert torch.equal(lo, (x - hi).half().float())
+    err = (hi.double() + lo.double() - x.double()).abs()
+    assert bool((err <= torch.maximum(x.double().abs() * 2.0 ** -21, torch.tensor(2.0 ** -25, device="cuda", dtype=torch.float64))).all())
+    y = x.clone()
+    _lib.call("mu_split_encode_h", y.data_ptr(), y.data_ptr(), y.numel(), _lib.stream())     # in place
+    assert torch.equal(y.view(torch.int32), e.view(torch.int32))
+    with pytest.raises(RuntimeError, match="MU_ERR_ARG"):
+        _lib.call("mu_split_encode_h", x.data_ptr(), e.data_ptr(), 12, _lib.stream())         # not whole groups
+
+
+def test_attention_overflow_redo_fp32x():
+    """fp32x: P is an fp16 operand like in the fp16 kernels, so the forward runs the optimistic sweep too -- force its redo."""
+    from tests import _gpu_checks as G
+    _assert_all(G.check_attention_overflow_redo(torch.float32, fp32x=True))
+
+
+@pytest.mark.parametrize("gscale", [1e-9, 1.0, 3e5])
+def test_attention_fp32x_backward_is_invariant_to_the_gradient_magnitude(gscale):
+    """fp32x backward: dY travels as fp16 pairs scaled by a power of two chosen from max|dY| on the device, dS as ONE fp16 operand scaled
+    by 2^pshift -- the relative error of dqkv must not depend on how large the incoming gradient is (1e-9: the magnitude of a mean-reduced
+    loss over 10^6 pixels; without the scale everything underflows fp16)."""
+    from tests import _gpu_checks as G
+    _assert_all(G.check_attention_overflow_redo(torch.float32, fp32x=True, hot=False, gout_scale=gscale))
+
