@@ -35,15 +35,22 @@ import torch.nn.functional as F
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-# dense, MI355X_MICROARCH.md; fp32x = fp32 storage with every product as THREE bf16 MFMAs on (hi, lo) operand splits: a third of the bf16 peak
-PEAK_MFMA_TFLOPS = {"fp16": 2500.0, "fp32": 157.3, "fp32x": 2500.0 / 3.0}
+# dense, MI355X_MICROARCH.md.  fp32x = fp32 storage, every matrix product evaluated as several 16-bit MFMAs on (hi, lo) operand splits:
+# three per product in the convolutions and in Q K^T / dO V^T, two where the softmax P / dS enters as a single fp16 operand.  The fp32x
+# `peak` is the dense 16-bit peak; `achieved` counts the MFMA FLOPs the kernel ISSUES (useful FLOPs x terms, TERMS below), so `frac` is
+# a matrix-pipe utilisation like the fp16 line's; the useful rate is carried next to it.
+PEAK_MFMA_TFLOPS = {"fp16": 2500.0, "fp32": 157.3, "fp32x": 2500.0}
 PEAK_HBM_GBS = 8000.0
 DOMINANT_KERNEL = "attn_bwd_dkv3_kernel"
+# the three sweeps of one attention block: products per (query, key) pair [each 2*C FLOP] and, for fp32x, 16-bit MFMA terms per product
+SWEEPS = {"fwd": {"kernel": "attn_fwd2_kernel", "products": 2, "terms_fp32x": (3, 2)},                  # S = Q K^T, O = P V
+          "dq": {"kernel": "attn_bwd_dq2_kernel", "products": 3, "terms_fp32x": (3, 3, 2)},             # S, dP = dO V^T, dQ = dS K
+          "dkv": {"kernel": "attn_bwd_dkv3_kernel", "products": 4, "terms_fp32x": (3, 3, 2, 2)}}        # S, dP, dV = P^T dO, dK = dS^T Q
 REF_CLOCK_MHZ = 1900.0       # convention for `clock.ms_per_step_at_ref_clock` (about what the pool's boxes hold in the MFMA probe)
-MFMA_SHARE = 0.8             # share of the step spent in MFMA-bound kernels (attention, conv, weight-grad: 23.5 of 29.5 ms)
-# PMC traffic of the dominant kernel per workload shape (key: b{batch}_c{c_out}_hw{hw}_{dtype}[_3head]); see profiles/README.md
-TRAFFIC_JSON = {k: f"r04_dkv_traffic_{k}.json" for k in ("b64_c150_hw128_fp16", "b128_c133_hw128_fp16", "b64_c19_hw128_fp16_3head",
-                                                          "b32_c133_hw256_fp16", "b64_c150_hw128_fp32", "b64_c150_hw128_fp32x")}
+# share of the step spent in MFMA-bound kernels (attention, conv, weight-grad: 23.5 of 29.5 ms, profiles/r04_kernel_time_split.txt) --
+# measured on the configs[1] fp16 line ONLY, so `ms_per_step_at_ref_clock` is emitted for that configuration only
+MFMA_SHARE = 0.8
+# PMC traffic of the dominant kernel per workload shape: profiles/r0N_dkv_traffic_b{batch}_c{c_out}_hw{hw}_{dtype}[_3head].json (load_traffic)
 DATASET_BY_COUT = {150: "ADE20K-semantic", 151: "ADE20K-semantic", 133: "COCO-panoptic", 19: "Cityscapes", 81: "COCO-instance"}
 
 
@@ -131,63 +138,70 @@ def cpu_baseline(c_out, hw, B=4, iters=3, budget_s=150.0):
 
 
 class SmiSampler:
-    """sclk / board power of the benched GPU from sysfs, sampled by a helper thread over the timed region (context for the bench
-    line only: MI355X_MICROARCH.md warns that pp_dpm_sclk reads up to ~10 % above the in-kernel clock of an MFMA-dense loop, which
-    is what `clock_probe` below measures).  Every field is None where the box does not expose the file to an ordinary user."""
+    """Board power rails of the benched GPU from sysfs hwmon, sampled by a helper thread over the timed region -- context only: the
+    clock figure of the line is `clock_mhz` from in-kernel stamps (MI355X_MICROARCH.md: sysfs sclk reads up to ~10 % off an MFMA-dense
+    loop's clock, and on this pool 95-2300 MHz for one load).  The sysfs node is found through the benched device's PCI address
+    (never by list position: `card10` sorts before `card2`, and render-only nodes shift the index); EVERY power*_average / power*_input
+    rail is reported with its label, because a single rail is not the board (round 4 reported one rail: 254 W for a saturated part).
+    Rank 0 only.  All fields None / empty where the box does not expose the files to an ordinary user."""
 
-    def __init__(self, index, period=0.05):
+    def __init__(self, dev, period=0.05):
         import glob
         import threading
-        cards = sorted(d for d in glob.glob("/sys/class/drm/card[0-9]*/device") if os.path.exists(os.path.join(d, "pp_dpm_sclk")))
-        self.dev = cards[index] if index < len(cards) else (cards[0] if cards else None)
-        self.power_file = None
+        self.dev = self.pci = None
+        self.rails = []                                           # (label, path)
+        try:
+            pr = torch.cuda.get_device_properties(dev)
+            dom, bus, dv = getattr(pr, "pci_domain_id", None), getattr(pr, "pci_bus_id", None), getattr(pr, "pci_device_id", None)
+            if bus is not None and dv is not None:
+                self.pci = f"{dom or 0:04x}:{bus:02x}:{dv:02x}.0"
+        except Exception:
+            pass
+        if self.pci:
+            for d in glob.glob("/sys/class/drm/card[0-9]*/device"):
+                try:
+                    if os.path.basename(os.path.realpath(d)).lower() == self.pci:
+                        self.dev = d
+                        break
+                except OSError:
+                    pass
         if self.dev:
-            import glob as g2
-            for name in ("power1_average", "power1_input"):
-                hits = g2.glob(os.path.join(self.dev, "hwmon", "hwmon*", name))
-                if hits:
-                    self.power_file = hits[0]
-                    break
-        self.period, self.sclk, self.power = period, [], []
+            for f in sorted(glob.glob(os.path.join(self.dev, "hwmon", "hwmon*", "power*_average")) +
+                            glob.glob(os.path.join(self.dev, "hwmon", "hwmon*", "power*_input"))):
+                lab = f.rsplit("_", 1)[0] + "_label"
+                try:
+                    name = open(lab).read().strip()
+                except OSError:
+                    name = ""
+                self.rails.append((f"{os.path.basename(f)}{' (' + name + ')' if name else ''}", f))
+        self.period = period
+        self.samples = {lab: [] for lab, _ in self.rails}
         self._stop = threading.Event()
         self._th = threading.Thread(target=self._run, daemon=True)
 
     def _run(self):
-        import glob
-        freq = glob.glob(os.path.join(self.dev, "hwmon", "hwmon*", "freq1_input")) if self.dev else []
         while not self._stop.is_set():
-            try:
-                if freq:                                         # hwmon sclk in Hz (pp_dpm_sclk's starred level read 95 MHz under load on one box)
-                    self.sclk.append(float(open(freq[0]).read()) * 1e-6)
-                else:
-                    for ln in open(os.path.join(self.dev, "pp_dpm_sclk")):
-                        if ln.rstrip().endswith("*"):
-                            self.sclk.append(float(ln.split(":")[1].strip().lower().split("mhz")[0]))
-            except (OSError, ValueError, IndexError):
-                pass
-            try:
-                if self.power_file:
-                    self.power.append(float(open(self.power_file).read()) * 1e-6)
-            except (OSError, ValueError):
-                pass
+            for lab, f in self.rails:
+                try:
+                    self.samples[lab].append(float(open(f).read()) * 1e-6)
+                except (OSError, ValueError):
+                    pass
             self._stop.wait(self.period)
 
     def __enter__(self):
-        if self.dev:
+        if self.rails:
             self._th.start()
         return self
 
     def __exit__(self, *exc):
         self._stop.set()
-        if self.dev:
+        if self.rails:
             self._th.join(timeout=1.0)
 
     def summary(self):
-        def mean(v):
-            return round(sum(v) / len(v), 1) if v else None
-        # (the sysfs sclk files are not reported: on this pool pp_dpm_sclk / hwmon freq1_input read 95-2300 MHz for the same load --
-        # `clock_mhz` from the in-kernel stamps is the clock figure of the line)
-        return {"power_w": mean(self.power), "samples": len(self.power), "source": self.power_file}
+        return {"pci": self.pci, "power_rails_w": {lab: (round(sum(v) / len(v), 1) if v else None) for lab, v in self.samples.items()},
+                "samples": max([len(v) for v in self.samples.values()] or [0]),
+                "note": "hwmon rails of the benched device, mean over the timed region; context only -- not used for any normalisation"}
 
 
 def clock_probe(dev, seconds=0.5, iters=16384):
@@ -217,7 +231,7 @@ def clock_probe(dev, seconds=0.5, iters=16384):
                       "100 MHz * d(s_memtime)/d(s_memrealtime), median over CUs of the last 4 sampled launches"}
 
 
-def parity_gate(args, dtype):
+def parity_gate(args, dtype, dtype_name=None):
     """The B = 2 whole-model golden (generated from the reference's own classes, tests/golden/make_golden.py) run once through the
     timed dtype BEFORE the timed region: which parity gate the benched path passes, in the bench line itself.  Checker only."""
     name = "unet3_c19_b2_train" if args.three_head else {150: "unet1_c150_b2_train", 133: "unet1_c133_b2_train"}.get(args.c_out)
@@ -235,20 +249,96 @@ def parity_gate(args, dtype):
     gates = {"out": G.TOL[dtype], "loss": G.TOL[dtype], "grad_maxnorm_worst_param": max(t for n, e, t in res if "worst grad" in n),
              "grad_1_minus_cos_per_param (tests/test_gpu_modules.py, vs the live oracle)": 1e-4 if dtype == torch.float32 else 2e-2}
     return {"fixture": f"tests/golden/{name}.npz (outputs / loss / gradients of the reference's own UNet, B=2, train mode)",
-            "dtype": {"fp16": "f16", "fp32": "f32", "fp32x": "f32 storage, bf16x3 split products"}[args.dtype], "gate": gates,
+            "dtype": {"fp16": "f16", "fp32": "f32", "fp32x": "f32 storage, split 16-bit products"}[dtype_name or args.dtype], "gate": gates,
             "observed": {k: float(f"{v:.3g}") for k, v in obs.items()}, "passed": all(e <= t for _, e, t in res),
             "north_star_gate": "1e-3 (fp32 outputs): met by --dtype fp32 (observed ~1e-5) and --dtype fp32x, not by the fp16-storage path timed here"
                                if dtype == torch.float16 else "1e-3 (fp32 outputs)"}
 
 
-def fp32x_side_line(args, dev, steps=3):
-    """The same workload in the fp32x mode (fp32 storage, split-bf16 matrix products: the fastest path under north_star's 1e-3 gate), a
-    few steps AFTER the timed region of the line's own dtype -- so that the record carries the parity-grade throughput next to the
-    benchmarked one.  Not `value`; a side measurement."""
+def attention_probe(hw):
+    """_lib.PROBE predicate: HIP events around the three sweeps of self_attention6 (N = hw * hw, C = 64), tagged fwd / dq / dkv.
+    mu_attn_fwd(qkv, x, kidx, kcnt, gamma, beta, out, oattn, lse2, mean, rstd, B, N, C, ...): args[12] = N;
+    mu_attn_bwd_phases(..., B, N, C, nkmax, ws, ws_bytes, dtype, phases, stream): args[16] = N, args[22] = phases."""
+    N6 = hw * hw
+
+    def pred(name, a):
+        if name == "mu_attn_fwd" and a[12] == N6:
+            return "fwd"
+        if name == "mu_attn_bwd_phases" and a[16] == N6:
+            return {2: "dq", 4: "dkv"}.get(a[22] & 7, False)
+        return False
+    return pred
+
+
+def sweep_rooflines(dtype_name, events, hw, batch, kept, clk, traffic=None, traffic_source=None):
+    """`roofline` (the dominant kernel: the dK/dV sweep of self_attention6) and `roofline.kernels` (all three sweeps of that block, each
+    with its own executed-FLOP fraction, so that the WEAKEST sweep is visible, not only the longest) from the HIP-event durations."""
+    N6, C6 = hw * hw, 64
+    peak = PEAK_MFMA_TFLOPS[dtype_name]
+    esz = 2 if dtype_name == "fp16" else 4
+    out = {}
+    for tag, sw in SWEEPS.items():
+        durs = [e0.elapsed_time(e1) * 1e-3 for t, e0, e1 in events if t == tag]
+        if not durs:
+            continue
+        tk = sum(durs) / len(durs)
+        useful_full = 2.0 * sw["products"] * N6 * N6 * C6 * batch            # SURVEY 8-d4: the full key set
+        useful = useful_full * kept                                          # executed: masked keys are skipped exactly
+        issued = useful * (sum(sw["terms_fp32x"]) / sw["products"] if dtype_name == "fp32x" else 1.0)
+        ach = issued / tk / 1e12
+        out[tag] = {"kernel": sw["kernel"], "ms_per_launch": round(tk * 1e3, 3), "launches_timed": len(durs),
+                    "achieved": round(ach, 2), "frac": round(ach / peak, 4),
+                    "frac_at_measured_clock": round(ach / (peak * clk["clock_mhz"] / 2400.0), 4) if clk else None,
+                    "useful_tflops": round(useful / tk / 1e12, 2), "flops_per_launch": issued,
+                    "algorithmic_achieved": round(useful_full / tk / 1e12, 2), "algorithmic_frac": round(useful_full / tk / 1e12 / peak, 4)}
+    d = out.get("dkv")
+    if d is None:
+        return None
+    note = ("achieved/frac = matrix FLOPs the kernel EXECUTES (8*N*Nk*C per image, Nk = kept keys; masked keys are skipped exactly) / "
+            "HIP-event time; algorithmic_* FLOPs = SURVEY 8-d4's full-key-set count 8*N*N*C; algorithmic_bytes = Q, dO, K, V read + dK, dV "
+            "written once (6*N*C elements per image)")
+    if dtype_name == "fp32x":
+        note += ("; fp32x: achieved/frac count the 16-bit MFMA FLOPs ISSUED (useful x terms: S and dP three terms, dV and dK two) against the "
+                 "dense 16-bit peak, `useful_tflops` the fp32-grade products delivered")
+    return {"bound": "mfma", "achieved": d["achieved"], "peak": peak, "unit": "TFLOP/s", "frac": d["frac"],
+            # the same FLOPs against the matrix peak at the clock this chip holds under a dense MFMA load
+            # (peak is quoted at 2400 MHz; `clock`): what is left is the kernel's own issue efficiency
+            "frac_at_measured_clock": d["frac_at_measured_clock"], "traffic": traffic, "traffic_source": traffic_source,
+            "kernel": f"{DOMINANT_KERNEL} (self_attention6 dK/dV sweep, N={N6}, C=64)",
+            "ms_per_launch": d["ms_per_launch"], "launches_timed": d["launches_timed"], "kept_keys": round(kept, 4),
+            "flops_per_launch": d["flops_per_launch"], "useful_tflops": d["useful_tflops"],
+            "algorithmic_achieved": d["algorithmic_achieved"], "algorithmic_frac": d["algorithmic_frac"],
+            # the dK/dV sweep's own operands, each once: reads Q, dO, K, V; writes dK, dV ([N, C] each; the 8*N*C of
+            # SURVEY 8-d4 is the whole attention block) -- the unit `traffic` is measured in
+            "algorithmic_bytes_per_launch": 6.0 * N6 * C6 * esz * batch,
+            "kernels": out, "note": note}
+
+
+def load_traffic(args, dtype_name):
+    """HBM-side bytes of the dominant launch from the PMC passes (FETCH_SIZE x 2 + WRITE_SIZE, MI355X_MICROARCH.md): counters cannot be
+    read inside this process, so the figure comes from the committed rocprofv3 --pmc run of the same command -- one file per workload
+    shape, named in `traffic_source`; null where no counter pass was taken for the shape."""
+    tkey = f"b{args.batch}_c{args.c_out}_hw{args.hw}_{dtype_name}" + ("_3head" if args.three_head else "")
+    for rnd in ("r05", "r04"):
+        tfile = f"{rnd}_dkv_traffic_{tkey}.json"
+        tpath = os.path.join(ROOT, "profiles", tfile)
+        if os.path.exists(tpath):
+            rec = json.load(open(tpath))
+            return rec.get("hbm_bytes_per_launch"), (f"profiles/{tfile} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over this command on another "
+                                                     f"box, not this run" + (f"; session {rec['session']}" if rec.get("session") else "") + ")")
+    return None, None
+
+
+def parity_grade_line(args, dev, steps, warmup, clk):
+    """The SAME workload in the fp32x mode (fp32 storage, split 16-bit matrix products: the fastest path under north_star's 1e-3 gate) as
+    a first-class measurement of its own: own model, own parity-gate run, `warmup` untimed + `steps` timed steps bracketed by
+    synchronize(), own `roofline` block from HIP events on the launch stream -- behind the timed region of the line's own dtype.
+    It is never `value`: the line benches the dtype named in `dtype` (BASELINE.json configs[1] names fp16)."""
     import maskunet_amd
+    from maskunet_amd import _lib
     maskunet_amd.set_float32_matmul_precision("high")
     try:
-        gate = parity_gate(args, torch.float32)
+        gate = parity_gate(args, torch.float32, "fp32x")
         torch.manual_seed(1234)
         model = (maskunet_amd.InstanceUNet(3, args.c_out, 16, hw=args.hw) if args.three_head else maskunet_amd.UNet(3, args.c_out, hw=args.hw)).to(dev)
         model.set_compute_dtype(torch.float32).train()
@@ -262,21 +352,30 @@ def fp32x_side_line(args, dev, steps=3):
             loss.backward()
             model.zero_grad(set_to_none=True)
             return loss
-        one()
+        for _ in range(warmup):
+            one()
+        _lib.PROBE = {"pred": attention_probe(args.hw), "events": []}
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for _ in range(steps):
             loss = one()
         torch.cuda.synchronize()
         dt_ = (time.perf_counter() - t0) / steps
-        ok = bool(torch.isfinite(loss.detach()).all())
-        return {"dtype": "f32 storage, bf16x3 split products (maskunet_amd.set_float32_matmul_precision('high'))",
-                "value": round(args.batch / dt_, 1), "unit": "images/sec", "ms_per_step": round(1e3 * dt_, 2), "steps": steps, "warmup": 1,
-                "finite": ok, "parity_gate": {"gate_out": 1e-3, "observed": gate.get("observed"), "passed": gate.get("passed")},
-                "note": "side measurement behind the timed region, same workload and batch; the line's `value` is the dtype named in `dtype`"}
+        events = _lib.PROBE["events"]
+        _lib.PROBE = None
+        kept = float(model.self_attention6._keep.float().mean().item())
+        traffic, src = load_traffic(args, "fp32x")
+        return {"dtype": "f32 storage, split 16-bit matrix products, f32 accumulate (maskunet_amd.set_float32_matmul_precision('high'))",
+                "value": round(args.batch / dt_, 1), "unit": "images/sec", "ms_per_step": round(1e3 * dt_, 3), "steps": steps, "warmup": warmup,
+                "finite": bool(torch.isfinite(loss.detach()).all()),
+                "roofline": sweep_rooflines("fp32x", events, args.hw, args.batch, kept, clk, traffic, src),
+                "parity_gate": {"gate_out": 1e-3, "observed": gate.get("observed"), "passed": gate.get("passed"), "fixture": gate.get("fixture")},
+                "note": "the same workload and batch in the parity-grade precision mode, timed behind the line's own timed region; the line's "
+                        "`value` is the dtype named in `dtype`"}
     except Exception as e:                                     # never break the bench line
-        return {"error": repr(e)[:200]}
+        return {"error": repr(e)[:300]}
     finally:
+        _lib.PROBE = None
         maskunet_amd.set_float32_matmul_precision("highest")
 
 
@@ -314,15 +413,16 @@ def main():
     ap.add_argument("--batch", type=int, default=64, help="per-GPU batch")
     ap.add_argument("--dtype", default="fp16", choices=["fp16", "fp32", "fp32x"],
                     help="fp16: fp16 storage / fp32 accumulate (the configs[1] line); fp32: exact-fp32 MFMA (the 1e-3 parity path); fp32x: fp32 "
-                         "storage, matrix products as three bf16 MFMAs on (hi, lo) splits (maskunet_amd.set_float32_matmul_precision('high'))")
+                         "storage, matrix products as two / three 16-bit MFMAs on (hi, lo) splits (maskunet_amd.set_float32_matmul_precision('high'))")
     ap.add_argument("--c-out", type=int, default=150)
     ap.add_argument("--hw", type=int, default=128)
     ap.add_argument("--loss-scale", type=float, default=1024.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-parity-gate", action="store_true", help="skip the B=2 golden check that fills `parity_gate`")
     ap.add_argument("--no-clock-probe", action="store_true", help="skip the MFMA-loop clock probe after the timed region")
-    ap.add_argument("--no-fp32x-line", action="store_true", help="skip the fp32x side measurement (3 steps of the same workload in the "
-                    "parity-grade mode, after the timed region; N = 1 and --dtype fp16 only)")
+    ap.add_argument("--no-fp32x-line", action="store_true", help="skip `parity_grade_path` (the same workload timed in the fp32x "
+                    "parity-grade mode behind the timed region; N = 1 and --dtype fp16 only)")
+    ap.add_argument("--pg-steps", type=int, default=0, help="timed steps of `parity_grade_path` (default: max(10, --steps // 2); 2 warm-up steps)")
     ap.add_argument("--three-head", action="store_true")
     ap.add_argument("--fused-loss", action="store_true",
                     help="SURVEY 8-f1 path: fused NHWC cross-entropy on the internal logits instead of module output + torch CE")
@@ -443,22 +543,25 @@ def main():
     for _ in range(args.warmup):
         step()
     fwd_events = []          # forward-only time: events around net(x) on the current stream (every launch of the path is on it)
-    # HIP-event probe on the dominant kernel: the dK/dV sweep (attn_bwd_dkv3_kernel) of self_attention6, N = hw*hw.
-    # mu_attn_bwd_phases(..., B, N, C, nkmax, ws, ws_bytes, dtype, phases, stream): args[16] = N, args[22] = phases
+    # HIP-event probe on the three sweeps of self_attention6 (N = hw*hw, C = 64): the dK/dV sweep (attn_bwd_dkv3_kernel) is the
+    # dominant kernel of the step, the forward and dQ sweeps are reported next to it (`roofline.kernels`)
     N6 = args.hw * args.hw
-    _lib.PROBE = {"pred": lambda name, a: name == "mu_attn_bwd_phases" and a[16] == N6 and (a[22] & 7) == 4, "events": []}
-    sampler = SmiSampler(local if rank == 0 else 1 << 30)      # sysfs sclk / power over the timed region (rank 0's GPU)
+    _lib.PROBE = {"pred": attention_probe(args.hw), "events": []}
+    sampler = SmiSampler(dev) if rank == 0 else None            # hwmon power rails over the timed region (rank 0's GPU only)
     if multi:
         dist.barrier()
     torch.cuda.synchronize()
-    with sampler:
-        t0 = time.perf_counter()
-        for _ in range(args.steps):
-            loss = step()
-        if multi:
-            dist.barrier()
-        torch.cuda.synchronize()
-        elapsed = time.perf_counter() - t0
+    if sampler is not None:
+        sampler.__enter__()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    if multi:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if sampler is not None:
+        sampler.__exit__()
     probe = _lib.PROBE
     _lib.PROBE = None
     clk = None
@@ -480,31 +583,17 @@ def main():
 
     if rank == 0:
         imgs = args.batch * world * args.steps
-        C6 = 64
         # fraction of keys the kernel really multiplies (the rest are skipped, not computed): of the mask the last step ran with
         kept = float(model.self_attention6._keep.float().mean().item())
-        # FLOPs of one launch: the four N x Nk x C products of the dK/dV sweep (S, dP, dV, dK), 4 * 2*N*Nk*C per image, over the
-        # kept keys (executed) and over the full key set (SURVEY 8-d4's algorithmic convention)
-        flops_full = 8.0 * N6 * N6 * C6 * args.batch
-        flops_exec = flops_full * kept
-        durs = [e0.elapsed_time(e1) * 1e-3 for _, e0, e1 in probe["events"]]
-        tk = sum(durs) / max(len(durs), 1)
-        achieved = flops_exec / max(tk, 1e-12) / 1e12
         peak = PEAK_MFMA_TFLOPS[args.dtype]
-        # HBM-side bytes of that launch from the PMC passes (FETCH_SIZE x 2 + WRITE_SIZE, MI355X_MICROARCH.md): counters cannot be
-        # read inside this process, so the figure comes from the committed rocprofv3 --pmc run of the same command -- one file per
-        # workload shape, named in `traffic_source`; null where no counter pass was taken for the shape
-        traffic = traffic_source = None
-        tkey = f"b{args.batch}_c{args.c_out}_hw{args.hw}_{args.dtype}" + ("_3head" if args.three_head else "")
-        tfile = TRAFFIC_JSON.get(tkey)
-        tpath = os.path.join(ROOT, "profiles", tfile) if tfile else None
-        if tpath and os.path.exists(tpath):
-            traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
-            traffic_source = f"profiles/{tfile} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over this command on another box, not this run)"
+        traffic, traffic_source = load_traffic(args, args.dtype)
+        roof = sweep_rooflines(args.dtype, probe["events"], args.hw, args.batch, kept, clk, traffic, traffic_source)
         # whole step and forward alone against both rooflines (per-image algorithmic figures)
         cnt = algorithmic_counts(args.c_out, args.hw, args.three_head)
         esz = 2 if dtype == torch.float16 else 4
         t_step = elapsed / args.steps
+        headline_cfg = (args.dtype == "fp16" and args.batch == 64 and args.c_out == 150 and args.hw == 128 and not args.three_head
+                        and not args.optimizer and not args.graph and not args.fused_loss and not args.torch_loss and world == 1)
         nimg = args.batch                      # per GPU: the step time is per GPU too (weak scaling)
         attn_exec = cnt["attn_flops"] * 0.5    # Bernoulli(0.5) key masks: half the keys are skipped
         step = {"flops_per_img": round(cnt["step_flops"] / 1e9, 1), "flops_per_img_unit": "GFLOP (3x conv/proj + 3.5x attention, full key set)",
@@ -526,42 +615,28 @@ def main():
             "metric": "128x128 images/sec (fwd+bwd)", "value": round(imgs / elapsed, 3), "unit": "images/sec",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": {"fp16": "f16", "fp32": "f32", "fp32x": "f32 storage, bf16x3 split products (f32 accumulate)"}[args.dtype],
+            "dtype": {"fp16": "f16", "fp32": "f32", "fp32x": "f32 storage, split 16-bit matrix products (f32 accumulate)"}[args.dtype],
             "data": "synthetic",
             "config": {"workload": f"{DATASET_BY_COUT.get(args.c_out, 'custom')} shape {args.hw}x{args.hw}, c_out={args.c_out}, batch={args.batch}/GPU, "
                                    f"{'3-head' if args.three_head else '1-head'} MaskAttn-UNet fwd+bwd, train mode",
                        "global_batch": args.batch * world, "parallelism": f"dp{world}", "loss_scale": scale, "mask_mode": mask_mode,
                        "loss": "fused NHWC CE kernel" if args.fused_loss else ("torch CE on module output" if args.torch_loss else
                                                                                 "maskunet_amd.CrossEntropyLoss on module output"), "optimizer_in_step": bool(opt), "hip_graph": bool(args.graph)},
-            "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
-                         "frac": round(achieved / peak, 4),
-                         # the same FLOPs against the matrix peak at the clock this chip holds under a dense MFMA load
-                         # (peak is quoted at 2400 MHz; `clock` below): what is left is the kernel's own issue efficiency
-                         "frac_at_measured_clock": round(achieved / (peak * clk["clock_mhz"] / 2400.0), 4) if clk else None,
-                         "traffic": traffic, "traffic_source": traffic_source,
-                         "kernel": f"{DOMINANT_KERNEL} (self_attention6 dK/dV sweep, N={N6}, C=64)",
-                         "ms_per_launch": round(tk * 1e3, 3), "launches_timed": len(durs),
-                         "kept_keys": round(kept, 4), "flops_per_launch": flops_exec,
-                         "algorithmic_achieved": round(flops_full / max(tk, 1e-12) / 1e12, 2),
-                         "algorithmic_frac": round(flops_full / max(tk, 1e-12) / 1e12 / peak, 4),
-                         # the dK/dV sweep's own operands, each once: reads Q, dO, K, V; writes dK, dV ([N, C] each; the 8*N*C of
-                         # SURVEY 8-d4 is the whole attention block) -- the unit `traffic` is measured in
-                         "algorithmic_bytes_per_launch": 6.0 * N6 * C6 * (2 if dtype == torch.float16 else 4) * args.batch,
-                         "note": "achieved/frac = matrix FLOPs the kernel EXECUTES (8*N*Nk*C per image, Nk = kept keys; masked keys are "
-                                 "skipped exactly) / HIP-event time; algorithmic_* FLOPs = SURVEY 8-d4's full-key-set count 8*N*N*C; "
-                                 "algorithmic_bytes = Q, dO, K, V read + dK, dV written once (6*N*C elements per image)"},
+            "roofline": roof,
             "step_roofline": step,
-            "clock": dict(clk, **{"smi": sampler.summary(),
-                                  # box-to-box comparison: ~0.8 of the step is MFMA kernels whose time follows this clock, the rest
-                                  # HBM streams that do not (profiles/r03_kernel_time_split.txt); REF_CLOCK_MHZ is a convention
-                                  "ms_per_step_at_ref_clock": round(1e3 * t_step * (MFMA_SHARE * clk["clock_mhz"] / REF_CLOCK_MHZ + 1.0 - MFMA_SHARE), 3),
-                                  "ref_clock_mhz": REF_CLOCK_MHZ, "mfma_share_of_step": MFMA_SHARE}) if clk else {"smi": sampler.summary()},
+            "clock": dict(clk or {}, smi=sampler.summary()),
             "parity_gate": gate,
         }
+        if clk and headline_cfg:
+            # box-to-box comparison: ~0.8 of the configs[1] fp16 step is MFMA kernels whose time follows this clock, the rest HBM streams
+            # that do not (profiles/r04_kernel_time_split.txt); REF_CLOCK_MHZ is a convention.  Only for the configuration the share was
+            # measured on (other dtypes / shapes / --optimizer have another split)
+            rec["clock"].update({"ms_per_step_at_ref_clock": round(1e3 * t_step * (MFMA_SHARE * clk["clock_mhz"] / REF_CLOCK_MHZ + 1.0 - MFMA_SHARE), 3),
+                                 "ref_clock_mhz": REF_CLOCK_MHZ, "mfma_share_of_step": MFMA_SHARE})
         if world == 1 and args.dtype == "fp16" and not args.no_fp32x_line and not args.graph:
             del model, net                                      # (the timed model's activations are gone; its parameters go with it)
             torch.cuda.empty_cache()
-            rec["parity_grade_path"] = fp32x_side_line(args, dev)
+            rec["parity_grade_path"] = parity_grade_line(args, dev, args.pg_steps or max(10, args.steps // 2), 2, clk)
         if world == 1 and not args.no_cpu_baseline:
             rec["cpu_baseline"] = cpu_baseline(args.c_out, args.hw)
         print(json.dumps(rec), flush=True)

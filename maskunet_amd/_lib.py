@@ -128,6 +128,8 @@ def dt(t_or_dtype) -> int:
 #   "high":    MU_F32X -- every fp32 operand split into bf16 hi + lo, three bf16 MFMAs per product, fp32 accumulate (~1e-5
 #              relative per product, unbiased): the scheme torch.set_float32_matmul_precision("high") names, ~2.5x faster.
 F32_MATMUL_PRECISION = os.environ.get("MU_F32_MATMUL", "highest")
+if F32_MATMUL_PRECISION not in ("highest", "high"):
+    raise ValueError(f'MU_F32_MATMUL must be "highest" or "high", got {F32_MATMUL_PRECISION!r}')
 
 
 def set_float32_matmul_precision(precision: str):
@@ -168,7 +170,7 @@ def stream():
     return torch.cuda.current_stream().cuda_stream
 
 
-# optional HIP-event probe (bench.py): {"pred": f(name, args) -> bool, "events": []} brackets the matching
+# optional HIP-event probe (bench.py): {"pred": f(name, args) -> bool | str, "events": []} brackets the matching
 # entry points with events on the launch stream; None = off (no overhead).
 PROBE = None
 
@@ -186,13 +188,14 @@ def _fn(name):
 def call(name: str, *args):
     """Invoke an int-returning entry point and raise on a non-zero status."""
     probe = PROBE
-    if probe is not None and probe["pred"](name, args):
+    tag = probe["pred"](name, args) if probe is not None else None
+    if tag:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         st = torch.cuda.ExternalStream(args[-1]) if isinstance(args[-1], int) and args[-1] else torch.cuda.current_stream()
         e0.record(st)                # on the stream the kernel is launched on (the last argument of every entry point)
         rc = _fn(name)(*args)
         e1.record(st)
-        probe["events"].append((name, e0, e1))
+        probe["events"].append((name if tag is True else tag, e0, e1))      # pred may name the launch (a str) instead of True
     else:
         rc = _fn(name)(*args)
     if rc != 0:

@@ -116,6 +116,18 @@
 #ifndef MU_XF_OCC
 #define MU_XF_OCC 2
 #endif
+#ifndef MU_XF_DKV_SCHED
+#define MU_XF_DKV_SCHED 0
+#endif
+#ifndef MU_XF_DKV_SCHED2
+#define MU_XF_DKV_SCHED2 0
+#endif
+#ifndef MU_XF_OPAQUE
+#define MU_XF_OPAQUE 1
+#endif
+#ifndef MU_XF_PK_MAXD
+#define MU_XF_PK_MAXD 512
+#endif
 #ifndef MU_FWD_PREFETCH
 #define MU_FWD_PREFETCH 0
 #endif
@@ -148,6 +160,17 @@ __device__ __forceinline__ void glds16s(const void* sbase, uint32_t voff, void* 
     } while (0)
 
 #define LDS_TR16(ptr) __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) fp16x4v*)(ptr))
+
+// A tile base the compiler cannot fold into its address arithmetic (fp32x tiles: linear images, every read = per-lane offset + constant).
+// DS instructions take a VGPR address + a 16-bit immediate; with the base a compile-time constant (ring slot / buffer index) hipcc
+// re-associates base + lane offset + constant into one loop-invariant address REGISTER per (slot, column block, ...) once the images
+// reach past 64 KB -- ~90 registers in the C = 128 dK/dV sweep, which then spilled its resident operands and ran every LDS read
+// synchronously.  An opaque scalar base costs one v_add per tile and kind of read; everything behind it is an immediate.
+template <typename T> __device__ __forceinline__ const T* lds_opaque(const T* p) {
+    uint32_t a = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const T*)p;
+    asm volatile("" : "+s"(a));
+    return (const T*)(__attribute__((address_space(3))) const T*)(uintptr_t)a;
+}
 
 // Block -> (image, tile) through the XCD-aware remap: the tiles of one image run on ONE XCD, so the K/V (forward, dQ) or Q/dO (dK/dV)
 // rows that every block of the image streams are fetched into that XCD's L2 once instead of once per XCD.
@@ -367,8 +390,10 @@ template <typename T, int D> struct SwzTile {
     static constexpr int VN = AT<T>::VN;
     static constexpr int ROWB = D * (int)sizeof(T);       // bytes per row
     static constexpr int CPR = ROWB / 16;                 // 16-byte chunks per row
-    static constexpr int RPW = 1024 / ROWB;               // rows per wave LDS-DMA instruction
+    static constexpr int RPW = 1024 / ROWB;               // rows per wave LDS-DMA instruction (one 1 KB block)
+    static constexpr int BLK = RPW * D;                   // elements between the LDS destinations of consecutive DMA instructions
     static constexpr int SW = CPR < 8 ? CPR - 1 : 7;
+    static __device__ __forceinline__ constexpr int TE(int rows) { return rows * D; }      // elements of a tile of `rows` rows
     // XOR key of a row (applied to the 16-byte chunk index by the DMA source permutation and by every read).
     //  * rows of <= 128 bytes: row & 7 -- both the ds_read_b128 row reads and the transposed ds_read_b64_tr_b16 reads are conflict-free;
     //  * fp16 rows of 256 / 512 bytes (C = 128 / 256): every row starts on bank 0, so the bank slot is the chunk index mod 16.
@@ -376,21 +401,42 @@ template <typename T, int D> struct SwzTile {
     //    kernels): the 16 lanes of a b128 group (rows {0-3, 12-15} at chunk c, rows {4-11} at chunk c+1) fell on 8 slots, and the
     //    8 rows x 2 chunks of a transposed read on 8 slots.  (row & 7) << 1 puts each of 8 consecutive rows on its own even/odd slot
     //    PAIR (transposed reads touch {c, c+1} with c even) and makes row -> slot injective over the 16 rows of a b128 group.
-    //  * fp32x rows (fp16-pair encoded, 4-byte elements): a group's hi parts and lo parts are two ADJACENT 16-byte chunks (2s, 2s + 1).  A
-    //    transposed read of a 16-column block takes, per row, the whole chunks 4 dt and 4 dt + 2 (hi) or 4 dt + 1 and 4 dt + 3 (lo) of
-    //    8 consecutive rows in one 32-lane half; a ds_read_b128 group takes chunk c of 8 rows and chunk c ^ 2 of 8 other rows (lane
-    //    groups g, g + 1), all 8 residues mod 8 on both sides.  Both are conflict-free iff the 8 keys are distinct on bits {0, 2, 3}:
-    //    key = b0 | b1 << 2 | b2 << 3 of the row.  (The round-4 layout -- [4 hi | 4 lo] in every chunk, key (row & 7) << 1 -- left every
-    //    transposed read on half of the banks: 25-33 % of the LDS cycles were conflicts, profiles/r04_fp32x_lds_conflicts.md.)
-    //    128-byte rows (C = 32): two rows share a bank row, b1 and b2 of the row on key bits 0 and 2.
     static __device__ __forceinline__ constexpr int key(int row) {
-        if (std::is_same<T, xf32>::value) return ROWB >= 256 ? ((row & 1) | ((row & 6) << 1)) : (((row >> 1) & 1) | (((row >> 2) & 1) << 2));
         return (sizeof(T) == 2 && ROWB >= 256) ? ((row & 7) << 1) : (row & SW);
     }
     // element offset of (row, col) in the swizzled image
     static __device__ __forceinline__ int off(int row, int col) {
         return row * D + ((((col / VN) ^ key(row))) * VN) + (col % VN);
     }
+    // LDS-DMA (lane-linear: lane l of instruction i lands at byte i * 1024 + 16 l): the row inside the block, and the source chunk of that row
+    static __device__ __forceinline__ int lrow(int lane) { return lane / CPR; }
+    static __device__ __forceinline__ int schunk(int row, int lane) { return (lane % CPR) ^ key(row); }
+};
+
+// fp32x tiles (fp16-pair encoded rows of 4-byte elements; chunk 2s = the hi parts of column group s, chunk 2s + 1 its lo parts): a LINEAR
+// image per 1 KB DMA block instead of an XOR swizzle.  An LDS-DMA instruction lands lane-linear, but which source chunk a lane fetches
+// is free, and so is every instruction's LDS base.  A block holds RPW = 1024 / ROWB rows; it is laid out
+//     [16-column block dt][hi | lo][row in block][half h of the block's two groups]        (S = 2 RPW chunks per [dt][part])
+// and consecutive blocks start 1024 + 16 (S mod 16) bytes apart.  Then
+//   * a transposed read (one 16-column block, hi or lo parts, 8 consecutive rows per 32-lane half) takes S consecutive chunks from each
+//     of the 8 / RPW blocks involved, which the block stride places on disjoint sixteenths of the bank row: conflict-free;
+//   * a ds_read_b128 lane group (8 rows of column group s, 8 rows of group s + 1) lands on the 16 chunks {2 row + h}: conflict-free;
+//   * every address is (per-lane constant) + dt * 32 S + part * 16 S bytes: immediates, no XOR arithmetic and no per-block address
+//     registers (the XOR image of round 4 -- [4 hi | 4 lo] per chunk, key (row & 7) << 1 -- spent 25-33 % of its LDS cycles in bank
+//     conflicts, profiles/r04_fp32x_lds_conflicts.md: a transposed read touched only the hi or only the lo half of every chunk).
+template <int D> struct SwzTile<xf32, D> {
+    static constexpr int VN = 4;
+    static constexpr int ROWB = D * 4, CPR = ROWB / 16, RPW = 1024 / ROWB;
+    static constexpr int S = 2 * RPW;
+    static constexpr int BLK = (1024 + 16 * (S % 16)) / 4;
+    static __device__ __forceinline__ constexpr int TE(int rows) { return (rows / RPW) * BLK; }
+    static __device__ __forceinline__ constexpr int key(int) { return 0; }
+    static __device__ __forceinline__ int off(int row, int col) {
+        const int c = col >> 2, sg = c >> 1;                 // chunk, column group
+        return (row / RPW) * BLK + (((sg >> 1) * 2 * S + (c & 1) * S + 2 * (row % RPW) + (sg & 1)) << 2) + (col & 3);
+    }
+    static __device__ __forceinline__ int lrow(int lane) { return (lane % S) >> 1; }
+    static __device__ __forceinline__ int schunk(int, int lane) { return 2 * (2 * (lane / (2 * S)) + (lane & 1)) + ((lane / S) & 1); }
 };
 
 // Kept-key row indices of one KT-key tile for this lane's DMA rows (-1 = past the end -> zero page).  Loaded one
@@ -405,7 +451,7 @@ template <typename T, int D, int KT, int NW> struct KvStage {
     // a conditional load needs a "-1" default, and overwriting a register with a possibly pending load costs a
     // s_waitcnt vmcnt(0) -- right behind the DMA issue, i.e. it would serialise the staging.
     __device__ __forceinline__ void load_idx(const int* kidx_b, int j0, int Nk, int wave, int lane) {
-        const int lrow = lane / Z::CPR;
+        const int lrow = Z::lrow(lane);
 #pragma unroll
         for (int n = 0; n < NPW; ++n) {
             const int i = wave + NW * n;
@@ -423,14 +469,14 @@ template <typename T, int D, int KT, int NW> struct KvStage {
     // SGPR-base + 32-bit-offset form.
     template <bool DOK = true, bool DOV = true>
     __device__ __forceinline__ void issue(T* Kt, T* Vt, const T* qkv_b, int wave, int lane) const {
-        const int lrow = lane / Z::CPR, lch = lane % Z::CPR;
+        const int lrow = Z::lrow(lane);
         // all offsets first: each consumes an index load, and the wait for the LAST index load is a vmcnt(0) as far as the
         // compiler can tell -- it must not come after the first (hidden) DMA or that DMA is drained on the spot
         uint32_t off[NPW];
 #pragma unroll
         for (int n = 0; n < NPW; ++n) {
             const int row = (wave + NW * n) * Z::RPW + lrow;
-            const int sc = lch ^ Z::key(row);
+            const int sc = Z::schunk(row, lane);
             off[n] = (uint32_t)((idx[n] * 3 * D + sc * Z::VN) * (int)sizeof(T));
             asm volatile("" ::"v"(off[n]));
         }
@@ -438,8 +484,8 @@ template <typename T, int D, int KT, int NW> struct KvStage {
         for (int n = 0; n < NPW; ++n) {
             const int i = wave + NW * n;
             if constexpr (NI % NW != 0) { if (i >= NI) break; }     // wave-uniform; no branch at all when every wave has NPW rows
-            if (DOK) glds16s(qkv_b + D, off[n], Kt + i * Z::RPW * D);
-            if (DOV) glds16s(qkv_b + 2 * D, off[n], Vt + i * Z::RPW * D);
+            if (DOK) glds16s(qkv_b + D, off[n], Kt + i * Z::BLK);
+            if (DOV) glds16s(qkv_b + 2 * D, off[n], Vt + i * Z::BLK);
         }
     }
 };
@@ -520,7 +566,8 @@ __global__ __launch_bounds__(NW * 64, OCC ? OCC : ((NW == 4 && D <= 128 && std::
     using Z = SwzTile<T, D>;
     constexpr int VN = A::VN, KR = A::KR, NKS = D / KR, NDT = D / 16, NKT = KT / 16, NH = KT / 32;
     constexpr bool MU_PRIO_BWD = false;
-    __shared__ __attribute__((aligned(16))) T lds[2 * 2 * KT * D];      // [buf][K|V][KT][D]
+    constexpr int TEK = Z::TE(KT);                                       // elements of one K (or V) tile image
+    __shared__ __attribute__((aligned(16))) T lds[2 * 2 * TEK];          // [buf][K|V][tile image]
 
     int bx_, b;
     attn_block(bx_, b);
@@ -535,7 +582,7 @@ __global__ __launch_bounds__(NW * 64, OCC ? OCC : ((NW == 4 && D <= 128 && std::
     // LDS address is (loop-invariant per-lane base) + (immediate): no address arithmetic is left in the loop.
     KvStage<T, D, KT, NW> stg;
     stg.load_idx(kidx_b, 0, Nk, wave, lane);
-    stg.issue(lds, lds + KT * D, qkv_b, wave, lane);
+    stg.issue(lds, lds + TEK, qkv_b, wave, lane);
     stg.load_idx(kidx_b, KT, Nk, wave, lane);            // indices of tile 1, consumed inside iteration 0
 
     // Q fragments pre-multiplied by log2(e)/sqrt(C): the score MFMA then yields exponents directly
@@ -566,12 +613,13 @@ __global__ __launch_bounds__(NW * 64, OCC ? OCC : ((NW == 4 && D <= 128 && std::
     auto tile = [&](auto BUFC, auto EXACTC, int j0) {
         constexpr int BUF = decltype(BUFC)::value;
         constexpr bool EXACT = decltype(EXACTC)::value;
-        const T* Kt = lds + BUF * 2 * KT * D;
-        const T* Vt = Kt + KT * D;
+        const T* Kt = lds + BUF * 2 * TEK;
+        if constexpr (std::is_same<T, xf32>::value && MU_XF_OPAQUE) Kt = lds_opaque(Kt);
+        const T* Vt = Kt + TEK;
 #ifndef MU_FWD_ABL_NODMA
         if (j0 + KT < Nk) {
-            T* Kn = lds + (BUF ^ 1) * 2 * KT * D;
-            stg.issue(Kn, Kn + KT * D, qkv_b, wave, lane);
+            T* Kn = lds + (BUF ^ 1) * 2 * TEK;
+            stg.issue(Kn, Kn + TEK, qkv_b, wave, lane);
             stg.load_idx(kidx_b, j0 + 2 * KT, Nk, wave, lane);
         }
 #endif
@@ -705,7 +753,7 @@ __global__ __launch_bounds__(NW * 64, OCC ? OCC : ((NW == 4 && D <= 128 && std::
                 for (int dt = 0; dt < NDT; ++dt) o[dt][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
             }
             stg.load_idx(kidx_b, 0, Nk, wave, lane);
-            stg.issue(lds, lds + KT * D, qkv_b, wave, lane);
+            stg.issue(lds, lds + TEK, qkv_b, wave, lane);
             stg.load_idx(kidx_b, KT, Nk, wave, lane);
             MU_SYNC_DMA();
         }
@@ -1005,7 +1053,8 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 && D <= 64 && std::is_same<T, xf3
     constexpr int VN = A::VN, KR = A::KR, NKS = D / KR, NDT = D / 16, NKT = KT / 16, NH = KT / 32;
     constexpr bool MU_PRIO_BWD = true;
     constexpr bool XF = std::is_same<T, xf32>::value;
-    __shared__ __attribute__((aligned(16))) T lds[2 * 2 * KT * D];
+    constexpr int TEK = Z::TE(KT);
+    __shared__ __attribute__((aligned(16))) T lds[2 * 2 * TEK];
     // fp32x: dY arrives scaled by the power of two gs (attn_bwd_t), the probabilities are computed as 2^pshift P: dS -- ONE fp16 operand --
     // then sits inside fp16's exponent range; the accumulators are un-scaled once, in the epilogue (exact: powers of two)
     float gs = 1.0f, un = 1.0f;
@@ -1025,7 +1074,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 && D <= 64 && std::is_same<T, xf3
 
     KvStage<T, D, KT, NW> stg;
     stg.load_idx(kidx_b, 0, Nk, wave, lane);
-    stg.issue(lds, lds + KT * D, qkv_b, wave, lane);
+    stg.issue(lds, lds + TEK, qkv_b, wave, lane);
     stg.load_idx(kidx_b, KT, Nk, wave, lane);            // indices of tile 1, consumed inside iteration 0
 
     // Q pre-scaled by log2(e)/sqrt(C) and dO by 1/sqrt(C): with the row constants -lse2 and -delta/sqrt(C) as the
@@ -1055,11 +1104,12 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 && D <= 64 && std::is_same<T, xf3
 
     auto tile = [&](auto BUFC, int j0) {
         constexpr int BUF = decltype(BUFC)::value;
-        const T* Kt = lds + BUF * 2 * KT * D;
-        const T* Vt = Kt + KT * D;
+        const T* Kt = lds + BUF * 2 * TEK;
+        if constexpr (XF && MU_XF_OPAQUE) Kt = lds_opaque(Kt);
+        const T* Vt = Kt + TEK;
         if (j0 + KT < Nk) {
-            T* Kn = lds + (BUF ^ 1) * 2 * KT * D;
-            stg.issue(Kn, Kn + KT * D, qkv_b, wave, lane);
+            T* Kn = lds + (BUF ^ 1) * 2 * TEK;
+            stg.issue(Kn, Kn + TEK, qkv_b, wave, lane);
             stg.load_idx(kidx_b, j0 + 2 * KT, Nk, wave, lane);
         }
         f32x4 s[NKT][2], dp[NKT][2];
@@ -1176,8 +1226,9 @@ __global__ __launch_bounds__(NW * 64, NW >= 8 ? 1 : ((D <= 64 && std::is_same<T,
     constexpr int NI = QT / Z::RPW;                          // DMA wave-instructions per tensor per tile
     static_assert(NI == 4 || NI == 8 || NI == 16 || NI == 32 || NI == 2, "unexpected tile geometry");
     constexpr int NPW = (NI + NW - 1) / NW;                  // per wave (Q and dO each)
-    constexpr int STG = 2 * QT * D;                          // elements per ring slot (Q | dO)
-    constexpr int DKV_RING = (STG * (int)sizeof(T) <= 32768) ? 4 : 2;      // ring depth; prefetch distance = depth - 1
+    constexpr int TEQ = Z::TE(QT);                           // elements of one Q (or dO) tile image
+    constexpr int STG = 2 * TEQ;                             // elements per ring slot (Q | dO)
+    constexpr int DKV_RING = (STG * (int)sizeof(T) <= 36864) ? 4 : 2;      // ring depth; prefetch distance = depth - 1 (36864: the padded fp32x image at C = 128)
     __shared__ __attribute__((aligned(16))) T lds[DKV_RING * STG];
     __shared__ __attribute__((aligned(16))) float rcs[DKV_RING * 256 + 256];   // 1 KB per slot: [{-lse2},{-delta*scale}][32] in its first 256 B; + 1 KB dump
 
@@ -1213,13 +1264,13 @@ __global__ __launch_bounds__(NW * 64, NW >= 8 ? 1 : ((D <= 64 && std::is_same<T,
     // only moves the scalar base.  (The generic index arithmetic made the three DMAs cost ~250 issue cycles per tile.)
     int qlane[NPW], olane[NPW], rowl[NPW];
     {
-        const int lrow = lane / Z::CPR, lch = lane % Z::CPR;
+        const int lrow = Z::lrow(lane);
 #pragma unroll
         for (int n = 0; n < NPW; ++n) {
             const int i = wave + NW * n;
             const int ii = i < NI ? i : 0;                   // (NI >= 4 for every instantiation: never clamps)
             const int row = ii * Z::RPW + lrow;
-            const int sc = lch ^ Z::key(row);
+            const int sc = Z::schunk(row, lane);
             rowl[n] = row;
             qlane[n] = row * 3 * D + sc * Z::VN;
             olane[n] = row * D + sc * Z::VN;
@@ -1228,7 +1279,7 @@ __global__ __launch_bounds__(NW * 64, NW >= 8 ? 1 : ((D <= 64 && std::is_same<T,
     auto issue = [&](int tile) {
         const int slot = tile % DKV_RING;
         T* Qt = lds + slot * STG;
-        T* Ot = Qt + QT * D;
+        T* Ot = Qt + TEQ;
         const T* qb = qkv_b + (long)tile * QT * 3 * D;       // wave-uniform bases
         const T* ob = dY_b + (long)tile * QT * D;
         const bool full = tile * QT + QT <= N;               // wave-uniform: only the last tile can be partial
@@ -1242,8 +1293,8 @@ __global__ __launch_bounds__(NW * 64, NW >= 8 ? 1 : ((D <= 64 && std::is_same<T,
                 qo -= back * 3 * D;
                 oo -= back * D;
             }
-            glds16s(qb, (uint32_t)(qo * (int)sizeof(T)), Qt + ii * Z::RPW * D);
-            glds16s(ob, (uint32_t)(oo * (int)sizeof(T)), Ot + ii * Z::RPW * D);
+            glds16s(qb, (uint32_t)(qo * (int)sizeof(T)), Qt + ii * Z::BLK);
+            glds16s(ob, (uint32_t)(oo * (int)sizeof(T)), Ot + ii * Z::BLK);
         }
         // row constants: 16 lanes x 16 B = the tile's 64 floats.  Every wave issues one DMA so that all waves count the same
         // number of vector-memory ops: wave 0's lanes >= 16 repeat the constants into the unused rest of the slot, waves 1-3
@@ -1324,7 +1375,8 @@ __global__ __launch_bounds__(NW * 64, NW >= 8 ? 1 : ((D <= 64 && std::is_same<T,
         if (tl + DKV_RING - 1 < ntile) issue(tl + DKV_RING - 1);
 #endif
         const T* Qt = lds + SLOT * STG;
-        const T* Ot = Qt + QT * D;
+        if constexpr (std::is_same<T, xf32>::value && MU_XF_OPAQUE) Qt = lds_opaque(Qt);
+        const T* Ot = Qt + TEQ;
         const float* rc = rcs + SLOT * 256;
         f32x4 s[2][NKT], dp[2][NKT];
         f32x4 nl[2], nd[2];
@@ -1350,6 +1402,7 @@ __global__ __launch_bounds__(NW * 64, NW >= 8 ? 1 : ((D <= 64 && std::is_same<T,
                         A::mma_row(oa, vf[kt][ks], dp[qt][kt]);
                     }
                 }
+                if constexpr (std::is_same<T, xf32>::value && D >= 128 && MU_XF_DKV_SCHED2) { if (qt == 1) __builtin_amdgcn_sched_barrier(0); }
             }
         MU_PRIO(0);
         if (tl * QT + QT > N) {                              // last, partial tile: padded queries contribute nothing
@@ -1380,7 +1433,7 @@ __global__ __launch_bounds__(NW * 64, NW >= 8 ? 1 : ((D <= 64 && std::is_same<T,
         // and dS = P * dP' is FOUR packed fp16 multiplies per 8 scores instead of 8 fp32 ones: 24 instead of 32 VALU instructions per
         // 32-query x 32-key tile behind the 16 exponentials (the sweep runs at MFMA + VALU issue time)
         // fp32x takes the same path (the row constants carry the power-of-two scales that keep P and dP' inside fp16's range: attn_bwd_t)
-        constexpr bool PKMUL = (MU_DKV_PKMUL && sizeof(T) == 2) || std::is_same<T, xf32>::value;
+        constexpr bool PKMUL = (MU_DKV_PKMUL && sizeof(T) == 2) || (std::is_same<T, xf32>::value && D < MU_XF_PK_MAXD);
         if constexpr (PKMUL) {
             typename A::Packed pb[NKT], db[NKT];
 #pragma unroll
@@ -1406,6 +1459,9 @@ __global__ __launch_bounds__(NW * 64, NW >= 8 ? 1 : ((D <= 64 && std::is_same<T,
                     A::mma_acc_pk(oa, pb[kt], dv[dt][kt]);
                     A::mma_acc_pk(qa, db[kt], dk[dt][kt]);
                 }
+                // fp32x at C >= 128: the resident K / V pairs and the accumulators alone are 128 registers; left alone the scheduler
+                // hoists the transposed reads of ALL column blocks (16 registers each) above the first MFMA and spills ~130 registers
+                if constexpr (std::is_same<T, xf32>::value && D >= 128 && MU_XF_DKV_SCHED) { if (dt % MU_XF_DKV_SCHED == MU_XF_DKV_SCHED - 1) __builtin_amdgcn_sched_barrier(0); }
             }
             MU_PRIO(0);
         } else {

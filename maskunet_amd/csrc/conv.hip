@@ -1904,9 +1904,11 @@ template <int BCH> __device__ __forceinline__ int wg_hash(int row) {
 }
 // fp32x tiles (chunk-encoded, 4-byte elements): the swizzle granule is still 16 channels (64 bytes = the four 16-byte chunks one 16-lane
 // group of a transposed read touches in a row); rows are 256 or 512 bytes = whole bank lines, so the four consecutive rows of a lane group
-// (a .. a+3) must land on four different granules modulo 4: row bits 0-1.  Rows a and a+8 then share banks -- the reads fetch only the
-// hi (or only the lo) half of every chunk, i.e. half of the banks, so a 32-lane group is 2-way whatever the layout (SQ_LDS_BANK_CONFLICT
-// 33 % of the LDS cycles of every fp32x kernel with transposed reads); the stage's reads are hidden behind the partner wave's MFMAs instead.
+// (a .. a+3) must land on four different granules modulo 4: row bits 0-1.  A transposed read that fetches only the hi (or only the lo)
+// half of every chunk touches half of the banks: 2-way for a 32-lane group whatever the layout (round 4: SQ_LDS_BANK_CONFLICT 33-50 % of
+// the LDS cycles).  Round 5 (MU_WGX_PAIRED): the two lane groups of a 32-lane half fetch the hi halves AND the lo halves of the SAME four
+// rows -- together 16 whole chunks on 16 distinct slots, conflict-free -- and v_permlane16_swap puts the lo halves a group fetched for its
+// neighbour's rows where they belong (rd_tr_x below).
 template <typename T, int BCH> __device__ __forceinline__ int wg_hash_t(int row) {
     if constexpr (sizeof(T) == 2) return wg_hash<BCH>(row);
     else return row & 3;
@@ -1950,6 +1952,9 @@ template <int N> __device__ __forceinline__ void wait_vmcnt_c() {
 #endif
 #ifndef MU_WGX_STAGGER
 #define MU_WGX_STAGGER 1
+#endif
+#ifndef MU_WGX_PAIRED
+#define MU_WGX_PAIRED 0
 #endif
 // SPS = 32-pixel k-steps per DMA stage.  SPS = 2 (W % 64 == 0): one barrier / DMA batch / ring step per 64 pixels -- the two
 // waves of a SIMD run in lockstep behind the per-stage barrier, so the ~500 cycles of scalar + address work per ring step sit
@@ -2122,6 +2127,23 @@ __global__ __launch_bounds__(NWV * 64, 1) void conv_wgrad3_kernel(const T* __res
             return (h16x8){(h16)lo[0], (h16)lo[1], (h16)lo[2], (h16)lo[3], (h16)hi[0], (h16)hi[1], (h16)hi[2], (h16)hi[3]};
         }
     };
+    // fp32x, paired fetch: read 1 = lane groups (0, 1) -> (hi, lo) halves of the rows of group 0, groups (2, 3) -> of group 2; read 2 = the same
+    // for the rows of groups 1 and 3; permlane16_swap(read 1, read 2) = {(hi g0, hi g1, hi g2, hi g3), (lo g0, lo g1, lo g2, lo g3)}.
+    // rbase = the fragment's first row for lane group 0 (+ q); col as in rd_tr.  Same four reads per fragment, +4 VALU, no bank conflicts.
+    auto rd_tr_x = [&](const T* tile, int stride, int rbase, int col) -> SplitF8 {
+        const int re = rbase + 8 * (g & 2), ro = re + 8, pb = (g & 1) * 8;
+        auto rd = [&](int row) -> uint2 {
+            const char* c = reinterpret_cast<const char*>(tile + row * stride + ((((col >> 4) ^ (row & 3)) << 4) | (col & 15))) + pb;
+            return __builtin_bit_cast(uint2, __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) fp16x4v*)(c)));
+        };
+        const uint2 d0 = rd(re), s0 = rd(ro), d1 = rd(re + 4), s1 = rd(ro + 4);
+        const auto a0 = __builtin_amdgcn_permlane16_swap(d0.x, s0.x, false, false), a1 = __builtin_amdgcn_permlane16_swap(d0.y, s0.y, false, false);
+        const auto b0 = __builtin_amdgcn_permlane16_swap(d1.x, s1.x, false, false), b1 = __builtin_amdgcn_permlane16_swap(d1.y, s1.y, false, false);
+        SplitF8 f;
+        f.hi = __builtin_bit_cast(bf16x8, make_uint4(a0[0], a1[0], b0[0], b1[0]));
+        f.lo = __builtin_bit_cast(bf16x8, make_uint4(a0[1], a1[1], b0[1], b1[1]));
+        return f;
+    };
     auto load_frags = [&](int buf, int half, Frags& f) {     // k-step `half` of the stage in slot `buf`
         const T* At = lds + buf * STAGE;
         const T* Bt = At + SP * BCO;
@@ -2132,7 +2154,8 @@ __global__ __launch_bounds__(NWV * 64, 1) void conv_wgrad3_kernel(const T* __res
         for (int i = 0; i < TM; ++i) {
             const int col = (wr * TM + i) * 16 + 4 * pc;    // 4 channels inside the 16-channel granule (col >> 4)
             const int r0 = ra + 8 * g + q;
-            f.a[i] = rd_tr(At, BCO, r0, col, wg_hash_t<T, BCO>(r0), wg_hash_t<T, BCO>(r0 + 4));
+            if constexpr (XF && MU_WGX_PAIRED) f.a[i] = rd_tr_x(At, BCO, ra + q, col);
+            else f.a[i] = rd_tr(At, BCO, r0, col, wg_hash_t<T, BCO>(r0), wg_hash_t<T, BCO>(r0 + 4));
         }
 #pragma unroll
         for (int t = 0; t < 3; ++t) {
@@ -2140,7 +2163,8 @@ __global__ __launch_bounds__(NWV * 64, 1) void conv_wgrad3_kernel(const T* __res
             for (int j = 0; j < TN; ++j) {
                 const int col = (wc * TN + j) * 16 + 4 * pc;
                 const int r0 = rb + 8 * g + q + t + wsh;
-                f.b[t][j] = rd_tr(Bt, BCI, r0, col, wg_hash_t<T, BCI>(r0), wg_hash_t<T, BCI>(r0 + 4));
+                if constexpr (XF && MU_WGX_PAIRED) f.b[t][j] = rd_tr_x(Bt, BCI, rb + q + t + wsh, col);
+                else f.b[t][j] = rd_tr(Bt, BCI, r0, col, wg_hash_t<T, BCI>(r0), wg_hash_t<T, BCI>(r0 + 4));
             }
         }
     };

@@ -465,7 +465,8 @@ __global__ __launch_bounds__(256) void adamw_kernel(const MuAdamEntry* __restric
     if (grad_scale) ginv = 1.0f / *grad_scale;      // GradScaler's device-side scale
     __shared__ float sbc[2];
     if (threadIdx.x == 0) {
-        const double t = (double)(e.step - (skipped ? skipped[ti] : 0));
+        long ti_ = e.step - (skipped ? skipped[ti] : 0);
+        const double t = (double)(ti_ < 1 ? 1 : ti_);    // never 0 or negative (bc1 = 0 -> lr / bc1 = inf), whatever the host counters say
         sbc[0] = (float)(1.0 - pow((double)beta1, t));
         sbc[1] = (float)sqrt(1.0 - pow((double)beta2, t));
     }

@@ -179,11 +179,12 @@ class ConvBlock(_HipModule):
         # fp32x: the dy of a conv is the dx of the BatchNorm behind it (one link per pair); not for the 3-channel stem, whose weight
         # gradient is a plain-FMA kernel.  mid: bn1's output feeds conv2 only.
         l0 = ops.enc_link(x) if cb[0].weight.shape[1] > 3 else None
-        l1 = ops.enc_link(x)
-        fx = l1 is not None                                              # fp32x mode with a backward to come
+        l1 = ops.enc_link(x) if cb[3].weight.shape[1] > 3 else None      # (a second conv with <= 3 input channels is a plain-FMA layer too)
+        fx = ops.enc_link(x) is not None                                 # fp32x mode with a backward to come
+        fm = l1 is not None                                              # ... and the mid activation feeds a matrix-core conv: written encoded
         y, st = ops.conv_stats(x, cb[0].weight, want=cb[1].training, x_encoded=x_encoded and ops._is_x(x), dy_link=l0)   # BatchNorm statistics from the conv epilogue where it has one
-        y = ops.bn_act(y, cb[1], ACT_GELU, stats=st, enc_out=fx, dx_link=l0)
-        y, st = ops.conv_stats(y, cb[3].weight, want=cb[4].training, x_encoded=fx, dy_link=l1)
+        y = ops.bn_act(y, cb[1], ACT_GELU, stats=st, enc_out=fm, dx_link=l0)
+        y, st = ops.conv_stats(y, cb[3].weight, want=cb[4].training, x_encoded=fm, dy_link=l1)
         if self.residual:
             y = ops.bn_act(y, cb[4], ACT_GELU, res=x, stats=st, res_link=res_link, dx_link=l1,
                            enc_out=enc_out and tail_bn is None and fx)            # gelu(x + BN(conv(...)))  (:208)

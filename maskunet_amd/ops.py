@@ -115,8 +115,16 @@ class EncLink:
 
 
 def enc_link(x):
-    """A fresh EncLink when x is an fp32 tensor in the fp32x mode and a backward can follow, else None."""
-    return EncLink() if (FUSED_ENCODE and torch.is_grad_enabled() and _is_x(x)) else None
+    """A fresh EncLink when x is an fp32 tensor in the fp32x mode and a backward can follow, else None (also None with the side-stream
+    weight gradient, MU_WGRAD_SIDE=1, which reads dy plain)."""
+    return EncLink() if (FUSED_ENCODE and not WGRAD_SIDE_STREAM and torch.is_grad_enabled() and _is_x(x)) else None
+
+
+def _same_mode(ctx_is_x, t):
+    """The fp32 matmul precision is process-wide state read in forward AND backward: saved operands were encoded (or not) under the
+    forward's mode, so a backward under the other mode would mix encoded tensors with plain-fp32 kernels.  Refuse loudly."""
+    if t.dtype == torch.float32 and bool(ctx_is_x) != _is_x(t):
+        raise RuntimeError("maskunet_amd: set_float32_matmul_precision() changed between a forward pass and its backward")
 
 
 FUSED_ENCODE = os.environ.get("MU_FUSED_ENCODE", "1") != "0"     # debug switch: 0 = every operand through mu_split_encode
@@ -504,7 +512,8 @@ class _Conv(torch.autograd.Function):
         part = None
         # fp32x: the chunk-encoded input is what both the forward conv and the weight gradient read -- encode once, save THAT (the first
         # layer's weight gradient is a plain-FMA kernel and keeps the plain tensor)
-        ctx.x_enc = _is_x(x) and not (taps == 9 and I <= 3)
+        ctx.is_x = _is_x(x)
+        ctx.x_enc = ctx.is_x and not (taps == 9 and I <= 3)
         if x_encoded and not ctx.x_enc:
             raise RuntimeError("conv: a pre-encoded input needs the fp32x mode and a matrix-core layer")
         if ctx.x_enc and not x_encoded:
@@ -531,6 +540,7 @@ class _Conv(torch.autograd.Function):
             return None, None, None, None, None, None, None
         x, weight = ctx.saved_tensors
         gy = gy.contiguous()
+        _same_mode(ctx.is_x, gy)
         gy_pre = ctx.dy_link is not None and ctx.dy_link.take()      # fp32x: dy arrived chunk-encoded from the BatchNorm's backward
         O, I = weight.shape[0], weight.shape[1]
         gx = gw = gb = None
@@ -1005,6 +1015,7 @@ class _MaskAttention(torch.autograd.Function):
             call("mu_attn_fwd_padded", ptr(qkv), ptr(x), ptr(kidx), ptr(kcnt), ptr(g), ptr(b_), ptr(out), ptr(oattn), ptr(lse2), ptr(mean),
                  ptr(rstd), B, N, C, cv, kidx.shape[1], float(eps), mdt(x), stream())
         ctx.save_for_backward(x, qkv, oattn, lse2, mean, rstd, g, kidx, kcnt)
+        ctx.is_x = _is_x(x)
         ctx.scramble, ctx.dims, ctx.kidx_perm = scramble, (B, H, W, C), bool(kidx_perm) and kidx.shape[1] == N
         if scramble:
             return _transpose_tokens(out.view(B, C, N), C, N).view(B, H, W, C)
@@ -1017,6 +1028,7 @@ class _MaskAttention(torch.autograd.Function):
         B, H, W, C = ctx.dims
         N = H * W
         gout = gout.contiguous()
+        _same_mode(ctx.is_x, gout)
         if ctx.scramble:
             gout = _transpose_tokens(gout.view(B, N, C), N, C)      # back to token-major flat [B, (N,C)]
         dY = torch.empty((B, N, C), dtype=x.dtype, device=x.device)

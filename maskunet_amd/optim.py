@@ -23,7 +23,8 @@ class FusedAdamW(torch.optim.Optimizer):
     def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2):
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
         self._plans = {}
-        self._found = {}                        # device -> float32 [1] overflow flag of the last step()
+        self._found = {}                        # device -> float32 [1] overflow flag of this optimiser's own finite check
+        self._last_found = []                   # the flags the LAST step() decided by (its own, or the ones GradScaler handed in)
 
     def _plan(self, gi, params):
         key = (gi, tuple(p.data_ptr() for p in params))
@@ -42,14 +43,19 @@ class FusedAdamW(torch.optim.Optimizer):
                      torch.empty((len(params), 6), dtype=torch.int64, device=dev), torch.cuda.Event()) for _ in range(4)]
             plan = (torch.tensor(bt, dtype=torch.int32, device=dev), torch.tensor(bc, dtype=torch.int32, device=dev), len(bt), ring, [0],
                     torch.zeros(len(params), dtype=torch.int32, device=dev))      # skipped steps per tensor (device side)
-            for k in [k for k in self._plans if k[0] == gi]:      # a re-allocated parameter list of THIS group: drop its old plan
-                del self._plans[k]
+            for k in [k for k in self._plans if k[0] == gi]:      # a re-allocated parameter list of THIS group (model.to() / .half() /
+                old = self._plans.pop(k)                          # .float()): its device-side skip counts move into the host step
+                if len(k[1]) == len(params):                      # counters first -- dropping them would over-count `step` for good
+                    for q, n in zip(params, old[5].tolist()):
+                        if n and q in self.state and "step" in self.state[q]:
+                            self.state[q]["step"] -= n
             self._plans[key] = plan
         return plan
 
     def last_step_skipped(self) -> bool:
-        """True when the last step() found a non-finite gradient and therefore changed nothing (one D2H read)."""
-        return any(bool(f.item() != 0) for f in self._found.values())
+        """True when the last step() found a non-finite gradient and therefore changed nothing (one D2H read).  Under
+        GradScaler.step(opt) the flag read is the scaler's own found_inf tensor of that step (valid until scaler.update() resets it)."""
+        return any(bool(f.item() != 0) for f in self._last_found)
 
     def effective_steps(self, p) -> int:
         """Updates really applied to parameter p: attempted steps minus the skipped ones (one D2H read)."""
@@ -80,6 +86,13 @@ class FusedAdamW(torch.optim.Optimizer):
         self._fold_skips()
         return super().state_dict()
 
+    def load_state_dict(self, state_dict):
+        """The loaded `step` counters already are "updates really applied": skips counted on the device since the last state_dict() belong to
+        the state being replaced and must not be subtracted from the loaded counters (a rollback would otherwise reach t <= 0)."""
+        super().load_state_dict(state_dict)
+        for plan in self._plans.values():
+            plan[5].zero_()
+
     @torch.no_grad()
     def step(self, closure=None, grad_scale: float = 1.0, check_finite=None):
         """grad_scale: static loss scale the gradients carry (divided out inside the kernel).  check_finite: look for inf / NaN gradients
@@ -91,6 +104,7 @@ class FusedAdamW(torch.optim.Optimizer):
         if check_finite is None:
             check_finite = amp_found is None and float(grad_scale) != 1.0
         jobs = []
+        self._last_found = []
         for gi, group in enumerate(self.param_groups):
             params = [p for p in group["params"] if p.requires_grad]
             if not params:
@@ -103,6 +117,8 @@ class FusedAdamW(torch.optim.Optimizer):
                     st["step"] = 0
                     st["exp_avg"] = torch.zeros_like(p)
                     st["exp_avg_sq"] = torch.zeros_like(p)
+            # (before the step counters are read: a re-planned group folds its old skip counts into them)
+            bt, bc, nblocks, ring, cursor, skipped = self._plan(gi, params)
             rows = []
             for p in params:
                 st = self.state[p]
@@ -115,7 +131,6 @@ class FusedAdamW(torch.optim.Optimizer):
                 rows.append((p.data_ptr(), g.data_ptr() if g is not None else 0, st["exp_avg"].data_ptr(),
                              st["exp_avg_sq"].data_ptr(), p.numel(), max(st["step"], 1)))
             # pointer table: {p, g, m, v, n, step} = 6 x 8 bytes per tensor, uploaded asynchronously (pinned staging)
-            bt, bc, nblocks, ring, cursor, skipped = self._plan(gi, params)
             dev = params[0].device
             if amp_found is not None:
                 found = amp_found.to(device=dev, dtype=torch.float32).reshape(-1)[:1]
@@ -125,6 +140,8 @@ class FusedAdamW(torch.optim.Optimizer):
                     found = self._found[dev] = torch.zeros(1, dtype=torch.float32, device=dev)
             else:
                 found = None
+            if found is not None and not any(f is found for f in self._last_found):
+                self._last_found.append(found)
             scale_dev = amp_scale.to(device=dev, dtype=torch.float32).reshape(-1)[:1] if amp_scale is not None else None
             host, table, ev = ring[cursor[0] % len(ring)]
             cursor[0] += 1
@@ -146,7 +163,7 @@ class FusedAdamW(torch.optim.Optimizer):
             b1, b2 = group["betas"]
             call("mu_adamw_multi", ptr(table), ptr(bt), ptr(bc), nblocks, len(params), float(group["lr"]), float(b1), float(b2),
                  float(group["eps"]), float(group["weight_decay"]), 1.0 / float(grad_scale), ptr(scale_dev), ptr(found),
-                 int(own_check and len(jobs) == 1), ptr(skipped) if found is not None else None, stream())
+                 int(own_check and len(jobs) == 1), ptr(skipped), stream())     # `skipped` always: t = step - skipped also in a step without a check
             for p in params:                 # the kernel wrote the parameters through raw pointers: tell autograd / the weight-layout cache
                 if p.grad is not None:
                     torch.autograd.graph.increment_version(p)

@@ -96,12 +96,15 @@ def main():
         for (B, H, Cin, Cout) in shapes:
             bufs.append((torch.randn(B, H, H, Cin, device=dev, dtype=dt), (torch.randn(9, Cout, Cin, device=dev) * 0.05).to(dt), torch.empty(B, H, H, Cout, device=dev, dtype=dt),
                          torch.randn(B, H, H, Cout, device=dev, dtype=dt), torch.empty(Cout, Cin, 3, 3, device=dev),
-                         torch.empty(_lib.load().mu_conv_wgrad_workspace_bytes(B, H, H, Cin, Cout, 9), dtype=torch.uint8, device=dev)))
+                         torch.empty(max(l.mu_conv_wgrad_workspace_bytes(B, H, H, Cin, Cout, 9) for l in libs.values()), dtype=torch.uint8, device=dev)))
+            if XF:          # MU_AB_FP32X=1: chunk-encoded operands (x, w, dy), dtype code 2
+                for t in (bufs[-1][0], bufs[-1][1], bufs[-1][3]):
+                    _lib.call("mu_split_encode", t.data_ptr(), t.data_ptr(), t.numel(), st)
         def mk(lib, phase):
             (B, H, Cin, Cout), (x, w, y, dy, gw, ws) = shapes[phase // 2], bufs[phase // 2]
             if phase % 2 == 0:
-                return lambda: lib.mu_conv_fwd(x.data_ptr(), w.data_ptr(), None, y.data_ptr(), B, H, H, Cin, Cout, 9, Cin, Cout, 1, st)
-            return lambda: lib.mu_conv_wgrad(x.data_ptr(), dy.data_ptr(), gw.data_ptr(), B, H, H, Cin, Cout, 9, Cin, Cout, Cin, Cout, ws.data_ptr(), ws.numel(), 1, st)
+                return lambda: lib.mu_conv_fwd(x.data_ptr(), w.data_ptr(), None, y.data_ptr(), B, H, H, Cin, Cout, 9, Cin, Cout, code, st)
+            return lambda: lib.mu_conv_wgrad(x.data_ptr(), dy.data_ptr(), gw.data_ptr(), B, H, H, Cin, Cout, 9, Cin, Cout, Cin, Cout, ws.data_ptr(), ws.numel(), code, st)
         sel = tuple(range(0, 2 * len(shapes), 2)) if what == "conv" else tuple(range(1, 2 * len(shapes), 2))
         cases = [(f"{'fwd' if p % 2 == 0 else 'wgrad'} {shapes[p // 2]} {2e-9 * 9 * shapes[p // 2][0] * shapes[p // 2][1] ** 2 * shapes[p // 2][2] * shapes[p // 2][3]:.0f} GF", p) for p in sel]
     for cname, phase in cases:

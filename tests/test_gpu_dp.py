@@ -319,3 +319,9 @@ def test_bench_line_is_self_describing():
     assert rec["roofline"]["frac_at_measured_clock"] >= rec["roofline"]["frac"] > 0
     pg = rec["parity_grade_path"]                      # the same workload in the fp32x mode, behind the timed region
     assert pg["value"] > 0 and pg["finite"] and pg["parity_gate"]["passed"] is True and pg["parity_gate"]["observed"]["out"] <= 1e-3
+    # ... as a first-class measurement: >= 10 timed steps after 2 warm-up steps and a roofline block of its own (VERDICT r4 #5a)
+    assert pg["steps"] >= 10 and pg["warmup"] >= 2 and 0 < pg["roofline"]["frac"] < 1 and pg["roofline"]["launches_timed"] == pg["steps"]
+    # every sweep of the dominant attention block with its own executed-FLOP fraction (VERDICT r4 #5d)
+    ks = rec["roofline"]["kernels"]
+    assert set(ks) == {"fwd", "dq", "dkv"} and all(0 < k["frac"] < 1 and k["launches_timed"] == 2 for k in ks.values())
+    assert "power_w" not in rec["clock"]["smi"] and "power_rails_w" in rec["clock"]["smi"]

@@ -329,3 +329,50 @@ def test_precision_modes_do_not_share_cached_weight_layouts():
     assert torch.equal(a, c)
     err = float((a - b).abs().max()) / max(1.0, float(a.abs().max()))
     assert 0 < err < 1e-3, err
+
+
+@pytest.mark.parametrize("cin,cout,residual", [(16, 3, False), (3, 3, True)])
+def test_convblock_with_a_three_channel_second_conv_fp32x(cin, cout, residual, fp32x):
+    """a ConvBlock whose SECOND conv has <= 3 input channels (a plain-FMA layer like the stem) must run in the fp32x training
+    mode too -- its mid activation / gradient stay plain instead of chunk-encoded."""
+    import maskunet_amd
+    from oracle import maskunet_oracle as O
+    shapes = O._conv_block_shapes("m", cin, cout)
+    p = O.make_params(shapes, 77)
+    m = maskunet_amd.ConvBlock(cin, cout, residual=residual)
+    m.load_state_dict({k[2:]: v for k, v in p.items()})
+    m.cuda().train()
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(2, cin, 16, 16, generator=g)
+    go = torch.randn(2, cout, 16, 16, generator=g)
+    for v in p.values():
+        if v.dtype.is_floating_point and v.dim() > 0:
+            v.requires_grad_(True)
+    xr = x.clone().requires_grad_(True)
+    yr = O.conv_block(xr, {k: v for k, v in p.items()}, "m", residual, True, {})
+    yr.backward(go)
+    xd = x.cuda().requires_grad_(True)
+    y = m(xd)
+    y.backward(go.cuda())
+    assert float((y.cpu() - yr).abs().max()) <= 1e-3 * max(1.0, float(yr.abs().max()))
+    assert float((xd.grad.cpu() - xr.grad).abs().max()) <= 1e-3 * float(xr.grad.abs().max())
+    gw = m.conv_block[3].weight.grad.cpu()
+    gr = p["m.conv_block.3.weight"].grad
+    assert float((gw - gr).abs().max()) <= 1e-3 * float(gr.abs().max())
+
+
+def test_precision_switch_between_forward_and_backward_is_refused():
+    """the fp32 matmul precision is process-wide and read in forward and backward; a backward under the other mode would mix
+    encoded saved operands with plain-fp32 kernels -- it raises instead."""
+    import maskunet_amd
+    from maskunet_amd import ops
+    x = torch.randn(1, 8, 8, 64, device="cuda", requires_grad=True)
+    w = (torch.randn(64, 64, 3, 3, device="cuda") * 0.05).requires_grad_(True)
+    y = ops.conv(x, w)
+    maskunet_amd.set_float32_matmul_precision("high")
+    try:
+        with pytest.raises(RuntimeError, match="changed between a forward pass and its backward"):
+            y.sum().backward()
+    finally:
+        maskunet_amd.set_float32_matmul_precision("highest")
+

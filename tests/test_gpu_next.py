@@ -424,3 +424,56 @@ def test_fused_adamw_under_torch_gradscaler():
         scaler.update()
         assert (scaler.get_scale() < s0) == (it == 2)
     assert torch.isfinite(w).all() and torch.allclose(w, w_ref, rtol=2e-5, atol=2e-6)
+
+
+def test_fused_adamw_skip_counters_survive_rollback_reallocation_and_an_unchecked_step():
+    """the device-side skip counters and the host `step` must stay consistent through (1) load_state_dict() in a
+    process that skipped steps since its last state_dict(), (2) a re-allocated parameter list (the plan is keyed on data_ptr), (3) a plain
+    step() without a finite check after scaled steps -- the bias-correction exponent t = step - skipped must never reach 0 or jump."""
+    import maskunet_amd
+    torch.manual_seed(3)
+    w = torch.randn(3000, device="cuda").requires_grad_(True)
+    w_ref = w.detach().clone().requires_grad_(True)
+    our = maskunet_amd.FusedAdamW([w], lr=1e-2, weight_decay=1e-2)
+    ref = torch.optim.AdamW([w_ref], lr=1e-2, weight_decay=1e-2)
+
+    def both(g, skip=False, scale=1.0, **kw):
+        w.grad = g * scale
+        if skip:
+            w.grad[5] = float("inf")
+        else:
+            w_ref.grad = g.clone()
+            ref.step()
+        our.step(grad_scale=scale, **kw)
+
+    both(torch.randn_like(w), scale=64.0)
+    snap = our.state_dict()                                      # step = 1 (nothing skipped yet)
+    snap = {"state": {k: {kk: (vv.clone() if torch.is_tensor(vv) else vv) for kk, vv in v.items()} for k, v in snap["state"].items()},
+            "param_groups": snap["param_groups"]}
+    w_snap, ref_snap, ref_w_snap = w.detach().clone(), ref.state_dict(), w_ref.detach().clone()
+    ref_snap = {"state": {k: {kk: (vv.clone() if torch.is_tensor(vv) else vv) for kk, vv in v.items()} for k, v in ref_snap["state"].items()},
+                "param_groups": ref_snap["param_groups"]}
+    both(torch.randn_like(w), skip=True, scale=64.0)             # skipped on the device: skipped[0] = 1, host step = 2
+    both(torch.randn_like(w), skip=True, scale=64.0)             # skipped[0] = 2, host step = 3
+    assert our.effective_steps(w) == 1
+    # (1) roll back to the snapshot: the loaded step (1) must not have the two stale skips subtracted (t would be -1 -> inf / NaN weights)
+    our.load_state_dict(snap)
+    ref.load_state_dict(ref_snap)
+    with torch.no_grad():
+        w.copy_(w_snap)
+        w_ref.copy_(ref_w_snap)
+    assert our.effective_steps(w) == 1
+    both(torch.randn_like(w), scale=64.0)
+    assert torch.isfinite(w).all() and torch.allclose(w, w_ref, rtol=2e-5, atol=2e-6)
+    # (3) a skipped step, then a plain unchecked step: t continues from the applied count (2 -> 3), it does not jump by the skips
+    both(torch.randn_like(w), skip=True, scale=64.0)
+    both(torch.randn_like(w))                                    # grad_scale 1 -> no finite check, skipped[] still subtracted
+    assert our.effective_steps(w) == 3
+    assert torch.allclose(w, w_ref, rtol=2e-5, atol=2e-6)
+    # (2) re-allocated storage (what model.to() / .float() do): the old plan's skip is folded into `step`, not dropped
+    with torch.no_grad():
+        w.data = w.data.clone()
+    both(torch.randn_like(w), scale=64.0)
+    assert our.effective_steps(w) == 4 and our.state_dict()["state"][0]["step"] == 4
+    assert torch.allclose(w, w_ref, rtol=2e-5, atol=2e-6)
+
