@@ -13,7 +13,7 @@ from ctypes import c_char_p, c_float, c_int, c_long, c_ulonglong, c_void_p
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.environ.get("MU_LIB_PATH") or os.path.join(_HERE, "libmaskunet_hip.so")     # MU_LIB_PATH: debug builds (tests/build_attn_variant.sh)
+LIB_PATH = os.environ.get("MU_LIB_PATH") or os.path.join(_HERE, "libmaskunet_hip.so")     # MU_LIB_PATH: debug builds (tools/build_attn_variant.sh)
 
 MU_F32, MU_F16, MU_F32X = 0, 1, 2
 ACT_NONE, ACT_GELU, ACT_RELU = 0, 1, 2

@@ -16,7 +16,7 @@
 #include "../../include/maskunet_hip.h"
 #include <stdlib.h>
 #include <type_traits>
-// Tuning knobs (overridable with -D for tests/ab_bench.py A/B runs).  Measured in-process, N=16384 C=64 B=64 fp16:
+// Tuning knobs (overridable with -D for tools/ab_bench.py A/B runs).  Measured in-process, N=16384 C=64 B=64 fp16:
 //   dK/dV  : 3 waves/SIMD (168 VGPRs, 4 spilled) 4.70 ms vs 2 waves/SIMD 5.24 ms; 1 wave/SIMD with 64 keys/wave 9 ms
 //   dQ     : 32-key tiles (152 VGPRs, 3 waves/SIMD) 3.07 ms vs 64-key tiles (196 VGPRs) 3.22 ms; forcing 3 waves/SIMD on the
 //            64-key version spills into the loop: 10.97 ms

@@ -58,13 +58,13 @@ def test_unet_b8_train_mode_vs_oracle():
 
 
 def test_kernels_are_bitwise_deterministic_at_bench_shapes():
-    """tests/stress_determinism.py (race screen of the hand-placed vmcnt / barrier schedules) with 20 launches per kernel and shape;
+    """tools/stress_determinism.py (race screen of the hand-placed vmcnt / barrier schedules) with 20 launches per kernel and shape;
     profiles/ holds the log of a 300-launch run."""
     import os
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    r = subprocess.run([sys.executable, os.path.join(root, "tests", "stress_determinism.py"), "20"], capture_output=True, text=True, timeout=900)
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "stress_determinism.py"), "20"], capture_output=True, text=True, timeout=900)
     assert r.returncode == 0 and "all launches bit-identical" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
 
 

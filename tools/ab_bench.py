@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""In-process interleaved A/B timing of library variants (cdna guide rule 24): python tests/ab_bench.py attn|bn|conv|wgrad A B [C ...]
-Variants are gpurun_variants/libmu_<NAME>.so built by tests/build_variant.sh.  Debug aid."""
+"""In-process interleaved A/B timing of library variants (cdna guide rule 24): python tools/ab_bench.py attn|bn|conv|wgrad A B [C ...]
+Variants are gpurun_variants/libmu_<NAME>.so built by tools/build_variant.sh.  Debug aid."""
 import ctypes, os, statistics, sys
 import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

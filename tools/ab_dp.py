@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """In-process timing of the data-parallel code path in a group of ONE rank (debug aid): plain step vs DataParallel with / without overlap.
-python tests/ab_dp.py   (single GPU; RCCL backend)"""
+python tools/ab_dp.py   (single GPU; RCCL backend)"""
 import os, sys, time, statistics
 import torch, torch.distributed as dist
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

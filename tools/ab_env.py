@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Whole-step A/B of environment switches on ONE box (debug aid): python tests/ab_env.py NAME[:VAR=V,VAR2=V2] ... [-- bench.py args]
+"""Whole-step A/B of environment switches on ONE box (debug aid): python tools/ab_env.py NAME[:VAR=V,VAR2=V2] ... [-- bench.py args]
 Every arm runs bench.py in its own process with its variables set (MU_LIB_PATH=... selects a library variant too); rounds interleaved,
 median ms/step per arm (cdna guide rule 24: never compare timings taken on different boxes)."""
 import json, os, statistics, subprocess, sys

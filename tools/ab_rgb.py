@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""In-process A/B of the first-layer weight-gradient kernel (3 -> 64 channels, 128x128, B = 64): python tests/ab_rgb.py A B ..."""
+"""In-process A/B of the first-layer weight-gradient kernel (3 -> 64 channels, 128x128, B = 64): python tools/ab_rgb.py A B ..."""
 import os, statistics, sys
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""Whole-step A/B of library variants on ONE box (debug aid): python tests/ab_step.py A B [C ...] [-- bench.py args]
-Each variant (gpurun_variants/libmu_<NAME>.so, see tests/build_variant.sh) runs bench.py in its own process, rounds interleaved."""
+"""Whole-step A/B of library variants on ONE box (debug aid): python tools/ab_step.py A B [C ...] [-- bench.py args]
+Each variant (gpurun_variants/libmu_<NAME>.so, see tools/build_variant.sh) runs bench.py in its own process, rounds interleaved."""
 import json, os, statistics, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 args = sys.argv[1:]

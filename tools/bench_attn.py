@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Micro-benchmark of the attention block kernels (debug aid): python tests/bench_attn.py [B N C]"""
+"""Micro-benchmark of the attention block kernels (debug aid): python tools/bench_attn.py [B N C]"""
 import os, sys, time
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Micro-benchmark of the 3x3 conv kernels (debug aid): python tests/bench_conv.py [B H Cin Cout]"""
+"""Micro-benchmark of the 3x3 conv kernels (debug aid): python tools/bench_conv.py [B H Cin Cout]"""
 import os, sys
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

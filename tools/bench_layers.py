@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Per-layer table of the 3x3 conv kernels at the bench configuration (debug aid / profiles evidence):
-python tests/bench_layers.py [B] [--fp32x]
+python tools/bench_layers.py [B] [--fp32x]
 Every 3x3 shape of UNet(3, c_out, hw=128) at batch B: forward, data-gradient (the same kernel family with Cin/Cout swapped) and
 weight-gradient, in-process HIP-event timings over 20 launches, algorithmic TFLOP/s = 2*B*H*W*Cin*Cout*9 / t."""
 import os, sys

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Weight-gradient-only micro run for PMC passes (debug aid): python tests/bench_wgrad_only.py [B H Cin Cout]"""
+"""Weight-gradient-only micro run for PMC passes (debug aid): python tools/bench_wgrad_only.py [B H Cin Cout]"""
 import os, sys
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

@@ -1,6 +1,6 @@
 #!/bin/bash
 # Variant of the HIP library that differs from the in-tree build only in ONE source file (default attn.hip):
-#   tests/build_attn_variant.sh NAME "-DMU_FLAG=1 ..." [file]     -> gpurun_variants/libmu_NAME.so  (tests/ab_bench.py)
+#   tools/build_attn_variant.sh NAME "-DMU_FLAG=1 ..." [file]     -> gpurun_variants/libmu_NAME.so  (tools/ab_bench.py)
 # The other objects are the in-tree ones (run `make -C maskunet_amd/csrc` first).  Debug aid.
 set -e
 NAME=$1; EXTRA="$2"; F=${3:-attn}

@@ -1,6 +1,6 @@
 #!/bin/bash
-# Build a variant of the HIP library for in-process A/B timing: tests/build_variant.sh NAME "-DMU_FLAG=1 ..."
-# -> gpurun_variants/libmu_NAME.so (used by tests/ab_bench.py).  Debug aid, not part of the product build.
+# Build a variant of the HIP library for in-process A/B timing: tools/build_variant.sh NAME "-DMU_FLAG=1 ..."
+# -> gpurun_variants/libmu_NAME.so (used by tools/ab_bench.py).  Debug aid, not part of the product build.
 set -e
 NAME=$1; shift
 EXTRA="$*"

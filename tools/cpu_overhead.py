@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Host-side enqueue time of one training step vs its GPU time (debug aid): python tests/cpu_overhead.py [--optimizer]"""
+"""Host-side enqueue time of one training step vs its GPU time (debug aid): python tools/cpu_overhead.py [--optimizer]"""
 import os, sys, time
 import torch
 import torch.nn.functional as F

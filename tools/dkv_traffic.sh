@@ -1,7 +1,7 @@
 #!/bin/bash
 # roofline.traffic of the bench line per workload shape: FETCH_SIZE / WRITE_SIZE (separate rocprofv3 --pmc passes, counters only with
 # --kernel-trace, every profiler command under `timeout`) of the dominant kernel -- the dK/dV sweep of self_attention6 -- inside the
-# bench step.  Usage (repo root on the GPU box):  bash tests/dkv_traffic.sh TAG KEY [bench.py args ...]
+# bench step.  Usage (repo root on the GPU box):  bash tools/dkv_traffic.sh TAG KEY [bench.py args ...]
 #   -> gpurun_out/<TAG>_dkv_traffic_<KEY>.json   (KEY = bench.py's traffic key: b{batch}_c{c_out}_hw{hw}_{dtype}[_3head])
 TAG=$1; KEY=$2; shift 2
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
@@ -31,7 +31,7 @@ if f is None or w is None:
     print("no dK/dV launches found"); sys.exit(1)
 rec = {"kernel": name, "workload_key": sys.argv[4], "bench_args": sys.argv[5],
        "how": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) -- python3 bench.py --no-cpu-baseline --no-parity-gate --no-clock-probe --no-fp32x-line --steps 2 --warmup 1 "
-              + sys.argv[5] + f" (tests/dkv_traffic.sh); mean over the {nf} largest-grid launches of the kernel (self_attention6)",
+              + sys.argv[5] + f" (tools/dkv_traffic.sh); mean over the {nf} largest-grid launches of the kernel (self_attention6)",
        "FETCH_SIZE_KB": round(f, 1), "WRITE_SIZE_KB": round(w, 1),
        "correction": "gfx950 FETCH_SIZE reports 1/2 of the bytes of wide (16 B/lane) streaming reads (MI355X_MICROARCH.md, HBM section): bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024",
        "hbm_bytes_per_launch": int((2 * f + w) * 1024)}

@@ -1,6 +1,6 @@
 #!/bin/bash
-# FETCH_SIZE / duration of the attention kernels under tests/bench_attn.py for library variants (debug aid):
-#   bash tests/fetch_probe.sh TAG [variant ...]      ("intree" = the in-tree library)
+# FETCH_SIZE / duration of the attention kernels under tools/bench_attn.py for library variants (debug aid):
+#   bash tools/fetch_probe.sh TAG [variant ...]      ("intree" = the in-tree library)
 TAG=$1; shift
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out
@@ -8,7 +8,7 @@ export TMPDIR=/tmp
 for v in "$@"; do
   if [ $v = intree ]; then unset MU_LIB_PATH; else export MU_LIB_PATH=$ROOT/gpurun_variants/libmu_$v.so; fi
   cd /tmp
-  timeout 600 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/${TAG}_$v -o a -- python3 $ROOT/tests/bench_attn.py > $OUT/${TAG}_$v.log 2>&1
+  timeout 600 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/${TAG}_$v -o a -- python3 $ROOT/tools/bench_attn.py > $OUT/${TAG}_$v.log 2>&1
   echo "$v rc=$?"
   cd $ROOT
   python3 - $OUT/${TAG}_$v/a_counter_collection.csv <<'PY'

@@ -1,7 +1,7 @@
 #!/bin/bash
 # One gpurun session: GPU test suite, the bench line, rocprofv3 kernel-trace stats and the PMC passes (separate passes, counters
 # only with --kernel-trace, every profiler command under `timeout`).  Usage (from the repo root on the GPU box):
-#     bash tests/gpu_session.sh TAG [tests|bench|prof|pmc ...]      (default: all four; MU_SESSION_FLAGS="--dtype fp32x" adds bench flags)
+#     bash tools/gpu_session.sh TAG [tests|bench|prof|pmc ...]      (default: all four; MU_SESSION_FLAGS="--dtype fp32x" adds bench flags)
 # Outputs land in gpurun_out/<TAG>_*.
 TAG=${1:-r02}; shift
 WHAT=${*:-tests bench prof pmc}
@@ -24,7 +24,7 @@ for w in $WHAT; do
       echo "prof rc=$?"
       cd $ROOT
       f=$(find $OUT/${TAG}_prof -name '*kernel_stats.csv' | head -1)
-      [ -n "$f" ] && python tests/prof_summary.py $f 10 24 > $OUT/${TAG}_prof_summary.txt && head -12 $OUT/${TAG}_prof_summary.txt ;;
+      [ -n "$f" ] && python tools/prof_summary.py $f 10 24 > $OUT/${TAG}_prof_summary.txt && head -12 $OUT/${TAG}_prof_summary.txt ;;
     pmc)
       cd /tmp
       timeout 900 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE --output-format csv -d $OUT/${TAG}_pmc_sq -o a -- python3 $ROOT/bench.py --no-cpu-baseline --no-parity-gate --no-clock-probe --no-fp32x-line $MU_SESSION_FLAGS --steps 2 --warmup 1 > $OUT/${TAG}_pmc_sq.log 2>&1
@@ -34,7 +34,7 @@ for w in $WHAT; do
       timeout 900 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/${TAG}_pmc_write -o a -- python3 $ROOT/bench.py --no-cpu-baseline --no-parity-gate --no-clock-probe --no-fp32x-line $MU_SESSION_FLAGS --steps 2 --warmup 1 > $OUT/${TAG}_pmc_write.log 2>&1
       echo "pmc write rc=$?"
       cd $ROOT
-      python tests/pmc_table.py $OUT/${TAG}_pmc_table.md 3 $OUT/${TAG}_pmc_sq $OUT/${TAG}_pmc_fetch $OUT/${TAG}_pmc_write | head -30
+      python tools/pmc_table.py $OUT/${TAG}_pmc_table.md 3 $OUT/${TAG}_pmc_sq $OUT/${TAG}_pmc_fetch $OUT/${TAG}_pmc_write | head -30
       ;;
   esac
 done

@@ -1,5 +1,5 @@
 #!/bin/bash
-# LDS bank-conflict share per kernel over one bench step (debug aid): bash tests/lds_conflicts.sh TAG [bench flags, e.g. --dtype fp32x]   (on the GPU box)
+# LDS bank-conflict share per kernel over one bench step (debug aid): bash tools/lds_conflicts.sh TAG [bench flags, e.g. --dtype fp32x]   (on the GPU box)
 TAG=${1:-lds}
 shift
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}

@@ -4,7 +4,7 @@
 //   mode 0: no synchronisation, W waves per SIMD (blocks of 256 threads, W blocks per CU)
 //   mode 1: ping-pong: 512-thread blocks (2 waves per SIMD), group B one phase behind group A, one s_barrier per phase
 //   mode 2: mode 0 with 512-thread blocks and a barrier per iteration, no stagger (lockstep partners)
-// build: hipcc --offload-arch=gfx950 -O3 tests/micro_pingpong.hip -o /tmp/micro_pingpong ; run: /tmp/micro_pingpong
+// build: hipcc --offload-arch=gfx950 -O3 tools/micro_pingpong.hip -o /tmp/micro_pingpong ; run: /tmp/micro_pingpong
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <vector>

@@ -1,4 +1,4 @@
-"""Aggregate a rocprofv3 --pmc counter_collection CSV per kernel: python tests/pmc_summary.py <csv> [name-substring]"""
+"""Aggregate a rocprofv3 --pmc counter_collection CSV per kernel: python tools/pmc_summary.py <csv> [name-substring]"""
 import collections
 import csv
 import sys

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Per-kernel counter table from rocprofv3 --pmc passes (debug/profiling aid, not a test).
 
-    python tests/pmc_table.py OUT.md steps PASS_DIR [PASS_DIR ...]
+    python tools/pmc_table.py OUT.md steps PASS_DIR [PASS_DIR ...]
 
 Each PASS_DIR holds one `*_counter_collection.csv` of a `rocprofv3 --kernel-trace --pmc <counters> --output-format csv` run of the
 SAME command (bench.py with `steps` steps in total, warm-up included).  Counters of all passes are merged per kernel name; the

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Debug aid: per-kernel time per step of two rocprofv3 kernel_stats.csv files side by side: python tests/prof_diff.py A.csv B.csv STEPS"""
+"""Debug aid: per-kernel time per step of two rocprofv3 kernel_stats.csv files side by side: python tools/prof_diff.py A.csv B.csv STEPS"""
 import csv, sys
 def load(p, steps):
     d = {}

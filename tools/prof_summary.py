@@ -1,4 +1,4 @@
-"""Summarise a rocprofv3 kernel_stats CSV per bench step: python tests/prof_summary.py <csv> <steps+warmup> [topN]."""
+"""Summarise a rocprofv3 kernel_stats CSV per bench step: python tools/prof_summary.py <csv> <steps+warmup> [topN]."""
 import csv
 import sys
 

@@ -1,6 +1,6 @@
 #!/bin/bash
 # fp32x A/B session (debug aid): kernel + module parity in the split-bf16 mode, the bench line and the rocprof kernel split.
-#     bash tests/session_fp32x.sh TAG      (from the repo root on the GPU box)
+#     bash tools/session_fp32x.sh TAG      (from the repo root on the GPU box)
 TAG=${1:-fx}
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out
@@ -16,5 +16,5 @@ timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_
 echo "prof rc=$?"
 cd $ROOT
 f=$(find $OUT/${TAG}_prof_fp32x -name '*kernel_stats.csv' | head -1)
-[ -n "$f" ] && python tests/prof_summary.py $f 8 30 > $OUT/${TAG}_prof_fp32x_summary.txt && head -40 $OUT/${TAG}_prof_fp32x_summary.txt
+[ -n "$f" ] && python tools/prof_summary.py $f 8 30 > $OUT/${TAG}_prof_fp32x_summary.txt && head -40 $OUT/${TAG}_prof_fp32x_summary.txt
 rm -rf $OUT/${TAG}_prof_fp32x

@@ -2,7 +2,7 @@
 """Race screen at the bench shapes (debug aid, GPU): every 3x3 conv shape of the model at B = 64 -- forward, data-gradient, weight-gradient --
 and the attention kernels at the model's (N, C) pairs are launched REPS times on the same inputs; every output must be bit-identical to the
 first launch (a hand-placed vmcnt / barrier schedule that is one phase short shows up as rare differing tiles, cdna guide section 5).
-python tests/stress_determinism.py [REPS]"""
+python tools/stress_determinism.py [REPS]"""
 import os, sys
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

@@ -1,5 +1,5 @@
 """End-to-end sanity check (debug aid, GPU): 300 fp16 training steps (HIP forward/backward, maskunet_amd.CrossEntropyLoss, FusedAdamW with a
-static loss scale) on a learnable synthetic task; the loss must fall and every parameter stay finite.  python tests/train_soak.py
+static loss scale) on a learnable synthetic task; the loss must fall and every parameter stay finite.  python tools/train_soak.py
 `--scaler`: the same under torch.amp.GradScaler (starting at 2^24, so the first steps overflow: FusedAdamW skips them on the device and the
 scaler backs off) -- the fp16 training-safety path of round 4.  `--fp32x`: fp32 storage with split-bf16 matrix products instead of fp16."""
 import os, sys, torch
