@@ -7,7 +7,7 @@ import os, sys
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from maskunet_amd import _lib
-from tests.bench_layers import LAYERS  # noqa: E402  (importing runs nothing: main() is guarded below)
+from tools.bench_layers import LAYERS  # noqa: E402  (importing runs nothing: main() is guarded below)
 
 def main():
     reps = int(sys.argv[1]) if len(sys.argv) > 1 else 20
