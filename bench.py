@@ -379,11 +379,21 @@ def parity_grade_line(args, dev, steps, warmup, clk):
         maskunet_amd.set_float32_matmul_precision("highest")
 
 
+def need_devices(n):
+    """One process per GPU over RCCL needs n visible devices: refuse with a message instead of n - ndev ranks dying in hipSetDevice /
+    ncclCommInitRank (torch.cuda.device_count() does not initialise the GPU).  MU_DIST_BACKEND=gloo (debug) lets ranks share a device."""
+    ndev = torch.cuda.device_count()
+    if os.environ.get("MU_DIST_BACKEND", "nccl") == "nccl" and n > ndev:
+        raise SystemExit(f"bench.py: --gpus {n} over the nccl (RCCL) backend needs {n} visible GPUs, this node shows {ndev} "
+                         f"(HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES?); MU_DIST_BACKEND=gloo shares one device between ranks for debugging")
+
+
 def spawn_ranks(n):
     """`python bench.py --gpus N` without a launcher: run `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr
     127.0.0.1 --master-port <free> bench.py <same arguments>` as a child process and hand back its output and exit code."""
     import socket
     import subprocess
+    need_devices(n)
     with socket.socket() as so:
         so.bind(("127.0.0.1", 0))
         port = so.getsockname()[1]
@@ -451,6 +461,8 @@ def main():
     multi = world > 1 or os.environ.get("MU_BENCH_FORCE_DP") == "1"
     if multi:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if world > 1:
+            need_devices(world)
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", local))
         else:

@@ -1097,6 +1097,13 @@ __device__ __forceinline__ void conv_nt4_body(const h16* __restrict__ x, const h
     stage_w(0);
     stage_w(1);
     stage_w(2);
+#ifdef MU_NT4_ABL_NODMA_REAL
+    // timing-only ablation (wrong results): every ring slot and both halo buffers hold REAL data from here on and the tap loop issues no
+    // DMA and waits for none -- the upper bound of what loader waves that own all DMA issue could give the consumer waves
+#pragma unroll
+    for (int k = 0; k < HPW; ++k) stage_h(k, 1);
+    stage_w(3);
+#endif
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     if (wr == 1) __builtin_amdgcn_s_barrier();
@@ -1120,10 +1127,12 @@ __device__ __forceinline__ void conv_nt4_body(const h16* __restrict__ x, const h
                 for (int j = 0; j < TN; ++j) b[j] = M_::ld(hb + j * (HW_ * 128));
                 // exactly three DMAs per wave per tap: the halo piece in the first phase (tap 0: in the second -- the buffer it
                 // refills was read until the previous chunk's last phase), the two weight pieces in the second
+#ifndef MU_NT4_ABL_NODMA_REAL
                 if ((kk == 0) == (t != 0)) {
                     if (t < HPW) stage_h(t, c + 1); else glds16(mu_zero_page, dump);
                 }
                 if (kk == 1) stage_w(s + 3);
+#endif
                 __builtin_amdgcn_s_barrier();
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 __builtin_amdgcn_sched_barrier(0);
@@ -1137,7 +1146,7 @@ __device__ __forceinline__ void conv_nt4_body(const h16* __restrict__ x, const h
 #ifndef MU_NT4_ABL_NOPRIO
                 __builtin_amdgcn_s_setprio(0);
 #endif
-#ifndef MU_NT4_ABL_NOWAIT
+#if !defined(MU_NT4_ABL_NOWAIT) && !defined(MU_NT4_ABL_NODMA_REAL)
                 if (kk == 0) {
                     if (t == 0) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");      // younger: H(8), W(s+2) x2
                     else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");             // younger: H(t-1), W(s+2) x2, H(t)

@@ -16,6 +16,13 @@ per-forward broadcast / scatter / gather / reduce-add collapses to a 
 The collective backend is whatever ``torch.distributed`` was initialised with: "nccl" (= RCCL) on GPUs,
 "gloo" in the CPU tests.
 
+Zero-copy exchange (round 5, ``arena=True``): once the dead parameters are known (after the first synchronised step) every bucket
+owns ONE persistent flat fp32 buffer and every live parameter a slice of it.  The kernels that produce the large gradients write
+into the slice directly (ops.GRAD_ARENA / ops.grad_out: conv and Linear weight gradients, the final LayerNorm's affine tensors --
+98 % of the elements), autograd adopts that tensor as ``p.grad``, the few small ones (BatchNorm / bias vectors) are moved in by one
+multi-tensor copy per bucket, and the bucket is all-reduced IN PLACE: no flattening ``torch.cat`` (a read + write of the 99.7 MB of
+gradients per step), no write-back, and ``p.grad`` never changes identity afterwards.
+
 Stream order on GPUs (the part a blocking CPU backend cannot test): gradients are produced on the current (main)
 stream; the comm stream waits for the main stream, flattens the bucket and issues the all-reduce; ``Work.wait()`` is
 called WITH THE COMM STREAM CURRENT, so the divide (and, with ``copy_back``, the copy into the existing ``p.grad``) are
@@ -48,6 +55,10 @@ class _Bucket:
         self.flat = None
         self.work = None
         self.included: List[nn.Parameter] = []
+        self.arena = None               # persistent flat fp32 buffer of the live parameters' gradients (zero-copy exchange)
+        self.views = {}                 # id(p) -> its slice of `arena`, shaped like p
+        self.live: List[nn.Parameter] = []
+        self.in_place = False           # this step's reduce runs on `arena` itself
 
 
 class DataParallel(nn.Module):
@@ -57,7 +68,7 @@ class DataParallel(nn.Module):
     ade_panoptic.py:434)."""
 
     def __init__(self, module: nn.Module, bucket_mb: float = 32.0, overlap: bool = True, process_group=None,
-                 force_sync: bool = False):
+                 force_sync: bool = False, arena: bool = True):
         super().__init__()
         self.module = module
         self.group = process_group
@@ -91,6 +102,8 @@ class DataParallel(nn.Module):
         self._sync = True
         # ids of parameters that produced no gradient in the last synchronised step (None until one step has been seen)
         self._dead = None
+        self._use_arena = bool(arena)
+        self._arena_dead = None         # the dead set the current arena was laid out for (None = no arena)
 
     # ------------------------------------------------------------------------------------------
     def broadcast_parameters(self, src: int = 0):
@@ -126,10 +139,53 @@ class DataParallel(nn.Module):
 
     def _arm(self):
         dead = self._dead or ()
+        if self.multi and self._use_arena and self._dead is not None and self._arena_dead != self._dead:
+            self._build_arena()
         for b in self.buckets:
             b.pending = sum(1 for p in b.params if id(p) not in dead)
-            b.flat, b.work, b.included = None, None, []
+            b.flat, b.work, b.included, b.in_place = None, None, [], False
         self._armed = self._sync
+
+    def _build_arena(self):
+        """One persistent flat fp32 gradient buffer per bucket, one slice per live parameter (bucket order), registered with ops so the
+        gradient kernels write into the slices.  Rebuilt when the set of dead parameters changes."""
+        from . import ops
+        self._drop_arena()
+        for b in self.buckets:
+            b.live = [p for p in b.params if id(p) not in self._dead]
+            if not b.live:
+                continue
+            b.arena = torch.zeros(sum(p.numel() for p in b.live), dtype=torch.float32, device=b.live[0].device)
+            off = 0
+            for p in b.live:
+                b.views[id(p)] = b.arena[off:off + p.numel()].view(p.shape)
+                off += p.numel()
+        if ops.GRAD_ARENA is None:
+            ops.GRAD_ARENA = {}
+        for b in self.buckets:
+            ops.GRAD_ARENA.update(b.views)
+        self._arena_dead = set(self._dead)
+
+    def _drop_arena(self):
+        from . import ops
+        for b in self.buckets:
+            if ops.GRAD_ARENA is not None:
+                for k in b.views:
+                    ops.GRAD_ARENA.pop(k, None)
+            b.arena, b.views, b.live = None, {}, []
+        self._arena_dead = None
+
+    def prepare_arena(self):
+        """Lay the arena out NOW from the gradients that exist (parameters whose ``.grad`` is None count as dead) instead of after the
+        first synchronised step -- GraphedStep calls this after its eager warm-up so that the captured kernels write into the slices."""
+        if self.multi and self._use_arena:
+            self._dead = {id(p) for b in self.buckets for p in b.params if p.grad is None}
+            self._build_arena()
+
+    def gradient_slice(self, p):
+        """The arena slice that is (or will be) ``p.grad`` after a synchronised step, or None (no arena yet / a dead parameter)."""
+        b = self._bucket_of.get(id(p))
+        return b.views.get(id(p)) if b is not None else None
 
     def _on_grad(self, p):
         if not self._armed:
@@ -171,7 +227,50 @@ class DataParallel(nn.Module):
         b.included = [p for p in b.params if p.grad is not None]
         if not b.included:
             return
-        b.flat, b.work = self._reduce(b.included)
+        if b.arena is not None and len(b.included) == len(b.live) and all(id(p) in b.views for p in b.included):
+            (b.flat, b.work), b.in_place = self._reduce_in_place(b), True
+        else:                               # no arena (first step / CPU-only parameters), or a live parameter without a gradient this step
+            b.flat, b.work = self._reduce(b.included)
+
+    def _reduce_in_place(self, b: _Bucket):
+        """All-reduce of the bucket's arena itself.  Gradients the kernels did not write into their slices (the small vectors; anything
+        autograd accumulated elsewhere) are moved in by one multi-tensor copy, and p.grad becomes the slice."""
+        dev = b.arena.device
+        src, dst = [], []
+        for p in b.live:
+            v = b.views[id(p)]
+            if p.grad.data_ptr() != v.data_ptr():
+                src.append(p.grad.reshape(v.shape) if p.grad.dtype == torch.float32 else p.grad.float().reshape(v.shape))
+                dst.append(v)
+        op = dist.ReduceOp.AVG if (self._avg and dev.type == "cuda") else dist.ReduceOp.SUM
+        if dev.type == "cuda":
+            comm = self._comm(dev)
+            comm.wait_stream(torch.cuda.current_stream(dev))
+            from . import ops
+            side = ops.wgrad_stream(dev)
+            if side is not None:
+                comm.wait_stream(side)
+            with torch.cuda.stream(comm):
+                if src:
+                    torch._foreach_copy_(dst, src)
+                    for t in src:
+                        t.record_stream(comm)
+                work = dist.all_reduce(b.arena, op=op, group=self.group, async_op=True)
+        else:
+            if src:
+                torch._foreach_copy_(dst, src)
+            work = dist.all_reduce(b.arena, op=op, group=self.group, async_op=True)
+        for p in b.live:
+            p.grad = b.views[id(p)]
+        return b.arena, work
+
+    def _finish_in_place(self, b: _Bucket):
+        dev = b.arena.device
+        ctx = torch.cuda.stream(self._comm(dev)) if dev.type == "cuda" else contextlib.nullcontext()
+        with ctx:
+            b.work.wait()                   # with the comm stream current (see _write_back)
+            if not (self._avg and dev.type == "cuda"):
+                b.arena.div_(self.world)
 
     def _write_back(self, params, flat, work, copy_back=False):
         dev = flat.device
@@ -218,7 +317,9 @@ class DataParallel(nn.Module):
                 self._launch(b)
         late = []
         for b in self.buckets:
-            if b.work is not None:
+            if b.work is not None and b.in_place:
+                self._finish_in_place(b)    # p.grad already IS the reduced slice: nothing to hand back, whatever `copy_back` says
+            elif b.work is not None:
                 self._write_back(b.included, b.flat, b.work, copy_back)
             inc = {id(p) for p in b.included}
             late += [p for p in b.params if p.grad is not None and id(p) not in inc]
@@ -230,7 +331,7 @@ class DataParallel(nn.Module):
         # the same autograd graph runs on every rank, so this set is identical everywhere
         self._dead = {id(p) for b in self.buckets for p in b.params if p.grad is None}
         for b in self.buckets:
-            b.flat, b.work, b.included = None, None, []
+            b.flat, b.work, b.included, b.in_place = None, None, [], False
         self._armed = False
 
     sync_gradients = finish_gradient_sync

@@ -17,7 +17,8 @@ attention keep-masks are whatever the modules hold at capture time (set_keep_mas
 With a maskunet_amd.DataParallel model the replica's step is captured (the graph holds no collective) and the gradient exchange runs
 eagerly after every replay: the same bucketed all-reduce on the comm stream, without overlap with the backward -- the hooks of
 DataParallel sit on the parameters' AccumulateGrad nodes, which the captured torch.autograd.grad on fresh leaves never runs.  The
-averaged gradients land in the graph's own gradient tensors (p.grad).  Gradient accumulation is NOT available through a graph: a
+captured weight-gradient kernels write straight into DataParallel's bucket slices (its gradient arena, laid out after the first warm-up
+step), the buckets are reduced in place and p.grad is the reduced slice -- no flattening and no copy back per replay.  Gradient accumulation is NOT available through a graph: a
 replay overwrites the graph's gradient tensors instead of adding to them, so a call inside `DataParallel.no_sync()` raises.
 """
 from __future__ import annotations
@@ -45,8 +46,10 @@ class GraphedStep:
         side = torch.cuda.Stream(dev)
         side.wait_stream(torch.cuda.current_stream(dev))
         with torch.cuda.stream(side):
-            for _ in range(max(int(warmup), 1)):
+            for it in range(max(int(warmup), 1)):
                 self._body()
+                if it == 0 and self.dp is not None:
+                    self.dp.prepare_arena()      # from here on the large gradients are written into their all-reduce bucket slices
                 model.zero_grad(set_to_none=True)
         torch.cuda.current_stream(dev).wait_stream(side)
         torch.cuda.synchronize(dev)
@@ -68,10 +71,22 @@ class GraphedStep:
         # by an earlier eager step (e.g. through a loss tensor the caller still holds) makes the engine synchronise the capture stream
         # with that stream, which is not capturable (segfault in hipStreamEndCapture on this stack).  Fresh leaves have fresh nodes.
         fresh = {n: p.detach().requires_grad_(True) for n, p in zip(self.names, self.params)}
-        out = torch.func.functional_call(self.model, fresh, (self.inputs,))
-        sem = out[0] if isinstance(out, (tuple, list)) else out
-        loss = self.criterion(sem, self.labels)
-        grads = torch.autograd.grad(loss * self.scale if self.scale != 1.0 else loss, list(fresh.values()), allow_unused=True)
+        # DataParallel's gradient arena is keyed on the parameters; the kernels here see the fresh leaves: register them for the call
+        arena_keys = []
+        if self.dp is not None and ops.GRAD_ARENA is not None:
+            for n, p in zip(self.names, self.params):
+                v = self.dp.gradient_slice(p)
+                if v is not None:
+                    ops.GRAD_ARENA[id(fresh[n])] = v
+                    arena_keys.append(id(fresh[n]))
+        try:
+            out = torch.func.functional_call(self.model, fresh, (self.inputs,))
+            sem = out[0] if isinstance(out, (tuple, list)) else out
+            loss = self.criterion(sem, self.labels)
+            grads = torch.autograd.grad(loss * self.scale if self.scale != 1.0 else loss, list(fresh.values()), allow_unused=True)
+        finally:
+            for k in arena_keys:
+                ops.GRAD_ARENA.pop(k, None)
         self.grads = grads
         for p, g in zip(self.params, grads):
             p.grad = g

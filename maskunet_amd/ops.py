@@ -7,6 +7,7 @@ ends in `_lib.call`, which raises if the HIP library is missing or a kernel repo
 """
 from __future__ import annotations
 
+import math
 import os
 
 import torch
@@ -387,7 +388,26 @@ def _conv_raw(x, wprep, bias_p, Cout_p, taps, want_stats=False, x_encoded=False)
     return y
 
 
-def _wgrad_raw(x, gy, w_shape, taps, st=None, ws=None, gy_encoded=False, x_encoded=False):
+# Gradient arena (maskunet_amd.DataParallel, round 5): id(parameter) -> that parameter's fp32 slice of its all-reduce bucket.  The
+# kernels that produce the LARGE parameter gradients (conv / Linear weight gradients: 24.5 M of the model's 24.9 M parameters; the two
+# affine tensors of LayerNorm([64,128,128])) write straight into the slice, autograd's AccumulateGrad adopts the tensor it is handed
+# as p.grad (no copy while p.grad is None), and the bucket is all-reduced IN PLACE: no flattening torch.cat, no write-back.  Only while
+# p.grad is None: an existing gradient (accumulation over micro-batches) is added to by autograd as always.
+GRAD_ARENA = None
+
+
+def grad_out(param, shape, device):
+    """Destination for the gradient of `param`: its arena slice (viewed as `shape`) when one is registered and p.grad is None, else a
+    fresh fp32 tensor."""
+    a = GRAD_ARENA
+    if a is not None and param is not None and getattr(param, "grad", None) is None:
+        v = a.get(id(param))
+        if v is not None and v.device == device and v.numel() == math.prod(shape):
+            return v.view(shape)
+    return torch.empty(shape, dtype=torch.float32, device=device)
+
+
+def _wgrad_raw(x, gy, w_shape, taps, st=None, ws=None, gy_encoded=False, x_encoded=False, param=None):
     B, H, W, Cin_p = x.shape
     O, I = w_shape[0], w_shape[1]
     code = mdt(x)
@@ -399,7 +419,7 @@ def _wgrad_raw(x, gy, w_shape, taps, st=None, ws=None, gy_encoded=False, x_encod
         if not gy_encoded:
             gy = _enc(gy)
     Cout_p = gy.shape[-1]
-    gw = torch.empty(w_shape, dtype=torch.float32, device=x.device)
+    gw = grad_out(param, tuple(w_shape), x.device)
     if ws is None:
         ws = workspace(_lib.load().mu_conv_wgrad_workspace_bytes(B, H, W, Cin_p, Cout_p, taps), x.device)
     call("mu_conv_wgrad", ptr(x), ptr(gy), ptr(gw), B, H, W, Cin_p, Cout_p, taps, I, O, Cin_p, Cout_p, ptr(ws), ws.numel(),
@@ -410,7 +430,7 @@ def _wgrad_raw(x, gy, w_shape, taps, st=None, ws=None, gy_encoded=False, x_encod
 WGRAD_BIAS = os.environ.get("MU_WGRAD_BIAS", "1") != "0"        # debug switch: 0 = separate column-sum sweep for the bias gradients
 
 
-def _wgrad_bias_raw(x, gy, w_shape, taps):
+def _wgrad_bias_raw(x, gy, w_shape, taps, param=None):
     """(dW, db) from one sweep where the library supports it (fp16 1x1 layers on the wide tiles), else None."""
     B, H, W, Cin_p = x.shape
     Cout_p = gy.shape[-1]
@@ -418,7 +438,7 @@ def _wgrad_bias_raw(x, gy, w_shape, taps):
     if not WGRAD_BIAS or not lib.mu_conv_wgrad_bias_supported(Cin_p, Cout_p, taps, dt(x)):
         return None
     O, I = w_shape[0], w_shape[1]
-    gw = torch.empty(w_shape, dtype=torch.float32, device=x.device)
+    gw = grad_out(param, tuple(w_shape), x.device)
     gb = torch.empty(O, dtype=torch.float32, device=x.device)
     ws = workspace(lib.mu_conv_wgrad_workspace_bytes(B, H, W, Cin_p, Cout_p, taps), x.device)
     call("mu_conv_wgrad_bias", ptr(x), ptr(gy), ptr(gw), ptr(gb), B, H, W, Cin_p, Cout_p, taps, I, O, Cin_p, Cout_p, ptr(ws), ws.numel(),
@@ -455,7 +475,7 @@ def _join_side(index):
     return cb
 
 
-def _wgrad_side(x, gy, w_shape, taps, x_encoded=False):
+def _wgrad_side(x, gy, w_shape, taps, x_encoded=False, param=None):
     dev = x.device
     side = _SIDE.get(dev.index)
     if side is None:
@@ -468,7 +488,7 @@ def _wgrad_side(x, gy, w_shape, taps, x_encoded=False):
         ws = _SIDE_WS.get(dev.index)
         if ws is None or ws.numel() < nbytes:
             ws = _SIDE_WS[dev.index] = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=dev)
-        gw = _wgrad_raw(x, gy, w_shape, taps, st=side.cuda_stream, ws=ws, x_encoded=x_encoded)
+        gw = _wgrad_raw(x, gy, w_shape, taps, st=side.cuda_stream, ws=ws, x_encoded=x_encoded, param=param)
     x.record_stream(side)
     gy.record_stream(side)
     gw.record_stream(main)
@@ -546,7 +566,7 @@ class _Conv(torch.autograd.Function):
         gx = gw = gb = None
         side = ctx.needs_input_grad[1] and WGRAD_SIDE_STREAM and ctx.wparam.grad is None
         if side and os.environ.get("MU_WGRAD_SIDE_FIRST"):
-            gw = _wgrad_side(x, gy, tuple(weight.shape), ctx.taps, ctx.x_enc)
+            gw = _wgrad_side(x, gy, tuple(weight.shape), ctx.taps, ctx.x_enc, ctx.wparam)
         if gy_pre:
             ge = gy
             if side or not ctx.x_enc or (ctx.has_bias and ctx.needs_input_grad[2]):
@@ -558,14 +578,15 @@ class _Conv(torch.autograd.Function):
             ctx.wd = None
             gx = _conv_raw(ge, wd, None, x.shape[-1], ctx.taps, x_encoded=True)
         if side and gw is None:                  # behind the data gradient (both want every CU's LDS): it then runs beside the
-            gw = _wgrad_side(x, gy, tuple(weight.shape), ctx.taps, ctx.x_enc)      # HBM-bound kernels that follow on the main stream
+            gw = _wgrad_side(x, gy, tuple(weight.shape), ctx.taps, ctx.x_enc, ctx.wparam)      # HBM-bound kernels that follow on the main stream
         if ctx.needs_input_grad[1] and not side:
-            both = _wgrad_bias_raw(x, gy, tuple(weight.shape), ctx.taps) if (ctx.has_bias and ctx.needs_input_grad[2]) else None
+            both = _wgrad_bias_raw(x, gy, tuple(weight.shape), ctx.taps, ctx.wparam) if (ctx.has_bias and ctx.needs_input_grad[2]) else None
             if both is not None:
                 gw, gb = both
             else:
                 first = not ctx.x_enc                                   # (the first layer's plain-FMA kernel: plain operands)
-                gw = _wgrad_raw(x, gy if first else ge, tuple(weight.shape), ctx.taps, gy_encoded=_is_x(gy) and not first, x_encoded=ctx.x_enc)
+                gw = _wgrad_raw(x, gy if first else ge, tuple(weight.shape), ctx.taps, gy_encoded=_is_x(gy) and not first, x_encoded=ctx.x_enc,
+                                param=ctx.wparam)
         if ctx.has_bias and ctx.needs_input_grad[2] and gb is None:
             gb = _colsum(gy, O)
         return gx, gw, gb, None, None, None, None
@@ -926,6 +947,7 @@ class _LNSample(torch.autograd.Function):
              dt(x), stream())
         ctx.save_for_backward(x, wf, mean, rstd)
         ctx.wshape = tuple(w.shape)
+        ctx.wparam, ctx.bparam = w, b            # the leaves themselves: their gradients may have arena slices (grad_out)
         return y
 
     @staticmethod
@@ -936,8 +958,8 @@ class _LNSample(torch.autograd.Function):
         B = x.shape[0]
         L = x.numel() // B
         dx = torch.empty_like(x)
-        dw = torch.empty(L, dtype=torch.float32, device=x.device)
-        db = torch.empty_like(dw)
+        dw = grad_out(ctx.wparam, (L,), x.device)
+        db = grad_out(ctx.bparam, (L,), x.device)
         ws = workspace(_lib.load().mu_ln_sample_workspace_bytes(B), x.device)
         call("mu_ln_sample_bwd", ptr(x), ptr(gy), ptr(wf), ptr(mean), ptr(rstd), ptr(dx), ptr(dw), ptr(db), B, L, ptr(ws),
              ws.numel(), dt(x), stream())

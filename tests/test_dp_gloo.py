@@ -61,6 +61,20 @@ def _worker(rank, world, port, overlap, q):
         first = one_step()
         assert ddp._dead == {id(p) for p in emb}, "parameters without a gradient must be learned on the first step"
         second = one_step()
+        # zero-copy exchange (round 5): from the second step every live parameter's gradient IS its slice of the bucket's persistent
+        # flat buffer (the arena), which was all-reduced in place -- no flattening copy, no write-back, a stable p.grad identity
+        for name, p in model.named_parameters():
+            if "emb_layer" in name:
+                assert ddp.gradient_slice(p) is None
+                continue
+            v = ddp.gradient_slice(p)
+            bk = ddp._bucket_of[id(p)]
+            assert v is not None and p.grad.data_ptr() == v.data_ptr(), name
+            lo, hi = bk.arena.data_ptr(), bk.arena.data_ptr() + bk.arena.numel() * 4
+            assert lo <= p.grad.data_ptr() and p.grad.data_ptr() + p.grad.numel() * 4 <= hi, name
+        ptrs = {n: p.grad.data_ptr() for n, p in model.named_parameters() if p.grad is not None}
+        third = one_step()
+        assert {n: p.grad.data_ptr() for n, p in model.named_parameters() if p.grad is not None} == ptrs and third == second
         if overlap:
             # from the second step on no bucket waits for a dead parameter: every bucket with a live gradient is launched
             # from the hooks, before finish_gradient_sync()

@@ -205,17 +205,43 @@ F.cross_entropy(model(xd), ld).backward()
 ref = {{n: p.grad.clone() for n, p in model.named_parameters() if p.grad is not None}}
 ddp = DataParallel(model, bucket_mb=4.0, force_sync=True)
 assert ddp.multi and ddp.overlap and len(ddp.buckets) > 3
+flattened = []
+_reduce = ddp._reduce
+ddp._reduce = lambda params: (flattened.append(len(params)), _reduce(params))[1]      # the torch.cat path
+big = [(n, p) for n, p in model.named_parameters() if n in ref and (p.dim() == 4 or n in ("norm.weight", "norm.bias"))]
 for step in range(3):                      # step 0 learns the dead parameters; later steps launch every bucket from the hooks
     model.zero_grad(set_to_none=True)
+    flattened.clear()
     F.cross_entropy(ddp(xd), ld).backward()
     if step:
         assert all(bk.work is not None for bk in ddp.buckets if any(id(p) not in ddp._dead for p in bk.params))
     ddp.finish_gradient_sync()
+    if step:
+        # zero-copy exchange (VERDICT r4 #6a): the conv / Linear weight-gradient kernels and the final LayerNorm's backward wrote into the
+        # bucket slices themselves, every live p.grad IS its slice of the bucket that was all-reduced in place, and no bucket was flattened
+        assert not flattened, flattened
+        for n, p in model.named_parameters():
+            if n in ref:
+                v = ddp.gradient_slice(p)
+                assert v is not None and p.grad.data_ptr() == v.data_ptr(), n
+        n_big = sum(p.numel() for _, p in big)
+        assert n_big > 0.97 * sum(p.numel() for n, p in model.named_parameters() if n in ref)
     for n, p in model.named_parameters():
         if n in ref:
             assert torch.equal(p.grad, ref[n]), n        # sum over one rank / 1: bit-exact through the fp32 buckets
         else:
             assert p.grad is None, n
+# ... and the large gradients are in their slices right after the backward, BEFORE the exchange touches anything (the kernels wrote there)
+model.zero_grad(set_to_none=True)
+with ddp.no_sync():
+    F.cross_entropy(ddp(xd), ld).backward()
+for n, p in big:
+    if "query" in n or "key" in n or "value" in n:
+        continue                                      # (the three Linear weights of a block come out of ONE [3C, C] kernel output: copied in)
+    assert p.grad.data_ptr() == ddp.gradient_slice(p).data_ptr(), n
+    assert torch.equal(p.grad, ref[n]), n
+ddp.finish_gradient_sync()
+model.zero_grad(set_to_none=True)
 # the same through one captured graph per replica + the exchange after the replay
 step_fn = maskunet_amd.GraphedStep(ddp, F.cross_entropy, xd, ld)
 step_fn(xd, ld)
@@ -325,3 +351,23 @@ def test_bench_line_is_self_describing():
     ks = rec["roofline"]["kernels"]
     assert set(ks) == {"fwd", "dq", "dkv"} and all(0 < k["frac"] < 1 and k["launches_timed"] == 2 for k in ks.values())
     assert "power_w" not in rec["clock"]["smi"] and "power_rails_w" in rec["clock"]["smi"]
+
+
+def test_bench_gpus2_over_rccl_on_a_one_gpu_box_refuses_with_a_message():
+    """VERDICT r4 #6c: `python bench.py --gpus 2` bare, RCCL backend, on a box with ONE GPU -- a clean non-zero exit with a message that
+    names the cause, from the parent (nothing spawned, no rank dying in hipSetDevice / ncclCommInitRank)."""
+    if torch.cuda.device_count() >= 2:
+        pytest.skip("needs a single-GPU box")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "MU_DIST_BACKEND")}
+    env["MU_DIST_BACKEND"] = "nccl"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--batch", "2",
+                        "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0
+    assert "needs 2 visible GPUs" in (r.stdout + r.stderr) and "Traceback" not in r.stderr, r.stderr[-2000:]
+    # the same refusal inside a launcher-started rank (WORLD_SIZE = 2 from torchrun, one device)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--batch", "2",
+           "--no-cpu-baseline"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "needs 2 visible GPUs" in (r.stdout + r.stderr)
+
