@@ -1215,6 +1215,213 @@ __global__ __launch_bounds__(512, 1) void conv_nt4f_kernel(const h16* __restrict
 }
 
 // ------------------------------------------------------------------------------------------
+// v4x: the ping-pong pipeline for fp32x (round 5).  Byte for byte the LDS image, DMA stream, counted waits and barrier schedule of
+// conv_nt4_body -- a K chunk is 32 fp32 channels = the same 128-byte rows (chunk-encoded: eight [4 bf16 hi | 4 bf16 lo] chunks), so halo
+// (2 x 41 KB), weight ring (4 x 16 KB) and the three-DMAs-per-wave-per-tap accounting carry over; what changes is the arithmetic per
+// (tap, chunk) step: ONE K = 32 step of three bf16 MFMAs per tile pair (lo hi + hi lo + hi hi) instead of two K = 32 steps of one, i.e.
+// 48 MFMAs per wave and step for the same 16 fragment reads (fp16: 32).  The step is split into two phases by PIXEL rows instead of by K:
+// phase 0 reads the four weight fragments (both chunks of a lane group: chunk g and g + 4 side by side are the eight-value operand) and
+// the first two pixel-row fragments -> 24 MFMAs; phase 1 reads the other two -> 24 MFMAs.  Until round 5 the fp32x mode ran the generic
+// two-stage kernel (conv_nt3: one __syncthreads per tap, 8 x 16 pixel tiles, 55 % MFMA-busy).  The epilogue writes fp32 rows (a wave's
+// 64 px x 64 co tile staged in 16 KB of LDS, XOR-swizzled 16-byte slots, whole 256-byte rows per store) and, like the fp16 kernel, the
+// per-tile BatchNorm statistics of the values it stores.
+// ------------------------------------------------------------------------------------------
+#ifndef MU_CONV_NT4X
+#define MU_CONV_NT4X 1
+#endif
+__global__ __launch_bounds__(512, 1) void conv_nt4x_kernel(const xf32* __restrict__ x, const xf32* __restrict__ w, const float* __restrict__ bias,
+                                                           xf32* __restrict__ y, int B, int H, int W, int Cin, int Cout, long x_ld, long y_ld,
+                                                           float* __restrict__ stat_part) {
+    using M_ = Mma<xf32>;
+    using Frag2 = M_::Frag2;
+    constexpr int VN = 4, KC = 32, TM = 4, TN = 4, NWV = 8, BCO = 128;
+    constexpr int TH = 16, TW = 16, HW_ = TW + 2, HROWS = (TH + 2) * HW_;       // 324 halo rows of 128 B
+    constexpr int HINST = (HROWS + 7) / 8;                                       // 41 wave-DMA instructions (8 rows each)
+    constexpr int HPW = 7;                                                       // halo pieces per wave: taps 0..6
+    constexpr int HBYTES = HINST * 1024, WBYTES = BCO * 128, NWB = 4;
+
+    __shared__ __attribute__((aligned(16))) char lds[2 * HBYTES + NWB * WBYTES + 1024];
+    char* Hs = lds;
+    char* Ws = lds + 2 * HBYTES;
+    char* dump = lds + 2 * HBYTES + NWB * WBYTES;
+
+    const int tiles_w = W / TW, tiles_h = H / TH;
+    const int ntile = B * tiles_h * tiles_w, ncb = Cout / BCO;
+    const int L = xcd_remap(blockIdx.x, ntile * ncb);
+    const int cb = L % ncb, tl = L / ncb;
+    const int co0 = cb * BCO;
+    const int tw_ = tl % tiles_w, th_ = (tl / tiles_w) % tiles_h, bimg = tl / (tiles_w * tiles_h);
+    const int h0 = th_ * TH, w0 = tw_ * TW;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 2, wc = wave & 3;                 // wr doubles as the ping-pong group (waves 0-3 / 4-7: one of each per SIMD)
+    const int r16 = lane & 15, g = lane >> 4;
+    const int srow = lane >> 3, sch = lane & 7;
+
+    const int kchunks = Cin / KC;
+    const int nsteps = 9 * kchunks;
+
+    int wl[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int row = (i * NWV + wave) * 8 + srow;
+        wl[i] = (co0 + row) * Cin + (sch ^ (row & 7)) * VN;
+    }
+    int hl[HPW];
+#pragma unroll
+    for (int k = 0; k < HPW; ++k) {
+        const int hr = (k * NWV + wave) * 8 + srow;
+        const int hy = hr / HW_, hx = hr - hy * HW_;
+        const int hh = h0 - 1 + hy, ww = w0 - 1 + hx;
+        const bool ok = hr < HROWS && hh >= 0 && hh < H && ww >= 0 && ww < W;
+        hl[k] = ok ? (int)(((long)hh * W + ww) * x_ld) + (sch ^ (hx & 7)) * VN : -1;
+    }
+    const xf32* xb = x + (long)bimg * H * W * x_ld;
+
+    auto stage_w = [&](int s) {
+        if (s < nsteps) {
+            const int tap = s % 9, ci0 = (s / 9) * KC;
+            const xf32* wb = w + (long)tap * Cout * Cin + ci0;
+            char* Wb = Ws + (s & 3) * WBYTES;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) glds16(wb + wl[i], Wb + (i * NWV + wave) * 1024);
+        } else {
+            glds16(mu_zero_page, dump);
+            glds16(mu_zero_page, dump);
+        }
+    };
+    auto stage_h = [&](int k, int c) {
+        const int off = hl[k];
+        if (c < kchunks && k * NWV + wave < HINST) {        // wave-uniform
+            const void* src = off >= 0 ? (const void*)(xb + off + c * KC) : (const void*)mu_zero_page;
+            glds16(src, Hs + (c & 1) * HBYTES + (k * NWV + wave) * 1024);
+        } else {
+            glds16(mu_zero_page, dump);
+        }
+    };
+
+    f32x4 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    int aoff[2], boff[3][2];
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+        aoff[kk] = (wr * TM * 16 + r16) * 128 + (((kk * 4 + g) ^ (r16 & 7)) << 4);
+#pragma unroll
+        for (int dw = 0; dw < 3; ++dw) boff[dw][kk] = (wc * TN * HW_ + r16 + dw) * 128 + (((kk * 4 + g) ^ ((r16 + dw) & 7)) << 4);
+    }
+
+#pragma unroll
+    for (int k = 0; k < HPW; ++k) stage_h(k, 0);
+    stage_w(0);
+    stage_w(1);
+    stage_w(2);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (wr == 1) __builtin_amdgcn_s_barrier();
+
+    int s = 0;
+    for (int c = 0; c < kchunks; ++c) {
+        const int hbuf = (c & 1) * HBYTES;
+#pragma unroll
+        for (int t = 0; t < 9; ++t, ++s) {
+            const int dh = t / 3, dw = t % 3;
+            const char* Wb = Ws + (s & 3) * WBYTES;
+            const char* Hb = Hs + hbuf + dh * (HW_ * 128);
+            const char* wa0 = Wb + aoff[0];
+            const char* wa1 = Wb + aoff[1];
+            const char* hb0 = Hb + boff[dw][0];
+            const char* hb1 = Hb + boff[dw][1];
+            Frag2 a[TM], b[2];
+            // ---- phase 0: the four weight fragments + pixel rows 0, 1 of the wave's four
+#pragma unroll
+            for (int i = 0; i < TM; ++i) a[i] = M_::ld2(wa0 + i * 2048, wa1 + i * 2048);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) b[j] = M_::ld2(hb0 + j * (HW_ * 128), hb1 + j * (HW_ * 128));
+            if (t != 0) {
+                if (t < HPW) stage_h(t, c + 1); else glds16(mu_zero_page, dump);
+            }
+            __builtin_amdgcn_s_barrier();
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) M_::mma2(a[i], b[j], acc[i][j]);
+            __builtin_amdgcn_s_setprio(0);
+            if (t == 0) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");      // younger: H(8), W(s+2) x2
+            else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");             // younger: H(t-1), W(s+2) x2, H(t)
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();
+            // ---- phase 1: pixel rows 2, 3 (the weight fragments stay in registers)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) b[j] = M_::ld2(hb0 + (j + 2) * (HW_ * 128), hb1 + (j + 2) * (HW_ * 128));
+            if (t == 0) stage_h(0, c + 1);
+            stage_w(s + 3);
+            __builtin_amdgcn_s_barrier();
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) M_::mma2(a[i], b[j], acc[i][j + 2]);
+            __builtin_amdgcn_s_setprio(0);
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();
+        }
+    }
+    if (wr == 0) __builtin_amdgcn_s_barrier();
+
+    // Epilogue, wave-private and barrier-free: the wave's 64 px x 64 co fp32 tile as [pixel][16 slots of 16 B], slot XORed with (p & 15)
+    // (the 16 lanes that write one (i, g) slot hold 16 different pixels), read back as whole 256-byte pixel rows: 4 rows per wave store.
+    char* Os = lds + wave * 16384;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int p = j * 16 + r16;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const int co = i * 16 + 4 * g;
+            f32x4 v = acc[i][j];
+            if (bias) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] += bias[co0 + wr * 64 + co + r];
+            }
+            *reinterpret_cast<f32x4*>(Os + p * 256 + ((((co >> 2)) ^ (p & 15)) << 4)) = v;
+        }
+    }
+    const int q = lane & 15, pl = lane >> 4;
+    f32x4 ssum = {0.f, 0.f, 0.f, 0.f}, ssq = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int it = 0; it < 16; ++it) {
+        const int p = it * 4 + pl;                            // pixel inside the wave tile: image row wc*4 + (p >> 4), column p & 15
+        const f32x4 o = *reinterpret_cast<const f32x4*>(Os + p * 256 + ((q ^ (p & 15)) << 4));
+        const long gp = ((long)bimg * H + h0 + wc * TN + (p >> 4)) * W + w0 + (p & 15);
+        *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(y) + gp * y_ld + co0 + wr * 64 + q * 4) = o;
+        if (stat_part) {
+            ssum += o;
+            ssq += o * o;
+        }
+    }
+    if (stat_part) {                                          // fold the four pixel groups (lanes q, q+16, q+32, q+48), lanes 0-15 write
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            ssum[c] += __shfl_xor(ssum[c], 16); ssq[c] += __shfl_xor(ssq[c], 16);
+            ssum[c] += __shfl_xor(ssum[c], 32); ssq[c] += __shfl_xor(ssq[c], 32);
+        }
+        if (lane < 16) {
+            float* row = stat_part + ((long)tl * 4 + wc) * Cout * 2 + (co0 + wr * 64 + q * 4) * 2;
+            *reinterpret_cast<float4*>(row) = make_float4(ssum[0], ssq[0], ssum[1], ssq[1]);
+            *reinterpret_cast<float4*>(row + 4) = make_float4(ssum[2], ssq[2], ssum[3], ssq[3]);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // v4p: the ping-pong kernel as a PERSISTENT tile loop -- one block per CU walks the 16x16 tiles of its output-channel block.
 // Measured on v4 (in-process, 128->128 @128^2): every tile pays ~4.8 us of launch / index / prologue (halo + three weight
 // tiles behind a vmcnt(0)) / epilogue around 18 taps x 0.87 us.  Here the DMA stream simply runs on across the tile
@@ -1431,6 +1638,14 @@ __global__ __launch_bounds__(512, 1) void conv_nt4p_kernel(const h16* __restrict
 
 // The same dispatch for the inference epilogue y = act(conv * scale + bias + res): FEPI instantiations of the non-persistent kernels
 // (the persistent ping-pong kernel counts its epilogue's memory operations in hand-placed vmcnt waits and takes no epilogue loads).
+// fp32x: which 3x3 shapes the ping-pong kernel serves.  One 512-thread block per CU: a grid of fewer than ~200 blocks (16^2 256 -> 256 at
+// B = 64: 128) leaves half of the chip idle, where the generic kernel's 8 x 16 pixel tiles still fill it (61 vs 72 us in-process)
+static inline bool nt4x_serves(int B, int H, int W, int Cin, int Cout) {
+    if (!MU_CONV_NT4X || getenv("MU_CONV_NO_NT4")) return false;
+    if (Cout % 128 || H % 16 || W % 16 || Cin % 32) return false;
+    return (long)B * (H / 16) * (W / 16) * (Cout / 128) >= 192;
+}
+
 template <typename T, int TAPS>
 static int conv_fwd_fused_launch(const T* x, const T* w, const float* scale, const float* bias, const T* res, int act, T* y, int B, int H, int W,
                                  int Cin, int Cout, long x_ld, long y_ld, hipStream_t st) {
@@ -1504,6 +1719,12 @@ static int conv_fwd_launch(const T* x, const T* w, const float* bias, T* y, int 
                 return MU_OK;
             }
         }
+        if constexpr (std::is_same<T, xf32>::value && MU_CONV_NT4X) {
+            if (nt4x_serves(B, H, W, Cin, Cout)) {
+                conv_nt4x_kernel<<<B * (H / 16) * (W / 16) * (Cout / 128), 512, 0, st>>>(x, w, bias, y, B, H, W, Cin, Cout, x_ld, y_ld, stat_part);
+                return MU_OK;
+            }
+        }
         if (Cout % 128 == 0 && H % 8 == 0) {
             const int ntile = B * (H / 8) * (W / 16), ncb = Cout / 128;
             // ~2 resident blocks per CU in total (MU_CONV_PERSIST_BLOCKS overrides the block count: parity tests use tiny grids)
@@ -1558,8 +1779,10 @@ static int conv_fwd_launch(const T* x, const T* w, const float* bias, T* y, int 
 // Rows of per-tile BatchNorm statistics mu_conv_fwd_stats writes for this layer shape (0: the kernel that serves it has no
 // statistics epilogue -- run mu_bn_train_stats on the output instead).  One row per 16x16 output tile and 4-image-row group.
 extern "C" int mu_conv_stats_rows(int B, int H, int W, int Cin, int Cout, int taps, int dtype) {
-    if (dtype != MU_F16 || taps != 9 || !MU_CONV_NT4 || getenv("MU_CONV_NO_NT4")) return 0;
-    if (Cin % 64 || Cout % 128 || H % 16 || W % 16 || B <= 0) return 0;
+    if (taps != 9 || getenv("MU_CONV_NO_NT4") || B <= 0) return 0;
+    if (dtype == MU_F16 && MU_CONV_NT4) { if (Cin % 64 || Cout % 128 || H % 16 || W % 16) return 0; }
+    else if (dtype == MU_F32X && MU_CONV_NT4X) { if (!nt4x_serves(B, H, W, Cin, Cout)) return 0; }
+    else return 0;
     return B * (H / 16) * (W / 16) * 4;
 }
 
@@ -1569,7 +1792,8 @@ extern "C" int mu_conv_fwd_stats(const void* x, const void* w, const float* bias
     if (Cin <= 0 || Cout <= 0 || Cin % 32 || Cout % 32 || x_ld < Cin || y_ld < Cout || x_ld % 8 || y_ld % 8) return MU_ERR_SHAPE;
     if (stat_part && mu_conv_stats_rows(B, H, W, Cin, Cout, taps, dtype) == 0) return MU_ERR_SHAPE;
     if (!stat_part) return mu_conv_fwd(x, w, bias, y, B, H, W, Cin, Cout, taps, x_ld, y_ld, dtype, stream);
-    conv_fwd_launch<h16, 9>((const h16*)x, (const h16*)w, bias, (h16*)y, B, H, W, Cin, Cout, x_ld, y_ld, (hipStream_t)stream, stat_part);
+    if (dtype == MU_F32X) conv_fwd_launch<xf32, 9>((const xf32*)x, (const xf32*)w, bias, (xf32*)y, B, H, W, Cin, Cout, x_ld, y_ld, (hipStream_t)stream, stat_part);
+    else conv_fwd_launch<h16, 9>((const h16*)x, (const h16*)w, bias, (h16*)y, B, H, W, Cin, Cout, x_ld, y_ld, (hipStream_t)stream, stat_part);
     MU_CHECK_LAUNCH();
     return MU_OK;
 }

@@ -376,10 +376,10 @@ def _conv_raw(x, wprep, bias_p, Cout_p, taps, want_stats=False, x_encoded=False)
     if not x_encoded:
         x = _enc(x)
     if want_stats:
-        rows = _lib.load().mu_conv_stats_rows(B, H, W, Cin_p, Cout_p, taps, dt(x))
+        rows = _lib.load().mu_conv_stats_rows(B, H, W, Cin_p, Cout_p, taps, mdt(x))
         if rows > 0:
             part = torch.empty((rows, Cout_p, 2), dtype=torch.float32, device=x.device)
-            call("mu_conv_fwd_stats", ptr(x), ptr(wprep), ptr(bias_p), ptr(y), B, H, W, Cin_p, Cout_p, taps, Cin_p, Cout_p, dt(x),
+            call("mu_conv_fwd_stats", ptr(x), ptr(wprep), ptr(bias_p), ptr(y), B, H, W, Cin_p, Cout_p, taps, Cin_p, Cout_p, mdt(x),
                  ptr(part), stream())
             return y, part
         call("mu_conv_fwd", ptr(x), ptr(wprep), ptr(bias_p), ptr(y), B, H, W, Cin_p, Cout_p, taps, Cin_p, Cout_p, mdt(x), stream())
