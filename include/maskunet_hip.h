@@ -130,7 +130,7 @@ int mu_conv_wgrad(const void* x, const void* dy, float* dw_oihw, int B, int H, i
 int mu_conv_wgrad_bias_supported(int Cin, int Cout, int taps, int dtype);
 int mu_conv_wgrad_bias(const void* x, const void* dy, float* dw_oihw, float* db, int B, int H, int W, int Cin, int Cout, int taps,
                        int cin_valid, int cout_valid, long x_ld, long dy_ld, void* workspace, long ws_bytes, int dtype, void* stream);
-/* out[c] = sum_r x[r][c]  (bias gradients) */
+/* out[c] = sum_r x[r][c]  (bias gradients); dtype MU_F32X: x is chunk-encoded (mu_split_encode form) */
 long mu_colsum_workspace_bytes(int C);
 int mu_colsum(const void* x, long M, int C, long ld, float* out, void* workspace, long ws_bytes, int dtype, void* stream);
 
@@ -263,6 +263,10 @@ int mu_attn_bwd_phases_padded(const void* qkv, const void* x, const void* oattn,
  * permutation of 0..N-1 with the masked keys listed after the kept ones (what a stable descending argsort of the keep mask
  * gives).  The dK/dV sweep then writes the masked keys' zero rows itself and phase 1 skips the memset of the whole dqkv buffer. */
 #define MU_ATTN_KIDX_PERMUTATION 8
+/* 16 (MU_ATTN_DQKV_ENCODED, OR-ed into every call of one backward; MU_F32X only, ignored otherwise): dqkv is written CHUNK-ENCODED
+ * ([4 bf16 hi | 4 bf16 lo] per 16 bytes, the mu_split_encode form) -- the operand form mu_conv_fwd / mu_conv1x1_fwd_add / mu_conv_wgrad
+ * take for the q/k/v projection's data- and weight-gradient, and mu_colsum(MU_F32X) for its bias gradient. */
+#define MU_ATTN_DQKV_ENCODED 16
 int mu_attn_bwd_phases(const void* qkv, const void* x, const void* oattn, const void* grad_out, const int* kidx, const int* kcnt,
                        const float* lse2, const float* ln_mean, const float* ln_rstd, const float* gamma, void* dY, float* delta,
                        void* dqkv, float* dgamma, float* dbeta, int B, int N, int C, int nkmax, void* workspace, long ws_bytes,

@@ -125,6 +125,9 @@
 #ifndef MU_XF_OPAQUE
 #define MU_XF_OPAQUE 1
 #endif
+#ifndef MU_H16_OPAQUE
+#define MU_H16_OPAQUE 0
+#endif
 #ifndef MU_XF_PK_MAXD
 #define MU_XF_PK_MAXD 512
 #endif
@@ -358,6 +361,13 @@ template <> __device__ __forceinline__ void store4<float>(float* p, const float 
 }
 template <> __device__ __forceinline__ void store4<xf32>(xf32* p, const float v[4]) {
     *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
+}
+// fp32x: a gradient row piece written as the matrix-operand encoding its consumer reads (common.h: [4 bf16 hi | 4 bf16 lo] per 16 bytes)
+template <typename T> __device__ __forceinline__ void store4e(T* p, const float v[4], bool enc) {
+    if constexpr (std::is_same<T, xf32>::value) {
+        if (enc) { *reinterpret_cast<uint4*>(p) = mu_enc4((f32x4){v[0], v[1], v[2], v[3]}); return; }
+    }
+    store4<T>(p, v);
 }
 template <typename T> __device__ __forceinline__ void load4(const T* p, float v[4]);
 template <> __device__ __forceinline__ void load4<h16>(const h16* p, float v[4]) {
@@ -1046,7 +1056,7 @@ template <typename T, int D, int KT, int NW>
 __global__ __launch_bounds__(NW * 64, (NW == 4 && D <= 64 && std::is_same<T, xf32>::value) ? MU_XF_OCC : (NW == 4 && D <= 64 && sizeof(T) == 2) ? MU_DQ_OCC : ((NW == 4 && D == 128 && sizeof(T) == 2) ? MU_DQ_OCC128 : ((NW == 4 && D == 256 && sizeof(T) == 2) ? MU_DQ_OCC256 : 1))) void attn_bwd_dq2_kernel(const T* __restrict__ qkv, const T* __restrict__ dY, const int* __restrict__ kidx,
                                                            const int* __restrict__ kcnt, const float* __restrict__ lse2,
                                                            const float* __restrict__ delta, T* __restrict__ dqkv, int N, int nkmax,
-                                                           float scale, float scale_log2, const float* __restrict__ gsp, float pshift) {
+                                                           float scale, float scale_log2, const float* __restrict__ gsp, float pshift, int enc_out) {
     using A = AT<T>;
     using Frag = typename A::Frag;
     using Z = SwzTile<T, D>;
@@ -1187,7 +1197,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 && D <= 64 && std::is_same<T, xf3
             // are all three gradients; this sweep visits every token row once, so it writes the NaN dQ, dK and dV of the row
             const float nanv[4] = {__builtin_nanf(""), __builtin_nanf(""), __builtin_nanf(""), __builtin_nanf("")};
 #pragma unroll
-            for (int c = 0; c < 3 * NDT; ++c) store4<T>(dst + c * 16 + 4 * g, nanv);
+            for (int c = 0; c < 3 * NDT; ++c) store4e<T>(dst + c * 16 + 4 * g, nanv, enc_out);
             continue;
         }
 #pragma unroll
@@ -1197,7 +1207,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 && D <= 64 && std::is_same<T, xf3
 #pragma unroll
                 for (int r = 0; r < 4; ++r) v[r] *= un;
             }
-            store4<T>(dst + dt * 16 + 4 * g, v);
+            store4e<T>(dst + dt * 16 + 4 * g, v, enc_out);
         }
     }
 }
@@ -1243,7 +1253,7 @@ __global__ __launch_bounds__(NW * 64, NW >= 8 ? 1 : ((D <= 64 && std::is_same<T,
     if (kb0 >= Nk) {
         // zero_masked (kidx rows are whole permutations, the masked keys listed after the kept ones): this block's keys are all
         // masked -- their dK / dV rows are exact zeros, written here instead of by a memset of the whole dqkv buffer
-        if (zero_masked) {
+        if (zero_masked & 1) {
             constexpr int LPK = 2 * D * (int)sizeof(T) / 16;             // 16-byte lanes per key row (K and V parts are adjacent)
             for (int i = threadIdx.x; i < NW * NKT * 16 * LPK; i += NW * 64) {
                 const int j = kb0 + i / LPK;
@@ -1375,7 +1385,7 @@ __global__ __launch_bounds__(NW * 64, NW >= 8 ? 1 : ((D <= 64 && std::is_same<T,
         if (tl + DKV_RING - 1 < ntile) issue(tl + DKV_RING - 1);
 #endif
         const T* Qt = lds + SLOT * STG;
-        if constexpr (std::is_same<T, xf32>::value && MU_XF_OPAQUE) Qt = lds_opaque(Qt);
+        if constexpr ((std::is_same<T, xf32>::value && MU_XF_OPAQUE) || (sizeof(T) == 2 && D >= 128 && MU_H16_OPAQUE)) Qt = lds_opaque(Qt);
         const T* Ot = Qt + TEQ;
         const float* rc = rcs + SLOT * 256;
         f32x4 s[2][NKT], dp[2][NKT];
@@ -1510,7 +1520,7 @@ __global__ __launch_bounds__(NW * 64, NW >= 8 ? 1 : ((D <= 64 && std::is_same<T,
         const bool live = row >= 0;
         if (!live) {                                         // masked key inside the last kept block: exact zeros (see above)
             const int j = kb0 + (wave * NKT + kt) * 16 + r16;
-            if (!zero_masked || j >= nkmax) continue;
+            if (!(zero_masked & 1) || j >= nkmax) continue;
             row = kidx_b[j];
         }
         T* dst = dqkv + ((long)b * N + row) * 3 * D;
@@ -1526,8 +1536,8 @@ __global__ __launch_bounds__(NW * 64, NW >= 8 ? 1 : ((D <= 64 && std::is_same<T,
 #pragma unroll
                 for (int r = 0; r < 4; ++r) { kv[r] = 0.f; vv[r] = 0.f; }
             }
-            store4<T>(dst + D + dt * 16 + 4 * g, kv);
-            store4<T>(dst + 2 * D + dt * 16 + 4 * g, vv);
+            store4e<T>(dst + D + dt * 16 + 4 * g, kv, zero_masked & 2);      // (bit 1 of zero_masked: dqkv written chunk-encoded, fp32x)
+            store4e<T>(dst + 2 * D + dt * 16 + 4 * g, vv, zero_masked & 2);
         }
     }
 }
@@ -1632,8 +1642,11 @@ static int attn_bwd_t(const T* qkv, const T* x, const T* oattn, const T* gout, c
     dim3 gq(mu_cdiv(N, 128), B);
     // phases & 8 (MU_ATTN_KIDX_PERMUTATION): every kidx row is a whole permutation of 0..N-1 with the masked keys after the kept
     // ones, so the dK/dV sweep writes the masked keys' zero rows itself (dQ parts are written for every row by the dQ sweep)
-    const int zero_masked = ((phases & 8) && nkmax == N) ? 1 : 0;
-    if ((phases & 1) && !zero_masked && hipMemsetAsync(dqkv, 0, (size_t)rows * 3 * C * sizeof(T), st) != hipSuccess) return MU_ERR_LAUNCH;
+    // phases & 16 (MU_ATTN_DQKV_ENCODED, MU_F32X only): dqkv is written in the chunk encoding the projection's data- and weight-gradient
+    // kernels read (mu_split_encode form) instead of plain fp32 -- saves the separate encoding pass over the largest tensor of the block
+    const int enc_out = (XF && (phases & 16)) ? 1 : 0;
+    const int zero_masked = (((phases & 8) && nkmax == N) ? 1 : 0) | (enc_out << 1);
+    if ((phases & 1) && !(zero_masked & 1) && hipMemsetAsync(dqkv, 0, (size_t)rows * 3 * C * sizeof(T), st) != hipSuccess) return MU_ERR_LAUNCH;
     // fp32x: the sweeps take dY chunk-encoded like qkv (the caller encodes qkv; dY is produced here, by phase 1): its encoded copy
     // lives in the workspace behind the row constants, and `dYs` is what the sweeps read
     const T* dYs = dY;
@@ -1648,7 +1661,7 @@ static int attn_bwd_t(const T* qkv, const T* x, const T* oattn, const T* gout, c
             attn_dy_encode_kernel<<<(int)(gr < 1 ? 1 : (gr > 8192 ? 8192 : gr)), 256, 0, st>>>((const f32x4*)dY, (uint4*)dYs, rowc, gsc, ng, DD / 8, N); \
         }                                                                                                                       \
     }                                                                                                                           \
-    if (phases & 2) attn_bwd_dq2_kernel<T, DD, KTQ, 4><<<gq, 256, 0, st>>>(qkv, dYs, kidx, kcnt, lse2, delta, dqkv, N, nkmax, scale, sl2, gsc, pshift); \
+    if (phases & 2) attn_bwd_dq2_kernel<T, DD, KTQ, 4><<<gq, 256, 0, st>>>(qkv, dYs, kidx, kcnt, lse2, delta, dqkv, N, nkmax, scale, sl2, gsc, pshift, enc_out); \
     if (phases & 4) {                                                                                                           \
         if constexpr (sizeof(T) == 2 && DD == 64 && MU_DKV_NW64 != 4)                                                           \
             attn_bwd_dkv3_kernel<T, DD, NKT, MU_DKV_NW64><<<dim3(mu_cdiv(nkmax, 16 * MU_DKV_NW64 * NKT), B), 64 * MU_DKV_NW64, 0, st>>>(qkv, dYs, kidx, kcnt, rowc, dqkv, N, nkmax, scale, sl2, zero_masked, gsc, pshift); \

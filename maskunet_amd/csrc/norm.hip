@@ -362,6 +362,50 @@ __global__ void colsum_final_kernel(const double* __restrict__ part, int nblk, i
 
 extern "C" long mu_colsum_workspace_bytes(int C) { return (long)MU_STAT_MAXBLK * C * 2 * sizeof(double); }
 
+// column sums of a CHUNK-ENCODED fp32x tensor (common.h: 16 bytes = [4 bf16 hi | 4 bf16 lo]): thread = (row in the block's iteration,
+// chunk column); fp32 sums of up to 64 decoded rows folded into doubles, the block's row-lanes reduced through LDS into the
+// [block][C][2] partial layout colsum_final_kernel reads.
+__global__ __launch_bounds__(256) void colsum_enc_partial_kernel(const uint4* __restrict__ x, long M, int C, long ld, double* __restrict__ part) {
+    const int cv = C / 4, rpi = 256 / cv;
+    const int tid = threadIdx.x, cc = tid % cv, lr = tid / cv;
+    const long rows_per_blk = (M + gridDim.x - 1) / gridDim.x;
+    const long r0 = (long)blockIdx.x * rows_per_blk, r1 = r0 + rows_per_blk < M ? r0 + rows_per_blk : M;
+    double acc[4] = {0.0, 0.0, 0.0, 0.0};
+    if (lr < rpi) {
+        f32x4 sh = {0.f, 0.f, 0.f, 0.f};
+        int n = 0;
+        for (long r = r0 + lr; r < r1; r += 4L * rpi) {      // four rows in flight per thread (a plain HBM stream)
+            uint4 e[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (r + (long)u * rpi < r1)
+                    e[u] = __builtin_bit_cast(uint4, __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(x) + ((r + (long)u * rpi) * ld) / 4 + cc));
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (r + (long)u * rpi < r1) sh += mu_dec4(e[u]);
+            if (++n == 16) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) acc[i] += (double)sh[i];
+                sh = (f32x4){0.f, 0.f, 0.f, 0.f};
+                n = 0;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc[i] += (double)sh[i];
+    }
+    extern __shared__ double shd[];                          // [rpi][C]
+    if (lr < rpi) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) shd[lr * C + cc * 4 + i] = acc[i];
+    }
+    __syncthreads();
+    for (int c = tid; c < C; c += 256) {
+        double t = 0.0;
+        for (int k = 0; k < rpi; ++k) t += shd[k * C + c];
+        part[((long)blockIdx.x * C + c) * 2] = t;
+    }
+}
+
 // out[c] = sum_r x[r][c]: bias gradients.  Same vectorised row sweep as the BN statistics.
 extern "C" int mu_colsum(const void* x, long M, int C, long ld, float* out, void* workspace, long ws_bytes, int dtype, void* stream) {
     if (!x || !out || !workspace || M <= 0 || C <= 0 || C % 8 || ld < C) return MU_ERR_ARG;
@@ -376,6 +420,10 @@ extern "C" int mu_colsum(const void* x, long M, int C, long ld, float* out, void
         const int cv = C / 8;
         if (cv > 256) return MU_ERR_SHAPE;
         bn_partial_kernel<h16, 0><<<nblk, 256, (size_t)(256 / cv) * C * 2 * sizeof(double), st>>>((const h16*)x, nullptr, nullptr, nullptr, M, C, ld, nullptr, nullptr, nullptr, nullptr, 0, (double*)workspace);
+    } else if (dtype == MU_F32X) {                           // x chunk-encoded (mu_split_encode form, or written so by mu_attn_bwd_phases)
+        const int cv = C / 4;
+        if (cv > 256 || ld % 4) return MU_ERR_SHAPE;
+        colsum_enc_partial_kernel<<<nblk, 256, (size_t)(256 / cv) * C * sizeof(double), st>>>((const uint4*)x, M, C, ld, (double*)workspace);
     } else return MU_ERR_ARG;
     colsum_final_kernel<<<mu_cdiv(C, 4), 256, 0, st>>>((const double*)workspace, nblk, C, out);
     MU_CHECK_LAUNCH();

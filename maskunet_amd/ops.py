@@ -498,12 +498,13 @@ def _wgrad_side(x, gy, w_shape, taps, x_encoded=False, param=None):
     return gw
 
 
-def _colsum(gy, n_valid):
+def _colsum(gy, n_valid, encoded=False):
+    """Column sums (bias gradients); encoded = gy is a chunk-encoded fp32x operand."""
     C = gy.shape[-1]
     M = gy.numel() // C
     out = torch.empty(C, dtype=torch.float32, device=gy.device)
     ws = workspace(_lib.load().mu_colsum_workspace_bytes(C), gy.device)
-    call("mu_colsum", ptr(gy), M, C, C, ptr(out), ptr(ws), ws.numel(), dt(gy), stream())
+    call("mu_colsum", ptr(gy), M, C, C, ptr(out), ptr(ws), ws.numel(), _lib.MU_F32X if encoded else dt(gy), stream())
     return out[:n_valid]
 
 
@@ -1023,8 +1024,9 @@ class _MaskAttention(torch.autograd.Function):
         else:
             bqkv, (wprep, wd_) = make_qkv()
         ctx.wd = wd_ if ctx.needs_input_grad[0] else None
-        qkv = _enc_h_(_conv_raw(x, wprep, bqkv, 3 * C, 1))             # [B,H,W,3C] == [B,N,3C]; fp32x: fp16-pair-encoded from here on (only the
-        # attention sweeps, forward and backward, ever read it)
+        xe = _enc(x)                                                   # fp32x: the projection's operand form, kept for its weight gradient (x itself otherwise)
+        qkv = _enc_h_(_conv_raw(xe, wprep, bqkv, 3 * C, 1, x_encoded=True))    # [B,H,W,3C] == [B,N,3C]; fp32x: fp16-pair-encoded from here on
+        # (only the attention sweeps, forward and backward, ever read it)
         out = torch.empty((B, N, C), dtype=x.dtype, device=x.device)
         oattn = torch.empty_like(out)
         lse2 = torch.empty((B, N), dtype=torch.float32, device=x.device)
@@ -1036,7 +1038,7 @@ class _MaskAttention(torch.autograd.Function):
         else:
             call("mu_attn_fwd_padded", ptr(qkv), ptr(x), ptr(kidx), ptr(kcnt), ptr(g), ptr(b_), ptr(out), ptr(oattn), ptr(lse2), ptr(mean),
                  ptr(rstd), B, N, C, cv, kidx.shape[1], float(eps), mdt(x), stream())
-        ctx.save_for_backward(x, qkv, oattn, lse2, mean, rstd, g, kidx, kcnt)
+        ctx.save_for_backward(x, qkv, oattn, lse2, mean, rstd, g, kidx, kcnt, xe)
         ctx.is_x = _is_x(x)
         ctx.scramble, ctx.dims, ctx.kidx_perm = scramble, (B, H, W, C), bool(kidx_perm) and kidx.shape[1] == N
         if scramble:
@@ -1046,7 +1048,7 @@ class _MaskAttention(torch.autograd.Function):
     @staticmethod
     @once_differentiable
     def backward(ctx, gout):
-        x, qkv, oattn, lse2, mean, rstd, g, kidx, kcnt = ctx.saved_tensors
+        x, qkv, oattn, lse2, mean, rstd, g, kidx, kcnt, xe = ctx.saved_tensors
         B, H, W, C = ctx.dims
         N = H * W
         gout = gout.contiguous()
@@ -1063,6 +1065,11 @@ class _MaskAttention(torch.autograd.Function):
         # permutation with the masked keys last, as mu_compact_keys / a stable descending argsort give): the dK/dV sweep then zeroes
         # the masked rows itself.  Without the promise phase 1 memsets dqkv (kidx from outside may be padded behind kcnt).
         perm = 8 if ctx.kidx_perm else 0
+        # fp32x: the sweeps write dqkv in the chunk encoding the projection's gradient kernels read (MU_ATTN_DQKV_ENCODED) -- no separate
+        # encoding pass over the block's largest tensor; its column sums (the bias gradients) are taken from the encoded form
+        enc_dqkv = ctx.is_x and DQKV_ENCODED
+        if enc_dqkv:
+            perm |= 16
         cv = ctx.cv
         for phase in (1, 2, 4):      # LayerNorm-backward prepass, dQ sweep, dK/dV sweep (separate calls: each can be timed)
             if cv == C:
@@ -1074,7 +1081,7 @@ class _MaskAttention(torch.autograd.Function):
                      ptr(rstd), ptr(g), ptr(dY), ptr(delta), ptr(dqkv), ptr(dg), ptr(db), B, N, C, cv, kidx.shape[1], ptr(ws), ws.numel(),
                      mdt(x), phase | perm, stream())
         dqkv4 = dqkv.view(B, H, W, 3 * C)
-        dqkv_e = _enc(dqkv4)                     # fp32x: dqkv as a matrix operand (projection data- and weight-gradient); dqkv4 otherwise
+        dqkv_e = dqkv4 if enc_dqkv else _enc(dqkv4)      # fp32x: dqkv as a matrix operand (projection data- and weight-gradient); dqkv4 otherwise
         gx = None
         if ctx.needs_input_grad[0]:
             wd = ctx.wd                          # kept on ctx (views of one small buffer): a second backward over a retained graph needs it again
@@ -1085,12 +1092,12 @@ class _MaskAttention(torch.autograd.Function):
             else:
                 gx = _conv_raw(dqkv_e, wd, None, C, 1, x_encoded=True)
                 call("mu_add", ptr(gx), ptr(dY), ptr(gx), gx.numel(), dt(gx), stream())
-        both = _wgrad_bias_raw(x, dqkv4, (3 * C, C, 1, 1), 1)       # projection weight and bias gradients from one sweep over dqkv
+        both = None if enc_dqkv else _wgrad_bias_raw(x, dqkv4, (3 * C, C, 1, 1), 1)       # projection weight and bias gradients from one sweep over dqkv
         if both is not None:
             gw, gb = both[0].view(3 * C, C), both[1]
         else:
-            gw = _wgrad_raw(x, dqkv_e, (3 * C, C, 1, 1), 1, gy_encoded=True).view(3 * C, C)
-            gb = _colsum(dqkv4, 3 * C)
+            gw = _wgrad_raw(xe, dqkv_e, (3 * C, C, 1, 1), 1, gy_encoded=True, x_encoded=ctx.is_x).view(3 * C, C)
+            gb = _colsum(dqkv4, 3 * C, encoded=enc_dqkv)
         if cv != C:                  # gradients of the real (unpadded) parameters
             return (gx, gw[:cv, :cv], gb[:cv], gw[C:C + cv, :cv], gb[C:C + cv], gw[2 * C:2 * C + cv, :cv], gb[2 * C:2 * C + cv],
                     dg[:cv], db[:cv], None, None, None, None, None, None)
@@ -1098,6 +1105,7 @@ class _MaskAttention(torch.autograd.Function):
 
 
 ATTN_FUSED_ADD = os.environ.get("MU_ATTN_FUSED_ADD", "1") != "0"      # debug switch: 0 = projection data-gradient + mu_add
+DQKV_ENCODED = os.environ.get("MU_DQKV_ENCODED", "1") != "0"          # debug switch: 0 = plain dqkv + a separate mu_split_encode pass
 
 
 ATTN_WIDTHS = (32, 64, 128, 256)

@@ -221,3 +221,23 @@ def test_attention_fp32x_backward_is_invariant_to_the_gradient_magnitude(gscale)
     from tests import _gpu_checks as G
     _assert_all(G.check_attention_overflow_redo(torch.float32, fp32x=True, hot=False, gout_scale=gscale))
 
+
+def test_colsum_of_a_chunk_encoded_tensor():
+    """mu_colsum(MU_F32X): column sums (bias gradients) straight from the chunk-encoded operand form -- what the fp32x attention backward
+    leaves in dqkv (MU_ATTN_DQKV_ENCODED) -- equal the sums of hi + lo of every element."""
+    from maskunet_amd import _lib
+    g = torch.Generator(device="cuda").manual_seed(9)
+    for M, C in [(4096 + 37, 192), (1000, 64), (257, 768)]:
+        x = torch.randn(M, C, device="cuda", generator=g) * 3.0
+        e = torch.empty_like(x)
+        _lib.call("mu_split_encode", x.data_ptr(), e.data_ptr(), x.numel(), _lib.stream())
+        out = torch.empty(C, device="cuda")
+        ws = _lib.workspace(_lib.load().mu_colsum_workspace_bytes(C), torch.device("cuda"))
+        _lib.call("mu_colsum", e.data_ptr(), M, C, C, out.data_ptr(), ws.data_ptr(), ws.numel(), _lib.MU_F32X, _lib.stream())
+        w = e.view(torch.int32).view(-1, 4)
+        def halves(d):
+            return torch.stack([(d << 16).view(torch.float32), (d & -65536).view(torch.float32)], -1)
+        dec = (torch.cat([halves(w[:, 0]), halves(w[:, 1])], -1) + torch.cat([halves(w[:, 2]), halves(w[:, 3])], -1)).reshape(M, C)
+        ref = dec.double().sum(0)
+        assert float((out.double() - ref).abs().max()) <= 1e-6 * float(ref.abs().max() + dec.abs().double().sum(0).max())
+
