@@ -2187,8 +2187,12 @@ template <int N> __device__ __forceinline__ void wait_vmcnt_c() {
 #define MU_WGX_STAGGER 1
 #endif
 #ifndef MU_WGX_PAIRED
-#define MU_WGX_PAIRED 0
+#define MU_WGX_PAIRED 0         // (round 5 probe: hi / lo halves of the same rows fetched by neighbouring lane groups + v_permlane16_swap -- conflict-free but
+#endif                          //  8-10 % SLOWER on every layer, gpurun_out/r05d_ab_wgrad.txt: the swaps cost more than the conflicts; superseded by MU_WGX_SHIFT)
+#ifndef MU_WGX_SHIFT
+#define MU_WGX_SHIFT 1
 #endif
+static_assert(!(MU_WGX_PAIRED && MU_WGX_SHIFT), "the paired-fetch probe reads the unshifted image");
 // SPS = 32-pixel k-steps per DMA stage.  SPS = 2 (W % 64 == 0): one barrier / DMA batch / ring step per 64 pixels -- the two
 // waves of a SIMD run in lockstep behind the per-stage barrier, so the ~500 cycles of scalar + address work per ring step sit
 // in front of both waves' MFMA bursts (PMC: SQ_ACTIVE_INST_SCA 18 % of wave cycles, MFMA pipe 44 % busy at SPS = 1).
@@ -2218,7 +2222,16 @@ __global__ __launch_bounds__(NWV * 64, 1) void conv_wgrad3_kernel(const T* __res
     constexpr int RW = SP / 2;                              // two-row mode: image width
     constexpr int XR = ((W16 ? SP + 4 : SP + 2) + RPWB - 1) / RPWB * RPWB;   // x-window rows allocated (SP + 2, or 2 x (RW + 2))
     constexpr int NIA = SP / RPWA, NIB = XR / RPWB;        // DMA wave-instructions per tile
-    constexpr int STAGE = SP * BCO + XR * BCI;             // elements per stage
+    // fp32x (MU_WGX_SHIFT, round 5): every 8-row group of a tile sits 8 more bytes into LDS than the previous one (row r at
+    // r * ROWB + 8 (r >> 3); the LDS-DMA takes any 4-byte-aligned base: tools/micro_dma_align.hip).  A transposed read fetches only the hi
+    // (or only the lo) 8 bytes of every 16-byte chunk, i.e. half of the banks -- 2-way for a 32-lane half whatever the chunk placement
+    // (50 % of this kernel's LDS cycles were conflicts).  With the shift the two lane groups of a half (rows a.., a+8..) hit complementary
+    // bank pairs: conflict-free on the dy tile, and on the x window up to one slot where a tap offset makes a read straddle three groups.
+    // In-process A/B (gpurun_out/r05l_ab_wgrad_shift.txt): conflict share 50 % -> 17 % of the LDS cycles, time unchanged on the 128 x 128 tiles
+    // (the reads hide behind the partner wave's MFMAs either way) and 3-4 % WORSE on the 64 x 64 tiles, which therefore keep the plain image.
+    constexpr int XSH = (XF && MU_WGX_SHIFT && BCO == 128 && BCI == 128) ? 1 : 0;
+    constexpr int PADA = XSH ? 16 : 0, PADB = XSH ? 16 : 0; // elements (the last group's shift, rounded up to 64 bytes)
+    constexpr int STAGE = SP * BCO + PADA + XR * BCI + PADB;   // elements per stage
 
     static_assert(!PP || (SPS == 2 && NWV == 8 && WR == 2), "ping-pong needs two 4-wave groups and two k-steps per stage");
     constexpr int NS = XF ? 4 : (SPS == 1 ? MU_WG_NS : 4);
@@ -2290,13 +2303,13 @@ __global__ __launch_bounds__(NWV * 64, 1) void conv_wgrad3_kernel(const T* __res
             const int i = wave + k * NWV;
             if (i < NIA) {
                 const void* src = live ? (const void*)(dyp + aoff[k]) : (const void*)mu_zero_page;
-                glds16a(src, At + i * RPWA * BCO);
+                glds16a(src, At + i * RPWA * BCO + XSH * 2 * ((i * RPWA) >> 3));
             }
         }
     };
     auto stage_b = [&](int buf) {
         T* At = lds + buf * STAGE;
-        T* Bt = At + SP * BCO;
+        T* Bt = At + SP * BCO + PADA;
         const bool live = pis < p_end;
         const int hh = hi + dh;
         const bool rowok = live && hh >= 0 && hh < H, rowok1 = live && hh + 1 >= 0 && hh + 1 < H;
@@ -2308,7 +2321,7 @@ __global__ __launch_bounds__(NWV * 64, 1) void conv_wgrad3_kernel(const T* __res
                 const bool ok = W16 ? ((rowok && bkind[k] == 4) || (rowok1 && bkind[k] == 5))
                                     : (rowok && (bkind[k] == 0 || (bkind[k] == 1 && lok) || (bkind[k] == 2 && rok)));
                 const void* src = ok ? (const void*)(xp + boff[k]) : (const void*)mu_zero_page;
-                glds16a(src, Bt + i * RPWB * BCI);
+                glds16a(src, Bt + i * RPWB * BCI + XSH * 2 * ((i * RPWB) >> 3));
             }
         }
         pis += SP;
@@ -2341,8 +2354,8 @@ __global__ __launch_bounds__(NWV * 64, 1) void conv_wgrad3_kernel(const T* __res
     struct Frags { Frag a[TM]; Frag b[3][TN]; };
     const int wsh = (W16 && SPS == 1 && g >= 2) ? 2 : 0;     // W = 16: the second image row's window starts 18 rows in
     auto rd_tr = [&](const T* tile, int stride, int r0, int col, int hash0, int hash1) -> Frag {
-        const T* p0 = tile + r0 * stride + ((((col >> 4) ^ hash0) << 4) | (col & 15));
-        const T* p1 = tile + (r0 + 4) * stride + ((((col >> 4) ^ hash1) << 4) | (col & 15));
+        const T* p0 = tile + r0 * stride + ((((col >> 4) ^ hash0) << 4) | (col & 15)) + XSH * 2 * (r0 >> 3);
+        const T* p1 = tile + (r0 + 4) * stride + ((((col >> 4) ^ hash1) << 4) | (col & 15)) + XSH * 2 * ((r0 + 4) >> 3);
         if constexpr (XF) {
             const char* c0 = reinterpret_cast<const char*>(p0);
             const char* c1 = reinterpret_cast<const char*>(p1);
@@ -2379,7 +2392,7 @@ __global__ __launch_bounds__(NWV * 64, 1) void conv_wgrad3_kernel(const T* __res
     };
     auto load_frags = [&](int buf, int half, Frags& f) {     // k-step `half` of the stage in slot `buf`
         const T* At = lds + buf * STAGE;
-        const T* Bt = At + SP * BCO;
+        const T* Bt = At + SP * BCO + PADA;
         // absolute tile rows (the swizzle hash is a function of the row the DMA wrote): k-step `half` starts at dy row half*32
         // and at window row half*32 (flat) or half*34 (W = 32: one window per image row)
         const int ra = half * KP, rb = half * (W16 ? KP + 2 : KP);
