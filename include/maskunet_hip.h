@@ -71,6 +71,11 @@ int mu_split_encode(const void* src, void* dst, long n_elems, void* stream);
 /* fp32x ATTENTION operand encoding (see MU_F32X): n_elems fp32 values (a multiple of 8, 32-byte aligned) -> [8 fp16 hi | 8 fp16 lo] per
  * group of eight, hi = fp16(x), lo = fp16(x - hi); dst may be src (in place).  qkv of mu_attn_fwd / mu_attn_bwd* with MU_F32X. */
 int mu_split_encode_h(const void* src, void* dst, long n_elems, void* stream);
+/* y[M][Cout] = x[M][Cin] w^T + bias with y written DIRECTLY in the attention operand encoding (the mu_split_encode_h form): the q/k/v
+ * projection nn.Linear(C, C) x 3 (ade_semantic.py:170-172) of the MU_F32X attention block as one 1x1 layer, without the separate
+ * encoding pass over qkv.  x, w chunk-encoded MU_F32X operands (mu_split_encode), bias fp32 or NULL; Cin % 32 == 0, Cout % 64 == 0. */
+int mu_conv1x1_fwd_enc_h(const void* x, const void* w, const float* bias, void* y, long M, int Cin, int Cout, long x_ld, long y_ld,
+                         void* stream);
 /* elementwise dtype conversion of n elements */
 int mu_cast(const void* src, int src_dtype, void* dst, int dst_dtype, long n, void* stream);
 /* OIHW fp32 parameter -> tap-major compute layout [taps][rows_pad][cols_pad].

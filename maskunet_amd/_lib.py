@@ -28,6 +28,7 @@ SIGNATURES = {
     "mu_cast": (I, [P, I, P, I, L, P]),
     "mu_split_encode": (I, [P, P, L, P]),
     "mu_split_encode_h": (I, [P, P, L, P]),
+    "mu_conv1x1_fwd_enc_h": (I, [P, P, P, P, L, I, I, L, L, P]),
     "mu_prep_weight": (I, [P, P, I, I, I, I, I, I, I, P]),
     "mu_conv_fwd": (I, [P, P, P, P, I, I, I, I, I, I, L, L, I, P]),
     "mu_conv_stats_rows": (I, [I, I, I, I, I, I, I]),

@@ -307,6 +307,7 @@ __device__ __forceinline__ void glds16a(const void* gsrc, void* lds_wave_base) {
 #ifndef MU_NT2_SB
 #define MU_NT2_SB 1
 #endif
+#define MU_NT2_ENC_H (-1)       // `act` of the fp32x training instantiation: write y in the attention operand encoding (mu_conv1x1_fwd_enc_h)
 template <typename T, int TM, int TN, int WR, int TAPS, bool SB = false, bool FEPI = false>
 __global__ __launch_bounds__(256, SB ? MU_NT2_SB_OCC : MU_NT2_OCC) void conv_nt2_kernel(const T* __restrict__ x, const T* __restrict__ w, const float* __restrict__ bias,
                                                        T* __restrict__ y, int B, int H, int W, int Cin, int Cout, long x_ld, long y_ld,
@@ -491,6 +492,20 @@ __global__ __launch_bounds__(256, SB ? MU_NT2_SB_OCC : MU_NT2_OCC) void conv_nt2
                 h16x4 o = {(h16)v[0], (h16)v[1], (h16)v[2], (h16)v[3]};
                 *reinterpret_cast<h16x4*>(y + p * y_ld + co) = o;
             } else {
+                if constexpr (std::is_same<T, xf32>::value && !FEPI) {
+                    if (act == MU_NT2_ENC_H) {
+                        // the attention operand encoding written by the producer (mu_conv1x1_fwd_enc_h; common.h): a group of eight channels is
+                        // [8 fp16 hi | 8 fp16 lo]; this lane holds four of them (the lower four for even g): its hi parts go to bytes
+                        // 8 (g & 1) of the group, its lo parts 16 bytes further -- two 8-byte stores instead of one 16-byte store
+                        uint32_t h0, h1, l0, l1;
+                        mu_hsplit2(v[0], v[1], h0, l0);
+                        mu_hsplit2(v[2], v[3], h1, l1);
+                        char* gp = reinterpret_cast<char*>(y + p * y_ld + (co & ~7)) + (g & 1) * 8;
+                        *reinterpret_cast<uint2*>(gp) = make_uint2(h0, h1);
+                        *reinterpret_cast<uint2*>(gp + 16) = make_uint2(l0, l1);
+                        continue;
+                    }
+                }
                 *reinterpret_cast<float4*>(y + p * y_ld + co) = make_float4(v[0], v[1], v[2], v[3]);
             }
         }
@@ -1854,6 +1869,24 @@ static void conv1x1_add_launch(const T* x, const T* w, const T* addend, T* y, lo
         conv_nt2_kernel<T, 4, 4, 2, 1, false, true><<<npb * (Cout / 128), 256, 0, st>>>(x, w, nullptr, y, 1, 1, (int)M, Cin, Cout, x_ld, y_ld, addend);
     else
         conv_nt2_kernel<T, 4, 4, 1, 1, false, true><<<(int)((M + 255) / 256) * (Cout / 64), 256, 0, st>>>(x, w, nullptr, y, 1, 1, (int)M, Cin, Cout, x_ld, y_ld, addend);
+}
+
+// The q/k/v projection of the fp32x attention block with its output written DIRECTLY in the attention operand encoding ([8 fp16 hi |
+// 8 fp16 lo] per eight channels, mu_split_encode_h form): saves the read + write pass over qkv [B, N, 3C] behind the projection.
+extern "C" int mu_conv1x1_fwd_enc_h(const void* x, const void* w, const float* bias, void* y, long M, int Cin, int Cout, long x_ld, long y_ld,
+                                    void* stream) {
+    if (!x || !w || !y || M <= 0 || M > 0x7fffffffL) return MU_ERR_ARG;
+    if (Cin <= 0 || Cout <= 0 || Cin % 32 || Cout % 64 || x_ld < Cin || y_ld < Cout || x_ld % 8 || y_ld % 8) return MU_ERR_SHAPE;
+    hipStream_t st = (hipStream_t)stream;
+    const xf32* xs = (const xf32*)x;
+    const xf32* ws = (const xf32*)w;
+    const int npb = (int)((M + 127) / 128);
+    if (Cout % 128 == 0)
+        conv_nt2_kernel<xf32, 4, 4, 2, 1><<<npb * (Cout / 128), 256, 0, st>>>(xs, ws, bias, (xf32*)y, 1, 1, (int)M, Cin, Cout, x_ld, y_ld, nullptr, nullptr, MU_NT2_ENC_H);
+    else
+        conv_nt2_kernel<xf32, 4, 4, 1, 1><<<(int)((M + 255) / 256) * (Cout / 64), 256, 0, st>>>(xs, ws, bias, (xf32*)y, 1, 1, (int)M, Cin, Cout, x_ld, y_ld, nullptr, nullptr, MU_NT2_ENC_H);
+    MU_CHECK_LAUNCH();
+    return MU_OK;
 }
 
 extern "C" int mu_conv1x1_fwd_add(const void* x, const void* w, const void* addend, void* y, long M, int Cin, int Cout, long x_ld, long y_ld,

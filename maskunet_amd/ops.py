@@ -1025,8 +1025,13 @@ class _MaskAttention(torch.autograd.Function):
             bqkv, (wprep, wd_) = make_qkv()
         ctx.wd = wd_ if ctx.needs_input_grad[0] else None
         xe = _enc(x)                                                   # fp32x: the projection's operand form, kept for its weight gradient (x itself otherwise)
-        qkv = _enc_h_(_conv_raw(xe, wprep, bqkv, 3 * C, 1, x_encoded=True))    # [B,H,W,3C] == [B,N,3C]; fp32x: fp16-pair-encoded from here on
-        # (only the attention sweeps, forward and backward, ever read it)
+        if _is_x(x) and QKV_ENCODED and (3 * C) % 64 == 0:
+            # [B,H,W,3C] == [B,N,3C], written by the projection's epilogue in the attention operand encoding (fp16 pairs): only the
+            # attention sweeps, forward and backward, ever read it
+            qkv = torch.empty((B, H, W, 3 * C), dtype=x.dtype, device=x.device)
+            call("mu_conv1x1_fwd_enc_h", ptr(xe), ptr(wprep), ptr(bqkv), ptr(qkv), B * N, C, 3 * C, C, 3 * C, stream())
+        else:
+            qkv = _enc_h_(_conv_raw(xe, wprep, bqkv, 3 * C, 1, x_encoded=True))
         out = torch.empty((B, N, C), dtype=x.dtype, device=x.device)
         oattn = torch.empty_like(out)
         lse2 = torch.empty((B, N), dtype=torch.float32, device=x.device)
@@ -1105,6 +1110,7 @@ class _MaskAttention(torch.autograd.Function):
 
 
 ATTN_FUSED_ADD = os.environ.get("MU_ATTN_FUSED_ADD", "1") != "0"      # debug switch: 0 = projection data-gradient + mu_add
+QKV_ENCODED = os.environ.get("MU_QKV_ENCODED", "1") != "0"            # debug switch: 0 = plain projection output + a separate mu_split_encode_h pass
 DQKV_ENCODED = os.environ.get("MU_DQKV_ENCODED", "1") != "0"          # debug switch: 0 = plain dqkv + a separate mu_split_encode pass
 
 
