@@ -116,6 +116,9 @@
 #ifndef MU_XF_OCC
 #define MU_XF_OCC 2
 #endif
+#ifndef MU_XF_DQ_OCC
+#define MU_XF_DQ_OCC 2
+#endif
 #ifndef MU_XF_DKV_SCHED
 #define MU_XF_DKV_SCHED 0
 #endif
@@ -1053,7 +1056,7 @@ extern "C" int mu_split_encode_h(const void* src, void* dst, long n_elems, void*
 // backward v2 kernels: LDS-DMA double-buffered tiles, swizzled images (see attn_fwd2_kernel)
 // ------------------------------------------------------------------------------------------
 template <typename T, int D, int KT, int NW>
-__global__ __launch_bounds__(NW * 64, (NW == 4 && D <= 64 && std::is_same<T, xf32>::value) ? MU_XF_OCC : (NW == 4 && D <= 64 && sizeof(T) == 2) ? MU_DQ_OCC : ((NW == 4 && D == 128 && sizeof(T) == 2) ? MU_DQ_OCC128 : ((NW == 4 && D == 256 && sizeof(T) == 2) ? MU_DQ_OCC256 : 1))) void attn_bwd_dq2_kernel(const T* __restrict__ qkv, const T* __restrict__ dY, const int* __restrict__ kidx,
+__global__ __launch_bounds__(NW * 64, (NW == 4 && D <= 64 && std::is_same<T, xf32>::value) ? MU_XF_DQ_OCC : (NW == 4 && D <= 64 && sizeof(T) == 2) ? MU_DQ_OCC : ((NW == 4 && D == 128 && sizeof(T) == 2) ? MU_DQ_OCC128 : ((NW == 4 && D == 256 && sizeof(T) == 2) ? MU_DQ_OCC256 : 1))) void attn_bwd_dq2_kernel(const T* __restrict__ qkv, const T* __restrict__ dY, const int* __restrict__ kidx,
                                                            const int* __restrict__ kcnt, const float* __restrict__ lse2,
                                                            const float* __restrict__ delta, T* __restrict__ dqkv, int N, int nkmax,
                                                            float scale, float scale_log2, const float* __restrict__ gsp, float pshift, int enc_out) {
