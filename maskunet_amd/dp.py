@@ -182,6 +182,20 @@ class DataParallel(nn.Module):
             self._dead = {id(p) for b in self.buckets for p in b.params if p.grad is None}
             self._build_arena()
 
+    def launch_complete_buckets(self, done_ids):
+        """Start the all-reduce of every not-yet-launched bucket whose live parameters all have their gradients (ids in `done_ids`) --
+        GraphedStep calls this between its two graph segments."""
+        if not self.multi or not self._sync:
+            return 0
+        n = 0
+        dead = self._dead or ()
+        for b in self.buckets:
+            live = [p for p in b.params if id(p) not in dead]
+            if b.work is None and live and all(id(p) in done_ids and p.grad is not None for p in live):
+                self._launch(b)
+                n += 1
+        return n
+
     def gradient_slice(self, p):
         """The arena slice that is (or will be) ``p.grad`` after a synchronised step, or None (no arena yet / a dead parameter)."""
         b = self._bucket_of.get(id(p))

@@ -18,7 +18,9 @@ With a maskunet_amd.DataParallel model the replica's step is captured (the graph
 eagerly after every replay: the same bucketed all-reduce on the comm stream, without overlap with the backward -- the hooks of
 DataParallel sit on the parameters' AccumulateGrad nodes, which the captured torch.autograd.grad on fresh leaves never runs.  The
 captured weight-gradient kernels write straight into DataParallel's bucket slices (its gradient arena, laid out after the first warm-up
-step), the buckets are reduced in place and p.grad is the reduced slice -- no flattening and no copy back per replay.  Gradient accumulation is NOT available through a graph: a
+step), the buckets are reduced in place and p.grad is the reduced slice -- no flattening and no copy back per replay.  The capture is
+SEGMENTED (round 5): two graphs split inside the one backward pass at ops.cut_point (encoder | bottleneck + decoder), so the all-reduce
+of the buckets the first segment completes runs on the comm stream beside the second segment's replay (see _capture_segmented).  Gradient accumulation is NOT available through a graph: a
 replay overwrites the graph's gradient tensors instead of adding to them, so a call inside `DataParallel.no_sync()` raises.
 """
 from __future__ import annotations
@@ -30,7 +32,7 @@ from .dp import DataParallel
 
 
 class GraphedStep:
-    def __init__(self, model, criterion, example_inputs, example_labels, loss_scale: float = 1.0, warmup: int = 2):
+    def __init__(self, model, criterion, example_inputs, example_labels, loss_scale: float = 1.0, warmup: int = 2, segments: int = 2):
         if not example_inputs.is_cuda:
             raise RuntimeError("GraphedStep needs CUDA example inputs (the HIP path has no CPU fallback)")
         self.dp = model if isinstance(model, DataParallel) else None
@@ -54,16 +56,62 @@ class GraphedStep:
         torch.cuda.current_stream(dev).wait_stream(side)
         torch.cuda.synchronize(dev)
         self.graph = torch.cuda.CUDAGraph()
+        self.graph2 = None                      # second segment (DataParallel): the backward behind ops.cut_point
+        self._seg1 = set()                      # ids of the parameters whose gradients are complete when the first segment ends
         ops.SEED_STEP = self.step_counter
         try:
             # thread_local: with an initialised nccl (RCCL) process group the backend's watchdog thread polls the events of finished
             # collectives (hipEventQuery) at any time; under the default "global" capture mode that call from ANOTHER thread is an
             # error ("operation not permitted when stream is capturing") and takes the process down
-            with torch.cuda.graph(self.graph, capture_error_mode="thread_local"):
-                self.step_counter.add_(1)
-                self.loss, self.outputs = self._body()
+            if self.dp is not None and self.dp.multi and segments >= 2:
+                self._capture_segmented()
+            else:
+                with torch.cuda.graph(self.graph, capture_error_mode="thread_local"):
+                    self.step_counter.add_(1)
+                    self.loss, self.outputs = self._body()
         finally:
             ops.SEED_STEP = None
+            ops.CUT_HOOK = None
+
+    def _capture_segmented(self):
+        """The step as TWO graphs sharing one memory pool, split INSIDE the single backward pass (a collective cannot be captured on this
+        stack: tools/probe_graph_rccl.py dumps core): the gradient hook of ops.cut_point -- it fires when every node behind the cut has
+        run -- ends the first capture and begins the second.  One backward pass, so ops.GradLink / EncLink pairs across the cut keep
+        working.  Replay: graph 1, the all-reduces of the buckets it completed (comm stream), graph 2 beside them, the rest."""
+        import gc
+        dev = self.inputs.device
+        g1, g2 = self.graph, torch.cuda.CUDAGraph()
+        state = {"cut": False, "fired": set()}
+
+        def cut(_grad):
+            if not state["cut"]:
+                state["cut"] = True
+                self._seg1 = set(state["fired"])
+                g1.capture_end()
+                g2.capture_begin(pool=g1.pool(), capture_error_mode="relaxed")
+            return None
+
+        torch.cuda.synchronize(dev)
+        gc.collect()
+        torch.cuda.empty_cache()
+        cap = torch.cuda.Stream(dev)
+        cap.wait_stream(torch.cuda.current_stream(dev))
+        ops.CUT_HOOK = cut
+        self._leaf_fired = state["fired"]
+        with torch.cuda.stream(cap):
+            # "relaxed": the hook runs on the autograd engine's device thread, and a capture begun in the stricter modes may only be
+            # ended by the thread that began it (relaxed also tolerates the RCCL watchdog's event queries, see above)
+            g1.capture_begin(capture_error_mode="relaxed")
+            try:
+                self.step_counter.add_(1)
+                self.loss, self.outputs = self._body()
+            finally:
+                ops.CUT_HOOK = None
+                (g2 if state["cut"] else g1).capture_end()
+        torch.cuda.current_stream(dev).wait_stream(cap)
+        self._leaf_fired = None
+        if state["cut"]:
+            self.graph2 = g2
 
     def _body(self):
         # The forward runs on fresh leaves aliasing the parameters (functional_call), and the gradients are taken with
@@ -71,6 +119,10 @@ class GraphedStep:
         # by an earlier eager step (e.g. through a loss tensor the caller still holds) makes the engine synchronise the capture stream
         # with that stream, which is not capturable (segfault in hipStreamEndCapture on this stack).  Fresh leaves have fresh nodes.
         fresh = {n: p.detach().requires_grad_(True) for n, p in zip(self.names, self.params)}
+        fired = getattr(self, "_leaf_fired", None)
+        if fired is not None:                    # segmented capture: note the order in which the parameter gradients complete
+            for n, p in zip(self.names, self.params):
+                fresh[n].register_hook(lambda g, k=id(p): fired.add(k))
         # DataParallel's gradient arena is keyed on the parameters; the kernels here see the fresh leaves: register them for the call
         arena_keys = []
         if self.dp is not None and ops.GRAD_ARENA is not None:
@@ -101,7 +153,14 @@ class GraphedStep:
         self.graph.replay()
         for p, g in zip(self.params, self.grads):     # optimizer.zero_grad(set_to_none=True) between replays detaches them
             p.grad = g
-        if self.dp is not None:                       # one exchange per step, after the replay (ade_semantic.py:373)
+        if self.dp is not None:                       # one exchange per step (ade_semantic.py:373)
             self.dp._arm()
-            self.dp.finish_gradient_sync(copy_back=True)      # into the graph's own gradient tensors
+            if self.graph2 is not None:
+                # the buckets whose gradients the first segment completed (bottleneck, decoder, heads: most of the bytes) are reduced on
+                # the comm stream WHILE the second segment -- the encoder's backward -- replays on this one
+                self.dp.launch_complete_buckets(self._seg1)
+                self.graph2.replay()
+            self.dp.finish_gradient_sync(copy_back=True)      # the rest; p.grad = the reduced bucket slices
+        elif self.graph2 is not None:
+            self.graph2.replay()
         return self.loss.clone()                      # self.loss is overwritten by the next replay

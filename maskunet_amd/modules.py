@@ -355,7 +355,7 @@ class UNet(_HipModule):
         x3 = self.self_attention2.forward_nhwc(x3)
         l3 = ops.grad_link(x3)
         x4 = self.downsample3.forward_nhwc(x3, skip_link=l3)
-        x4 = self.self_attention3.forward_nhwc(x4)
+        x4 = ops.cut_point(self.self_attention3.forward_nhwc(x4))     # encoder | bottleneck + decoder: where GraphedStep may split its capture
 
         fx = ops.enc_link(x4) is not None                # fp32x mode with a backward to come: the bottleneck blocks hand their outputs on chunk-encoded
         x4 = self.bottom1.forward_nhwc(x4, enc_out=fx)

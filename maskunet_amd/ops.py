@@ -388,6 +388,18 @@ def _conv_raw(x, wprep, bias_p, Cout_p, taps, want_stats=False, x_encoded=False)
     return y
 
 
+# Cut point of a segmented capture (maskunet_amd.GraphedStep over DataParallel): while CUT_HOOK is set, the tensor handed to cut_point()
+# gets it as a gradient hook -- it fires in the backward pass once every node created AFTER the tensor in the forward has run (the
+# engine orders nodes by creation), i.e. when the gradients of the bottleneck, the decoder and the heads are complete.
+CUT_HOOK = None
+
+
+def cut_point(t):
+    if CUT_HOOK is not None and t.requires_grad:
+        t.register_hook(CUT_HOOK)
+    return t
+
+
 # Gradient arena (maskunet_amd.DataParallel, round 5): id(parameter) -> that parameter's fp32 slice of its all-reduce bucket.  The
 # kernels that produce the LARGE parameter gradients (conv / Linear weight gradients: 24.5 M of the model's 24.9 M parameters; the two
 # affine tensors of LayerNorm([64,128,128])) write straight into the slice, autograd's AccumulateGrad adopts the tensor it is handed
@@ -461,6 +473,9 @@ _JOIN_QUEUED = set()
 # Measured (B=64 bench, same box, two rounds): 36.20 / 36.25 ms per step in-stream vs 36.54 / 36.45 ms with the side stream
 # (36.78 / 36.50 when launched ahead of the data gradient): the kernels do not overlap usefully, so this stays opt-in.
 WGRAD_SIDE_STREAM = os.environ.get("MU_WGRAD_SIDE", "0") != "0"
+# only layers whose feature map is at most this high (at 16^2 / 32^2 the data- and weight-gradient grids each fill half of the
+# chip at B = 64, so the pair could run side by side; the big layers compete for HBM / LDS -- the round-3 finding)
+WGRAD_SIDE_MAXHW = int(os.environ.get("MU_WGRAD_SIDE_MAXHW", "100000"))
 
 
 def wgrad_stream(device):
@@ -565,7 +580,7 @@ class _Conv(torch.autograd.Function):
         gy_pre = ctx.dy_link is not None and ctx.dy_link.take()      # fp32x: dy arrived chunk-encoded from the BatchNorm's backward
         O, I = weight.shape[0], weight.shape[1]
         gx = gw = gb = None
-        side = ctx.needs_input_grad[1] and WGRAD_SIDE_STREAM and ctx.wparam.grad is None
+        side = ctx.needs_input_grad[1] and WGRAD_SIDE_STREAM and ctx.wparam.grad is None and x.shape[1] <= WGRAD_SIDE_MAXHW
         if side and os.environ.get("MU_WGRAD_SIDE_FIRST"):
             gw = _wgrad_side(x, gy, tuple(weight.shape), ctx.taps, ctx.x_enc, ctx.wparam)
         if gy_pre:
