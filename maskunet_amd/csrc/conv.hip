@@ -1010,6 +1010,9 @@ __device__ __forceinline__ void tile_stats_store(float (&ssum)[8], float (&ssq)[
 #ifndef MU_CONV_NT4P
 #define MU_CONV_NT4P 1
 #endif
+#ifndef MU_NT4_MINBLK
+#define MU_NT4_MINBLK 0         // (round 5 probe: grids below this many blocks fall back to the 8 x 16-pixel-tile kernel)
+#endif
 #ifndef MU_CONV_WIDE1X1
 #define MU_CONV_WIDE1X1 1
 #endif
@@ -1720,7 +1723,8 @@ static int conv_fwd_launch(const T* x, const T* w, const float* bias, T* y, int 
             }
         }
         if constexpr (sizeof(T) == 2 && MU_CONV_NT4) {
-            if (Cout % 128 == 0 && H % 16 == 0 && Cin % 64 == 0 && !getenv("MU_CONV_NO_NT4")) {
+            if (Cout % 128 == 0 && H % 16 == 0 && Cin % 64 == 0 && !getenv("MU_CONV_NO_NT4") &&
+                (long)B * (H / 16) * (W / 16) * (Cout / 128) >= MU_NT4_MINBLK) {
 #if MU_CONV_NT4P
                 const int ntile4 = B * (H / 16) * (W / 16), ncb4 = Cout / 128;
                 // measured (in-process A/B): 128->128 @128^2 322 -> 307 us, 64->128 @128^2 205 -> 176 us, 256->256 @64^2 equal,
@@ -1795,7 +1799,7 @@ static int conv_fwd_launch(const T* x, const T* w, const float* bias, T* y, int 
 // statistics epilogue -- run mu_bn_train_stats on the output instead).  One row per 16x16 output tile and 4-image-row group.
 extern "C" int mu_conv_stats_rows(int B, int H, int W, int Cin, int Cout, int taps, int dtype) {
     if (taps != 9 || getenv("MU_CONV_NO_NT4") || B <= 0) return 0;
-    if (dtype == MU_F16 && MU_CONV_NT4) { if (Cin % 64 || Cout % 128 || H % 16 || W % 16) return 0; }
+    if (dtype == MU_F16 && MU_CONV_NT4) { if (Cin % 64 || Cout % 128 || H % 16 || W % 16 || (long)B * (H / 16) * (W / 16) * (Cout / 128) < MU_NT4_MINBLK) return 0; }
     else if (dtype == MU_F32X && MU_CONV_NT4X) { if (!nt4x_serves(B, H, W, Cin, Cout)) return 0; }
     else return 0;
     return B * (H / 16) * (W / 16) * 4;

@@ -4,6 +4,7 @@
 # bench step.  Usage (repo root on the GPU box):  bash tools/dkv_traffic.sh TAG KEY [bench.py args ...]
 #   -> gpurun_out/<TAG>_dkv_traffic_<KEY>.json   (KEY = bench.py's traffic key: b{batch}_c{c_out}_hw{hw}_{dtype}[_3head])
 TAG=$1; KEY=$2; shift 2
+export MU_SESSION_TAG=$TAG
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out
 mkdir -p $OUT
@@ -29,7 +30,7 @@ f, nf, name = launches(sys.argv[1], "FETCH_SIZE")
 w, nw, _ = launches(sys.argv[2], "WRITE_SIZE")
 if f is None or w is None:
     print("no dK/dV launches found"); sys.exit(1)
-rec = {"kernel": name, "workload_key": sys.argv[4], "bench_args": sys.argv[5],
+rec = {"kernel": name, "workload_key": sys.argv[4], "bench_args": sys.argv[5], "session": os.environ.get("MU_SESSION_TAG", ""),
        "how": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) -- python3 bench.py --no-cpu-baseline --no-parity-gate --no-clock-probe --no-fp32x-line --steps 2 --warmup 1 "
               + sys.argv[5] + f" (tools/dkv_traffic.sh); mean over the {nf} largest-grid launches of the kernel (self_attention6)",
        "FETCH_SIZE_KB": round(f, 1), "WRITE_SIZE_KB": round(w, 1),
