@@ -175,6 +175,17 @@ class DataParallel(nn.Module):
             b.arena, b.views, b.live = None, {}, []
         self._arena_dead = None
 
+    def close(self):
+        """Release the arena (its slices stay registered with ops while this wrapper lives: ~4 bytes per parameter).  Called on
+        garbage collection too; gradients that ARE slices keep their bucket alive on their own."""
+        try:
+            self._drop_arena()
+        except Exception:                # interpreter shutdown: modules may be gone
+            pass
+
+    def __del__(self):
+        self.close()
+
     def prepare_arena(self):
         """Lay the arena out NOW from the gradients that exist (parameters whose ``.grad`` is None count as dead) instead of after the
         first synchronised step -- GraphedStep calls this after its eager warm-up so that the captured kernels write into the slices."""

@@ -94,6 +94,11 @@ def _worker(rank, world, port, overlap, q):
             assert all(torch.equal(p.grad, torch.full_like(p, float(rank + 1))) for p in model.parameters())
         # state_dict keys carry the nn.DataParallel "module." prefix
         assert all(k.startswith("module.") for k in ddp.state_dict().keys())
+        # the arena's registration with ops goes away with the wrapper (no leak when wrappers are re-created)
+        from maskunet_amd import ops
+        assert ops.GRAD_ARENA and sum(id(p) in ops.GRAD_ARENA for p in model.parameters()) >= 10
+        ddp.close()
+        assert not any(id(p) in ops.GRAD_ARENA for p in model.parameters())
         q.put((rank, "ok"))
     except Exception as e:  # pragma: no cover
         q.put((rank, repr(e)))
