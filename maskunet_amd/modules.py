@@ -401,8 +401,8 @@ class UNet(_HipModule):
         """Forward from decoded image bytes: uint8 [B,H,W,3] (HWC) of ANY size, standing in for the reference's pipeline
         ``forward(ToTensor(cv2.resize(img, (hw, hw), interpolation=cv2.INTER_LINEAR)))`` (ade_semantic.py:72-76,85); ``bgr=True`` also
         applies ``cv2.cvtColor(img, cv2.COLOR_BGR2RGB)`` (:65), i.e. takes what cv2.imread returns.  The resize is the RESTATED OpenCV
-        4.10 8-bit algorithm (oracle/cv2_resize_oracle.py: 11-bit fixed-point coefficients, 2x2 area shortcut) -- exact against that
-        restatement, NOT pinned to bytes produced by a real cv2 build (cv2 is not installed here and not vendored by the reference:
+        4.10 8-bit algorithm (11-bit fixed-point coefficients, 2x2 area shortcut; its CPU restatement lives with the test
+        infrastructure) -- exact against that restatement, NOT pinned to bytes produced by a real cv2 build (cv2 is not installed here and not vendored by the reference:
         SURVEY 8-f4 stays "partial" for this half).  ToTensor's division by 255 is exact.  Images that already have the network's size
         skip the resize (cv2.resize to the same size is the identity)."""
         self._check_device(images_u8_hwc)

@@ -154,6 +154,16 @@ def test_bench_spawns_a_child_launcher_for_bare_gpus(monkeypatch):
 
     monkeypatch.setattr(subprocess, "run", fake_run)
     monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "4", "--steps", "3"])
+    monkeypatch.delenv("MU_DIST_BACKEND", raising=False)
+    # N ranks over RCCL need N visible devices: refused with a message BEFORE anything is spawned (device_count() does not touch the GPU)
+    monkeypatch.setattr(torch.cuda, "device_count", lambda: 1)
+    with pytest.raises(SystemExit) as e:
+        bench.spawn_ranks(4)
+    assert "needs 4 visible GPUs" in str(e.value) and "cmd" not in seen
+    monkeypatch.setenv("MU_DIST_BACKEND", "gloo")               # debug backend: ranks may share a device
+    bench.need_devices(4)
+    monkeypatch.delenv("MU_DIST_BACKEND")
+    monkeypatch.setattr(torch.cuda, "device_count", lambda: 4)
     bench.spawn_ranks(4)
     cmd = seen["cmd"]
     assert cmd[:3] == [sys.executable, "-m", "torch.distributed.run"] and "--nproc-per-node=4" in cmd
