@@ -114,7 +114,7 @@ __device__ __forceinline__ void mu_mma_split(const SplitF8& a, const SplitF8& b,
 // matrix core as ONE fp16 operand straight from the accumulators, as in the fp16 kernels: P V, dV = P^T dO, dK = dS^T Q and
 // dQ = dS K are two fp16 MFMAs per product (P x hi, P x lo) instead of three bf16 ones, and the ~50 VALU instructions per 32 x 32 tile
 // that split P / dS in registers are gone.  Q K^T and dO V^T keep three terms (lo x hi + hi x lo + hi x hi).  Sizing on the CPU
-// oracle (tools/numerics_attn_single_term.py, the reference's own golden unet1_c150_b2_train): outputs 2.0e-5, worst parameter
+// oracle (tests/aids/numerics_attn_single_term.py, the reference's own golden unet1_c150_b2_train): outputs 2.0e-5, worst parameter
 // gradient 5.9e-3 against gates of 1e-3 / 5e-2.  |s x| must stay below 65504 (a larger value encodes as inf and surfaces as NaN).
 // A 32-byte group = two 16-byte LDS-DMA pieces, so strides, pieces and tile shapes of the fp32 kernels are untouched.
 // ------------------------------------------------------------------------------------------

@@ -1,6 +1,6 @@
 """Shared GPU parity checks: every function runs HIP ops (through maskunet_amd -> C ABI) and the CPU
 oracle / stock torch reference on the same seeded inputs and returns [(name, err, tol)] where err is the
-max abs error normalised by max(1, |ref|_max).  Used by the pytest files and by tools/gpu_report.py.
+max abs error normalised by max(1, |ref|_max).  Used by the pytest files and by tests/aids/gpu_report.py.
 
 Tolerances: fp32 compute 1e-3 (the north_star gate; observed errors are ~1e-5), fp16 compute 3e-2
 (fp16 storage, fp32 accumulate; BASELINE.md expects ~1e-2-class errors for half precision).

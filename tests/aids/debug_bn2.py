@@ -1,6 +1,6 @@
 import os, sys
 import numpy as np, torch, torch.nn.functional as F
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from tests import _gpu_checks as G
 from maskunet_amd import ops
 model, params, keeps, x, labels = G.build_unet(150, False, 310, torch.float32, True, 2)

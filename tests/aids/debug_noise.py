@@ -1,9 +1,9 @@
 #!/usr/bin/env python3
 """Debug aid: per-parameter gradient error of the HIP fp32 path and of the fp32 oracle against the fp64 oracle, in network order
-(python tools/debug_noise.py [B] [links 0/1])."""
+(python tests/aids/debug_noise.py [B] [links 0/1])."""
 import os, sys
 import numpy as np, torch, torch.nn.functional as F
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from tests import _gpu_checks as G
 from oracle import maskunet_oracle as O
 from maskunet_amd import ops

@@ -7,7 +7,7 @@ import traceback
 
 import torch
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from tests import _gpu_checks as G  # noqa: E402
 
 
@@ -42,7 +42,7 @@ if __name__ == "__main__":
             run(f"attention {tag}", G.check_attention, dt)
         if "modules" in which:
             import glob
-            for p in sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "*.npz"))):
+            for p in sorted(glob.glob(os.path.join(os.path.dirname(__file__), "..", "golden", "*.npz"))):
                 n = os.path.basename(p)[:-4]
                 if n.startswith(("unet", "up_32_16")):
                     continue

@@ -3,7 +3,7 @@ operand and q/k/v/dY are stored as fp16 (hi | lo) pairs?  Emulates the planned k
 and runs the reference-generated whole-model golden `unet1_c150_b2_train` through it (same metrics as
 tests/_gpu_checks.check_unet_golden).  Not a test, not product code: sizing evidence quoted in NOTES_r05.md.
 
-usage: python tools/numerics_attn_single_term.py [exact|pair16|p16|p16ds16|p16ds16_noscale]
+usage: python tests/aids/numerics_attn_single_term.py [exact|pair16|p16|p16ds16|p16ds16_noscale]
 """
 import math
 import os
@@ -13,7 +13,7 @@ import numpy as np
 import torch
 import torch.nn.functional as F
 
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))
 from oracle import maskunet_oracle as O  # noqa: E402
 
 MODE = sys.argv[1] if len(sys.argv) > 1 else "p16ds16"
@@ -102,7 +102,7 @@ def mask_attention(x, p, prefix, keep, q_block=None):
 
 def main():
     name = "unet1_c150_b2_train"
-    z = np.load(os.path.join(os.path.dirname(__file__), "..", "tests", "golden", name + ".npz"))
+    z = np.load(os.path.join(os.path.dirname(__file__), "..", "golden", name + ".npz"))
     rec = {k: z[k] for k in z.files}
     B, c_out, seed = int(rec["B"]), int(rec["c_out"]), int(rec["seed"])
     p = O.make_params(O.unet_state_shapes(3, c_out, False), seed)
