@@ -48,6 +48,12 @@
 #ifndef MU_FWD_OCC256
 #define MU_FWD_OCC256 2
 #endif
+#ifndef MU_DQ_NQT128
+#define MU_DQ_NQT128 2          // 1 = one 16-query tile per wave in the C = 128 dQ sweep (A/B below)
+#endif
+#ifndef MU_DQ_OCC128_Q1
+#define MU_DQ_OCC128_Q1 3
+#endif
 #ifndef MU_DQ_OCC256
 #define MU_DQ_OCC256 1
 #endif
@@ -1055,8 +1061,10 @@ extern "C" int mu_split_encode_h(const void* src, void* dst, long n_elems, void*
 // ------------------------------------------------------------------------------------------
 // backward v2 kernels: LDS-DMA double-buffered tiles, swizzled images (see attn_fwd2_kernel)
 // ------------------------------------------------------------------------------------------
-template <typename T, int D, int KT, int NW>
-__global__ __launch_bounds__(NW * 64, (NW == 4 && D <= 64 && std::is_same<T, xf32>::value) ? MU_XF_DQ_OCC : (NW == 4 && D <= 64 && sizeof(T) == 2) ? MU_DQ_OCC : ((NW == 4 && D == 128 && sizeof(T) == 2) ? MU_DQ_OCC128 : ((NW == 4 && D == 256 && sizeof(T) == 2) ? MU_DQ_OCC256 : 1))) void attn_bwd_dq2_kernel(const T* __restrict__ qkv, const T* __restrict__ dY, const int* __restrict__ kidx,
+// NQT = 16-query tiles per wave (2 everywhere but C = 128: there one tile per wave halves the resident Q / dO fragments and the dQ
+// accumulators -- 222 -> ~130 registers in fp16, two -> three waves per SIMD)
+template <typename T, int D, int KT, int NW, int NQT = 2, int OCCQ = 0>
+__global__ __launch_bounds__(NW * 64, OCCQ ? OCCQ : (NW == 4 && D <= 64 && std::is_same<T, xf32>::value) ? MU_XF_DQ_OCC : (NW == 4 && D <= 64 && sizeof(T) == 2) ? MU_DQ_OCC : ((NW == 4 && D == 128 && sizeof(T) == 2) ? MU_DQ_OCC128 : ((NW == 4 && D == 256 && sizeof(T) == 2) ? MU_DQ_OCC256 : 1))) void attn_bwd_dq2_kernel(const T* __restrict__ qkv, const T* __restrict__ dY, const int* __restrict__ kidx,
                                                            const int* __restrict__ kcnt, const float* __restrict__ lse2,
                                                            const float* __restrict__ delta, T* __restrict__ dqkv, int N, int nkmax,
                                                            float scale, float scale_log2, const float* __restrict__ gsp, float pshift, int enc_out) {
@@ -1080,7 +1088,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 && D <= 64 && std::is_same<T, xf3
     attn_block(bx_, b);
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r16 = lane & 15, g = lane >> 4;
-    const int q0 = bx_ * (NW * 32) + wave * 32;
+    const int q0 = bx_ * (NW * NQT * 16) + wave * (NQT * 16);
     const T* qkv_b = qkv + (long)b * N * 3 * D;
     const int Nk = kcnt[b];
     const int* kidx_b = kidx + (long)b * nkmax;
@@ -1092,10 +1100,10 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 && D <= 64 && std::is_same<T, xf3
 
     // Q pre-scaled by log2(e)/sqrt(C) and dO by 1/sqrt(C): with the row constants -lse2 and -delta/sqrt(C) as the
     // MFMA C operands, the matrix core hands back the exponent of P and the scaled (dP - delta) directly.
-    Frag qf[2][NKS], dof[2][NKS];
-    f32x4 nlse[2], ndel[2];
+    Frag qf[NQT][NKS], dof[NQT][NKS];
+    f32x4 nlse[NQT], ndel[NQT];
 #pragma unroll
-    for (int t = 0; t < 2; ++t) {
+    for (int t = 0; t < NQT; ++t) {
         int qrow = q0 + t * 16 + r16;
         if (qrow > N - 1) qrow = N - 1;
         const long tok = (long)b * N + qrow;
@@ -1108,11 +1116,11 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 && D <= 64 && std::is_same<T, xf3
         nlse[t] = (f32x4){l, l, l, l};
         ndel[t] = (f32x4){d, d, d, d};
     }
-    f32x4 dq[NDT][2];
+    f32x4 dq[NDT][NQT];
 #pragma unroll
     for (int dt = 0; dt < NDT; ++dt)
 #pragma unroll
-        for (int t = 0; t < 2; ++t) dq[dt][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int t = 0; t < NQT; ++t) dq[dt][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
     MU_SYNC_DMA();
 
     auto tile = [&](auto BUFC, int j0) {
@@ -1125,7 +1133,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 && D <= 64 && std::is_same<T, xf3
             stg.issue(Kn, Kn + TEK, qkv_b, wave, lane);
             stg.load_idx(kidx_b, j0 + 2 * KT, Nk, wave, lane);
         }
-        f32x4 s[NKT][2], dp[NKT][2];
+        f32x4 s[NKT][NQT], dp[NKT][NQT];
         MU_PRIO(1);
 #pragma unroll
         for (int ks = 0; ks < NKS; ++ks)
@@ -1134,7 +1142,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 && D <= 64 && std::is_same<T, xf3
                 Frag ka = A::template ldt<Z>(Kt, kt * 16 + r16, ks * KR + g * A::GS);
                 Frag va = A::template ldt<Z>(Vt, kt * 16 + r16, ks * KR + g * A::GS);
 #pragma unroll
-                for (int t = 0; t < 2; ++t) {
+                for (int t = 0; t < NQT; ++t) {
                     if (ks == 0) {                            // row constants as the C operand of the first k-step (no copies)
                         s[kt][t] = A::mma_row_from(ka, qf[t][0], nlse[t]);
                         dp[kt][t] = A::mma_row_from(va, dof[t][0], ndel[t]);
@@ -1147,7 +1155,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 && D <= 64 && std::is_same<T, xf3
         MU_PRIO(0);
         if (j0 + KT > Nk) {                          // wave-uniform: only the last, partial tile pays for key-range masking
 #pragma unroll
-            for (int t = 0; t < 2; ++t)
+            for (int t = 0; t < NQT; ++t)
 #pragma unroll
                 for (int kt = 0; kt < NKT; ++kt)
 #pragma unroll
@@ -1162,7 +1170,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 && D <= 64 && std::is_same<T, xf3
             __builtin_amdgcn_sched_barrier(0);
         }
 #pragma unroll
-        for (int t = 0; t < 2; ++t)
+        for (int t = 0; t < NQT; ++t)
 #pragma unroll
             for (int kt = 0; kt < NKT; ++kt)
 #pragma unroll
@@ -1177,7 +1185,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 && D <= 64 && std::is_same<T, xf3
                 if (h == 0 && dt < PREQ) ka = kap[dt];
                 else ka = AccLd<T, D>::ld(Kt, 32 * h, dt * 16, g, r16);
 #pragma unroll
-                for (int t = 0; t < 2; ++t) A::mma_acc(ka, s[2 * h][t], s[2 * h + 1][t], dq[dt][t]);
+                for (int t = 0; t < NQT; ++t) A::mma_acc(ka, s[2 * h][t], s[2 * h + 1][t], dq[dt][t]);
             }
         MU_PRIO(0);
 #ifdef MU_DQ_ABL_NOBAR
@@ -1191,7 +1199,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 && D <= 64 && std::is_same<T, xf3
         if (j0 + KT < Nk) tile(std::integral_constant<int, 1>{}, j0 + KT);
     }
 #pragma unroll
-    for (int t = 0; t < 2; ++t) {
+    for (int t = 0; t < NQT; ++t) {
         const int qrow = q0 + t * 16 + r16;
         if (qrow >= N) continue;
         T* dst = dqkv + ((long)b * N + qrow) * 3 * D;
@@ -1664,7 +1672,12 @@ static int attn_bwd_t(const T* qkv, const T* x, const T* oattn, const T* gout, c
             attn_dy_encode_kernel<<<(int)(gr < 1 ? 1 : (gr > 8192 ? 8192 : gr)), 256, 0, st>>>((const f32x4*)dY, (uint4*)dYs, rowc, gsc, ng, DD / 8, N); \
         }                                                                                                                       \
     }                                                                                                                           \
-    if (phases & 2) attn_bwd_dq2_kernel<T, DD, KTQ, 4><<<gq, 256, 0, st>>>(qkv, dYs, kidx, kcnt, lse2, delta, dqkv, N, nkmax, scale, sl2, gsc, pshift, enc_out); \
+    if (phases & 2) {                                                                                                           \
+        if constexpr (DD == 128 && MU_DQ_NQT128 == 1)                                                                           \
+            attn_bwd_dq2_kernel<T, DD, KTQ, 4, 1, MU_DQ_OCC128_Q1><<<dim3(mu_cdiv(N, 64), B), 256, 0, st>>>(qkv, dYs, kidx, kcnt, lse2, delta, dqkv, N, nkmax, scale, sl2, gsc, pshift, enc_out); \
+        else                                                                                                                    \
+            attn_bwd_dq2_kernel<T, DD, KTQ, 4><<<gq, 256, 0, st>>>(qkv, dYs, kidx, kcnt, lse2, delta, dqkv, N, nkmax, scale, sl2, gsc, pshift, enc_out); \
+    }                                                                                                                           \
     if (phases & 4) {                                                                                                           \
         if constexpr (sizeof(T) == 2 && DD == 64 && MU_DKV_NW64 != 4)                                                           \
             attn_bwd_dkv3_kernel<T, DD, NKT, MU_DKV_NW64><<<dim3(mu_cdiv(nkmax, 16 * MU_DKV_NW64 * NKT), B), 64 * MU_DKV_NW64, 0, st>>>(qkv, dYs, kidx, kcnt, rowc, dqkv, N, nkmax, scale, sl2, zero_masked, gsc, pshift); \
