@@ -213,11 +213,11 @@ def test_attention_overflow_redo_fp32x():
     _assert_all(G.check_attention_overflow_redo(torch.float32, fp32x=True))
 
 
-@pytest.mark.parametrize("gscale", [1e-9, 1.0, 3e5])
+@pytest.mark.parametrize("gscale", [0.0, 1e-9, 1.0, 3e5])
 def test_attention_fp32x_backward_is_invariant_to_the_gradient_magnitude(gscale):
     """fp32x backward: dY travels as fp16 pairs scaled by a power of two chosen from max|dY| on the device, dS as ONE fp16 operand scaled
     by 2^pshift -- the relative error of dqkv must not depend on how large the incoming gradient is (1e-9: the magnitude of a mean-reduced
-    loss over 10^6 pixels; without the scale everything underflows fp16)."""
+    loss over 10^6 pixels; without the scale everything underflows fp16; 0.0: an all-zero gradient gives exact zeros, not 0 * inf)."""
     from tests import _gpu_checks as G
     _assert_all(G.check_attention_overflow_redo(torch.float32, fp32x=True, hot=False, gout_scale=gscale))
 
