@@ -189,3 +189,36 @@ def test_enc_link_is_valid_only_within_the_marking_backward_pass(monkeypatch):
     task["id"] = 4
     assert link.take() is False                                   # another pass
     assert ops.enc_link(torch.zeros(4)) is None                   # exact-fp32 mode: no links at all
+
+
+def test_bench_sweep_roofline_arithmetic():
+    """bench.sweep_rooflines: executed FLOPs = 2 * products * N * Nk * C per image (Nk = kept keys), fp32x counts the 16-bit MFMA FLOPs
+    ISSUED (three terms for S and dP, two for the products that take P / dS as single fp16 operands) against the dense 16-bit peak and
+    carries the fp32-grade rate next to it; `kernels` holds all three sweeps."""
+    import bench
+
+    class Ev:
+        def __init__(self, t=0.0):
+            self.t = t
+
+        def elapsed_time(self, other):
+            return other.t - self.t                        # milliseconds
+
+    def events(ms):
+        return [(tag, Ev(0.0), Ev(v)) for tag, v in ms.items() for _ in range(3)]
+
+    B, hw, kept = 64, 128, 0.5
+    N = hw * hw
+    r = bench.sweep_rooflines("fp16", events({"fwd": 2.0, "dq": 2.5, "dkv": 3.5}), hw, B, kept, {"clock_mhz": 2000.0})
+    exec_dkv = 8.0 * N * N * 64 * B * kept
+    assert abs(r["flops_per_launch"] - exec_dkv) < 1 and r["launches_timed"] == 3 and r["ms_per_launch"] == 3.5
+    assert abs(r["achieved"] - exec_dkv / 3.5e-3 / 1e12) < 0.01 and abs(r["frac"] - r["achieved"] / 2500.0) < 1e-4
+    assert abs(r["frac_at_measured_clock"] - r["achieved"] / (2500.0 * 2000.0 / 2400.0)) < 1e-4
+    assert set(r["kernels"]) == {"fwd", "dq", "dkv"} and abs(r["kernels"]["fwd"]["flops_per_launch"] - exec_dkv / 2) < 1
+    assert abs(r["algorithmic_achieved"] - 2 * r["achieved"]) < 0.02           # full key set = twice the kept half
+    x = bench.sweep_rooflines("fp32x", events({"fwd": 4.0, "dq": 6.0, "dkv": 8.0}), hw, B, kept, None)
+    assert abs(x["flops_per_launch"] - exec_dkv * 10 / 4) < 1                   # (3 + 3 + 2 + 2) terms over 4 products
+    assert abs(x["kernels"]["fwd"]["flops_per_launch"] - (exec_dkv / 2) * 5 / 2) < 1 and abs(x["kernels"]["dq"]["flops_per_launch"] - (exec_dkv * 3 / 4) * 8 / 3) < 1
+    assert abs(x["useful_tflops"] - exec_dkv / 8e-3 / 1e12) < 0.01 and x["peak"] == 2500.0 and x["frac_at_measured_clock"] is None
+    assert bench.sweep_rooflines("fp16", events({"fwd": 2.0}), hw, B, kept, None) is None     # no dominant-kernel launch timed
+
