@@ -524,13 +524,48 @@ __global__ __launch_bounds__(256, SB ? MU_NT2_SB_OCC : MU_NT2_OCC) void conv_nt2
 #ifndef MU_NT3_RING
 #define MU_NT3_RING 1
 #endif
+#ifndef MU_NT3_STATS
+#define MU_NT3_STATS 1          // BatchNorm-statistics epilogue of the halo-tile kernel (fp16 and fp32x training launches)
+#endif
 #ifndef MU_XF_NT3_RING8
 #define MU_XF_NT3_RING8 0       // measured: 14.45 vs 14.5 ms/step over the 51 launches (session r04s) -- neutral, the 4-wave two-block form stays
 #endif
+// Per-channel (sum, sum of squares) of a wave's staged 64-pixel x 64-channel output tile, taken from the SAME fp16-rounded
+// values that were just stored (what BatchNorm will read): lane = (pixel sub-index lane>>3, 8-channel group q), 8 pixels per lane,
+// then the eight lanes of a channel group are folded with xor-shuffles and lanes 0-7 write 8 channels x {sum, sumsq} each.
+// part row layout [Cout][2] floats; rows = one per (tile, 4-image-row group).  Saves BatchNorm's separate statistics sweep.
+__device__ __forceinline__ void tile_stats_accum(const h16x8& o, float (&ssum)[8], float (&ssq)[8]) {
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+        const float v = (float)o[c];
+        ssum[c] += v;
+        ssq[c] = fmaf(v, v, ssq[c]);
+    }
+}
+__device__ __forceinline__ void tile_stats_store(float (&ssum)[8], float (&ssq)[8], float* __restrict__ row, int co, int lane) {
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+#pragma unroll
+        for (int m = 8; m < 64; m <<= 1) {
+            ssum[c] += __shfl_xor(ssum[c], m);
+            ssq[c] += __shfl_xor(ssq[c], m);
+        }
+    }
+    if (lane < 8) {
+#pragma unroll
+        for (int c = 0; c < 8; c += 2)
+            *reinterpret_cast<float4*>(row + (co + c) * 2) = make_float4(ssum[c], ssq[c], ssum[c + 1], ssq[c + 1]);
+    }
+}
+
 template <typename T, int TM, int TN, int WR, int NWV, bool RINGP, bool FEPI>
 __device__ __forceinline__ void conv_nt3_body(const T* __restrict__ x, const T* __restrict__ w, const float* __restrict__ bias,
                                               T* __restrict__ y, int B, int H, int W, int Cin, int Cout, long x_ld, long y_ld,
-                                              const float* __restrict__ scale, const T* __restrict__ res, int act) {
+                                              const float* __restrict__ scale, const T* __restrict__ res, int act,
+                                              float* __restrict__ stat_part = nullptr) {
+    // stat_part (training kernels, may be NULL): per-channel (sum, sum of squares) of the values this kernel stores, one row per
+    // (tile, wave row wc) -- [ntile * WC][Cout][2] floats, the layout mu_bn_train_stats_rows folds (round 5: the statistics epilogue the
+    // ping-pong kernels have had since round 1, for the layers the halo-tile kernel serves: Cout = 64 and small grids)
     using M_ = Mma<T>;
     using Frag = typename M_::Frag;
     constexpr int VN = M_::VN, KC = 8 * VN;
@@ -724,6 +759,7 @@ __device__ __forceinline__ void conv_nt3_body(const T* __restrict__ x, const T* 
             }
         }
         const int q = lane & 7;
+        float ssum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, ssq[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int it = 0; it < TN * 2; ++it) {
             const int p = it * 8 + (lane >> 3);
@@ -736,9 +772,18 @@ __device__ __forceinline__ void conv_nt3_body(const T* __restrict__ x, const T* 
                 for (int e = 0; e < 8; ++e) o[e] = (h16)epi_act<T>((float)o[e] + (float)rv[e], act);
             }
             *reinterpret_cast<h16x8*>(y + gp * y_ld + co0 + wr * 64 + q * 8) = o;
+            if constexpr (!FEPI) { if (stat_part) tile_stats_accum(o, ssum, ssq); }
+        }
+        if constexpr (!FEPI) {
+            if (stat_part) tile_stats_store(ssum, ssq, stat_part + ((long)tl * WC + wc) * Cout * 2, co0 + wr * 64 + q * 8, lane);
         }
         return;
     }
+    float tsum[TM][4], tsq[TM][4];                          // fp32 / fp32x: statistics of the directly stored fragments
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { tsum[i][r] = 0.f; tsq[i][r] = 0.f; }
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
         const long p = ((long)bimg * H + h0 + wc * TN + j) * W + w0 + r16;
@@ -758,7 +803,42 @@ __device__ __forceinline__ void conv_nt3_body(const T* __restrict__ x, const T* 
                 *reinterpret_cast<h16x4*>(y + p * y_ld + co) = o;
             } else {
                 *reinterpret_cast<float4*>(y + p * y_ld + co) = make_float4(v[0], v[1], v[2], v[3]);
+                if constexpr (!FEPI) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) { tsum[i][r] += v[r]; tsq[i][r] = fmaf(v[r], v[r], tsq[i][r]); }
+                }
             }
+        }
+    }
+    if constexpr (!FEPI && sizeof(T) == 4) {
+        if (stat_part) {
+            // transposing fold over the 16 pixel lanes (r16): every step halves the values a lane still owns and adds its partner's half,
+            // 16 + 8 + 4 + 2 shuffles for the 32 (sum, sumsq) values instead of 4 per value; lane r16 ends with channel
+            // i = r16 >> 2, r = r16 & 3 of its quad group g
+            static_assert(TM == 4, "statistics epilogue: four channel fragments per wave");
+            float v8[2][4][2], v4[4][2], v2[2][2], v1[2];
+            const bool b3 = r16 & 8, b2 = r16 & 4, b1 = r16 & 2, b0 = r16 & 1;
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float ks = b3 ? tsum[i + 2][r] : tsum[i][r], ss = b3 ? tsum[i][r] : tsum[i + 2][r];
+                    const float kq = b3 ? tsq[i + 2][r] : tsq[i][r], sq = b3 ? tsq[i][r] : tsq[i + 2][r];
+                    v8[i][r][0] = ks + __shfl_xor(ss, 8);
+                    v8[i][r][1] = kq + __shfl_xor(sq, 8);
+                }
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int k = 0; k < 2; ++k) v4[r][k] = (b2 ? v8[1][r][k] : v8[0][r][k]) + __shfl_xor(b2 ? v8[0][r][k] : v8[1][r][k], 4);
+#pragma unroll
+            for (int r = 0; r < 2; ++r)
+#pragma unroll
+                for (int k = 0; k < 2; ++k) v2[r][k] = (b1 ? v4[r + 2][k] : v4[r][k]) + __shfl_xor(b1 ? v4[r][k] : v4[r + 2][k], 2);
+#pragma unroll
+            for (int k = 0; k < 2; ++k) v1[k] = (b0 ? v2[1][k] : v2[0][k]) + __shfl_xor(b0 ? v2[0][k] : v2[1][k], 1);
+            float* row = stat_part + ((long)tl * WC + wc) * Cout * 2;
+            *reinterpret_cast<float2*>(row + (co0 + (wr * TM + (r16 >> 2)) * 16 + 4 * g + (r16 & 3)) * 2) = make_float2(v1[0], v1[1]);
         }
     }
 }
@@ -766,8 +846,9 @@ __device__ __forceinline__ void conv_nt3_body(const T* __restrict__ x, const T* 
 
 template <typename T, int TM, int TN, int WR, int NWV = 4, bool RINGP = false>
 __global__ __launch_bounds__(NWV * 64, NWV == 4 ? 2 : 1) void conv_nt3_kernel(const T* __restrict__ x, const T* __restrict__ w, const float* __restrict__ bias,
-                                                       T* __restrict__ y, int B, int H, int W, int Cin, int Cout, long x_ld, long y_ld) {
-    conv_nt3_body<T, TM, TN, WR, NWV, RINGP, false>(x, w, bias, y, B, H, W, Cin, Cout, x_ld, y_ld, nullptr, nullptr, 0);
+                                                       T* __restrict__ y, int B, int H, int W, int Cin, int Cout, long x_ld, long y_ld,
+                                                       float* __restrict__ stat_part = nullptr) {
+    conv_nt3_body<T, TM, TN, WR, NWV, RINGP, false>(x, w, bias, y, B, H, W, Cin, Cout, x_ld, y_ld, nullptr, nullptr, 0, stat_part);
 }
 template <typename T, int TM, int TN, int WR>
 __global__ __launch_bounds__(256, 2) void conv_nt3f_kernel(const T* __restrict__ x, const T* __restrict__ w, const float* __restrict__ bias,
@@ -949,34 +1030,6 @@ __global__ __launch_bounds__(256, 2) void conv_nt3p_kernel(const T* __restrict__
         tl = tn;
 #pragma unroll
         for (int k = 0; k < HPW; ++k) hl[k] = hn[k];
-    }
-}
-
-// Per-channel (sum, sum of squares) of a wave's staged 64-pixel x 64-channel output tile, taken from the SAME fp16-rounded
-// values that were just stored (what BatchNorm will read): lane = (pixel sub-index lane>>3, 8-channel group q), 8 pixels per lane,
-// then the eight lanes of a channel group are folded with xor-shuffles and lanes 0-7 write 8 channels x {sum, sumsq} each.
-// part row layout [Cout][2] floats; rows = one per (tile, 4-image-row group).  Saves BatchNorm's separate statistics sweep.
-__device__ __forceinline__ void tile_stats_accum(const h16x8& o, float (&ssum)[8], float (&ssq)[8]) {
-#pragma unroll
-    for (int c = 0; c < 8; ++c) {
-        const float v = (float)o[c];
-        ssum[c] += v;
-        ssq[c] = fmaf(v, v, ssq[c]);
-    }
-}
-__device__ __forceinline__ void tile_stats_store(float (&ssum)[8], float (&ssq)[8], float* __restrict__ row, int co, int lane) {
-#pragma unroll
-    for (int c = 0; c < 8; ++c) {
-#pragma unroll
-        for (int m = 8; m < 64; m <<= 1) {
-            ssum[c] += __shfl_xor(ssum[c], m);
-            ssq[c] += __shfl_xor(ssq[c], m);
-        }
-    }
-    if (lane < 8) {
-#pragma unroll
-        for (int c = 0; c < 8; c += 2)
-            *reinterpret_cast<float4*>(row + (co + c) * 2) = make_float4(ssum[c], ssq[c], ssum[c + 1], ssq[c + 1]);
     }
 }
 
@@ -1754,13 +1807,13 @@ static int conv_fwd_launch(const T* x, const T* w, const float* bias, T* y, int 
                 conv_nt3p_kernel<T, 4, 4, 2><<<dim3(per_cb, ncb), 256, 0, st>>>(x, w, bias, y, B, H, W, Cin, Cout, x_ld, y_ld);
                 return MU_OK;
             }
-            conv_nt3_kernel<T, 4, 4, 2><<<ntile * ncb, 256, 0, st>>>(x, w, bias, y, B, H, W, Cin, Cout, x_ld, y_ld);
+            conv_nt3_kernel<T, 4, 4, 2><<<ntile * ncb, 256, 0, st>>>(x, w, bias, y, B, H, W, Cin, Cout, x_ld, y_ld, stat_part);
             return MU_OK;
         }
         if (Cout % 64 == 0 && H % 8 == 0) {
             const int grid3 = B * (H / 8) * (W / 16) * (Cout / 64);
-            if (Cin * (int)sizeof(T) >= 256) conv_nt3_kernel<T, 4, 2, 1, 4, true><<<grid3, 256, 0, st>>>(x, w, bias, y, B, H, W, Cin, Cout, x_ld, y_ld);
-            else conv_nt3_kernel<T, 4, 2, 1><<<grid3, 256, 0, st>>>(x, w, bias, y, B, H, W, Cin, Cout, x_ld, y_ld);
+            if (Cin * (int)sizeof(T) >= 256) conv_nt3_kernel<T, 4, 2, 1, 4, true><<<grid3, 256, 0, st>>>(x, w, bias, y, B, H, W, Cin, Cout, x_ld, y_ld, stat_part);
+            else conv_nt3_kernel<T, 4, 2, 1><<<grid3, 256, 0, st>>>(x, w, bias, y, B, H, W, Cin, Cout, x_ld, y_ld, stat_part);
             return MU_OK;
         }
     }
@@ -1798,11 +1851,19 @@ static int conv_fwd_launch(const T* x, const T* w, const float* bias, T* y, int 
 // Rows of per-tile BatchNorm statistics mu_conv_fwd_stats writes for this layer shape (0: the kernel that serves it has no
 // statistics epilogue -- run mu_bn_train_stats on the output instead).  One row per 16x16 output tile and 4-image-row group.
 extern "C" int mu_conv_stats_rows(int B, int H, int W, int Cin, int Cout, int taps, int dtype) {
-    if (taps != 9 || getenv("MU_CONV_NO_NT4") || B <= 0) return 0;
-    if (dtype == MU_F16 && MU_CONV_NT4) { if (Cin % 64 || Cout % 128 || H % 16 || W % 16 || (long)B * (H / 16) * (W / 16) * (Cout / 128) < MU_NT4_MINBLK) return 0; }
-    else if (dtype == MU_F32X && MU_CONV_NT4X) { if (!nt4x_serves(B, H, W, Cin, Cout)) return 0; }
-    else return 0;
-    return B * (H / 16) * (W / 16) * 4;
+    // mirrors conv_fwd_launch<T, 9>: which kernel serves the shape, and how many statistics rows its epilogue writes
+    if (taps != 9 || B <= 0 || (dtype != MU_F16 && dtype != MU_F32X)) return 0;
+    const int es = dtype == MU_F16 ? 2 : 4;
+    if ((Cin * es) % 128 || W % 16 || Cout % 32) return 0;
+    if (getenv("MU_CONV_NW8") || getenv("MU_CONV_PERSIST") || getenv("MU_CONV_PERSIST_BLOCKS") || (dtype == MU_F32X && MU_XF_NT3_RING8)) return 0;
+    if (dtype == MU_F16 && MU_CONV_NT4 && !getenv("MU_CONV_NO_NT4") && Cout % 128 == 0 && H % 16 == 0 && Cin % 64 == 0 &&
+        (long)B * (H / 16) * (W / 16) * (Cout / 128) >= MU_NT4_MINBLK)
+        return B * (H / 16) * (W / 16) * 4;
+    if (dtype == MU_F32X && nt4x_serves(B, H, W, Cin, Cout)) return B * (H / 16) * (W / 16) * 4;
+    if (!MU_NT3_STATS || H % 8) return 0;
+    if (Cout % 128 == 0) return B * (H / 8) * (W / 16) * 2;           // conv_nt3_kernel<T, 4, 4, 2>: two wave rows per 8 x 16 tile
+    if (Cout % 64 == 0) return B * (H / 8) * (W / 16) * 4;            // conv_nt3_kernel<T, 4, 2, 1>: four
+    return 0;
 }
 
 extern "C" int mu_conv_fwd_stats(const void* x, const void* w, const float* bias, void* y, int B, int H, int W, int Cin, int Cout,

@@ -171,21 +171,34 @@ def check_conv(dtype, cases=None):
 
 
 def check_conv_stats(dtype):
-    """BatchNorm statistics rows left by the conv epilogue == column sums / sums of squares of the conv output it wrote."""
-    from maskunet_amd import ops
+    """BatchNorm statistics rows left by the conv epilogue == column sums / sums of squares of the conv output it wrote.  fp16: the
+    ping-pong kernel (Cout % 128, H % 16) and the halo-tile kernel (Cout = 64; H % 8 only; Cin >= 128 takes its ring variant).
+    fp32: the same shapes in the fp32x mode (exact fp32 has no statistics epilogue: rows == 0)."""
+    from maskunet_amd import ops, _lib
     gen = np.random.default_rng(12)
     out = []
-    if dtype != torch.float16 or not ops.CONV_STATS:          # MU_CONV_STATS=0 (debug switch): nothing to check
-        return [("conv_stats (fp16 only)", 0.0, 0.0)]
-    for (B, H, W, Cin, Cout) in [(2, 16, 32, 64, 128), (3, 32, 32, 128, 256), (8, 64, 64, 64, 128)]:     # the last runs the persistent kernel
-        x = ops.to_nhwc(_rnd(gen, B, Cin, H, W).to(DEV), dtype)
-        w = _rnd(gen, Cout, Cin, 3, 3, scale=1.0 / math.sqrt(Cin * 9)).to(DEV)
-        y, part = ops.conv_stats(x, w)
-        assert part.numel() > 0 and part.shape[0] == B * (H // 16) * (W // 16) * 4
-        yf = y.float().reshape(-1, Cout)
-        ssum, ssq = part[:, :, 0].double().sum(0), part[:, :, 1].double().sum(0)
-        out += [(f"conv_stats{(B, H, W, Cin, Cout)} sum", float((ssum - yf.double().sum(0)).abs().max() / yf.abs().sum(0).max()), 1e-5),
-                (f"conv_stats{(B, H, W, Cin, Cout)} sumsq", float((ssq - (yf.double() ** 2).sum(0)).abs().max() / (yf.double() ** 2).sum(0).max()), 1e-5)]
+    if dtype == torch.bfloat16 or not ops.CONV_STATS:         # MU_CONV_STATS=0 (debug switch): nothing to check
+        return [("conv_stats (fp16 / fp32x only)", 0.0, 0.0)]
+    shapes = [(2, 16, 32, 64, 128), (3, 32, 32, 128, 256), (8, 64, 64, 64, 128),      # the last runs the persistent kernel
+              (2, 16, 32, 64, 64), (2, 24, 16, 128, 64), (3, 8, 48, 64, 128), (1, 40, 16, 256, 256)]
+    import maskunet_amd
+    prev = maskunet_amd.get_float32_matmul_precision()
+    if dtype == torch.float32:
+        maskunet_amd.set_float32_matmul_precision("high")
+    try:
+        for (B, H, W, Cin, Cout) in shapes:
+            x = ops.to_nhwc(_rnd(gen, B, Cin, H, W).to(DEV), dtype)
+            w = _rnd(gen, Cout, Cin, 3, 3, scale=1.0 / math.sqrt(Cin * 9)).to(DEV)
+            bias = _rnd(gen, Cout, scale=0.3).to(DEV)
+            y, part = ops.conv_stats(x, w, bias)
+            rows = _lib.load().mu_conv_stats_rows(B, H, W, Cin, Cout, 9, ops.mdt(x))
+            assert rows > 0 and part.numel() > 0 and part.shape[0] == rows, (B, H, W, Cin, Cout, rows, tuple(part.shape))
+            yf = y.float().reshape(-1, Cout)
+            ssum, ssq = part[:, :, 0].double().sum(0), part[:, :, 1].double().sum(0)
+            out += [(f"conv_stats{(B, H, W, Cin, Cout)} sum", float((ssum - yf.double().sum(0)).abs().max() / yf.abs().sum(0).max()), 1e-5),
+                    (f"conv_stats{(B, H, W, Cin, Cout)} sumsq", float((ssq - (yf.double() ** 2).sum(0)).abs().max() / (yf.double() ** 2).sum(0).max()), 1e-5)]
+    finally:
+        maskunet_amd.set_float32_matmul_precision(prev)
     return out
 
 
