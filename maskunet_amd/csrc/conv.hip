@@ -524,6 +524,9 @@ __global__ __launch_bounds__(256, SB ? MU_NT2_SB_OCC : MU_NT2_OCC) void conv_nt2
 #ifndef MU_NT3_RING
 #define MU_NT3_RING 1
 #endif
+#ifndef MU_NT3_ABL_WONCE
+#define MU_NT3_ABL_WONCE 0
+#endif
 #ifndef MU_NT3_STATS
 #define MU_NT3_STATS 1          // BatchNorm-statistics epilogue of the halo-tile kernel (fp16 and fp32x training launches)
 #endif
@@ -683,11 +686,15 @@ __device__ __forceinline__ void conv_nt3_body(const T* __restrict__ x, const T* 
                     if (t < HPW && c + 1 < kchunks && t * NWV + wave < HINST) stage_h(t, (c + 1) * KC, (c + 1) & 1);
                     else glds16(mu_zero_page, dump);
                 } else {
+#if MU_NT3_ABL_WONCE            // timing-only ablation (wrong results): weights staged once, no per-tap wait -- upper bound of a weights-resident kernel
+                if (false) stage_w(s + 1, (s + 1) & 1);
+#else
                 if (s + 1 < nsteps) stage_w(s + 1, (s + 1) & 1);
+#endif
                 if (t < HPW && c + 1 < kchunks && t * NWV + wave < HINST)        // one halo piece of the next chunk per tap step
                     stage_h(t, (c + 1) * KC, (c + 1) & 1);
                 }
-                const char* Wb = Ws + (RING ? wslot : (s & 1)) * WBYTES;
+                const char* Wb = Ws + (RING ? wslot : (MU_NT3_ABL_WONCE ? 0 : (s & 1))) * WBYTES;
                 const char* Hb = Hs + hbuf + dh * (HW_ * 128);
                 if constexpr (M_::PAIR) {
                     typename M_::Frag2 a[TM], b[TN];
@@ -724,7 +731,9 @@ __device__ __forceinline__ void conv_nt3_body(const T* __restrict__ x, const T* 
                     __builtin_amdgcn_sched_barrier(0);
                     wslot = wslot == 2 ? 0 : wslot + 1;
                 } else {
+#if !MU_NT3_ABL_WONCE
                     __syncthreads();
+#endif
                 }
             }
         }
@@ -1707,6 +1716,191 @@ __global__ __launch_bounds__(512, 1) void conv_nt4p_kernel(const h16* __restrict
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// v5, fp16 3x3 with Cin == Cout == 64 (the 64 -> 64 layers at 128^2 / 64^2 and their data gradients): WEIGHTS-RESIDENT persistent kernel.
+// The halo-tile kernel spends these layers waiting: with one 64-channel chunk a tile is nine taps of 16 MFMAs per wave, each behind a
+// block barrier that waits for an 8 KB weight tile requested one tap earlier (PMC: matrix pipe 25 % busy, 120 us against ~65 us of HBM
+// time for the 268 MB of x + y at 128^2).  Here the whole weight tensor (9 x 64 x 64 fp16 = 72 KB) is loaded into LDS ONCE per block and
+// stays; a block (one per CU) walks 16 x 16 pixel tiles and the only stream is the 18 x 18 halo (41 KB per tile).
+// Two 4-wave groups (one wave per SIMD each) work on alternate tiles, HALF A PERIOD APART: in a phase one group runs its tile's 288 MFMAs
+// per wave (64 co x 64 px per wave, no barrier inside) while the other one requests its next halo (LDS-DMA into its own, single, buffer:
+// every wave of the group finished reading it before the phase barrier), writes its previous tile's outputs straight from the
+// accumulators (8-byte stores, 4 per 128-byte row; BatchNorm statistics of the stored values by a transposing cross-lane fold) and waits
+// for the halo -- counted vmcnt: only the output stores are younger.  One block barrier per phase.  154 KB of LDS.
+// First form (all 8 waves in lockstep on one tile, double-buffered halo, staged epilogue): 120 -> 88 us at 128^2, B = 64; ablations:
+// without MFMAs 40 us, without stores 80, without halo DMAs 71 -- data movement and arithmetic were not overlapping.
+// ------------------------------------------------------------------------------------------
+#ifndef MU_CONV_NT5
+#define MU_CONV_NT5 1
+#endif
+#ifndef MU_NT5_MINTILES
+#define MU_NT5_MINTILES 256
+#endif
+__global__ __launch_bounds__(512, 1) void conv_nt5_kernel(const h16* __restrict__ x, const h16* __restrict__ w, const float* __restrict__ bias,
+                                                          h16* __restrict__ y, int B, int H, int W, long x_ld, long y_ld,
+                                                          float* __restrict__ stat_part) {
+    using M_ = Mma<h16>;
+    using Frag = M_::Frag;
+    constexpr int VN = 8, CI = 64, CO = 64, TM = 4, TN = 4, NWV = 8, GW = 4;
+    constexpr int TH = 16, TW = 16, HW_ = TW + 2, HROWS = (TH + 2) * HW_;
+    constexpr int HINST = (HROWS + 7) / 8, HPW = (HINST + GW - 1) / GW;
+    constexpr int HBYTES = HINST * 1024, TAPB = CO * 128, WBYTES = 9 * TAPB;
+    constexpr int NST = TM * TN;                              // output stores per wave and tile (one 8-byte store per fragment)
+
+    __shared__ __attribute__((aligned(16))) char lds[2 * HBYTES + WBYTES + 1024];
+    char* Ws = lds + 2 * HBYTES;
+    char* dump = Ws + WBYTES;
+
+    const int tiles_w = W / TW, tiles_h = H / TH;
+    const int ntile = B * tiles_h * tiles_w, nblk = gridDim.x;
+    const int bx = xcd_remap(blockIdx.x, gridDim.x);         // neighbouring tiles (shared halo rows) on one XCD's L2
+    if (bx >= ntile) return;                                 // (whole block: no barrier has been executed yet)
+    const int nt = (ntile - bx + nblk - 1) / nblk;           // tiles of this block: bx, bx + nblk, ...
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int grp = wave >> 2, wg = wave & 3;                // group (tile parity), wave inside the group = 4-row strip of the tile
+    const int r16 = lane & 15, g = lane >> 4;
+    const int srow = lane >> 3, sch = lane & 7;
+    char* Hg = lds + grp * HBYTES;
+
+    auto stage_halo = [&](int tl) {                          // this group's waves request the halo of tile tl: HPW DMAs per wave
+        const int tw_ = tl % tiles_w, th_ = (tl / tiles_w) % tiles_h, bi = tl / (tiles_w * tiles_h);
+        const int hh0 = th_ * TH - 1, ww0 = tw_ * TW - 1;
+        const h16* xb = x + (long)bi * H * W * x_ld;
+#pragma unroll
+        for (int k = 0; k < HPW; ++k) {
+            const int inst = k * GW + wg;
+            const int hr = inst * 8 + srow;
+            const int hy = hr / HW_, hx = hr - hy * HW_;
+            const int hh = hh0 + hy, ww = ww0 + hx;
+            const bool ok = hr < HROWS && hh >= 0 && hh < H && ww >= 0 && ww < W;
+            const void* src = ok ? (const void*)(xb + ((long)hh * W + ww) * x_ld + (sch ^ (hx & 7)) * VN) : (const void*)mu_zero_page;
+            if (inst < HINST) glds16a(src, Hg + inst * 1024);
+            else glds16a(mu_zero_page, dump);
+        }
+    };
+
+    int aoff[2], boff[3][2];
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+        aoff[kk] = r16 * 128 + (((kk * 4 + g) ^ (r16 & 7)) << 4);
+#pragma unroll
+        for (int dw = 0; dw < 3; ++dw) boff[dw][kk] = (wg * TN * HW_ + r16 + dw) * 128 + (((kk * 4 + g) ^ ((r16 + dw) & 7)) << 4);
+    }
+    float bv[TM][4];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) bv[i][r] = bias ? bias[i * 16 + 4 * g + r] : 0.f;
+
+    {                                                        // the nine weight tiles, once: [tap][64 co rows of 128 B], 16-byte chunk ^ (row & 7)
+        const int row = wave * 8 + srow;
+#pragma unroll
+        for (int t = 0; t < 9; ++t) glds16a(w + ((long)t * CO + row) * CI + (sch ^ (row & 7)) * VN, Ws + t * TAPB + wave * 1024);
+    }
+    if (grp == 0) stage_halo(bx);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+
+    f32x4 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    // phase p: group (p & 1) multiplies local tile p; the other group requests local tile p + 1 and writes out local tile p - 1
+    for (int p = 0; p <= nt; ++p) {
+        if (grp == (p & 1)) {
+            if (p < nt) {
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+                for (int t = 0; t < 9; ++t) {
+                    const int dh = t / 3, dw = t % 3;
+                    const char* Wb = Ws + t * TAPB;
+                    const char* Hb = Hg + dh * (HW_ * 128);
+#pragma unroll
+                    for (int kk = 0; kk < 2; ++kk) {
+                        Frag a[TM], b[TN];
+#pragma unroll
+                        for (int i = 0; i < TM; ++i) a[i] = M_::ld(Wb + aoff[kk] + i * 2048);
+#pragma unroll
+                        for (int j = 0; j < TN; ++j) b[j] = M_::ld(Hb + boff[dw][kk] + j * (HW_ * 128));
+#pragma unroll
+                        for (int i = 0; i < TM; ++i)
+#pragma unroll
+                            for (int j = 0; j < TN; ++j) M_::mma(a[i], b[j], acc[i][j]);
+                    }
+                }
+                __builtin_amdgcn_s_setprio(0);
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the halo buffer is free once every wave of the group is at the barrier
+        } else {
+            const bool pf = p + 1 < nt, ep = p >= 1;
+            if (pf) stage_halo(bx + (p + 1) * nblk);
+            if (ep) {
+                const int tl = bx + (p - 1) * nblk;
+                const int tw_ = tl % tiles_w, th_ = (tl / tiles_w) % tiles_h, bimg = tl / (tiles_w * tiles_h);
+                h16* yb = y + (((long)bimg * H + th_ * TH + wg * TN) * W + tw_ * TW + r16) * y_ld + 4 * g;
+                float tsum[TM][4], tsq[TM][4];
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) { tsum[i][r] = 0.f; tsq[i][r] = 0.f; }
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+#pragma unroll
+                    for (int i = 0; i < TM; ++i) {
+                        const h16x4 o = {(h16)(acc[i][j][0] + bv[i][0]), (h16)(acc[i][j][1] + bv[i][1]), (h16)(acc[i][j][2] + bv[i][2]),
+                                         (h16)(acc[i][j][3] + bv[i][3])};
+                        *reinterpret_cast<h16x4*>(yb + (long)j * W * y_ld + i * 16) = o;
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) { const float v = (float)o[r]; tsum[i][r] += v; tsq[i][r] = fmaf(v, v, tsq[i][r]); }
+                    }
+                if (stat_part) {
+                    // transposing fold over the 16 pixel lanes (see conv_nt3_body): lane r16 ends with channel (r16 >> 2) * 16 + 4 g + (r16 & 3)
+                    float v8[2][4][2], v4[4][2], v2[2][2], v1[2];
+                    const bool b3 = r16 & 8, b2 = r16 & 4, b1 = r16 & 2, b0 = r16 & 1;
+#pragma unroll
+                    for (int i = 0; i < 2; ++i)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            v8[i][r][0] = (b3 ? tsum[i + 2][r] : tsum[i][r]) + __shfl_xor(b3 ? tsum[i][r] : tsum[i + 2][r], 8);
+                            v8[i][r][1] = (b3 ? tsq[i + 2][r] : tsq[i][r]) + __shfl_xor(b3 ? tsq[i][r] : tsq[i + 2][r], 8);
+                        }
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+#pragma unroll
+                        for (int k = 0; k < 2; ++k) v4[r][k] = (b2 ? v8[1][r][k] : v8[0][r][k]) + __shfl_xor(b2 ? v8[0][r][k] : v8[1][r][k], 4);
+#pragma unroll
+                    for (int r = 0; r < 2; ++r)
+#pragma unroll
+                        for (int k = 0; k < 2; ++k) v2[r][k] = (b1 ? v4[r + 2][k] : v4[r][k]) + __shfl_xor(b1 ? v4[r][k] : v4[r + 2][k], 2);
+#pragma unroll
+                    for (int k = 0; k < 2; ++k) v1[k] = (b0 ? v2[1][k] : v2[0][k]) + __shfl_xor(b0 ? v2[0][k] : v2[1][k], 1);
+                    *reinterpret_cast<float2*>(stat_part + (((long)tl * GW + wg) * CO + (r16 >> 2) * 16 + 4 * g + (r16 & 3)) * 2) = make_float2(v1[0], v1[1]);
+                }
+            }
+            // the requested halo has landed in this wave's share: only this phase's output stores are younger than its DMAs
+            if (!pf || !ep) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            else if (stat_part) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NST + 1) : "memory");
+            else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NST) : "memory");
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+static inline bool nt5_serves(int B, int H, int W, int Cin, int Cout) {
+    if (!MU_CONV_NT5 || getenv("MU_CONV_NO_NT5")) return false;
+    return Cin == 64 && Cout == 64 && H % 16 == 0 && W % 16 == 0 && (long)B * (H / 16) * (W / 16) >= MU_NT5_MINTILES;
+}
+
 // The same dispatch for the inference epilogue y = act(conv * scale + bias + res): FEPI instantiations of the non-persistent kernels
 // (the persistent ping-pong kernel counts its epilogue's memory operations in hand-placed vmcnt waits and takes no epilogue loads).
 // fp32x: which 3x3 shapes the ping-pong kernel serves.  One 512-thread block per CU: a grid of fewer than ~200 blocks (16^2 256 -> 256 at
@@ -1772,6 +1966,13 @@ static int conv_fwd_launch(const T* x, const T* w, const float* bias, T* y, int 
         if constexpr (std::is_same<T, xf32>::value && MU_XF_NT3_RING8) {
             if (Cout % 128 == 0 && H % 16 == 0) {
                 conv_nt3_kernel<T, 4, 4, 2, 8, true><<<B * (H / 16) * (W / 16) * (Cout / 128), 512, 0, st>>>(x, w, bias, y, B, H, W, Cin, Cout, x_ld, y_ld);
+                return MU_OK;
+            }
+        }
+        if constexpr (sizeof(T) == 2) {
+            if (nt5_serves(B, H, W, Cin, Cout)) {
+                const int ntile5 = B * (H / 16) * (W / 16);
+                conv_nt5_kernel<<<ntile5 < 256 ? ntile5 : 256, 512, 0, st>>>((const h16*)x, (const h16*)w, bias, (h16*)y, B, H, W, x_ld, y_ld, stat_part);
                 return MU_OK;
             }
         }
@@ -1860,6 +2061,7 @@ extern "C" int mu_conv_stats_rows(int B, int H, int W, int Cin, int Cout, int ta
         (long)B * (H / 16) * (W / 16) * (Cout / 128) >= MU_NT4_MINBLK)
         return B * (H / 16) * (W / 16) * 4;
     if (dtype == MU_F32X && nt4x_serves(B, H, W, Cin, Cout)) return B * (H / 16) * (W / 16) * 4;
+    if (dtype == MU_F16 && nt5_serves(B, H, W, Cin, Cout)) return B * (H / 16) * (W / 16) * 4;     // conv_nt5_kernel: one row per wave of a group
     if (!MU_NT3_STATS || H % 8) return 0;
     if (Cout % 128 == 0) return B * (H / 8) * (W / 16) * 2;           // conv_nt3_kernel<T, 4, 4, 2>: two wave rows per 8 x 16 tile
     if (Cout % 64 == 0) return B * (H / 8) * (W / 16) * 4;            // conv_nt3_kernel<T, 4, 2, 1>: four
