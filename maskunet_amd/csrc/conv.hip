@@ -1734,7 +1734,7 @@ __global__ __launch_bounds__(512, 1) void conv_nt4p_kernel(const h16* __restrict
 #define MU_CONV_NT5 1
 #endif
 #ifndef MU_NT5_MINTILES
-#define MU_NT5_MINTILES 256
+#define MU_NT5_MINTILES 512          // two tiles per block at least: below, one of the two wave groups would idle
 #endif
 __global__ __launch_bounds__(512, 1) void conv_nt5_kernel(const h16* __restrict__ x, const h16* __restrict__ w, const float* __restrict__ bias,
                                                           h16* __restrict__ y, int B, int H, int W, long x_ld, long y_ld,

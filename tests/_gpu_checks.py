@@ -141,9 +141,9 @@ def check_conv(dtype, cases=None):
                       # weight-grad stages), 32-wide with even / odd height (two-row stages / flat stages), persistent conv with a tail
                       (2, 48, 80, 64, 128, 3), (1, 32, 192, 128, 128, 3), (2, 6, 32, 128, 128, 3), (1, 5, 32, 128, 128, 3),
                       (5, 64, 64, 64, 128, 3),
-                      # weights-resident persistent kernel (fp16, 64 -> 64, >= 256 tiles of 16 x 16 pixels): one tile per block with idle blocks'
-                      # worth of tail, and two to three tiles per block on a non-square image
-                      (5, 128, 112, 64, 64, 3), (3, 192, 240, 64, 64, 3),
+                      # weights-resident persistent kernel (fp16, 64 -> 64, >= 512 tiles of 16 x 16 pixels): two to three tiles per block
+                      # (each of its two wave groups one or two), ragged tail, non-square images
+                      (10, 128, 112, 64, 64, 3), (3, 192, 240, 64, 64, 3),
                       # 1x1 layers: q/k/v projection shapes (Cout = 3C: row-staged epilogue, single-stage Cin = 64 kernel, wide
                       # weight-grad tiles), their data-gradient shape, the 150-class head with a ragged pixel count
                       (2, 9, 7, 64, 192, 1), (1, 16, 16, 128, 384, 1), (2, 5, 5, 256, 768, 1), (3, 7, 9, 192, 64, 1), (2, 33, 17, 64, 150, 1),
@@ -184,7 +184,7 @@ def check_conv_stats(dtype):
         return [("conv_stats (fp16 / fp32x only)", 0.0, 0.0)]
     shapes = [(2, 16, 32, 64, 128), (3, 32, 32, 128, 256), (8, 64, 64, 64, 128),      # the last runs the persistent kernel
               (2, 16, 32, 64, 64), (2, 24, 16, 128, 64), (3, 8, 48, 64, 128), (1, 40, 16, 256, 256),
-              (5, 128, 112, 64, 64), (3, 192, 240, 64, 64)]      # the last two (fp16): weights-resident kernel, 4 rows per tile
+              (10, 128, 112, 64, 64), (3, 192, 240, 64, 64)]      # the last two (fp16): weights-resident kernel, 4 rows per tile
     import maskunet_amd
     prev = maskunet_amd.get_float32_matmul_precision()
     if dtype == torch.float32:
