@@ -1213,7 +1213,9 @@ __device__ __forceinline__ void conv_nt4_body(const h16* __restrict__ x, const h
                 }
                 if (kk == 1) stage_w(s + 3);
 #endif
+#ifndef MU_NT4_ABL_NOBAR1
                 __builtin_amdgcn_s_barrier();
+#endif
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 __builtin_amdgcn_sched_barrier(0);
 #ifndef MU_NT4_ABL_NOPRIO
@@ -1233,7 +1235,9 @@ __device__ __forceinline__ void conv_nt4_body(const h16* __restrict__ x, const h
                 }
 #endif
                 __builtin_amdgcn_sched_barrier(0);
+#ifndef MU_NT4_ABL_NOBAR2
                 __builtin_amdgcn_s_barrier();
+#endif
             }
         }
     }
