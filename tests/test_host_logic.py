@@ -222,3 +222,28 @@ def test_bench_sweep_roofline_arithmetic():
     assert abs(x["useful_tflops"] - exec_dkv / 8e-3 / 1e12) < 0.01 and x["peak"] == 2500.0 and x["frac_at_measured_clock"] is None
     assert bench.sweep_rooflines("fp16", events({"fwd": 2.0}), hw, B, kept, None) is None     # no dominant-kernel launch timed
 
+
+
+def test_conv_stats_rows_mirror_the_kernel_dispatch():
+    """mu_conv_stats_rows is host logic: it names the number of BatchNorm-statistics rows the 3x3 forward kernel of a shape writes
+    (0 = that kernel has no statistics epilogue and the caller runs the separate sweep).  One case per kernel of the dispatch."""
+    from maskunet_amd import _lib
+    rows = _lib.load().mu_conv_stats_rows
+    F32, F16, F32X = _lib.MU_F32, _lib.MU_F16, _lib.MU_F32X
+    # fp16 ping-pong kernel (Cout % 128, H % 16, Cin % 64): four wave rows per 16 x 16 tile
+    assert rows(64, 128, 128, 128, 128, 9, F16) == 64 * 8 * 8 * 4
+    # fp16 weights-resident kernel (64 -> 64, >= 512 tiles): one row per wave of a group
+    assert rows(64, 128, 128, 64, 64, 9, F16) == 64 * 8 * 8 * 4
+    assert rows(64, 64, 64, 64, 64, 9, F16) == 64 * 4 * 4 * 4
+    # ... below 512 tiles the halo-tile kernel serves the shape: 8 x 16 tiles, four wave rows (Cout = 64) / two (Cout % 128, H % 16 != 0)
+    assert rows(2, 128, 128, 64, 64, 9, F16) == 2 * 16 * 8 * 4
+    assert rows(3, 8, 48, 64, 128, 9, F16) == 3 * 1 * 3 * 2
+    # fp32x: ping-pong kernel from 192 blocks on, the halo-tile kernel below
+    assert rows(64, 32, 32, 128, 128, 9, F32X) == 64 * 2 * 2 * 4
+    assert rows(2, 16, 16, 128, 128, 9, F32X) == 2 * 2 * 1 * 2
+    assert rows(64, 128, 128, 64, 64, 9, F32X) == 64 * 16 * 8 * 4
+    # no epilogue: exact fp32, 1x1 layers, widths that are not a multiple of 16, channel counts the tile kernels do not take
+    assert rows(64, 128, 128, 64, 64, 9, F32) == 0
+    assert rows(64, 128, 128, 64, 192, 1, F16) == 0
+    assert rows(2, 16, 24, 64, 64, 9, F16) == 0
+    assert rows(2, 16, 16, 32, 64, 9, F16) == 0
