@@ -185,6 +185,14 @@ int mu_bn_act_bwd_scaled(const void* x, const void* res, const void* grad_out, v
                          const float* mean, const float* rstd, const float* gamma, const float* beta, int act, int training,
                          float* dgamma, float* dbeta, const float* xhat_scale, void* workspace, long ws_bytes, int dtype, void* stream);
 
+/* The pair's whole backward in one call (training mode, no residual, no activation): mu_bn_act_bwd_scaled(.., gamma_eff, beta2, ..,
+ * xhat_scale) plus the three parameter gradients that follow from A, written by the same finalize kernel:
+ * pair_grads[0][c] = dgamma2_coef[c] * A[c] (dgamma2), pair_grads[1][c] = dgamma1_coef[c] * A[c] (dgamma1), pair_grads[2][c] = 0 (dbeta1);
+ * dbeta2 as mu_bn_act_bwd's dbeta.  pair_grads: 3 * C floats. */
+int mu_bn_pair_bwd(const void* x, const void* grad_out, void* dx, long M, int C, long ld, const float* mean, const float* rstd,
+                   const float* gamma_eff, const float* beta2, const float* xhat_scale, const float* dgamma2_coef,
+                   const float* dgamma1_coef, float* pair_grads, float* dbeta2, void* workspace, long ws_bytes, int dtype, void* stream);
+
 /* ---- per-sample LayerNorm with full-shape affine: nn.LayerNorm([64,128,128]) (:281,311) ------ */
 long mu_ln_sample_workspace_bytes(int B);
 int mu_ln_sample_fwd(const void* x, const float* w, const float* b, void* y, float* mean, float* rstd, int B, long L, float eps,

@@ -47,6 +47,7 @@ SIGNATURES = {
     "mu_bn_act_bwd": (I, [P, P, P, P, P, L, I, L, P, P, P, P, I, I, P, P, P, L, I, P]),
     "mu_bn_pair_compose": (I, [P, P, P, P, I, I, L, F, F, F, P, P, P, P, P, P, P, P]),
     "mu_bn_act_bwd_scaled": (I, [P, P, P, P, P, L, I, L, P, P, P, P, I, I, P, P, P, P, L, I, P]),
+    "mu_bn_pair_bwd": (I, [P, P, P, L, I, L, P, P, P, P, P, P, P, P, P, P, L, I, P]),
     "mu_ln_sample_workspace_bytes": (L, [I]),
     "mu_ln_sample_fwd": (I, [P, P, P, P, P, P, I, L, F, P, L, I, P]),
     "mu_ln_sample_bwd": (I, [P, P, P, P, P, P, P, P, I, L, P, L, I, P]),

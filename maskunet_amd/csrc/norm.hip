@@ -191,7 +191,8 @@ __global__ void bn_eval_stats_kernel(const float* __restrict__ running_mean, con
 // BN backward finalize: dgamma = sum dz*xhat, dbeta = sum dz; s1 = dbeta/M, s2 = dgamma/M (0 in eval)
 __global__ void bn_bwd_final_kernel(const double* __restrict__ part, int nblk, int C, long M, int training,
                                     float* __restrict__ dgamma, float* __restrict__ dbeta, float* __restrict__ s1, float* __restrict__ s2,
-                                    const float* __restrict__ xscale = nullptr) {
+                                    const float* __restrict__ xscale = nullptr, const float* __restrict__ pc2 = nullptr,
+                                    const float* __restrict__ pc1 = nullptr, float* __restrict__ pair_grads = nullptr) {
     const int c = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (c >= C) return;
     double av[MU_STAT_MAXBLK / 64], bv[MU_STAT_MAXBLK / 64];       // every load in flight before the first add (see bn_fwd_final_kernel)
@@ -208,6 +209,11 @@ __global__ void bn_bwd_final_kernel(const double* __restrict__ part, int nblk, i
     if (lane) return;
     dbeta[c] = (float)a;
     dgamma[c] = (float)b;
+    if (pair_grads) {                                              // BatchNorm pair (mu_bn_pair_bwd): dgamma2, dgamma1, dbeta1 = 0
+        pair_grads[c] = pc2[c] * (float)b;
+        pair_grads[C + c] = pc1[c] * (float)b;
+        pair_grads[2 * C + c] = 0.f;
+    }
     s1[c] = training ? (float)(a / (double)M) : 0.f;
     s2[c] = training ? (float)((xscale ? (double)xscale[c] : 1.0) * b / (double)M) : 0.f;      // xscale: BatchNorm pair (below)
 }
@@ -430,7 +436,8 @@ extern "C" int mu_colsum(const void* x, long M, int C, long ld, float* out, void
     return MU_OK;
 }
 
-extern "C" long mu_bn_workspace_bytes(int C) { return (long)MU_STAT_MAXBLK * C * 2 * sizeof(double) + 2L * C * sizeof(float); }
+// fp64 partial slab | s1, s2 (the apply pass's per-channel means) | A (mu_bn_pair_bwd: the single-layer dgamma nobody outside reads)
+extern "C" long mu_bn_workspace_bytes(int C) { return (long)MU_STAT_MAXBLK * C * 2 * sizeof(double) + 3L * C * sizeof(float); }
 
 template <typename T>
 static int bn_train_stats_t(const T* x, long M, int C, long ld, float* mean, float* rstd, float* rmean, float* rvar, long* nbt,
@@ -554,7 +561,8 @@ extern "C" int mu_bn_act_fwd(const void* x, const void* res, void* y, long M, in
 template <typename T>
 static int bn_act_bwd_t(const T* x, const T* res, const T* g, T* dx, T* dres, long M, int C, long ld, const float* mean,
                         const float* rstd, const float* gamma, const float* beta, int act, int training, float* dgamma,
-                        float* dbeta, void* ws, hipStream_t st, const float* xscale = nullptr, bool enc = false) {
+                        float* dbeta, void* ws, hipStream_t st, const float* xscale = nullptr, bool enc = false, const float* pc2 = nullptr,
+                        const float* pc1 = nullptr, float* pair_grads = nullptr) {
     constexpr int N = Vec16<T>::N;
     int cv = C / N;
     if (cv > 256) return MU_ERR_SHAPE;
@@ -576,7 +584,7 @@ static int bn_act_bwd_t(const T* x, const T* res, const T* g, T* dx, T* dres, lo
         bn_bwd_apply_kernel<T, false><<<ew_grid(M * cv, cv), 256, 0, st>>>(x, dres, dx, M, C, ld, mean, rstd, gamma, beta, act, s1, s2);
     } else {                        // no residual: nothing is written by the statistics sweep, dz is recomputed in the apply pass
         bn_partial_kernel<T, 1><<<nblk, 256, lds, st>>>(x, g, nullptr, nullptr, M, C, ld, mean, rstd, gamma, beta, act, part);
-        bn_bwd_final_kernel<<<mu_cdiv(C, 4), 256, 0, st>>>(part, nblk, C, M, training, dgamma, dbeta, s1, s2, xscale);
+        bn_bwd_final_kernel<<<mu_cdiv(C, 4), 256, 0, st>>>(part, nblk, C, M, training, dgamma, dbeta, s1, s2, xscale, pc2, pc1, pair_grads);
         if constexpr (sizeof(T) == 4) {
             if (enc) { bn_bwd_apply_kernel<T, true, true><<<ew_grid(M * cv, cv), 256, 0, st>>>(x, g, dx, M, C, ld, mean, rstd, gamma, beta, act, s1, s2); return MU_OK; }
         }
@@ -661,6 +669,30 @@ extern "C" int mu_bn_act_bwd_scaled(const void* x, const void* res, const void* 
         rc = bn_act_bwd_t<float>((const float*)x, (const float*)res, (const float*)grad_out, (float*)dx, (float*)dres, M, C, ld, mean, rstd, gamma, beta, act, training, dgamma, dbeta, workspace, st, xhat_scale, true);
     else if (dtype == MU_F16)
         rc = bn_act_bwd_t<h16>((const h16*)x, (const h16*)res, (const h16*)grad_out, (h16*)dx, (h16*)dres, M, C, ld, mean, rstd, gamma, beta, act, training, dgamma, dbeta, workspace, st, xhat_scale);
+    else return MU_ERR_ARG;
+    if (rc) return rc;
+    MU_CHECK_LAUNCH();
+    return MU_OK;
+}
+
+extern "C" int mu_bn_pair_bwd(const void* x, const void* grad_out, void* dx, long M, int C, long ld, const float* mean, const float* rstd,
+                              const float* gamma_eff, const float* beta2, const float* xhat_scale, const float* dgamma2_coef,
+                              const float* dgamma1_coef, float* pair_grads, float* dbeta2, void* workspace, long ws_bytes, int dtype,
+                              void* stream) {
+    if (!x || !grad_out || !dx || !mean || !rstd || !gamma_eff || !beta2 || !xhat_scale || !dgamma2_coef || !dgamma1_coef || !pair_grads ||
+        !dbeta2 || !workspace)
+        return MU_ERR_ARG;
+    if (M <= 0 || C <= 0 || C % 8 || ld < C) return MU_ERR_ARG;
+    if (ws_bytes < mu_bn_workspace_bytes(C)) return MU_ERR_WORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    float* A = (float*)((char*)workspace + (size_t)MU_STAT_MAXBLK * C * 2 * sizeof(double)) + 2 * (size_t)C;
+    int rc;
+    if (dtype == MU_F32)
+        rc = bn_act_bwd_t<float>((const float*)x, nullptr, (const float*)grad_out, (float*)dx, nullptr, M, C, ld, mean, rstd, gamma_eff, beta2, MU_ACT_NONE, 1, A, dbeta2, workspace, st, xhat_scale, false, dgamma2_coef, dgamma1_coef, pair_grads);
+    else if (dtype == MU_F32X)
+        rc = bn_act_bwd_t<float>((const float*)x, nullptr, (const float*)grad_out, (float*)dx, nullptr, M, C, ld, mean, rstd, gamma_eff, beta2, MU_ACT_NONE, 1, A, dbeta2, workspace, st, xhat_scale, true, dgamma2_coef, dgamma1_coef, pair_grads);
+    else if (dtype == MU_F16)
+        rc = bn_act_bwd_t<h16>((const h16*)x, nullptr, (const h16*)grad_out, (h16*)dx, nullptr, M, C, ld, mean, rstd, gamma_eff, beta2, MU_ACT_NONE, 1, A, dbeta2, workspace, st, xhat_scale, false, dgamma2_coef, dgamma1_coef, pair_grads);
     else return MU_ERR_ARG;
     if (rc) return rc;
     MU_CHECK_LAUNCH();

@@ -727,17 +727,16 @@ class _BNPair(torch.autograd.Function):
         C = x.shape[-1]
         M = x.numel() // C
         dx = torch.empty_like(x)
-        a = torch.empty(C, dtype=torch.float32, device=x.device)
-        dbeta2 = torch.empty_like(a)
+        dg = torch.empty(3, C, dtype=torch.float32, device=x.device)      # rows: dgamma2, dgamma1, dbeta1 (= 0), written by the finalize kernel
+        dbeta2 = torch.empty(C, dtype=torch.float32, device=x.device)
         ws = workspace(_lib.load().mu_bn_workspace_bytes(C), x.device)
         enc = ctx.dx_link is not None
-        call("mu_bn_act_bwd_scaled", ptr(x), None, ptr(gy), ptr(dx), None, M, C, C, ptr(mean), ptr(rstd), ptr(coef[0]), ptr(b2p), ACT_NONE, 1,
-             ptr(a), ptr(dbeta2), ptr(coef[1]), ptr(ws), ws.numel(), _lib.MU_F32X if enc else dt(x), stream())
+        call("mu_bn_pair_bwd", ptr(x), ptr(gy), ptr(dx), M, C, C, ptr(mean), ptr(rstd), ptr(coef[0]), ptr(b2p), ptr(coef[1]), ptr(coef[2]),
+             ptr(coef[3]), ptr(dg), ptr(dbeta2), ptr(ws), ws.numel(), _lib.MU_F32X if enc else dt(x), stream())
         if enc:
             ctx.dx_link.mark()
-        dg = coef[2:4] * a                                   # rows: dgamma2, dgamma1
         cv = ctx.cv
-        return (dx, dg[1, :cv], torch.zeros(cv, dtype=torch.float32, device=x.device), dg[0, :cv], dbeta2[:cv]) + (None,) * 12
+        return (dx, dg[1, :cv], dg[2, :cv], dg[0, :cv], dbeta2[:cv]) + (None,) * 12
 
 
 BN_PAIR = os.environ.get("MU_BN_PAIR", "1") != "0"          # debug switch: 0 = the two layers one after the other
