@@ -43,15 +43,21 @@
 // short sum into the fp64 accumulators -- U-fold fewer fp64 instructions, same final precision (fp32 sum of <= 8 terms).
 // FAST = the fp16-storage GELU (common.h mu_phi_fast); fp32 storage keeps erff.
 // ------------------------------------------------------------------------------------------
-template <typename T, int MODE>
+// ACT / RES (round 5): the activation and the presence of a residual operand as COMPILE-TIME constants (-1 = read the runtime argument).
+// With `act` a kernel argument every element pair sat in its own basic block behind two scalar branches (GELU / ReLU / none), the
+// residual select cost a v_cndmask + a conversion per element even without a residual, and -- the expensive part in these VALU-bound
+// sweeps -- the dependent Horner chains of different pairs could not be interleaved (s_nop between every two packed FMAs).
+template <typename T, int MODE, int ACT = -1, int RES = -1>
 __global__ __launch_bounds__(256, MODE == 1 ? MU_BN_OCC1 : 1) void bn_partial_kernel(const T* __restrict__ x, const T* __restrict__ g, const T* __restrict__ res,
                                                          T* __restrict__ dzbuf, long M, int C, long ld,
                                                          const float* __restrict__ mean, const float* __restrict__ rstd,
-                                                         const float* __restrict__ gamma, const float* __restrict__ beta, int act,
+                                                         const float* __restrict__ gamma, const float* __restrict__ beta, int act_arg,
                                                          double* __restrict__ part) {
     constexpr int N = Vec16<T>::N;
     constexpr int U = MODE == 0 ? 8 : MU_BN_U1;
     constexpr bool FAST = sizeof(T) == 2;
+    const int act = ACT >= 0 ? ACT : act_arg;
+    const bool has_res = RES >= 0 ? (RES != 0) : (res != nullptr);
     extern __shared__ __attribute__((aligned(16))) double sh[];   // [rpi][C][2]
     const int cv = C / N;
     const int rpi = 256 / cv;
@@ -85,7 +91,7 @@ __global__ __launch_bounds__(256, MODE == 1 ? MU_BN_OCC1 : 1) void bn_partial_ke
                     MU_LD(4, xv[u], x + rr * ld + c);
                     if (MODE == 1) {
                         MU_LD(4, gv[u], g + rr * ld + c);
-                        if (res) MU_LD(16, rv[u], res + rr * ld + c);
+                        if (has_res) MU_LD(16, rv[u], res + rr * ld + c);
                     }
                 } else {
                     xv[u].zero();
@@ -109,20 +115,22 @@ __global__ __launch_bounds__(256, MODE == 1 ? MU_BN_OCC1 : 1) void bn_partial_ke
                     Vec16<T> dz;
 #pragma unroll
                     for (int i = 0; i < N; i += 2) {
-                        float xh[2], pre[2], ag[2];
-#pragma unroll
-                        for (int e = 0; e < 2; ++e) {
-                            xh[e] = (xv[u].get(i + e) - mu[i + e]) * rs[i + e];
-                            pre[e] = fmaf(xh[e], ga[i + e], be[i + e]) + (res ? rv[u].get(i + e) : 0.f);
-                        }
+                        // element pairs as 2-vectors: v_pk_add / v_pk_mul / v_pk_fma_f32 (the same IEEE operations per element as the
+                        // scalar forms the apply pass mirrors)
+                        const mu_f32x2 xh = (mu_f32x2{xv[u].get(i), xv[u].get(i + 1)} - mu_f32x2{mu[i], mu[i + 1]}) * mu_f32x2{rs[i], rs[i + 1]};
+                        mu_f32x2 pre = __builtin_elementwise_fma(xh, mu_f32x2{ga[i], ga[i + 1]}, mu_f32x2{be[i], be[i + 1]});
+                        if (has_res) pre += mu_f32x2{rv[u].get(i), rv[u].get(i + 1)};
+                        float ag[2];
                         mu_act_grad2_t<FAST>(pre[0], pre[1], act, ag[0], ag[1]);
-#pragma unroll
-                        for (int e = 0; e < 2; ++e) {
-                            dz.set(i + e, gv[u].get(i + e) * ag[e]);
-                            const float d = dz.get(i + e);       // the value the apply pass will re-read (rounded to T)
-                            f0[i + e] += d;
-                            f1[i + e] = fmaf(d, xh[e], f1[i + e]);
-                        }
+                        const mu_f32x2 dzf = mu_f32x2{gv[u].get(i), gv[u].get(i + 1)} * mu_f32x2{ag[0], ag[1]};
+                        dz.set(i, dzf[0]);
+                        dz.set(i + 1, dzf[1]);
+                        const mu_f32x2 d = {dz.get(i), dz.get(i + 1)};       // the values the apply pass will re-read (rounded to T)
+                        mu_f32x2 a0 = {f0[i], f0[i + 1]}, a1 = {f1[i], f1[i + 1]};
+                        a0 += d;
+                        a1 = __builtin_elementwise_fma(d, xh, a1);
+                        f0[i] = a0[0]; f0[i + 1] = a0[1];
+                        f1[i] = a1[0]; f1[i + 1] = a1[1];
                     }
                     if (dzbuf && rr < r1) dz.store(dzbuf + rr * ld + c);
                 }
@@ -222,13 +230,15 @@ __global__ void bn_bwd_final_kernel(const double* __restrict__ part, int nblk, i
 // so a thread's channel chunk -- and its per-channel constants -- never change; U vectors per operand in flight.
 // ENC (fp32 storage only, MU_F32X at the entry point): y feeds nothing but a convolution, so it is written as that convolution's chunk-encoded
 // matrix operand (common.h mu_enc4: a thread's 16-byte vector IS one chunk) -- the separate mu_split_encode pass (read + write) disappears.
-template <typename T, bool ENC = false>
+template <typename T, bool ENC = false, int ACT = -1, int RES = -1>
 __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const T* __restrict__ x, const T* __restrict__ res, T* __restrict__ y, long M,
                                                          int C, long ld, const float* __restrict__ mean, const float* __restrict__ rstd,
-                                                         const float* __restrict__ gamma, const float* __restrict__ beta, int act) {
+                                                         const float* __restrict__ gamma, const float* __restrict__ beta, int act_arg) {
     constexpr int N = Vec16<T>::N;
     constexpr int U = MU_BN_UF;
     constexpr bool FAST = sizeof(T) == 2;
+    const int act = ACT >= 0 ? ACT : act_arg;
+    const bool has_res = RES >= 0 ? (RES != 0) : (res != nullptr);
     const int cv = C / N;
     const long total = M * cv;
     const long stride = (long)gridDim.x * 256;
@@ -248,7 +258,7 @@ __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const T* __restrict__ x
         for (int u = 0; u < U; ++u) {
             if (idx + u * stride < total) {
                 MU_LD(1, xv[u], x + (r + u * rstep) * ld + c);
-                if (res) MU_LD(16, rv[u], res + (r + u * rstep) * ld + c);
+                if (has_res) MU_LD(16, rv[u], res + (r + u * rstep) * ld + c);
             }
         }
 #pragma unroll
@@ -257,10 +267,10 @@ __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const T* __restrict__ x
                 Vec16<T> o;
 #pragma unroll
                 for (int i = 0; i < N; i += 2) {
-                    const float p0 = fmaf(xv[u].get(i), a[i], b[i]) + (res ? rv[u].get(i) : 0.f);
-                    const float p1 = fmaf(xv[u].get(i + 1), a[i + 1], b[i + 1]) + (res ? rv[u].get(i + 1) : 0.f);
+                    mu_f32x2 pp = __builtin_elementwise_fma(mu_f32x2{xv[u].get(i), xv[u].get(i + 1)}, mu_f32x2{a[i], a[i + 1]}, mu_f32x2{b[i], b[i + 1]});
+                    if (has_res) pp += mu_f32x2{rv[u].get(i), rv[u].get(i + 1)};
                     float o0, o1;
-                    mu_act2_t<FAST>(p0, p1, act, o0, o1);
+                    mu_act2_t<FAST>(pp[0], pp[1], act, o0, o1);
                     o.set(i, o0);
                     o.set(i + 1, o1);
                 }
@@ -281,14 +291,15 @@ __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const T* __restrict__ x
 // dx = gamma*rstd*(dz - s1 - xhat*s2).  RECOMP = false: dz is read from dzbuf (may alias dx) -- the residual form, whose
 // d(residual) IS dz and has to be written anyway.  RECOMP = true (no residual): dz = g * act'(pre) is recomputed from x and
 // the incoming gradient, so the statistics sweep writes nothing: 5 tensor passes per BatchNorm backward instead of 6.
-template <typename T, bool RECOMP, bool ENC = false>
+template <typename T, bool RECOMP, bool ENC = false, int ACT = -1>
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__ x, const T* dzbuf, T* dx, long M, int C, long ld,
                                                            const float* __restrict__ mean, const float* __restrict__ rstd,
-                                                           const float* __restrict__ gamma, const float* __restrict__ beta, int act,
+                                                           const float* __restrict__ gamma, const float* __restrict__ beta, int act_arg,
                                                            const float* __restrict__ s1, const float* __restrict__ s2) {
     constexpr int N = Vec16<T>::N;
     constexpr int U = MU_BN_UA;
     constexpr bool FAST = sizeof(T) == 2;
+    const int act = ACT >= 0 ? ACT : act_arg;
     const int cv = C / N;
     const long total = M * cv;
     const long stride = (long)gridDim.x * 256;
@@ -322,19 +333,23 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
                 Vec16<T> o;
 #pragma unroll
                 for (int i = 0; i < N; i += 2) {
-                    float d[2] = {dz[u].get(i), dz[u].get(i + 1)};
+                    const mu_f32x2 xf = {xv[u].get(i), xv[u].get(i + 1)};
+                    mu_f32x2 d = {dz[u].get(i), dz[u].get(i + 1)};
                     if (RECOMP) {
                         Vec16<T> t;                         // round dz to T exactly like the statistics sweep did
-                        const float xh0 = (xv[u].get(i) - mu[i]) * rsv[i], xh1 = (xv[u].get(i + 1) - mu[i + 1]) * rsv[i + 1];
+                        const mu_f32x2 xh = (xf - mu_f32x2{mu[i], mu[i + 1]}) * mu_f32x2{rsv[i], rsv[i + 1]};
+                        const mu_f32x2 pre = __builtin_elementwise_fma(xh, mu_f32x2{ga[i], ga[i + 1]}, mu_f32x2{be[i], be[i + 1]});
                         float ag[2];
-                        mu_act_grad2_t<FAST>(fmaf(xh0, ga[i], be[i]), fmaf(xh1, ga[i + 1], be[i + 1]), act, ag[0], ag[1]);
-                        t.set(i, d[0] * ag[0]);
-                        t.set(i + 1, d[1] * ag[1]);
-                        d[0] = t.get(i);
-                        d[1] = t.get(i + 1);
+                        mu_act_grad2_t<FAST>(pre[0], pre[1], act, ag[0], ag[1]);
+                        const mu_f32x2 dzf = d * mu_f32x2{ag[0], ag[1]};
+                        t.set(i, dzf[0]);
+                        t.set(i + 1, dzf[1]);
+                        d = mu_f32x2{t.get(i), t.get(i + 1)};
                     }
-                    o.set(i, fmaf(gr[i], d[0], fmaf(k1[i], xv[u].get(i), k0[i])));
-                    o.set(i + 1, fmaf(gr[i + 1], d[1], fmaf(k1[i + 1], xv[u].get(i + 1), k0[i + 1])));
+                    const mu_f32x2 ov = __builtin_elementwise_fma(mu_f32x2{gr[i], gr[i + 1]}, d,
+                                                                  __builtin_elementwise_fma(mu_f32x2{k1[i], k1[i + 1]}, xf, mu_f32x2{k0[i], k0[i + 1]}));
+                    o.set(i, ov[0]);
+                    o.set(i + 1, ov[1]);
                 }
                 if constexpr (ENC) *reinterpret_cast<uint4*>(dx + (r + u * rstep) * ld + c) = mu_enc4((f32x4){o.get(0), o.get(1), o.get(2), o.get(3)});
                 else o.store(dx + (r + u * rstep) * ld + c);
@@ -543,16 +558,33 @@ extern "C" int mu_bn_eval_fold(const float* running_mean1, const float* running_
     return MU_OK;
 }
 
+// one instantiation per (activation, residual or not): see bn_partial_kernel
+#define MU_BN_ACT_SWITCH(act, CALL)                              \
+    switch (act) {                                               \
+        case MU_ACT_GELU: { constexpr int A_ = MU_ACT_GELU; CALL; } break; \
+        case MU_ACT_RELU: { constexpr int A_ = MU_ACT_RELU; CALL; } break; \
+        default:          { constexpr int A_ = MU_ACT_NONE; CALL; } break; \
+    }
+template <typename T, bool ENC>
+static void bn_act_fwd_launch(const T* x, const T* res, T* y, long M, int C, long ld, const float* mean, const float* rstd,
+                              const float* gamma, const float* beta, int act, hipStream_t st) {
+    constexpr int N = Vec16<T>::N;
+    const int grid = ew_grid(M * (C / N), C / N);
+    if (res) { MU_BN_ACT_SWITCH(act, (bn_act_fwd_kernel<T, ENC, A_, 1><<<grid, 256, 0, st>>>(x, res, y, M, C, ld, mean, rstd, gamma, beta, act))) }
+    else     { MU_BN_ACT_SWITCH(act, (bn_act_fwd_kernel<T, ENC, A_, 0><<<grid, 256, 0, st>>>(x, res, y, M, C, ld, mean, rstd, gamma, beta, act))) }
+}
+
 extern "C" int mu_bn_act_fwd(const void* x, const void* res, void* y, long M, int C, long ld, const float* mean, const float* rstd,
                              const float* gamma, const float* beta, int act, int dtype, void* stream) {
     if (!x || !y || !mean || !rstd || !gamma || !beta || M <= 0 || C <= 0 || C % 8 || ld < C) return MU_ERR_ARG;
     hipStream_t st = (hipStream_t)stream;
+    if (act != MU_ACT_NONE && act != MU_ACT_GELU && act != MU_ACT_RELU) return MU_ERR_ARG;
     if (dtype == MU_F32)
-        bn_act_fwd_kernel<float><<<ew_grid(M * (C / 4), C / 4), 256, 0, st>>>((const float*)x, (const float*)res, (float*)y, M, C, ld, mean, rstd, gamma, beta, act);
+        bn_act_fwd_launch<float, false>((const float*)x, (const float*)res, (float*)y, M, C, ld, mean, rstd, gamma, beta, act, st);
     else if (dtype == MU_F32X)      // fp32 storage, y written chunk-encoded (it only feeds a convolution in the fp32x mode)
-        bn_act_fwd_kernel<float, true><<<ew_grid(M * (C / 4), C / 4), 256, 0, st>>>((const float*)x, (const float*)res, (float*)y, M, C, ld, mean, rstd, gamma, beta, act);
+        bn_act_fwd_launch<float, true>((const float*)x, (const float*)res, (float*)y, M, C, ld, mean, rstd, gamma, beta, act, st);
     else if (dtype == MU_F16)
-        bn_act_fwd_kernel<h16><<<ew_grid(M * (C / 8), C / 8), 256, 0, st>>>((const h16*)x, (const h16*)res, (h16*)y, M, C, ld, mean, rstd, gamma, beta, act);
+        bn_act_fwd_launch<h16, false>((const h16*)x, (const h16*)res, (h16*)y, M, C, ld, mean, rstd, gamma, beta, act, st);
     else return MU_ERR_ARG;
     MU_CHECK_LAUNCH();
     return MU_OK;
@@ -575,20 +607,21 @@ static int bn_act_bwd_t(const T* x, const T* res, const T* g, T* dx, T* dres, lo
     double* part = (double*)ws;
     float* s1 = (float*)((char*)ws + (size_t)MU_STAT_MAXBLK * C * 2 * sizeof(double));
     float* s2 = s1 + C;
+    if (act != MU_ACT_NONE && act != MU_ACT_GELU && act != MU_ACT_RELU) return MU_ERR_ARG;
     if (res) {                      // d(residual) == dz exactly, so it doubles as the dz buffer
-        bn_partial_kernel<T, 1><<<nblk, 256, lds, st>>>(x, g, res, dres, M, C, ld, mean, rstd, gamma, beta, act, part);
+        MU_BN_ACT_SWITCH(act, (bn_partial_kernel<T, 1, A_, 1><<<nblk, 256, lds, st>>>(x, g, res, dres, M, C, ld, mean, rstd, gamma, beta, act, part)))
         bn_bwd_final_kernel<<<mu_cdiv(C, 4), 256, 0, st>>>(part, nblk, C, M, training, dgamma, dbeta, s1, s2, xscale);
         if constexpr (sizeof(T) == 4) {
             if (enc) { bn_bwd_apply_kernel<T, false, true><<<ew_grid(M * cv, cv), 256, 0, st>>>(x, dres, dx, M, C, ld, mean, rstd, gamma, beta, act, s1, s2); return MU_OK; }
         }
         bn_bwd_apply_kernel<T, false><<<ew_grid(M * cv, cv), 256, 0, st>>>(x, dres, dx, M, C, ld, mean, rstd, gamma, beta, act, s1, s2);
     } else {                        // no residual: nothing is written by the statistics sweep, dz is recomputed in the apply pass
-        bn_partial_kernel<T, 1><<<nblk, 256, lds, st>>>(x, g, nullptr, nullptr, M, C, ld, mean, rstd, gamma, beta, act, part);
+        MU_BN_ACT_SWITCH(act, (bn_partial_kernel<T, 1, A_, 0><<<nblk, 256, lds, st>>>(x, g, nullptr, nullptr, M, C, ld, mean, rstd, gamma, beta, act, part)))
         bn_bwd_final_kernel<<<mu_cdiv(C, 4), 256, 0, st>>>(part, nblk, C, M, training, dgamma, dbeta, s1, s2, xscale, pc2, pc1, pair_grads);
         if constexpr (sizeof(T) == 4) {
-            if (enc) { bn_bwd_apply_kernel<T, true, true><<<ew_grid(M * cv, cv), 256, 0, st>>>(x, g, dx, M, C, ld, mean, rstd, gamma, beta, act, s1, s2); return MU_OK; }
+            if (enc) { MU_BN_ACT_SWITCH(act, (bn_bwd_apply_kernel<T, true, true, A_><<<ew_grid(M * cv, cv), 256, 0, st>>>(x, g, dx, M, C, ld, mean, rstd, gamma, beta, act, s1, s2))) return MU_OK; }
         }
-        bn_bwd_apply_kernel<T, true><<<ew_grid(M * cv, cv), 256, 0, st>>>(x, g, dx, M, C, ld, mean, rstd, gamma, beta, act, s1, s2);
+        MU_BN_ACT_SWITCH(act, (bn_bwd_apply_kernel<T, true, false, A_><<<ew_grid(M * cv, cv), 256, 0, st>>>(x, g, dx, M, C, ld, mean, rstd, gamma, beta, act, s1, s2)))
     }
     return MU_OK;
 }
