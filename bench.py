@@ -430,6 +430,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-parity-gate", action="store_true", help="skip the B=2 golden check that fills `parity_gate`")
     ap.add_argument("--no-clock-probe", action="store_true", help="skip the MFMA-loop clock probe after the timed region")
+    ap.add_argument("--no-host-inclusive", action="store_true", help="skip `host_inclusive` (the step with the batch copied from pinned host "
+                    "memory every iteration, timed behind the timed region; N = 1 only)")
     ap.add_argument("--no-fp32x-line", action="store_true", help="skip `parity_grade_path` (the same workload timed in the fp32x "
                     "parity-grade mode behind the timed region; N = 1 and --dtype fp16 only)")
     ap.add_argument("--pg-steps", type=int, default=0, help="timed steps of `parity_grade_path` (default: max(10, --steps // 2); 2 warm-up steps)")
@@ -580,12 +582,33 @@ def main():
     if rank == 0 and not args.no_clock_probe:
         clk = clock_probe(dev)                                   # right behind the timed steps: the chip is still warm
     _lib.PROBE = probe
+    graphed_mode = graphed is not None
     if graphed is not None:                     # a replayed graph makes no Python calls to probe: time the kernel in two eager steps
         graphed = None                          # after the timed region (on every rank: eager steps all-reduce)
         for _ in range(2):
             step()
         torch.cuda.synchronize()
     _lib.PROBE = None
+    # the same step with the batch handed over as HOST buffers (what the reference's loop does: `inputs.to(device)`, `labels.to(device)`
+    # per iteration, ade_semantic.py:394-395): pinned fp32 NCHW images + int64 labels copied on the launch stream inside every step.
+    # A side figure (`host_inclusive`), never `value`.
+    host_incl = None
+    if world == 1 and not args.no_host_inclusive and graphed_mode is False and not args.fused_loss:
+        xh, lh = x.detach().cpu().pin_memory(), labels.detach().cpu().pin_memory()
+        for _ in range(2):
+            x.copy_(xh, non_blocking=True); labels.copy_(lh, non_blocking=True)
+            step()
+        torch.cuda.synchronize()
+        th = time.perf_counter()
+        for _ in range(args.steps):
+            x.copy_(xh, non_blocking=True); labels.copy_(lh, non_blocking=True)
+            step()
+        torch.cuda.synchronize()
+        th = (time.perf_counter() - th) / args.steps
+        host_incl = {"value": round(args.batch / th, 1), "unit": "images/sec", "ms_per_step": round(1e3 * th, 3), "steps": args.steps,
+                     "bytes_per_step": int(xh.numel() * xh.element_size() + lh.numel() * lh.element_size()),
+                     "note": "the timed step preceded by the copy of the batch from pinned host memory (fp32 NCHW images + int64 labels, "
+                             "as the reference's loop hands them over) on the launch stream; `value` of the line has the inputs resident in HBM"}
     if multi:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -639,6 +662,8 @@ def main():
             "clock": dict(clk or {}, smi=sampler.summary()),
             "parity_gate": gate,
         }
+        if host_incl is not None:
+            rec["host_inclusive"] = host_incl
         if clk and headline_cfg:
             # box-to-box comparison: ~0.8 of the configs[1] fp16 step is MFMA kernels whose time follows this clock, the rest HBM streams
             # that do not (profiles/r04_kernel_time_split.txt); REF_CLOCK_MHZ is a convention.  Only for the configuration the share was

@@ -5,7 +5,7 @@ ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/${TAG}_configs.jsonl
 : > $OUT
 cd $ROOT
-run() { echo "# bench.py $*" >> $OUT; timeout 900 python bench.py --no-cpu-baseline --no-fp32x-line --steps 10 --warmup 3 "$@" 2>>$ROOT/gpurun_out/${TAG}_configs.err | grep '^{' >> $OUT; }
+run() { echo "# bench.py $*" >> $OUT; timeout 900 python bench.py --no-cpu-baseline --no-fp32x-line --no-host-inclusive --steps 10 --warmup 3 "$@" 2>>$ROOT/gpurun_out/${TAG}_configs.err | grep '^{' >> $OUT; }
 run                                               # configs[1]: ADE20K semantic, B=64, fp16
 run --c-out 133 --batch 128                       # configs[2]: COCO panoptic shape, B=128
 run --three-head --c-out 19 --batch 64            # configs[3] per-GPU shape: Cityscapes instance, 3-head, B=64/GPU

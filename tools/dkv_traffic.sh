@@ -11,7 +11,7 @@ mkdir -p $OUT
 export TMPDIR=/tmp
 cd /tmp
 for c in FETCH_SIZE WRITE_SIZE; do
-  timeout 900 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $OUT/${TAG}_traf_${KEY}_$c -o a -- python3 $ROOT/bench.py --no-cpu-baseline --no-parity-gate --no-clock-probe --no-fp32x-line --steps 2 --warmup 1 "$@" > $OUT/${TAG}_traf_${KEY}_$c.log 2>&1
+  timeout 900 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $OUT/${TAG}_traf_${KEY}_$c -o a -- python3 $ROOT/bench.py --no-cpu-baseline --no-parity-gate --no-clock-probe --no-fp32x-line --no-host-inclusive --steps 2 --warmup 1 "$@" > $OUT/${TAG}_traf_${KEY}_$c.log 2>&1
   echo "$KEY $c rc=$?"
 done
 cd $ROOT
@@ -31,7 +31,7 @@ w, nw, _ = launches(sys.argv[2], "WRITE_SIZE")
 if f is None or w is None:
     print("no dK/dV launches found"); sys.exit(1)
 rec = {"kernel": name, "workload_key": sys.argv[4], "bench_args": sys.argv[5], "session": os.environ.get("MU_SESSION_TAG", ""),
-       "how": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) -- python3 bench.py --no-cpu-baseline --no-parity-gate --no-clock-probe --no-fp32x-line --steps 2 --warmup 1 "
+       "how": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) -- python3 bench.py --no-cpu-baseline --no-parity-gate --no-clock-probe --no-fp32x-line --no-host-inclusive --steps 2 --warmup 1 "
               + sys.argv[5] + f" (tools/dkv_traffic.sh); mean over the {nf} largest-grid launches of the kernel (self_attention6)",
        "FETCH_SIZE_KB": round(f, 1), "WRITE_SIZE_KB": round(w, 1),
        "correction": "gfx950 FETCH_SIZE reports 1/2 of the bytes of wide (16 B/lane) streaming reads (MI355X_MICROARCH.md, HBM section): bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024",

@@ -5,7 +5,7 @@ shift
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 export TMPDIR=/tmp
 cd /tmp
-timeout 900 rocprofv3 --kernel-trace --pmc SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_INSTS_LDS SQ_WAVE_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $ROOT/gpurun_out/${TAG}_lds -o a -- python3 $ROOT/bench.py --no-cpu-baseline --no-parity-gate --no-clock-probe --no-fp32x-line --steps 2 --warmup 1 "$@" > $ROOT/gpurun_out/${TAG}_lds.log 2>&1
+timeout 900 rocprofv3 --kernel-trace --pmc SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_INSTS_LDS SQ_WAVE_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $ROOT/gpurun_out/${TAG}_lds -o a -- python3 $ROOT/bench.py --no-cpu-baseline --no-parity-gate --no-clock-probe --no-fp32x-line --no-host-inclusive --steps 2 --warmup 1 "$@" > $ROOT/gpurun_out/${TAG}_lds.log 2>&1
 echo rc=$?
 cd $ROOT
 python3 - $ROOT/gpurun_out/${TAG}_lds/a_counter_collection.csv <<'PY'

@@ -12,7 +12,7 @@ echo "pytest rc=$?"; tail -4 $OUT/${TAG}_pytest.log
 timeout 600 python bench.py --dtype fp32x --steps 10 --warmup 3 --no-cpu-baseline > $OUT/${TAG}_bench_fp32x.json 2> $OUT/${TAG}_bench_fp32x.err
 echo "bench rc=$?"; cut -c1-400 $OUT/${TAG}_bench_fp32x.json
 cd /tmp
-timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_prof_fp32x -o a -- python3 $ROOT/bench.py --dtype fp32x --no-cpu-baseline --no-parity-gate --no-clock-probe --no-fp32x-line --steps 6 --warmup 2 > $OUT/${TAG}_prof_fp32x.log 2>&1
+timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_prof_fp32x -o a -- python3 $ROOT/bench.py --dtype fp32x --no-cpu-baseline --no-parity-gate --no-clock-probe --no-fp32x-line --no-host-inclusive --steps 6 --warmup 2 > $OUT/${TAG}_prof_fp32x.log 2>&1
 echo "prof rc=$?"
 cd $ROOT
 f=$(find $OUT/${TAG}_prof_fp32x -name '*kernel_stats.csv' | head -1)
