@@ -247,3 +247,19 @@ def test_conv_stats_rows_mirror_the_kernel_dispatch():
     assert rows(64, 128, 128, 64, 192, 1, F16) == 0
     assert rows(2, 16, 24, 64, 64, 9, F16) == 0
     assert rows(2, 16, 16, 32, 64, 9, F16) == 0
+
+
+def test_data_parallel_buckets_end_with_a_small_tail_bucket():
+    """The last bucket of maskunet_amd.DataParallel (the first layers' gradients: its all-reduce starts when the backward has ended and is
+    exposed in full) is a small one; every trainable parameter sits in exactly one bucket, in reverse registration order."""
+    import maskunet_amd
+    m = maskunet_amd.UNet(3, 150)
+    dp = maskunet_amd.DataParallel(m)
+    flat = [p for b in dp.buckets for p in b.params]
+    want = [p for p in reversed(list(m.parameters())) if p.requires_grad]
+    assert [id(p) for p in flat] == [id(p) for p in want]
+    assert len(dp.buckets) >= 3
+    assert dp.buckets[-1].numel * 4 <= 2 * (1 << 20) < dp.buckets[-2].numel * 4
+    assert any(p is m.initial_conv.conv_block[0].weight for p in dp.buckets[-1].params)
+    one = maskunet_amd.DataParallel(maskunet_amd.UNet(3, 150), tail_mb=0.0)       # tail_mb = 0: the plain size-capped split
+    assert len(one.buckets) == len(dp.buckets) - 1
