@@ -3018,6 +3018,9 @@ static inline void wgrad3_plan(long M, int Cin, int Cout, int tco, int tci, int*
 // Partial slab layout [block][tap][Cout][4] feeds the same deterministic reduce as the other kernels.
 // ------------------------------------------------------------------------------------------
 #define MU_RGB_MAXW 256
+#ifndef MU_RGB2
+#define MU_RGB2 1              // fp16, W % 32 == 0: the matrix-core form below (0 = the plain-FMA kernel everywhere)
+#endif
 // Round 3: the sweep was latency-bound (157 us against ~40 us of HBM time for the 200 MB of dy / x): every 4-pixel step loaded its dy
 // values and then ran 108 dependent FMAs, with two block barriers per image row around a scalar-load staging of the three input
 // rows.  Now a lane fetches the dy values of a whole 128-pixel chunk (8 steps) one chunk AHEAD of the FMAs that consume them, the
@@ -3160,6 +3163,151 @@ __global__ __launch_bounds__(256, 2) void wgrad_rgb_kernel(const T* __restrict__
 }
 #define MU_RGB_MAXBLK 1024
 
+// ------------------------------------------------------------------------------------------
+// The same weight gradient on the matrix cores (fp16 storage, W % 32 == 0; round 5).  dW[co][(tap, ci)] = sum_p dy[p][co] x[p + tap][ci] is a
+// GEMM with K = pixels, M = 64 output channels and N = 9 taps x 4 stored input channels = 36 columns (three 16-column tiles, the last
+// one three quarters empty).  Both operands are K-major in memory, so both fragments come from transposing LDS reads
+// (ds_read_b64_tr_b16: each lane hands in the address of ONE 8-byte piece, a 16-lane group gets the 4 x 16 block of pieces
+// transposed) -- and since the piece addresses are free, the im2col matrix is never built: piece (pixel, tap) IS the 8-byte pixel
+// x[pixel + tap] of the staged input rows.  A block owns a band of consecutive image rows: the dy row (16 KB at W = 128) and ONE new
+// input row per step arrive through registers (loaded a row ahead) into a double-buffered dy image / a 4-slot ring of input rows, so
+// dy and x are read from HBM once (the FMA kernel above re-reads every input row three times and issues 1728 FMAs per pixel: 111-132 us
+// at B = 64; this one: ~12 MFMAs per 32 pixels).  Wave w takes the k-steps w, w + 4, ..; its 12 accumulator tiles are folded over the
+// four waves in a fixed order at the end.  Slab layout [block][tap][Cout][4] as above (same deterministic reduce).
+// ------------------------------------------------------------------------------------------
+#define MU_RGB2_DYS 80         // halves per staged dy pixel row: 64 channels + 16 pad (160 bytes: the four pixel rows of a transposed read on disjoint banks)
+template <int NPT>             // NPT = W / 32: 16-byte dy pieces per thread and row (and 32-pixel k-steps per row)
+__global__ __launch_bounds__(256, 3) void wgrad_rgb2_kernel(const h16* __restrict__ x, const h16* __restrict__ dy, float* __restrict__ part,
+                                                         int B, int H, int W, int Cout, long x_ld, long dy_ld, int rows_per_blk) {
+    extern __shared__ __attribute__((aligned(16))) h16 rgb2_lds[];
+    // [2][W][80] dy images | [4][W + 2][4] input-row ring | [W + 2][4] zeros
+    h16* dys = rgb2_lds;
+    h16* xs = dys + 2 * W * MU_RGB2_DYS;
+    h16* xz = xs + 4 * (W + 2) * 4;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r16 = lane & 15, g = lane >> 4, q = r16 >> 2, pc = r16 & 3;
+    const int co0 = blockIdx.y * 64;
+    const int rows = B * H;
+    const int rbeg = blockIdx.x * rows_per_blk, rend = rbeg + rows_per_blk < rows ? rbeg + rows_per_blk : rows;
+    constexpr int nks = NPT;                                  // 32-pixel k-steps per image row (W = 32 NPT: W * 8 = 256 NPT pieces per dy row)
+    const int xw = W + 2;
+
+    f32x4 acc[4][3];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int n = 0; n < 3; ++n) acc[a][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    for (int i = tid; i < xw; i += 256) *reinterpret_cast<uint2*>(xz + i * 4) = make_uint2(0u, 0u);
+
+    // staging through registers: NPT dy pieces and <= 2 input pixels per thread and row.  (Named scalars, not arrays: hipcc left a
+    // `uint4 dreg[NPT]` touched from unrolled loops in scratch memory -- 16 NPT + 16 bytes per lane, every piece through a scratch
+    // store and load.)
+    uint4 d0, d1, d2, d3, d4, d5, d6, d7;
+    uint2 x0, x1;
+#define RGB2_EACH(OP) do { OP(0, d0); if constexpr (NPT > 1) OP(1, d1); if constexpr (NPT > 2) OP(2, d2); if constexpr (NPT > 3) OP(3, d3); \
+                           if constexpr (NPT > 4) OP(4, d4); if constexpr (NPT > 5) OP(5, d5); if constexpr (NPT > 6) OP(6, d6); if constexpr (NPT > 7) OP(7, d7); } while (0)
+#define RGB2_LD(K, D) D = *reinterpret_cast<const uint4*>(dsrc + (long)((tid + K * 256) >> 3) * dy_ld + ((tid + K * 256) & 7) * 8)
+#define RGB2_ST(K, D) *reinterpret_cast<uint4*>(ddst + ((tid + K * 256) >> 3) * MU_RGB2_DYS + ((tid + K * 256) & 7) * 8) = D
+#define RGB2_LOAD_DY(r_) do { const h16* dsrc = dy + (long)(r_) * W * dy_ld + co0; RGB2_EACH(RGB2_LD); } while (0)
+#define RGB2_STORE_DY(buf_) do { h16* ddst = dys + (buf_) * W * MU_RGB2_DYS; RGB2_EACH(RGB2_ST); } while (0)
+    // input row `xr` (a global row index b * H + h; the rows a tap must not see -- outside the image -- are replaced by the zero row below)
+#define RGB2_LOAD_X(xr_) do {                                                                                                   \
+        const int xr = (xr_);                                                                                                    \
+        const bool ok = xr >= 0 && xr < rows;                                                                                    \
+        const h16* xsrc = x + (long)(ok ? xr : 0) * W * x_ld;                                                                    \
+        x0 = make_uint2(0u, 0u); x1 = make_uint2(0u, 0u);                                                                        \
+        if (ok && tid >= 1 && tid <= W) x0 = *reinterpret_cast<const uint2*>(xsrc + (long)(tid - 1) * x_ld);                     \
+        if (ok && tid + 256 <= W) x1 = *reinterpret_cast<const uint2*>(xsrc + (long)(tid + 255) * x_ld);                         \
+    } while (0)
+#define RGB2_STORE_X(xr_) do {                                                                                                  \
+        h16* xdst = xs + ((xr_) & 3) * xw * 4;                                                                                   \
+        if (tid < xw) *reinterpret_cast<uint2*>(xdst + tid * 4) = x0;                                                            \
+        if (tid + 256 < xw) *reinterpret_cast<uint2*>(xdst + (tid + 256) * 4) = x1;                                              \
+    } while (0)
+
+    // this lane's three pieces (column tiles n = 0 .. 2): tap 4 n + pc = (dh, dw); taps 9 .. 11 do not exist (zero row)
+    int pdh[3], pdw[3];
+#pragma unroll
+    for (int n = 0; n < 3; ++n) {
+        const int tap = n * 4 + pc;
+        pdh[n] = tap < 9 ? tap / 3 : 3;
+        pdw[n] = tap < 9 ? tap - (tap / 3) * 3 : 0;
+    }
+
+    if (rbeg < rend) {
+        // prologue: input rows rbeg - 1 and rbeg into the ring, dy row rbeg and input row rbeg + 1 into registers
+        RGB2_LOAD_X(rbeg - 1); RGB2_STORE_X(rbeg - 1);
+        RGB2_LOAD_X(rbeg); RGB2_STORE_X(rbeg);
+        RGB2_LOAD_X(rbeg + 1);
+        RGB2_LOAD_DY(rbeg);
+    }
+    int buf = 0;
+    for (int r = rbeg; r < rend; ++r) {
+        RGB2_STORE_DY(buf);
+        RGB2_STORE_X(r + 1);
+        __syncthreads();                                       // row r's dy image and input rows r - 1 .. r + 1 are complete
+        if (r + 1 < rend) { RGB2_LOAD_DY(r + 1); RGB2_LOAD_X(r + 2); }    // in flight during this row's arithmetic
+        const int h = r % H;
+        // the three input rows of this image row (ring slots by global row index; rows outside the image: the zero row)
+        const h16* rowp0 = h > 0 ? xs + ((r - 1) & 3) * xw * 4 : xz;
+        const h16* rowp1 = xs + (r & 3) * xw * 4;
+        const h16* rowp2 = h + 1 < H ? xs + ((r + 1) & 3) * xw * 4 : xz;
+        const h16* pbase[3];
+#pragma unroll
+        for (int n = 0; n < 3; ++n)
+            pbase[n] = (pdh[n] == 0 ? rowp0 : (pdh[n] == 1 ? rowp1 : (pdh[n] == 2 ? rowp2 : xz))) + pdw[n] * 4 + (4 * g + q) * 4;
+        const h16* dyt = dys + buf * W * MU_RGB2_DYS;
+        for (int ks = wave; ks < nks; ks += 4) {
+            const int p0 = ks * 32;
+            // k-slot j of lane group g: pixel p0 + 4 g + j (j < 4), p0 + 16 + 4 g + (j - 4) -- the same for both operands
+            h16x8 bf[3];
+#pragma unroll
+            for (int n = 0; n < 3; ++n) {
+                const h16* a0 = pbase[n] + p0 * 4;
+                auto lo = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) fp16x4v*)(a0));
+                auto hi = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) fp16x4v*)(a0 + 16 * 4));
+                bf[n] = (h16x8){(h16)lo[0], (h16)lo[1], (h16)lo[2], (h16)lo[3], (h16)hi[0], (h16)hi[1], (h16)hi[2], (h16)hi[3]};
+            }
+#pragma unroll
+            for (int a = 0; a < 4; ++a) {
+                const h16* a0 = dyt + (p0 + 4 * g + q) * MU_RGB2_DYS + a * 16 + 4 * pc;
+                auto lo = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) fp16x4v*)(a0));
+                auto hi = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) fp16x4v*)(a0 + 16 * MU_RGB2_DYS));
+                const h16x8 af = {(h16)lo[0], (h16)lo[1], (h16)lo[2], (h16)lo[3], (h16)hi[0], (h16)hi[1], (h16)hi[2], (h16)hi[3]};
+#pragma unroll
+                for (int n = 0; n < 3; ++n) acc[a][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af, bf[n], acc[a][n], 0, 0, 0);
+            }
+        }
+        buf ^= 1;
+    }
+    // fold the four waves in a fixed order, one column tile at a time through a [4 waves][64 co][16] float buffer (16 KB over the dy
+    // images; the launch sizes the LDS for both): accumulator tile (a, n) holds D[co = 16 a + 4 g + i][column 16 n + r16]
+    float* red = reinterpret_cast<float*>(rgb2_lds);
+#pragma unroll
+    for (int n = 0; n < 3; ++n) {
+        __syncthreads();                                       // the last row's readers / the previous tile's readers are done
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) red[(wave * 64 + a * 16 + 4 * g + i) * 16 + r16] = acc[a][n][i];
+        __syncthreads();
+        for (int e = tid; e < 64 * 16; e += 256) {
+            const int co = e >> 4, col = e & 15;
+            const float v = (red[(0 * 64 + co) * 16 + col] + red[(1 * 64 + co) * 16 + col]) + (red[(2 * 64 + co) * 16 + col] + red[(3 * 64 + co) * 16 + col]);
+            const int tap = n * 4 + (col >> 2), ci = col & 3;
+            if (tap < 9) part[(((long)blockIdx.x * 9 + tap) * Cout + co0 + co) * 4 + ci] = v;
+        }
+    }
+}
+#undef RGB2_EACH
+#undef RGB2_LD
+#undef RGB2_ST
+#undef RGB2_LOAD_DY
+#undef RGB2_STORE_DY
+#undef RGB2_LOAD_X
+#undef RGB2_STORE_X
+
 extern "C" long mu_conv_wgrad_workspace_bytes(int B, int H, int W, int Cin, int Cout, int taps) {
     int bco, bci, nsplit; long pps;
     wgrad_tile(Cin, Cout, &bco, &bci);
@@ -3236,7 +3384,22 @@ static int conv_wgrad_impl(const void* x, const void* dy, float* dw_oihw, float*
         if (nb > (long)B * H) nb = (long)B * H;
         if (nb < 1) return MU_ERR_WORKSPACE;
         dim3 grid((int)nb, Cout / 64);
-        if (dtype == MU_F16) wgrad_rgb_kernel<h16><<<grid, 256, 0, st>>>((const h16*)x, (const h16*)dy, part, B, H, W, Cout, cin_valid, x_ld, dy_ld);
+        if (dtype == MU_F16 && MU_RGB2 && W % 32 == 0 && x_ld % 4 == 0) {
+            // matrix-core form: a band of consecutive image rows per block (the grid covers the rows exactly: an idle block writes a zero slab)
+            if (nb > 768) nb = 768;                            // three 45 KB blocks per CU: one round
+            const int rpb = (int)(((long)B * H + nb - 1) / nb);
+            nb = ((long)B * H + rpb - 1) / rpb;
+            grid.x = (int)nb;
+            const size_t lds = ((size_t)2 * W * MU_RGB2_DYS + 5 * (size_t)(W + 2) * 4) * sizeof(h16);
+            const size_t lds_red = (size_t)4 * 64 * 16 * sizeof(float);
+#define RGB2(NPT) wgrad_rgb2_kernel<NPT><<<grid, 256, lds > lds_red ? lds : lds_red, st>>>((const h16*)x, (const h16*)dy, part, B, H, W, Cout, x_ld, dy_ld, rpb)
+            switch (W / 32) {
+                case 1: RGB2(1); break; case 2: RGB2(2); break; case 3: RGB2(3); break; case 4: RGB2(4); break;
+                case 5: RGB2(5); break; case 6: RGB2(6); break; case 7: RGB2(7); break; default: RGB2(8); break;
+            }
+#undef RGB2
+        }
+        else if (dtype == MU_F16) wgrad_rgb_kernel<h16><<<grid, 256, 0, st>>>((const h16*)x, (const h16*)dy, part, B, H, W, Cout, cin_valid, x_ld, dy_ld);
         else wgrad_rgb_kernel<float><<<grid, 256, 0, st>>>((const float*)x, (const float*)dy, part, B, H, W, Cout, cin_valid, x_ld, dy_ld);
         const long n = (long)cout_valid * cin_valid * 9;
         const long nblk = (n + 63) / 64;
