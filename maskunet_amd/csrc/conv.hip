@@ -3308,6 +3308,139 @@ __global__ __launch_bounds__(256, 3) void wgrad_rgb2_kernel(const h16* __restric
 #undef RGB2_LOAD_X
 #undef RGB2_STORE_X
 
+// ------------------------------------------------------------------------------------------
+// Nine taps per block for the 64-channel-wide 3x3 layers (fp16, W % 32 == 0, W <= 128; round 5).  The three-taps-per-block ring kernel
+// above gives a 64 x 64 channel tile 48 MFMAs per 32-pixel stage behind a full set of LDS-DMAs and a block barrier (MFMA pipe 24 % busy
+// on these layers).  Here a block owns a band of consecutive image rows of ONE 64 x 64 channel tile and all nine taps: the dy row and a
+// 4-slot ring of input rows sit in LDS as plain padded pixel rows (144 bytes: the four pixel rows of a transposing read on disjoint
+// banks), both MFMA operands come from ds_read_b64_tr_b16, and a tap is nothing but a pixel offset into the ring (rows outside the
+// image: a zero row).  Wave w owns the 16 input channels 16 w .. 16 w + 15 for all taps and all 64 output channels: 8 + 18 fragment
+// reads and 36 MFMAs per 32 pixels, 144 accumulators, no cross-wave fold.  dy and x are read from HBM once per channel tile.
+// Slab layout [band][tap][Cout][Cin] = the ring kernel's, same deterministic reduce.
+// ------------------------------------------------------------------------------------------
+#ifndef MU_WG9
+#define MU_WG9 1
+#endif
+#define MU_WG9_S 72            // halves per staged pixel row (64 channels + 8 pad = 144 bytes)
+#ifndef MU_WG9_BLOCKS
+#define MU_WG9_BLOCKS 256
+#endif
+#ifndef MU_WG9_BLOCKS_W64
+#define MU_WG9_BLOCKS_W64 256  // (W <= 64: 66 KB of LDS, two blocks fit a CU)
+#endif
+#ifndef MU_WG9_MAXC
+#define MU_WG9_MAXC 128
+#endif
+#ifndef MU_WG9_NEED64
+#define MU_WG9_NEED64 1
+#endif
+template <int NPT>             // NPT = W / 32
+__global__ __launch_bounds__(256, 1) void conv_wgrad9_kernel(const h16* __restrict__ x, const h16* __restrict__ dy, float* __restrict__ part,
+                                                          int B, int H, int W, int Cin, int Cout, long x_ld, long dy_ld, int rows_per_blk) {
+    constexpr int WC = 32 * NPT;                               // == W (the launch picks NPT = W / 32)
+    __shared__ __attribute__((aligned(16))) h16 wg9_lds[(2 * WC + 5 * (WC + 2)) * MU_WG9_S];      // 130 KB at W = 128
+    const int xw = W + 2;
+    h16* dys = wg9_lds;                                        // [2][W][72]
+    h16* xs = dys + 2 * W * MU_WG9_S;                          // [4][W + 2][72] ring (columns 0 and W + 1 stay zero) | [W + 2][72] zeros
+    h16* xz = xs + 4 * xw * MU_WG9_S;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r16 = lane & 15, g = lane >> 4, q = r16 >> 2, pc = r16 & 3;
+    const int co0 = blockIdx.y * 64, ci0 = blockIdx.z * 64;
+    const int rows = B * H;
+    const int rbeg = blockIdx.x * rows_per_blk, rend = rbeg + rows_per_blk < rows ? rbeg + rows_per_blk : rows;
+
+    f32x4 acc[4][9];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int t = 0; t < 9; ++t) acc[a][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    // zero the ring (its border columns are never written again) and the zero row
+    for (int i = tid; i < 5 * xw * MU_WG9_S / 8; i += 256) *reinterpret_cast<uint4*>(xs + i * 8) = make_uint4(0u, 0u, 0u, 0u);
+    __syncthreads();
+
+    // staging through registers (named scalars: see wgrad_rgb2_kernel): NPT 16-byte pieces of the dy row and of the input row per thread
+    uint4 d0, d1, d2, d3, e0, e1, e2, e3;
+#define WG9_EACH(OP, P) do { OP(0, P##0); if constexpr (NPT > 1) OP(1, P##1); if constexpr (NPT > 2) OP(2, P##2); if constexpr (NPT > 3) OP(3, P##3); } while (0)
+#define WG9_LD(K, D) D = *reinterpret_cast<const uint4*>(gsrc + (long)((tid + K * 256) >> 3) * gld + ((tid + K * 256) & 7) * 8)
+#define WG9_ST(K, D) *reinterpret_cast<uint4*>(ldst + ((tid + K * 256) >> 3) * MU_WG9_S + ((tid + K * 256) & 7) * 8) = D
+#define WG9_LOAD_DY(r_) do { const h16* gsrc = dy + (long)(r_) * W * dy_ld + co0; const long gld = dy_ld; WG9_EACH(WG9_LD, d); } while (0)
+#define WG9_STORE_DY(buf_) do { h16* ldst = dys + (buf_) * W * MU_WG9_S; WG9_EACH(WG9_ST, d); } while (0)
+    // input row xr_ (global row index; rows < 0 / >= rows are never used: the taps that would see them read the zero row)
+#define WG9_LOAD_X(xr_) do { const int xr = (xr_); const h16* gsrc = x + (long)(xr >= 0 && xr < rows ? xr : 0) * W * x_ld + ci0; const long gld = x_ld; WG9_EACH(WG9_LD, e); } while (0)
+#define WG9_STORE_X(xr_) do { h16* ldst = xs + (((xr_) & 3) * xw + 1) * MU_WG9_S; WG9_EACH(WG9_ST, e); } while (0)
+
+    if (rbeg < rend) {
+        WG9_LOAD_X(rbeg - 1); WG9_STORE_X(rbeg - 1);
+        WG9_LOAD_X(rbeg); WG9_STORE_X(rbeg);
+        WG9_LOAD_X(rbeg + 1);
+        WG9_LOAD_DY(rbeg);
+    }
+    int buf = 0;
+    for (int r = rbeg; r < rend; ++r) {
+        WG9_STORE_DY(buf);
+        WG9_STORE_X(r + 1);
+        __syncthreads();                                       // row r's dy image and input rows r - 1 .. r + 1 are complete
+        if (r + 1 < rend) { WG9_LOAD_DY(r + 1); WG9_LOAD_X(r + 2); }      // in flight during this row's arithmetic
+        const int h = r % H;
+        const h16* rowp[3];
+        rowp[0] = (h > 0 ? xs + ((r - 1) & 3) * xw * MU_WG9_S : xz) + (4 * g + q) * MU_WG9_S + wave * 16 + 4 * pc;
+        rowp[1] = xs + (r & 3) * xw * MU_WG9_S + (4 * g + q) * MU_WG9_S + wave * 16 + 4 * pc;
+        rowp[2] = (h + 1 < H ? xs + ((r + 1) & 3) * xw * MU_WG9_S : xz) + (4 * g + q) * MU_WG9_S + wave * 16 + 4 * pc;
+        const h16* dyt = dys + buf * W * MU_WG9_S + (4 * g + q) * MU_WG9_S + 4 * pc;
+#pragma unroll
+        for (int ks = 0; ks < NPT; ++ks) {
+            const int p0 = ks * 32;
+            // k-slot j of lane group g: pixel p0 + 4 g + j (j < 4), p0 + 16 + 4 g + (j - 4) -- the same for both operands
+            h16x8 af[4];
+#pragma unroll
+            for (int a = 0; a < 4; ++a) {
+                const h16* a0 = dyt + p0 * MU_WG9_S + a * 16;
+                auto lo = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) fp16x4v*)(a0));
+                auto hi = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) fp16x4v*)(a0 + 16 * MU_WG9_S));
+                af[a] = (h16x8){(h16)lo[0], (h16)lo[1], (h16)lo[2], (h16)lo[3], (h16)hi[0], (h16)hi[1], (h16)hi[2], (h16)hi[3]};
+            }
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {
+                const h16* b0 = rowp[t / 3] + (p0 + t % 3) * MU_WG9_S;          // window column = image column + 1 + (kw - 1)
+                auto lo = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) fp16x4v*)(b0));
+                auto hi = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) fp16x4v*)(b0 + 16 * MU_WG9_S));
+                const h16x8 bf = {(h16)lo[0], (h16)lo[1], (h16)lo[2], (h16)lo[3], (h16)hi[0], (h16)hi[1], (h16)hi[2], (h16)hi[3]};
+#pragma unroll
+                for (int a = 0; a < 4; ++a) acc[a][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[a], bf, acc[a][t], 0, 0, 0);
+            }
+        }
+        buf ^= 1;
+    }
+    // accumulator tile (a, t) holds D[co = 16 a + 4 g + i][ci = 16 wave + r16] of tap t
+    float* slab = part + (long)blockIdx.x * 9 * Cout * Cin;
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                slab[((long)t * Cout + co0 + 16 * a + 4 * g + i) * Cin + ci0 + 16 * wave + r16] = acc[a][t][i];
+}
+#undef WG9_EACH
+#undef WG9_LD
+#undef WG9_ST
+#undef WG9_LOAD_DY
+#undef WG9_STORE_DY
+#undef WG9_LOAD_X
+#undef WG9_STORE_X
+static inline bool wgrad9_choose(int B, int H, int W, int Cin, int Cout, int taps, int dtype, int* nb, int* rpb) {
+    if (!MU_WG9 || dtype != MU_F16 || taps != 9 || W % 32 || W > 128 || Cin % 64 || Cout % 64 || (MU_WG9_NEED64 && !(Cin == 64 || Cout == 64)) ||
+        Cin > MU_WG9_MAXC || Cout > MU_WG9_MAXC) return false;
+    const long rows = (long)B * H;
+    long want = (W <= 64 ? MU_WG9_BLOCKS_W64 : MU_WG9_BLOCKS) / ((Cin / 64) * (Cout / 64));
+    if (want > rows) want = rows;
+    if (want < 1) want = 1;
+    *rpb = (int)((rows + want - 1) / want);
+    *nb = (int)((rows + *rpb - 1) / *rpb);
+    return true;
+}
+
 extern "C" long mu_conv_wgrad_workspace_bytes(int B, int H, int W, int Cin, int Cout, int taps) {
     int bco, bci, nsplit; long pps;
     wgrad_tile(Cin, Cout, &bco, &bci);
@@ -3321,6 +3454,11 @@ extern "C" long mu_conv_wgrad_workspace_bytes(int B, int H, int W, int Cin, int 
     if (wgrad3_choose(H, W, Cin, Cout, taps, MU_F16, &tco, &tci)) {
         wgrad3_plan((long)B * H * W, Cin, Cout, tco, tci, &nsplit, &pps);
         long b = (long)nsplit * taps * Cout * Cin * sizeof(float);
+        if (b > a) a = b;
+    }
+    int nb9, rpb9;
+    if (wgrad9_choose(B, H, W, Cin, Cout, taps, MU_F16, &nb9, &rpb9)) {
+        long b = (long)nb9 * taps * Cout * Cin * sizeof(float);
         if (b > a) a = b;
     }
     if (taps == 9 && Cin == 32) {                       // first-layer kernel (<= 4 valid input channels): [blocks][9][Cout][4]
@@ -3407,7 +3545,15 @@ static int conv_wgrad_impl(const void* x, const void* dy, float* dw_oihw, float*
         MU_CHECK_LAUNCH();
         return MU_OK;
     }
-    int tco, tci;
+    int tco, tci, nb9, rpb9;
+    if (wgrad9_choose(B, H, W, Cin, Cout, taps, dtype, &nb9, &rpb9) && x_ld % 8 == 0 && dy_ld % 8 == 0) {
+        if (ws_bytes < (long)nb9 * taps * Cout * Cin * (long)sizeof(float)) return MU_ERR_WORKSPACE;
+        const dim3 grid9(nb9, Cout / 64, Cin / 64);
+#define WG9(NPT) conv_wgrad9_kernel<NPT><<<grid9, 256, 0, st>>>((const h16*)x, (const h16*)dy, part, B, H, W, Cin, Cout, x_ld, dy_ld, rpb9)
+        switch (W / 32) { case 1: WG9(1); break; case 2: WG9(2); break; case 3: WG9(3); break; default: WG9(4); break; }
+#undef WG9
+        nsplit = nb9;
+    } else
     if (wgrad3_choose(H, W, Cin, Cout, taps, dtype, &tco, &tci)) {
         wgrad3_plan((long)B * H * W, Cin, Cout, tco, tci, &nsplit, &pps);
         if (ws_bytes < (long)nsplit * taps * Cout * Cin * (long)sizeof(float)) return MU_ERR_WORKSPACE;

@@ -138,6 +138,9 @@ def check_conv(dtype, cases=None):
                       # its matrix-core form (fp16, W % 32 == 0): one row per block, two channel blocks, 2 valid channels, bands of two rows
                       # that straddle image borders (4 x 255 rows over 512 blocks), four k-steps per row
                       (2, 8, 32, 3, 64, 3), (1, 5, 64, 3, 128, 3), (3, 4, 96, 2, 64, 3), (4, 255, 32, 3, 64, 3), (1, 6, 128, 3, 64, 3),
+                      # nine-taps-per-block weight-gradient kernel (fp16, 64-channel-wide layers, W % 32 == 0, W <= 128): bands of two rows
+                      # that straddle image borders, W = 96 / 128, both mixed channel shapes
+                      (4, 99, 32, 64, 64, 3), (2, 5, 96, 64, 64, 3), (1, 6, 128, 128, 64, 3), (2, 7, 64, 64, 128, 3),
                       # 16-pixel-wide images through the 3-tap weight-gradient kernel (two image rows per stage)
                       (2, 8, 16, 256, 128, 3), (5, 16, 16, 64, 64, 3),
                       # shapes around the kernel-selection edges: 80-wide (16x16 conv tiles, one-tap weight-grad), 192-wide (64-pixel
