@@ -3331,6 +3331,9 @@ __global__ __launch_bounds__(256, 3) void wgrad_rgb2_kernel(const h16* __restric
 #ifndef MU_WG9_MAXC
 #define MU_WG9_MAXC 128
 #endif
+#ifndef MU_WG9_MAXC32
+#define MU_WG9_MAXC32 128
+#endif
 #ifndef MU_WG9_NEED64
 #define MU_WG9_NEED64 1
 #endif
@@ -3430,8 +3433,12 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad9_kernel(const h16* __restri
 #undef WG9_LOAD_X
 #undef WG9_STORE_X
 static inline bool wgrad9_choose(int B, int H, int W, int Cin, int Cout, int taps, int dtype, int* nb, int* rpb) {
-    if (!MU_WG9 || dtype != MU_F16 || taps != 9 || W % 32 || W > 128 || Cin % 64 || Cout % 64 || (MU_WG9_NEED64 && !(Cin == 64 || Cout == 64)) ||
-        Cin > MU_WG9_MAXC || Cout > MU_WG9_MAXC) return false;
+    // which layers: one of the two channel counts 64 (the ring kernel's 64-wide tiles), or both <= MU_WG9_MAXC32 at W = 32 -- in-process A/B, B = 64:
+    // 32^2 128->128 40.9 -> 36.1 us; the 128-wide layers at 64^2 / 128^2 are 5-7 % SLOWER here than on the ring kernel's 128 x 128 tiles
+    const int maxc = W <= 32 ? MU_WG9_MAXC32 : MU_WG9_MAXC;
+    const bool need64 = MU_WG9_NEED64 && W > 32;
+    if (!MU_WG9 || dtype != MU_F16 || taps != 9 || W % 32 || W > 128 || Cin % 64 || Cout % 64 || (need64 && !(Cin == 64 || Cout == 64)) ||
+        Cin > maxc || Cout > maxc) return false;
     const long rows = (long)B * H;
     long want = (W <= 64 ? MU_WG9_BLOCKS_W64 : MU_WG9_BLOCKS) / ((Cin / 64) * (Cout / 64));
     if (want > rows) want = rows;
