@@ -3432,6 +3432,110 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad9_kernel(const h16* __restri
 #undef WG9_STORE_DY
 #undef WG9_LOAD_X
 #undef WG9_STORE_X
+// The same for the 16-pixel-wide layers (W == 16, H even): a 32-pixel k-step is a PAIR of image rows -- k-slots 0-15 the pixels of row r,
+// 16-31 those of row r + 1 (the transposing reads take any piece address, so the second half of every fragment simply points into the
+// other row's image).  8-slot input-row ring (rows r - 1 .. r + 2 live, r + 3 and r + 4 arriving), one barrier per row pair.
+__global__ __launch_bounds__(256, 1) void conv_wgrad9_w16_kernel(const h16* __restrict__ x, const h16* __restrict__ dy, float* __restrict__ part,
+                                                              int B, int H, int Cin, int Cout, long x_ld, long dy_ld, int rows_per_blk) {
+    constexpr int W = 16, xw = W + 2;
+    __shared__ __attribute__((aligned(16))) h16 lds[(2 * 32 + 9 * xw) * MU_WG9_S];
+    h16* dys = lds;                                            // [2][32][72]: the dy rows r, r + 1
+    h16* xs = dys + 2 * 32 * MU_WG9_S;                         // [8][18][72] ring | [18][72] zeros
+    h16* xz = xs + 8 * xw * MU_WG9_S;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r16 = lane & 15, g = lane >> 4, q = r16 >> 2, pc = r16 & 3;
+    const int co0 = blockIdx.y * 64, ci0 = blockIdx.z * 64;
+    const int rows = B * H;
+    const int rbeg = blockIdx.x * rows_per_blk, rend = rbeg + rows_per_blk < rows ? rbeg + rows_per_blk : rows;      // both even
+
+    f32x4 acc[4][9];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int t = 0; t < 9; ++t) acc[a][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int i = tid; i < 9 * xw * MU_WG9_S / 8; i += 256) *reinterpret_cast<uint4*>(xs + i * 8) = make_uint4(0u, 0u, 0u, 0u);
+    __syncthreads();
+
+    // one 16-byte piece of a 32-pixel run (two image rows) per thread: pixel tid >> 3, channels 8 (tid & 7) ..
+    const int pp = tid >> 3, pch = (tid & 7) * 8;
+    uint4 dreg, xreg;
+    auto load_x2 = [&](int xr) {                               // rows xr, xr + 1 (clamped: rows past the end are never read by a valid tap)
+        const int r0 = xr + (pp >> 4);
+        const int rc = r0 < 0 ? 0 : (r0 >= rows ? rows - 1 : r0);
+        xreg = *reinterpret_cast<const uint4*>(x + ((long)rc * W + (pp & 15)) * x_ld + ci0 + pch);
+    };
+    auto store_x2 = [&](int xr) {
+        const int r0 = xr + (pp >> 4);
+        *reinterpret_cast<uint4*>(xs + (((r0 & 7) * xw) + 1 + (pp & 15)) * MU_WG9_S + pch) = xreg;
+    };
+    auto load_dy2 = [&](int r) { dreg = *reinterpret_cast<const uint4*>(dy + ((long)r * W + pp) * dy_ld + co0 + pch); };
+    auto store_dy2 = [&](int buf) { *reinterpret_cast<uint4*>(dys + (buf * 32 + pp) * MU_WG9_S + pch) = dreg; };
+
+    if (rbeg < rend) {
+        load_x2(rbeg - 1); store_x2(rbeg - 1);                 // rows rbeg - 1, rbeg
+        load_x2(rbeg + 1); store_x2(rbeg + 1);                 // rows rbeg + 1, rbeg + 2
+        load_x2(rbeg + 3);                                     // rows rbeg + 3, rbeg + 4: stored by the first iteration
+        load_dy2(rbeg);
+    }
+    int buf = 0;
+    const int lane_off = (4 * g + q) * MU_WG9_S + 4 * pc;
+    for (int r = rbeg; r < rend; r += 2) {
+        store_dy2(buf);
+        store_x2(r + 3);
+        __syncthreads();
+        if (r + 2 < rend) { load_dy2(r + 2); load_x2(r + 5); }
+        const int h = r % H;                                   // even; h + 1 < H
+        const h16* ring[4];                                    // rows r - 1 .. r + 2 (outside the image: zeros)
+        ring[0] = (h > 0 ? xs + ((r - 1) & 7) * xw * MU_WG9_S : xz) + lane_off + wave * 16;
+        ring[1] = xs + (r & 7) * xw * MU_WG9_S + lane_off + wave * 16;
+        ring[2] = xs + ((r + 1) & 7) * xw * MU_WG9_S + lane_off + wave * 16;
+        ring[3] = (h + 2 < H ? xs + ((r + 2) & 7) * xw * MU_WG9_S : xz) + lane_off + wave * 16;
+        const h16* dyt = dys + buf * 32 * MU_WG9_S + lane_off;
+        h16x8 af[4];
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+            auto lo = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) fp16x4v*)(dyt + a * 16));
+            auto hi = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) fp16x4v*)(dyt + a * 16 + 16 * MU_WG9_S));
+            af[a] = (h16x8){(h16)lo[0], (h16)lo[1], (h16)lo[2], (h16)lo[3], (h16)hi[0], (h16)hi[1], (h16)hi[2], (h16)hi[3]};
+        }
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            // k-slots 0-15: row r, its tap row r + kh - 1 = ring[kh]; k-slots 16-31: row r + 1, tap row ring[kh + 1]
+            auto lo = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) fp16x4v*)(ring[t / 3] + (t % 3) * MU_WG9_S));
+            auto hi = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) fp16x4v*)(ring[t / 3 + 1] + (t % 3) * MU_WG9_S));
+            const h16x8 bf = {(h16)lo[0], (h16)lo[1], (h16)lo[2], (h16)lo[3], (h16)hi[0], (h16)hi[1], (h16)hi[2], (h16)hi[3]};
+#pragma unroll
+            for (int a = 0; a < 4; ++a) acc[a][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[a], bf, acc[a][t], 0, 0, 0);
+        }
+        buf ^= 1;
+    }
+    float* slab = part + (long)blockIdx.x * 9 * Cout * Cin;
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                slab[((long)t * Cout + co0 + 16 * a + 4 * g + i) * Cin + ci0 + 16 * wave + r16] = acc[a][t][i];
+}
+#ifndef MU_WG9_W16
+#define MU_WG9_W16 1
+#endif
+#ifndef MU_WG9_MAXC16
+#define MU_WG9_MAXC16 512
+#endif
+static inline bool wgrad9_w16_choose(int B, int H, int W, int Cin, int Cout, int taps, int dtype, int* nb, int* rpb) {
+    if (!MU_WG9_W16 || dtype != MU_F16 || taps != 9 || W != 16 || H % 2 || Cin % 64 || Cout % 64 || Cin > MU_WG9_MAXC16 || Cout > MU_WG9_MAXC16) return false;
+    const long rows = (long)B * H;
+    long want = MU_WG9_BLOCKS / ((Cin / 64) * (Cout / 64));
+    if (want < 1) want = 1;
+    long r = (rows + want - 1) / want;
+    r = (r + 1) / 2 * 2;                                       // whole row pairs
+    *rpb = (int)r;
+    *nb = (int)((rows + r - 1) / r);
+    return true;
+}
+
 static inline bool wgrad9_choose(int B, int H, int W, int Cin, int Cout, int taps, int dtype, int* nb, int* rpb) {
     // which layers: one of the two channel counts 64 (the ring kernel's 64-wide tiles), or both <= MU_WG9_MAXC32 at W = 32 -- in-process A/B, B = 64:
     // 32^2 128->128 40.9 -> 36.1 us; the 128-wide layers at 64^2 / 128^2 are 5-7 % SLOWER here than on the ring kernel's 128 x 128 tiles
@@ -3464,7 +3568,7 @@ extern "C" long mu_conv_wgrad_workspace_bytes(int B, int H, int W, int Cin, int 
         if (b > a) a = b;
     }
     int nb9, rpb9;
-    if (wgrad9_choose(B, H, W, Cin, Cout, taps, MU_F16, &nb9, &rpb9)) {
+    if (wgrad9_choose(B, H, W, Cin, Cout, taps, MU_F16, &nb9, &rpb9) || wgrad9_w16_choose(B, H, W, Cin, Cout, taps, MU_F16, &nb9, &rpb9)) {
         long b = (long)nb9 * taps * Cout * Cin * sizeof(float);
         if (b > a) a = b;
     }
@@ -3559,6 +3663,10 @@ static int conv_wgrad_impl(const void* x, const void* dy, float* dw_oihw, float*
 #define WG9(NPT) conv_wgrad9_kernel<NPT><<<grid9, 256, 0, st>>>((const h16*)x, (const h16*)dy, part, B, H, W, Cin, Cout, x_ld, dy_ld, rpb9)
         switch (W / 32) { case 1: WG9(1); break; case 2: WG9(2); break; case 3: WG9(3); break; default: WG9(4); break; }
 #undef WG9
+        nsplit = nb9;
+    } else if (wgrad9_w16_choose(B, H, W, Cin, Cout, taps, dtype, &nb9, &rpb9) && x_ld % 8 == 0 && dy_ld % 8 == 0) {
+        if (ws_bytes < (long)nb9 * taps * Cout * Cin * (long)sizeof(float)) return MU_ERR_WORKSPACE;
+        conv_wgrad9_w16_kernel<<<dim3(nb9, Cout / 64, Cin / 64), 256, 0, st>>>((const h16*)x, (const h16*)dy, part, B, H, Cin, Cout, x_ld, dy_ld, rpb9);
         nsplit = nb9;
     } else
     if (wgrad3_choose(H, W, Cin, Cout, taps, dtype, &tco, &tci)) {
