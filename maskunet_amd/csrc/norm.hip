@@ -29,6 +29,9 @@
 #ifndef MU_BN_STRIDED
 #define MU_BN_STRIDED 1            // whole step 28.80 -> 28.71 ms, the backward sweep 0.275 -> 0.268 ms on a 256 MiB tensor
 #endif
+#ifndef MU_BN_FROWS
+#define MU_BN_FROWS 1
+#endif
 #ifndef MU_BN_OCC1
 #define MU_BN_OCC1 1
 #endif
@@ -154,9 +157,14 @@ __global__ __launch_bounds__(256, MODE == 1 ? MU_BN_OCC1 : 1) void bn_partial_ke
 }
 
 // BN forward finalize: mean, rstd (biased var) + running-stat update (unbiased var, momentum)
-__global__ void bn_fwd_final_kernel(const double* __restrict__ part, int nblk, int C, long M, float eps, float momentum,
+// FROWS: `part` holds the conv epilogue's FLOAT statistics rows themselves ([row][C][2], nblk = rows <= MU_STAT_MAXBLK) instead of the
+// fold kernel's double partials -- the small layers (16^2 / 32^2: 256-1024 rows) skip the fold launch (round 5: 20 launches per step)
+template <bool FROWS = false>
+__global__ void bn_fwd_final_kernel(const void* __restrict__ part_, int nblk, int C, long M, float eps, float momentum,
                                     float* __restrict__ mean, float* __restrict__ rstd, float* __restrict__ running_mean,
                                     float* __restrict__ running_var, int c_valid, long* __restrict__ num_batches_tracked) {
+    const double* part = reinterpret_cast<const double*>(part_);
+    const float* fpart = reinterpret_cast<const float*>(part_);
     if (num_batches_tracked && blockIdx.x == 0 && threadIdx.x == 0) *num_batches_tracked += 1;   // nn.BatchNorm2d's step counter
     // one wave per channel: lanes stride over the partial blocks, then a wave reduction
     const int c = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), lane = threadIdx.x & 63;
@@ -167,8 +175,13 @@ __global__ void bn_fwd_final_kernel(const double* __restrict__ part, int nblk, i
 #pragma unroll
     for (int u = 0; u < MU_STAT_MAXBLK / 64; ++u) {
         const int b = lane + 64 * u;
-        const double2 v = b < nblk ? *reinterpret_cast<const double2*>(part + ((long)b * C + c) * 2) : make_double2(0.0, 0.0);
-        sv[u] = v.x; qv[u] = v.y;
+        if constexpr (FROWS) {
+            const float2 v = b < nblk ? *reinterpret_cast<const float2*>(fpart + ((long)b * C + c) * 2) : make_float2(0.f, 0.f);
+            sv[u] = (double)v.x; qv[u] = (double)v.y;
+        } else {
+            const double2 v = b < nblk ? *reinterpret_cast<const double2*>(part + ((long)b * C + c) * 2) : make_double2(0.0, 0.0);
+            sv[u] = v.x; qv[u] = v.y;
+        }
     }
     double s = 0.0, q = 0.0;
 #pragma unroll
@@ -464,7 +477,7 @@ static int bn_train_stats_t(const T* x, long M, int C, long ld, float* mean, flo
     int nblk = stat_blocks(M);
     size_t lds = (size_t)rpi * C * 2 * sizeof(double);
     bn_partial_kernel<T, 0><<<nblk, 256, lds, st>>>(x, nullptr, nullptr, nullptr, M, C, ld, nullptr, nullptr, nullptr, nullptr, 0, (double*)ws);
-    bn_fwd_final_kernel<<<mu_cdiv(C, 4), 256, 0, st>>>((const double*)ws, nblk, C, M, eps, momentum, mean, rstd, rmean, rvar, c_valid, nbt);
+    bn_fwd_final_kernel<false><<<mu_cdiv(C, 4), 256, 0, st>>>((const double*)ws, nblk, C, M, eps, momentum, mean, rstd, rmean, rvar, c_valid, nbt);
     return MU_OK;
 }
 
@@ -510,8 +523,14 @@ extern "C" int mu_bn_train_stats_rows(const float* stat_part, int rows, long M, 
     const int nblk = (rows + rpb - 1) / rpb;
     if (ws_bytes < mu_bn_workspace_bytes(C)) return MU_ERR_WORKSPACE;
     hipStream_t st = (hipStream_t)stream;
+    if (MU_BN_FROWS && rows <= MU_STAT_MAXBLK) {        // few rows: the finalize kernel sums them itself (one launch less)
+        bn_fwd_final_kernel<true><<<mu_cdiv(C, 4), 256, 0, st>>>(stat_part, rows, C, M, eps, momentum, mean, rstd, running_mean, running_var,
+                                                                 c_valid, num_batches_tracked);
+        MU_CHECK_LAUNCH();
+        return MU_OK;
+    }
     bn_fold_rows_kernel<<<nblk, 256, 0, st>>>(stat_part, rows, rpb, 2 * C, (double*)workspace);
-    bn_fwd_final_kernel<<<mu_cdiv(C, 4), 256, 0, st>>>((const double*)workspace, nblk, C, M, eps, momentum, mean, rstd, running_mean,
+    bn_fwd_final_kernel<false><<<mu_cdiv(C, 4), 256, 0, st>>>((const double*)workspace, nblk, C, M, eps, momentum, mean, rstd, running_mean,
                                                         running_var, c_valid, num_batches_tracked);
     MU_CHECK_LAUNCH();
     return MU_OK;
