@@ -1740,9 +1740,11 @@ __global__ __launch_bounds__(512, 1) void conv_nt4p_kernel(const h16* __restrict
 #ifndef MU_NT5_MINTILES
 #define MU_NT5_MINTILES 512          // two tiles per block at least: below, one of the two wave groups would idle
 #endif
+// Cout_total = 128 (grid.y = 2; launches without a statistics epilogue, i.e. the data-gradient of a 128 -> 64 layer): blockIdx.y picks a
+// 64-channel half of the output -- two independent 64 -> 64 problems on the same input, each with its half of the weights resident.
 __global__ __launch_bounds__(512, 1) void conv_nt5_kernel(const h16* __restrict__ x, const h16* __restrict__ w, const float* __restrict__ bias,
                                                           h16* __restrict__ y, int B, int H, int W, long x_ld, long y_ld,
-                                                          float* __restrict__ stat_part) {
+                                                          float* __restrict__ stat_part, int Cout_total) {
     using M_ = Mma<h16>;
     using Frag = M_::Frag;
     constexpr int VN = 8, CI = 64, CO = 64, TM = 4, TN = 4, NWV = 8, GW = 4;
@@ -1766,6 +1768,7 @@ __global__ __launch_bounds__(512, 1) void conv_nt5_kernel(const h16* __restrict_
     const int r16 = lane & 15, g = lane >> 4;
     const int srow = lane >> 3, sch = lane & 7;
     char* Hg = lds + grp * HBYTES;
+    const int co_base = blockIdx.y * CO;
 
     auto stage_halo = [&](int tl) {                          // this group's waves request the halo of tile tl: HPW DMAs per wave
         const int tw_ = tl % tiles_w, th_ = (tl / tiles_w) % tiles_h, bi = tl / (tiles_w * tiles_h);
@@ -1795,12 +1798,12 @@ __global__ __launch_bounds__(512, 1) void conv_nt5_kernel(const h16* __restrict_
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) bv[i][r] = bias ? bias[i * 16 + 4 * g + r] : 0.f;
+        for (int r = 0; r < 4; ++r) bv[i][r] = bias ? bias[co_base + i * 16 + 4 * g + r] : 0.f;
 
     {                                                        // the nine weight tiles, once: [tap][64 co rows of 128 B], 16-byte chunk ^ (row & 7)
         const int row = wave * 8 + srow;
 #pragma unroll
-        for (int t = 0; t < 9; ++t) glds16a(w + ((long)t * CO + row) * CI + (sch ^ (row & 7)) * VN, Ws + t * TAPB + wave * 1024);
+        for (int t = 0; t < 9; ++t) glds16a(w + ((long)t * Cout_total + co_base + row) * CI + (sch ^ (row & 7)) * VN, Ws + t * TAPB + wave * 1024);
     }
     if (grp == 0) stage_halo(bx);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1850,7 +1853,7 @@ __global__ __launch_bounds__(512, 1) void conv_nt5_kernel(const h16* __restrict_
             if (ep) {
                 const int tl = bx + (p - 1) * nblk;
                 const int tw_ = tl % tiles_w, th_ = (tl / tiles_w) % tiles_h, bimg = tl / (tiles_w * tiles_h);
-                h16* yb = y + (((long)bimg * H + th_ * TH + wg * TN) * W + tw_ * TW + r16) * y_ld + 4 * g;
+                h16* yb = y + (((long)bimg * H + th_ * TH + wg * TN) * W + tw_ * TW + r16) * y_ld + co_base + 4 * g;
                 float tsum[TM][4], tsq[TM][4];
 #pragma unroll
                 for (int i = 0; i < TM; ++i)
@@ -1900,6 +1903,12 @@ __global__ __launch_bounds__(512, 1) void conv_nt5_kernel(const h16* __restrict_
         __builtin_amdgcn_sched_barrier(0);
     }
 }
+#ifndef MU_NT5_SPLIT128
+#define MU_NT5_SPLIT128 1
+#endif
+#ifndef MU_NT5_SPLIT_MINTILES
+#define MU_NT5_SPLIT_MINTILES 1024
+#endif
 static inline bool nt5_serves(int B, int H, int W, int Cin, int Cout) {
     if (!MU_CONV_NT5 || getenv("MU_CONV_NO_NT5")) return false;
     return Cin == 64 && Cout == 64 && H % 16 == 0 && W % 16 == 0 && (long)B * (H / 16) * (W / 16) >= MU_NT5_MINTILES;
@@ -1976,7 +1985,12 @@ static int conv_fwd_launch(const T* x, const T* w, const float* bias, T* y, int 
         if constexpr (sizeof(T) == 2) {
             if (nt5_serves(B, H, W, Cin, Cout)) {
                 const int ntile5 = B * (H / 16) * (W / 16);
-                conv_nt5_kernel<<<ntile5 < 256 ? ntile5 : 256, 512, 0, st>>>((const h16*)x, (const h16*)w, bias, (h16*)y, B, H, W, x_ld, y_ld, stat_part);
+                conv_nt5_kernel<<<ntile5 < 256 ? ntile5 : 256, 512, 0, st>>>((const h16*)x, (const h16*)w, bias, (h16*)y, B, H, W, x_ld, y_ld, stat_part, 64);
+                return MU_OK;
+            }
+            // 64 -> 128 without a statistics epilogue (the data-gradient of the 128 -> 64 layers) as two resident 64 -> 64 halves
+            if (MU_NT5_SPLIT128 && !stat_part && Cout == 128 && nt5_serves(B, H, W, Cin, 64) && (long)B * (H / 16) * (W / 16) >= MU_NT5_SPLIT_MINTILES) {
+                conv_nt5_kernel<<<dim3(256, 2), 512, 0, st>>>((const h16*)x, (const h16*)w, bias, (h16*)y, B, H, W, x_ld, y_ld, nullptr, 128);
                 return MU_OK;
             }
         }

@@ -143,6 +143,8 @@ def check_conv(dtype, cases=None):
                       (4, 99, 32, 64, 64, 3), (2, 5, 96, 64, 64, 3), (1, 6, 128, 128, 64, 3), (2, 7, 64, 64, 128, 3),
                       # its 16-pixel-wide form (a k-step = a pair of image rows): bands of four rows over images of six rows, 128 -> 256
                       (100, 6, 16, 64, 64, 3), (3, 4, 16, 128, 256, 3),
+                      # weights-resident kernel in its two-halves form (fp16, 64 -> 128 without a statistics epilogue, >= 1024 tiles)
+                      (16, 128, 128, 64, 128, 3),
                       # 16-pixel-wide images through the 3-tap weight-gradient kernel (two image rows per stage)
                       (2, 8, 16, 256, 128, 3), (5, 16, 16, 64, 64, 3),
                       # shapes around the kernel-selection edges: 80-wide (16x16 conv tiles, one-tap weight-grad), 192-wide (64-pixel
