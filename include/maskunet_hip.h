@@ -270,6 +270,30 @@ int mu_attn_bwd_phases_padded(const void* qkv, const void* x, const void* oattn,
                               const float* lse2, const float* ln_mean, const float* ln_rstd, const float* gamma, void* dY, float* delta,
                               void* dqkv, float* dgamma, float* dbeta, int B, int N, int C, int c_valid, int nkmax, void* workspace,
                               long ws_bytes, int dtype, int phases, void* stream);
+/* ---- generic path for channel counts above the sweeps' widths (C > 256) ------------------------------------------
+ * `Mask2FormerAttention(channels, size)` accepts any `channels` (ade_semantic.py:153-161); the model uses 64 / 128 / 256.  For wider
+ * blocks the products of one image run as GEMMs on mu_conv_fwd / mu_conv_wgrad (taps = 1) over the KEPT key rows -- S = Q Kg^T,
+ * O = P Vg, dP = dO Vg^T, dQ = dS Kg, dKg = dS^T Q, dVg = P^T dO, an N x Nk score tile per image does exist on this path -- and the
+ * row kernels below sit in between (maskunet_amd/ops.py `_WideMaskAttention`).  dtype MU_F16 or MU_F32 (MU_F32X is taken as MU_F32:
+ * plain, un-encoded fp32 tensors); cnt = a device pointer to ONE int (kcnt + b), idx = kidx + b * nkmax.
+ *   mu_gather_rows : dst[j][0..C) = j < *cnt ? src[idx[j]][0..C) : 0 for j < rows_out (src rows src_ld elements apart, dst dense)
+ *   mu_scatter_rows: dst[idx[j]][0..C) = (T) src[j][0..C) for j < *cnt (fp32 src dense, dst rows dst_ld apart; other rows untouched);
+ *                    *cnt == 0: all dst_rows rows NaN (the reference's dK / dV of an image without a visible key)
+ *   mu_softmax_rows: S[r][j] <- softmax_j(scale * S[r][j]) over j < *cnt, 0 for *cnt <= j < ld (:174-184; no visible key: NaN rows,
+ *                    as the reference's softmax of an all -inf row)
+ *   mu_attn_wide_ds: dP[r][j] <- P[r][j] * (dP[r][j] - sum_k P[r][k] dP[r][k]) * scale for j < *cnt, 0 behind (softmax backward)
+ *   mu_ln_rows_fwd : out = LayerNorm over the first c_valid of C stored channels of (o + x), * gamma + beta (:187-188); mean / rstd
+ *                    [rows] saved for the backward; pad channels 0
+ *   mu_ln_rows_bwd : dY = d(o + x) of the above; g_xhat = grad_out * xhat (its column sums are dgamma, those of grad_out dbeta:
+ *                    mu_colsum) */
+int mu_gather_rows(const void* src, long src_ld, const int* idx, const int* cnt, void* dst, int rows_out, int C, int dtype, void* stream);
+int mu_scatter_rows(const float* src, const int* idx, const int* cnt, void* dst, long dst_ld, int dst_rows, int C, int dtype, void* stream);
+int mu_softmax_rows(void* S, int N, int ld, const int* cnt, float scale, int dtype, void* stream);
+int mu_attn_wide_ds(const void* P, void* dP, int N, int ld, const int* cnt, float scale, int dtype, void* stream);
+int mu_ln_rows_fwd(const void* o, const void* x, const float* gamma, const float* beta, void* out, float* mean, float* rstd, long rows,
+                   int C, int c_valid, float eps, int dtype, void* stream);
+int mu_ln_rows_bwd(const void* grad_out, const void* o, const void* x, const float* mean, const float* rstd, const float* gamma, void* dY,
+                   void* g_xhat, long rows, int C, int c_valid, int dtype, void* stream);
 /* the same, one phase group at a time (bit mask): 1 = zero dqkv + LayerNorm backward / delta / dgamma,dbeta,
  * 2 = dQ sweep, 4 = dK/dV sweep.  Phases 2 and 4 need phase 1's dY, delta and workspace contents.
  * 8 (MU_ATTN_KIDX_PERMUTATION, OR-ed into every call of one backward) = a promise about kidx: nkmax == N and every row is a whole

@@ -63,6 +63,12 @@ SIGNATURES = {
     "mu_attn_fwd": (I, [P, P, P, P, P, P, P, P, P, P, P, I, I, I, I, F, I, P]),
     "mu_attn_bwd_workspace_bytes": (L, [I, I, I]),
     "mu_attn_bwd": (I, [P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, I, I, I, I, P, L, I, P]),
+    "mu_gather_rows": (I, [P, L, P, P, P, I, I, I, P]),
+    "mu_scatter_rows": (I, [P, P, P, P, L, I, I, I, P]),
+    "mu_softmax_rows": (I, [P, I, I, P, F, I, P]),
+    "mu_attn_wide_ds": (I, [P, P, I, I, P, F, I, P]),
+    "mu_ln_rows_fwd": (I, [P, P, P, P, P, P, P, L, I, I, F, I, P]),
+    "mu_ln_rows_bwd": (I, [P, P, P, P, P, P, P, P, L, I, I, I, P]),
     "mu_ce_workspace_bytes": (L, []),
     "mu_ce_fwd": (I, [P, P, L, I, I, L, P, P, P, P, L, I, P]),
     "mu_ce_bwd": (I, [P, P, P, P, P, F, L, I, I, L, P, I, P]),

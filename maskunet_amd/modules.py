@@ -132,8 +132,9 @@ class Mask2FormerAttention(_HipModule):
         if channels != self.channels:
             raise ValueError("Input channel size does not match initialized channel size.")
         self._check_device(x)
-        # any channel count up to 256 (the reference takes any, :153-161): widths the kernels are not built for run zero-padded to
-        # the next of 32 / 64 / 128 / 256 (scores scaled by the true 1/sqrt(C), LayerNorm over the true channels)
+        # any channel count (the reference takes any, :153-161): widths the flash-style kernels are not built for run zero-padded to
+        # the next of 32 / 64 / 128 / 256 (scores scaled by the true 1/sqrt(C), LayerNorm over the true channels); above 256 the
+        # generic GEMM path at the next multiple of 32 (ops._WideMaskAttention)
         cw = ops.attn_width(channels)
         y = self.forward_nhwc(ops.to_nhwc(x, self.compute_dtype, cw), scramble=False)    # [B,N,cw] token-major
         if cw != channels:

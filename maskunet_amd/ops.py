@@ -1132,18 +1132,138 @@ ATTN_WIDTHS = (32, 64, 128, 256)
 
 
 def attn_width(channels: int) -> int:
-    """Stored (zero-padded) width the attention kernels run a block of `channels` channels at."""
+    """Stored (zero-padded) width an attention block of `channels` channels runs at: one of the flash-style sweeps' widths up to 256,
+    the next multiple of 32 above (the generic GEMM path, _WideMaskAttention)."""
     for w in ATTN_WIDTHS:
         if channels <= w:
             return w
-    raise RuntimeError(f"maskunet_amd: Mask2FormerAttention supports up to {ATTN_WIDTHS[-1]} channels, got {channels} "
-                       "(INTEGRATION.md section 3)")
+    return pad32(channels)
+
+
+def _gemm_nt(a, a_ld, M, K, w, n_out, out, out_ld, code, bias=None):
+    """out[M, n_out] (rows out_ld apart) = a[M, K] (rows a_ld apart) @ w[n_out, K]^T (+ bias): the 1x1-conv entry point as a plain GEMM."""
+    call("mu_conv_fwd", ptr(a), ptr(w), ptr(bias) if bias is not None else None, ptr(out), 1, 1, M, K, n_out, 1, a_ld, out_ld, code, stream())
+
+
+def _gemm_tn(x, x_ld, dy, dy_ld, M, K, n_out, code):
+    """fp32 [n_out, K] = dy[M, n_out]^T @ x[M, K]: the 1x1 weight-gradient entry point as a plain GEMM."""
+    out = torch.empty((n_out, K), dtype=torch.float32, device=x.device)
+    ws = workspace(_lib.load().mu_conv_wgrad_workspace_bytes(1, 1, M, K, n_out, 1), x.device)
+    call("mu_conv_wgrad", ptr(x), ptr(dy), ptr(out), 1, 1, M, K, n_out, 1, K, n_out, x_ld, dy_ld, ptr(ws), ws.numel(), code, stream())
+    return out
+
+
+def _colsum_wide(t2d):
+    """Column sums of a [M, C] tensor of any width (mu_colsum sweeps up to 1024 columns per call: column blocks of 512 with ld = C)."""
+    M, C = t2d.shape
+    out = torch.empty(C, dtype=torch.float32, device=t2d.device)
+    ws = workspace(_lib.load().mu_colsum_workspace_bytes(512), t2d.device)
+    for c0 in range(0, C, 512):
+        cb = min(512, C - c0)
+        call("mu_colsum", ptr(t2d[:, c0:]), M, cb, C, ptr(out[c0:]), ptr(ws), ws.numel(), dt(t2d), stream())
+    return out
+
+
+class _WideMaskAttention(torch.autograd.Function):
+    """Mask2FormerAttention.forward (ade_semantic.py:163-190) for channel counts above the flash-style sweeps' widths (C > 256): the
+    GENERIC path.  Per image the products run as GEMMs on the 1x1-conv entry points over the kept key rows, with the row kernels of
+    csrc/attn_wide.hip in between; one N x N score tile per image exists at a time (the backward recomputes it).  fp16 or exact fp32
+    (the fp32x mode runs this block in exact fp32).  Off the model's path: generality, not speed."""
+
+    @staticmethod
+    def forward(ctx, x, wq, bq, wk, bk, wv, bv, lnw, lnb, kidx, kcnt, eps, scramble):
+        x = x.contiguous()
+        B, H, W, C = x.shape
+        N = H * W
+        cv = wq.shape[0]
+        if scramble and cv != C:
+            raise RuntimeError("mask_attention: the re-viewed (scrambled) output needs an unpadded channel count")
+        code = _lib.MU_F16 if x.dtype == torch.float16 else _lib.MU_F32
+        pw = lambda w: F.pad(w.detach().float(), (0, C - cv, 0, C - cv))      # noqa: E731
+        pv = lambda v: F.pad(v.detach().float(), (0, C - cv))                # noqa: E731
+        wqkv = torch.cat([pw(wq), pw(wk), pw(wv)], 0).to(x.dtype).contiguous()          # [3C, C]
+        bqkv = torch.cat([pv(bq), pv(bk), pv(bv)]).contiguous()
+        g, b_ = pv(lnw).contiguous(), pv(lnb).contiguous()
+        qkv = torch.empty((B, N, 3 * C), dtype=x.dtype, device=x.device)
+        _gemm_nt(x, C, B * N, C, wqkv, 3 * C, qkv, 3 * C, code, bias=bqkv)
+        nk = pad32(kidx.shape[1])
+        oattn = torch.empty((B, N, C), dtype=x.dtype, device=x.device)
+        S = torch.empty((N, nk), dtype=x.dtype, device=x.device)
+        scale = 1.0 / math.sqrt(cv)
+        for b in range(B):
+            Kg, Vg = _WideMaskAttention._kept(qkv[b], kidx[b], kcnt[b:b + 1], nk, C, code)
+            _gemm_nt(qkv[b], 3 * C, N, C, Kg, nk, S, nk, code)                                       # S = Q Kg^T
+            call("mu_softmax_rows", ptr(S), N, nk, ptr(kcnt[b:b + 1]), scale, code, stream())
+            VgT = _transpose_tokens(Vg.view(1, nk, C), nk, C).view(C, nk)
+            _gemm_nt(S, nk, N, nk, VgT, C, oattn[b], C, code)                                        # O = P Vg
+        out = torch.empty_like(oattn)
+        mean = torch.empty((B, N), dtype=torch.float32, device=x.device)
+        rstd = torch.empty_like(mean)
+        call("mu_ln_rows_fwd", ptr(oattn), ptr(x), ptr(g), ptr(b_), ptr(out), ptr(mean), ptr(rstd), B * N, C, cv, float(eps), code, stream())
+        ctx.save_for_backward(x, qkv, oattn, mean, rstd, g, kidx, kcnt, wqkv)
+        ctx.dims, ctx.cv, ctx.scramble, ctx.code, ctx.nk = (B, H, W, C), cv, scramble, code, nk
+        if scramble:
+            return _transpose_tokens(out.view(B, C, N), C, N).view(B, H, W, C)
+        return out
+
+    @staticmethod
+    def _kept(qkv_b, kidx_b, kcnt_b, nk, C, code):
+        """The kept key / value rows of one image, [nk, C] each, zero rows behind the kept ones."""
+        Kg = torch.empty((nk, C), dtype=qkv_b.dtype, device=qkv_b.device)
+        Vg = torch.empty_like(Kg)
+        call("mu_gather_rows", ptr(qkv_b[:, C:]), 3 * C, ptr(kidx_b), ptr(kcnt_b), ptr(Kg), nk, C, code, stream())
+        call("mu_gather_rows", ptr(qkv_b[:, 2 * C:]), 3 * C, ptr(kidx_b), ptr(kcnt_b), ptr(Vg), nk, C, code, stream())
+        return Kg, Vg
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, gout):
+        x, qkv, oattn, mean, rstd, g, kidx, kcnt, wqkv = ctx.saved_tensors
+        B, H, W, C = ctx.dims
+        N, cv, code, nk = H * W, ctx.cv, ctx.code, ctx.nk
+        gout = gout.contiguous()
+        if ctx.scramble:
+            gout = _transpose_tokens(gout.view(B, N, C), N, C)
+        dY = torch.empty((B, N, C), dtype=x.dtype, device=x.device)
+        gxh = torch.empty_like(dY)
+        call("mu_ln_rows_bwd", ptr(gout), ptr(oattn), ptr(x), ptr(mean), ptr(rstd), ptr(g), ptr(dY), ptr(gxh), B * N, C, cv, code, stream())
+        dg, db = _colsum_wide(gxh.view(B * N, C)), _colsum_wide(gout.view(B * N, C))
+        dqkv = torch.zeros((B, N, 3 * C), dtype=x.dtype, device=x.device)              # masked keys: zero dK / dV rows
+        S = torch.empty((N, nk), dtype=x.dtype, device=x.device)
+        dP = torch.empty_like(S)
+        scale = 1.0 / math.sqrt(cv)
+        for b in range(B):
+            cnt = kcnt[b:b + 1]
+            Kg, Vg = _WideMaskAttention._kept(qkv[b], kidx[b], cnt, nk, C, code)
+            _gemm_nt(qkv[b], 3 * C, N, C, Kg, nk, S, nk, code)
+            call("mu_softmax_rows", ptr(S), N, nk, ptr(cnt), scale, code, stream())                   # P again
+            _gemm_nt(dY[b], C, N, C, Vg, nk, dP, nk, code)                                           # dP = dO Vg^T
+            dVg = _gemm_tn(dY[b], C, S, nk, N, C, nk, code)                                          # dVg = P^T dO
+            call("mu_attn_wide_ds", ptr(S), ptr(dP), N, nk, ptr(cnt), scale, code, stream())          # dP <- dS
+            KgT = _transpose_tokens(Kg.view(1, nk, C), nk, C).view(C, nk)
+            _gemm_nt(dP, nk, N, nk, KgT, C, dqkv[b], 3 * C, code)                                    # dQ = dS Kg
+            dKg = _gemm_tn(qkv[b], 3 * C, dP, nk, N, C, nk, code)                                    # dKg = dS^T Q
+            call("mu_scatter_rows", ptr(dKg), ptr(kidx[b]), ptr(cnt), ptr(dqkv[b][:, C:]), 3 * C, N, C, code, stream())
+            call("mu_scatter_rows", ptr(dVg), ptr(kidx[b]), ptr(cnt), ptr(dqkv[b][:, 2 * C:]), 3 * C, N, C, code, stream())
+        gx = None
+        if ctx.needs_input_grad[0]:
+            wT = _transpose_tokens(wqkv.view(1, 3 * C, C), 3 * C, C).view(C, 3 * C)
+            gx = torch.empty((B, H, W, C), dtype=x.dtype, device=x.device)
+            _gemm_nt(dqkv, 3 * C, B * N, 3 * C, wT, C, gx, C, code)
+            call("mu_add", ptr(gx), ptr(dY), ptr(gx), gx.numel(), dt(gx), stream())
+        gw = _gemm_tn(x, C, dqkv, 3 * C, B * N, C, 3 * C, code)                                      # [3C, C]
+        gb = _colsum_wide(dqkv.view(B * N, 3 * C))
+        return (gx, gw[:cv, :cv], gb[:cv], gw[C:C + cv, :cv], gb[C:C + cv], gw[2 * C:2 * C + cv, :cv], gb[2 * C:2 * C + cv],
+                dg[:cv], db[:cv], None, None, None, None)
 
 
 def mask_attention(x, q, k, v, norm, kidx, kcnt, scramble=True, kidx_perm=False):
     """q,k,v: nn.Linear containers; norm: nn.LayerNorm([C]) container.  kidx [B, nkmax] int32 lists the visible keys of image b in
     kidx[b, :kcnt[b]].  kidx_perm=True promises that nkmax == N and every row is a whole permutation of 0..N-1 with the masked keys
     behind the visible ones (compact_keys() output); leave it False for index lists from anywhere else."""
+    if x.shape[-1] > ATTN_WIDTHS[-1]:            # wider than the flash-style sweeps: the generic GEMM path
+        return _WideMaskAttention.apply(x, q.weight, q.bias, k.weight, k.bias, v.weight, v.bias, norm.weight, norm.bias, kidx, kcnt,
+                                        norm.eps, scramble)
     return _MaskAttention.apply(x, q.weight, q.bias, k.weight, k.bias, v.weight, v.bias, norm.weight, norm.bias, kidx, kcnt,
                                 norm.eps, scramble, _cache_ok(), kidx_perm)
 

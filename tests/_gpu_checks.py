@@ -1183,7 +1183,7 @@ def check_attention_no_visible_key(dtype):
     the dead image in the batch)."""
     import maskunet_amd
     res = []
-    for C, hw in ((64, 16), (128, 8), (256, 8), (32, 8)):
+    for C, hw in ((64, 16), (128, 8), (256, 8), (32, 8), (288, 8)):      # 288: the generic path above 256 channels
         torch.manual_seed(C)
         m = maskunet_amd.Mask2FormerAttention(C, C).to(DEV).set_compute_dtype(dtype)
         N = hw * hw

@@ -144,6 +144,20 @@ def generality_cases(ns):
         run_module_case(f"down_16_32_odd13x9_{'train' if tr else 'eval'}", ns["DownSample"](16, 32), [rnd(2, 16, 13, 9)], tr, weights_seed=73)
 
 
+def wide_cases(ns):
+    """Round 5: Mask2FormerAttention above 256 channels (the generic GEMM path of the HIP build; the reference takes any `channels`,
+    ade_semantic.py:153-161) -- 300 channels (runs zero-padded to 320; multiples of 32 are covered against the oracle in
+    tests/test_gpu_kernels.py).  Own rng."""
+    r = np.random.default_rng(90)
+
+    def rnd(*s):
+        return torch.from_numpy(r.standard_normal(s).astype(np.float32))
+
+    r.integers(0, 2, size=(2, 64)); rnd(2, 320, 8, 8)        # (a 320-channel case was drawn here first: keep the stream of the next one)
+    kb = torch.from_numpy(r.integers(0, 2, size=(1, 6 * 10)).astype(np.uint8))
+    run_module_case("attn_300_6x10", ns["Mask2FormerAttention"](300, 300), [rnd(1, 300, 6, 10)], True, keep=kb, weights_seed=92)
+
+
 def unet_case(name, UNet, c_out, B, training, three_head, seed):
     torch.manual_seed(0)
     model = UNet(3, c_out, 16) if three_head else UNet(3, c_out)
@@ -198,8 +212,12 @@ def main():
     if "--generality-only" in sys.argv:        # (re)write only the round-4 cases
         generality_cases(ns1)
         return
+    if "--wide-only" in sys.argv:              # (re)write only the round-5 wide-attention cases
+        wide_cases(ns1)
+        return
     module_cases(ns1)
     generality_cases(ns1)
+    wide_cases(ns1)
     unet_case("unet1_c150_b2_train", ns1["UNet"], 150, 2, True, False, 100)
     unet_case("unet1_c150_b2_eval", ns1["UNet"], 150, 2, False, False, 100)
     # B=2, not 1: torch 2.10 CPU returns wrong BatchNorm grads at B=1 when grad_out arrives with

@@ -71,11 +71,12 @@ def test_attention_any_channel_count(dtype):
     _assert_all(G.check_attention(dtype, cases=[(2, 8, 8, 24), (2, 8, 12, 48), (1, 12, 12, 96), (1, 8, 8, 200), (1, 16, 4, 130)]))
 
 
-def test_attention_rejects_more_than_256_channels():
-    import maskunet_amd
-    m = maskunet_amd.Mask2FormerAttention(320, 8).cuda()
-    with pytest.raises(RuntimeError, match="up to 256 channels"):
-        m(torch.zeros(1, 320, 4, 4, device="cuda"))
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float16], ids=["fp32", "fp16"])
+def test_attention_above_256_channels_generic_path(dtype):
+    """Mask2FormerAttention(channels > 256): the generic GEMM path (ops._WideMaskAttention, csrc/attn_wide.hip) against the CPU oracle,
+    forward + every gradient -- 288 and 512 channels, a channel count that is no multiple of 32, a batch-1 image, odd token counts."""
+    from tests import _gpu_checks as G
+    _assert_all(G.check_attention(dtype, cases=[(2, 8, 8, 288), (1, 6, 10, 300), (2, 4, 4, 512), (1, 16, 8, 320)]))
 
 
 @pytest.mark.parametrize("dtype", DTYPES)

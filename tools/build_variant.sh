@@ -8,7 +8,7 @@ ROOT=$(cd "$(dirname "$0")/.." && pwd)
 SRC=${MU_SRC:-$ROOT/maskunet_amd/csrc}      # MU_SRC=<dir> builds another checkout's sources (e.g. a git worktree of HEAD)
 OUT=$ROOT/gpurun_variants
 mkdir -p $OUT/obj_$NAME
-for f in elementwise norm conv attn loss probe version; do
+for f in elementwise norm conv attn attn_wide loss probe version; do
   FL=""; [ $f = attn ] && FL="-fno-slp-vectorize"      # as the Makefile builds attn.hip (FLAGS_attn)
   [ $f = conv ] && [ -z "$MU_CONV_SLP" ] && FL="-fno-slp-vectorize"      # FLAGS_conv (MU_CONV_SLP=1: the former build)
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -fPIC -std=c++17 -Wno-unused-value -Wno-pass-failed $FL $EXTRA -c $SRC/$f.hip -o $OUT/obj_$NAME/$f.o &
