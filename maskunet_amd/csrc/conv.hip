@@ -3326,16 +3326,20 @@ __global__ __launch_bounds__(256, 3) void wgrad_rgb2_kernel(const h16* __restric
 // Nine taps per block for the 64-channel-wide 3x3 layers (fp16, W % 32 == 0, W <= 128; round 5).  The three-taps-per-block ring kernel
 // above gives a 64 x 64 channel tile 48 MFMAs per 32-pixel stage behind a full set of LDS-DMAs and a block barrier (MFMA pipe 24 % busy
 // on these layers).  Here a block owns a band of consecutive image rows of ONE 64 x 64 channel tile and all nine taps: the dy row and a
-// 4-slot ring of input rows sit in LDS as plain padded pixel rows (144 bytes: the four pixel rows of a transposing read on disjoint
-// banks), both MFMA operands come from ds_read_b64_tr_b16, and a tap is nothing but a pixel offset into the ring (rows outside the
+// 4-slot ring of input rows sit in LDS as plain padded pixel rows (160 bytes: the eight pixel rows a 32-lane half of a transposing read
+// touches on disjoint banks -- 144 bytes measured 44 % of the LDS cycles as conflicts, 160: 5 %, at equal time), both MFMA operands come
+// from ds_read_b64_tr_b16, and a tap is nothing but a pixel offset into the ring (rows outside the
 // image: a zero row).  Wave w owns the 16 input channels 16 w .. 16 w + 15 for all taps and all 64 output channels: 8 + 18 fragment
-// reads and 36 MFMAs per 32 pixels, 144 accumulators, no cross-wave fold.  dy and x are read from HBM once per channel tile.
+// reads and 36 MFMAs per 32 pixels, 144 accumulators, no cross-wave fold; 145 KB of LDS at W = 128.  dy and x are read from HBM once per channel tile.
 // Slab layout [band][tap][Cout][Cin] = the ring kernel's, same deterministic reduce.
 // ------------------------------------------------------------------------------------------
 #ifndef MU_WG9
 #define MU_WG9 1
 #endif
-#define MU_WG9_S 72            // halves per staged pixel row (64 channels + 8 pad = 144 bytes)
+#ifndef MU_WG9_S
+#define MU_WG9_S 80            // halves per staged pixel row: 64 channels + 16 pad = 160 bytes = 32 x 5 -- the 8 pixel rows a 32-lane half of a transposing
+#endif                         // read touches (4 pieces of 8 bytes each) then start on 8 distinct multiples of 32 bytes modulo the 256-byte bank row
+
 #ifndef MU_WG9_BLOCKS
 #define MU_WG9_BLOCKS 256
 #endif
@@ -3355,7 +3359,7 @@ template <int NPT>             // NPT = W / 32
 __global__ __launch_bounds__(256, 1) void conv_wgrad9_kernel(const h16* __restrict__ x, const h16* __restrict__ dy, float* __restrict__ part,
                                                           int B, int H, int W, int Cin, int Cout, long x_ld, long dy_ld, int rows_per_blk) {
     constexpr int WC = 32 * NPT;                               // == W (the launch picks NPT = W / 32)
-    __shared__ __attribute__((aligned(16))) h16 wg9_lds[(2 * WC + 5 * (WC + 2)) * MU_WG9_S];      // 130 KB at W = 128
+    __shared__ __attribute__((aligned(16))) h16 wg9_lds[(2 * WC + 5 * (WC + 2)) * MU_WG9_S];      // 145 KB at W = 128
     const int xw = W + 2;
     h16* dys = wg9_lds;                                        // [2][W][72]
     h16* xs = dys + 2 * W * MU_WG9_S;                          // [4][W + 2][72] ring (columns 0 and W + 1 stay zero) | [W + 2][72] zeros
