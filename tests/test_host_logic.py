@@ -263,3 +263,23 @@ def test_data_parallel_buckets_end_with_a_small_tail_bucket():
     assert any(p is m.initial_conv.conv_block[0].weight for p in dp.buckets[-1].params)
     one = maskunet_amd.DataParallel(maskunet_amd.UNet(3, 150), tail_mb=0.0)       # tail_mb = 0: the plain size-capped split
     assert len(one.buckets) == len(dp.buckets) - 1
+
+
+def test_wgrad_workspace_covers_the_row_band_kernels():
+    """mu_conv_wgrad_workspace_bytes (host-only) must reserve the slabs of the nine-taps-per-block kernels: up to 256 bands per channel-tile
+    grid (256 / ((Cin/64)(Cout/64)) bands of [9][Cout][Cin] floats), for the fp16 layers those kernels serve."""
+    from maskunet_amd import _lib
+    lib = _lib.load()
+    B = 64
+    for H, Cin, Cout in [(128, 64, 64), (128, 128, 64), (64, 64, 64), (64, 64, 128), (64, 128, 64), (32, 128, 128),
+                         (16, 256, 256), (16, 512, 512), (16, 256, 512)]:
+        tiles = (Cin // 64) * (Cout // 64)
+        rows = B * H
+        want = max(1, min(256 // tiles, rows))
+        rpb = -(-rows // want)
+        if H == 16:
+            rpb = (rpb + 1) // 2 * 2
+        nb = -(-rows // rpb)
+        need = nb * 9 * Cout * Cin * 4
+        got = lib.mu_conv_wgrad_workspace_bytes(B, H, H, Cin, Cout, 9)
+        assert got >= need, (H, Cin, Cout, got, need)
