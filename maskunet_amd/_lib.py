@@ -133,15 +133,23 @@ def dt(t_or_dtype) -> int:
 
 # fp32 compute: how the MATRIX products run (conv / Linear / attention; everything else is plain fp32 either way).
 #   "highest": exact-fp32 MFMA (v_mfma_f32_16x16x4_f32, 157 TF/s peak) -- bit-level fp32 FMA chains, the parity path;
-#   "high":    MU_F32X -- every fp32 operand split into bf16 hi + lo, three bf16 MFMAs per product, fp32 accumulate (~1e-5
-#              relative per product, unbiased): the scheme torch.set_float32_matmul_precision("high") names, ~2.5x faster.
+#   "high":    MU_F32X -- fp32 storage, matrix products on the 16-bit matrix cores with split operands, ~3x faster:
+#              * conv / Linear forward: every operand as bf16 hi + lo, three bf16 MFMAs per product, fp32 accumulate (~1e-5 relative
+#                per product, unbiased) -- the scheme torch.set_float32_matmul_precision("high") names;
+#              * attention: q / k / v / dY as fp16 hi + lo pairs, the softmax probabilities P and dS as ONE fp16 operand straight from
+#                the accumulators (2^-12 relative per element) under exact power-of-two range scales: two MFMAs per P / dS product;
+#              * 3x3 conv backward (round 6): dy as ONE power-of-two-scaled fp16 operand against an fp16 hi + lo partner (weights for
+#                the data gradient, the saved input for the weight gradient): two MFMAs per product.
+#              Outputs stay within north_star's 1e-3 of the reference, gradients within the fp32 gates of tests/_gpu_checks.py.
 F32_MATMUL_PRECISION = os.environ.get("MU_F32_MATMUL", "highest")
 if F32_MATMUL_PRECISION not in ("highest", "high"):
     raise ValueError(f'MU_F32_MATMUL must be "highest" or "high", got {F32_MATMUL_PRECISION!r}')
 
 
 def set_float32_matmul_precision(precision: str):
-    """Process-wide, like torch.set_float32_matmul_precision: "highest" (default) or "high" (see above).  fp16 compute is unaffected."""
+    """Process-wide, like torch.set_float32_matmul_precision: "highest" (default: exact-fp32 MFMA) or "high" (MU_F32X: fp32 storage, split
+    16-bit operands on the matrix cores -- three bf16 terms per forward product, single-term fp16 P / dS / dy with fp16-pair partners in
+    attention and the 3x3 backward; see the comment above F32_MATMUL_PRECISION).  fp16 compute is unaffected."""
     global F32_MATMUL_PRECISION
     if precision not in ("highest", "high"):
         raise ValueError('precision must be "highest" or "high"')

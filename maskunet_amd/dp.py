@@ -59,6 +59,7 @@ class _Bucket:
         self.views = {}                 # id(p) -> its slice of `arena`, shaped like p
         self.live: List[nn.Parameter] = []
         self.in_place = False           # this step's reduce runs on `arena` itself
+        self.held = []                  # (parameter, the gradient tensor it held before the in-place reduce rebound p.grad to its slice)
 
 
 class DataParallel(nn.Module):
@@ -151,12 +152,14 @@ class DataParallel(nn.Module):
         return self.module(*args, **kwargs)
 
     def _arm(self):
+        from . import ops
+        ops.GRAD_HANDED.clear()         # a new step: every slice may be handed to ONE gradient kernel again (ops.grad_out)
         dead = self._dead or ()
         if self.multi and self._use_arena and self._dead is not None and self._arena_dead != self._dead:
             self._build_arena()
         for b in self.buckets:
             b.pending = sum(1 for p in b.params if id(p) not in dead)
-            b.flat, b.work, b.included, b.in_place = None, None, [], False
+            b.flat, b.work, b.included, b.in_place, b.held = None, None, [], False, []
         self._armed = self._sync
 
     def _build_arena(self):
@@ -167,6 +170,13 @@ class DataParallel(nn.Module):
         for b in self.buckets:
             b.live = [p for p in b.params if id(p) not in self._dead]
             if not b.live:
+                continue
+            # the slices are fp32 views that become p.grad: a parameter of another dtype cannot adopt one (autograd refuses a
+            # gradient whose dtype differs from the parameter's), nor one on another device -- such a bucket keeps the flatten /
+            # write-back path of _reduce / _write_back, which converts on the way in and copies back on the way out
+            dev0 = b.live[0].device
+            if any(p.dtype != torch.float32 or p.device != dev0 for p in b.live):
+                b.live = []
                 continue
             b.arena = torch.zeros(sum(p.numel() for p in b.live), dtype=torch.float32, device=b.live[0].device)
             off = 0
@@ -275,11 +285,13 @@ class DataParallel(nn.Module):
         autograd accumulated elsewhere) are moved in by one multi-tensor copy, and p.grad becomes the slice."""
         dev = b.arena.device
         src, dst = [], []
+        b.held = []
         for p in b.live:
             v = b.views[id(p)]
             if p.grad.data_ptr() != v.data_ptr():
-                src.append(p.grad.reshape(v.shape) if p.grad.dtype == torch.float32 else p.grad.float().reshape(v.shape))
+                src.append(p.grad.reshape(v.shape))
                 dst.append(v)
+                b.held.append((p, p.grad))
         op = dist.ReduceOp.AVG if (self._avg and dev.type == "cuda") else dist.ReduceOp.SUM
         if dev.type == "cuda":
             comm = self._comm(dev)
@@ -302,13 +314,21 @@ class DataParallel(nn.Module):
             p.grad = b.views[id(p)]
         return b.arena, work
 
-    def _finish_in_place(self, b: _Bucket):
+    def _finish_in_place(self, b: _Bucket, copy_back=False):
         dev = b.arena.device
         ctx = torch.cuda.stream(self._comm(dev)) if dev.type == "cuda" else contextlib.nullcontext()
         with ctx:
             b.work.wait()                   # with the comm stream current (see _write_back)
             if not (self._avg and dev.type == "cuda"):
                 b.arena.div_(self.world)
+            if copy_back and b.held:
+                # the caller holds these gradient tensors (pre-allocated buffers, a graph's outputs, flat-optimiser views): the averaged
+                # values go back INTO them and p.grad stays bound to them; gradients the kernels wrote into their slices have no
+                # other tensor to go back to -- there p.grad is the slice
+                torch._foreach_copy_([g for _, g in b.held], [b.views[id(p)].view_as(g) for p, g in b.held])
+                for p, g in b.held:
+                    p.grad = g
+        b.held = []
 
     def _write_back(self, params, flat, work, copy_back=False):
         dev = flat.device
@@ -344,7 +364,10 @@ class DataParallel(nn.Module):
         ALIASING (default, ``copy_back=False``): ``p.grad`` is REBOUND to a view of the bucket.  A reference taken to the previous
         ``p.grad`` tensor before this call (a user-held gradient list, a flat-gradient optimiser's views, pre-allocated gradient
         buffers) keeps the LOCAL, un-averaged gradient -- read gradients through ``p.grad`` after this call, or pass
-        ``copy_back=True`` to have the averaged values written into the tensors you already hold.  Each ``p.grad`` also keeps its
+        ``copy_back=True`` to have the averaged values written into the tensors you already hold (this holds for the zero-copy
+        buckets too: a gradient that was NOT already its arena slice when the bucket was launched is copied back into the tensor
+        that held it and ``p.grad`` stays bound to that tensor; a gradient the kernels wrote straight into the slice has no other
+        home and stays the slice).  Each ``p.grad`` also keeps its
         whole bucket (``bucket_mb``) alive until it is released (``zero_grad(set_to_none=True)``).
         Buckets whose hooks did not all fire (parameters without gradients this step) are reduced here with what they have."""
         if not self.multi or not self._sync:
@@ -356,7 +379,7 @@ class DataParallel(nn.Module):
         late = []
         for b in self.buckets:
             if b.work is not None and b.in_place:
-                self._finish_in_place(b)    # p.grad already IS the reduced slice: nothing to hand back, whatever `copy_back` says
+                self._finish_in_place(b, copy_back)
             elif b.work is not None:
                 self._write_back(b.included, b.flat, b.work, copy_back)
             inc = {id(p) for p in b.included}

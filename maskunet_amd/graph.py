@@ -64,7 +64,18 @@ class GraphedStep:
             # collectives (hipEventQuery) at any time; under the default "global" capture mode that call from ANOTHER thread is an
             # error ("operation not permitted when stream is capturing") and takes the process down
             if self.dp is not None and self.dp.multi and segments >= 2:
-                self._capture_segmented()
+                try:
+                    self._capture_segmented()
+                except Exception as e:              # noqa: BLE001 -- fall back to ONE graph + the exchange behind it (segments=1)
+                    import warnings
+                    warnings.warn(f"GraphedStep: segmented capture failed ({e!r}); capturing the step as one graph, the gradient "
+                                  "exchange then runs after the replay without overlap")
+                    torch.cuda.synchronize(dev)
+                    self.graph, self.graph2, self._seg1 = torch.cuda.CUDAGraph(), None, set()
+                    ops.CUT_HOOK = None
+                    with torch.cuda.graph(self.graph, capture_error_mode="thread_local"):
+                        self.step_counter.add_(1)
+                        self.loss, self.outputs = self._body()
             else:
                 with torch.cuda.graph(self.graph, capture_error_mode="thread_local"):
                     self.step_counter.add_(1)
@@ -81,14 +92,15 @@ class GraphedStep:
         import gc
         dev = self.inputs.device
         g1, g2 = self.graph, torch.cuda.CUDAGraph()
-        state = {"cut": False, "fired": set()}
+        state = {"cut": False, "ended1": False, "fired": set()}
 
         def cut(_grad):
-            if not state["cut"]:
-                state["cut"] = True
+            if not state["cut"] and not state["ended1"]:
                 self._seg1 = set(state["fired"])
                 g1.capture_end()
+                state["ended1"] = True                   # from here on g1 must not be ended again
                 g2.capture_begin(pool=g1.pool(), capture_error_mode="relaxed")
+                state["cut"] = True                      # only now is g2 the capture to end
             return None
 
         torch.cuda.synchronize(dev)
@@ -100,14 +112,28 @@ class GraphedStep:
         self._leaf_fired = state["fired"]
         with torch.cuda.stream(cap):
             # "relaxed": the hook runs on the autograd engine's device thread, and a capture begun in the stricter modes may only be
-            # ended by the thread that began it (relaxed also tolerates the RCCL watchdog's event queries, see above)
+            # ended by the thread that began it (relaxed also tolerates the RCCL watchdog's event queries, see above).  The price:
+            # relaxed mode switches OFF the runtime's capture safety checks -- an allocation or a synchronising call made by any
+            # thread while the capture runs is no longer rejected -- so nothing else may touch the device during construction.
             g1.capture_begin(capture_error_mode="relaxed")
+            err = None
             try:
                 self.step_counter.add_(1)
                 self.loss, self.outputs = self._body()
+            except BaseException as e:                   # keep the ORIGINAL error: ending an invalidated capture raises its own
+                err = e
             finally:
                 ops.CUT_HOOK = None
-                (g2 if state["cut"] else g1).capture_end()
+                try:
+                    if state["cut"]:
+                        g2.capture_end()
+                    elif not state["ended1"]:
+                        g1.capture_end()
+                except Exception:
+                    if err is None:
+                        raise
+            if err is not None:
+                raise err
         torch.cuda.current_stream(dev).wait_stream(cap)
         self._leaf_fired = None
         if state["cut"]:
@@ -125,6 +151,7 @@ class GraphedStep:
                 fresh[n].register_hook(lambda g, k=id(p): fired.add(k))
         # DataParallel's gradient arena is keyed on the parameters; the kernels here see the fresh leaves: register them for the call
         arena_keys = []
+        ops.GRAD_HANDED.clear()
         if self.dp is not None and ops.GRAD_ARENA is not None:
             for n, p in zip(self.names, self.params):
                 v = self.dp.gradient_slice(p)
@@ -160,7 +187,10 @@ class GraphedStep:
                 # the comm stream WHILE the second segment -- the encoder's backward -- replays on this one
                 self.dp.launch_complete_buckets(self._seg1)
                 self.graph2.replay()
-            self.dp.finish_gradient_sync(copy_back=True)      # the rest; p.grad = the reduced bucket slices
+            # the rest.  No copy back: the large gradients ARE their bucket slices (the captured kernels wrote there), the small ones
+            # are moved into theirs by the exchange, and p.grad is rebound to the reduced slice -- the graph's own tensors are
+            # re-attached (and overwritten) by the next replay anyway
+            self.dp.finish_gradient_sync()
         elif self.graph2 is not None:
             self.graph2.replay()
         return self.loss.clone()                      # self.loss is overwritten by the next replay

@@ -406,15 +406,23 @@ def cut_point(t):
 # as p.grad (no copy while p.grad is None), and the bucket is all-reduced IN PLACE: no flattening torch.cat, no write-back.  Only while
 # p.grad is None: an existing gradient (accumulation over micro-batches) is added to by autograd as always.
 GRAD_ARENA = None
+# Slices handed out since the current step was armed (DataParallel._arm / GraphedStep._body clear it), by address.  A parameter that
+# feeds TWO autograd nodes of one backward pass (tied weights, a module applied twice) asks twice while p.grad is still None: the
+# second kernel would overwrite the first one's result and the engine would then add two aliases of the same memory (2 x the last
+# contribution instead of g1 + g2) -- the second request gets a fresh tensor and autograd sums the two as always.
+# A slice is rewritten by the NEXT step's backward: a reference to p.grad held across steps sees the new values (like a graph's
+# static gradient tensors); clone what must outlive the step.
+GRAD_HANDED = set()
 
 
 def grad_out(param, shape, device):
-    """Destination for the gradient of `param`: its arena slice (viewed as `shape`) when one is registered and p.grad is None, else a
-    fresh fp32 tensor."""
+    """Destination for the gradient of `param`: its arena slice (viewed as `shape`) when one is registered, p.grad is None and the slice
+    has not been handed out in this step yet, else a fresh fp32 tensor."""
     a = GRAD_ARENA
     if a is not None and param is not None and getattr(param, "grad", None) is None:
         v = a.get(id(param))
-        if v is not None and v.device == device and v.numel() == math.prod(shape):
+        if v is not None and v.device == device and v.numel() == math.prod(shape) and v.data_ptr() not in GRAD_HANDED:
+            GRAD_HANDED.add(v.data_ptr())
             return v.view(shape)
     return torch.empty(shape, dtype=torch.float32, device=device)
 

@@ -181,3 +181,83 @@ def test_force_sync_runs_the_exchange_in_a_group_of_one_rank():
     p.start()
     p.join(120)
     assert q.get(timeout=5) == "ok"
+
+
+def _advice_r5_worker(rank, world, port, q):
+    """(1) a half / bf16 model through the arena-enabled wrapper, (2) copy_back=True with caller-held gradient tensors on the
+    zero-copy buckets, (3) a parameter feeding two autograd nodes of one backward pass must not get its slice twice."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import torch.nn as nn
+        from maskunet_amd import ops
+        # (1) bf16 parameters: their gradients cannot be fp32 arena views -- such buckets keep the flatten / write-back path
+        torch.manual_seed(7)
+        mixed = nn.Sequential(nn.Linear(8, 16), nn.Linear(16, 4).to(torch.bfloat16))
+        ddp = DataParallel(mixed, bucket_mb=1e-4)                      # one parameter per bucket
+        for step in range(4):
+            mixed.zero_grad(set_to_none=True)
+            x = torch.full((3, 8), float(rank + 1))
+            y = mixed[1](mixed[0](x).to(torch.bfloat16)).float().sum()
+            ddp._arm()
+            y.backward()
+            ddp.finish_gradient_sync()
+            for p in mixed.parameters():
+                assert p.grad is not None and p.grad.dtype == p.dtype
+                g = p.grad.float().clone()
+                dist.all_reduce(g)
+                assert torch.allclose(g / world, p.grad.float(), rtol=1e-2), "ranks disagree on the averaged gradient"
+        assert all(ddp.gradient_slice(p) is None for p in mixed[1].parameters())          # bf16: no slice
+        assert all(ddp.gradient_slice(p) is not None for p in mixed[0].parameters())      # fp32: zero-copy
+        ddp.close()
+        # (2) copy_back=True: the averaged values land in the tensors the caller holds, p.grad stays bound to them
+        lin = nn.Linear(6, 5)
+        ddp = DataParallel(lin, bucket_mb=1e-4)
+        held = {n: torch.zeros_like(p) for n, p in lin.named_parameters()}
+        for step in range(3):
+            ddp._arm()
+            for n, p in lin.named_parameters():
+                held[n].fill_(float(rank + 1) * (step + 1))
+                p.grad = held[n]
+                ddp._on_grad(p)
+            ddp.finish_gradient_sync(copy_back=True)
+            for n, p in lin.named_parameters():
+                assert p.grad is held[n], (step, n)
+                assert torch.equal(held[n], torch.full_like(held[n], 1.5 * (step + 1))), (step, n, held[n].flatten()[:2])
+        ddp.close()
+        # (3) one slice per parameter per step from ops.grad_out
+        lin = nn.Linear(4, 4)
+        ddp = DataParallel(lin, bucket_mb=1.0)
+        ddp._arm()
+        for p in lin.parameters():
+            p.grad = torch.ones_like(p)
+            ddp._on_grad(p)
+        ddp.finish_gradient_sync()                                      # the arena exists from the next _arm on
+        lin.zero_grad(set_to_none=True)
+        ddp._arm()
+        w = lin.weight
+        a = ops.grad_out(w, tuple(w.shape), w.device)
+        b = ops.grad_out(w, tuple(w.shape), w.device)                  # the second autograd node of the same backward pass
+        assert a.data_ptr() == ddp.gradient_slice(w).data_ptr() and b.data_ptr() != a.data_ptr()
+        ddp._arm()                                                      # the next step: the slice is available again
+        assert ops.grad_out(w, tuple(w.shape), w.device).data_ptr() == a.data_ptr()
+        ddp.close()
+        q.put((rank, "ok"))
+    except Exception as e:  # pragma: no cover
+        import traceback
+        q.put((rank, traceback.format_exc()))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_mixed_dtype_buckets_copy_back_and_one_slice_per_step():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_advice_r5_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=180) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    assert sorted(res) == [(0, "ok"), (1, "ok")], res
