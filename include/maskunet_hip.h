@@ -33,19 +33,26 @@ extern "C" {
 
 #define MU_F32 0
 #define MU_F16 1
-/* fp32 storage, matrix products as three 16-bit MFMAs on (hi, lo) splits of the fp32 operands, fp32 accumulate (~1e-5 relative per
- * product; torch's float32_matmul_precision "high").  Accepted by the matrix entry points (mu_conv_fwd, mu_conv_fwd_fused,
+/* fp32 storage, matrix products on the 16-bit matrix cores with (hi, lo) splits of the fp32 operands, fp32 accumulate (~1e-5 relative per
+ * product or better; torch's float32_matmul_precision "high").  Accepted by the matrix entry points (mu_conv_fwd, mu_conv_fwd_fused,
  * mu_conv1x1_fwd_add, mu_conv_wgrad, mu_attn_*); every other entry point takes MU_F32 for the same tensors.
  * With MU_F32X the MATRIX OPERANDS of those entry points are passed ENCODED (same size, same strides; the split then costs one pass per
  * tensor instead of VALU work per fragment per wave):
- *   - x and w of the convolutions, x and dy of the weight gradient: every aligned 16-byte chunk of four fp32 values re-written as
- *     [4 x bf16 hi | 4 x bf16 lo] by mu_split_encode;
+ *   - 1x1 layers / Linear (taps = 1) -- x and w of the convolutions, x and dy of the weight gradient: every aligned 16-byte chunk of four
+ *     fp32 values re-written as [4 x bf16 hi | 4 x bf16 lo] by mu_split_encode; three bf16 MFMAs per product;
+ *   - 3x3 layers (taps = 9; round 6) -- x and w of mu_conv_fwd / mu_conv_fwd_stats / mu_conv_fwd_fused: every aligned 16-byte chunk
+ *     re-written as [4 x fp16 hi | 4 x fp16 lo] by mu_split_encode_h4 (|value| < 65504; 22 mantissa bits down to an absolute floor of
+ *     2^-25), the weights under a static shift of 2^6 that the epilogues undo (mu_prep_weight / mu_prep_weights_multi with MU_F32X
+ *     write every layer's layouts in the right encoding); three fp16 MFMAs per product.  Their BACKWARD has its own entry points:
+ *     mu_conv_dgrad_h / mu_conv_wgrad_h take dy as ONE power-of-two-scaled fp16 operand (mu_bn_act_bwd_h, mu_bn_pair_bwd_h or
+ *     mu_dy_encode_h) against the fp16 pair of the partner: two MFMAs per product.  mu_conv_wgrad with taps = 9 and MU_F32X serves
+ *     only the <= 3-channel first layer (a plain-FMA kernel on plain fp32 operands);
  *   - qkv of the attention sweeps (mu_attn_*): every aligned 32-byte group of eight fp32 values re-written as
  *     [8 x fp16 hi | 8 x fp16 lo] by mu_split_encode_h (|value| < 65504; the softmax probabilities and dS then enter the matrix core as
  *     single fp16 operands: two MFMAs per P V / dS K / dS^T Q / P^T dO product, three for Q K^T and dO V^T).
- * Outputs, biases, residual / addend tensors, x / oattn / grad_out / dY of the attention block are plain fp32.  Two producers can write the encoded form directly and save the mu_split_encode pass: mu_bn_act_fwd with MU_F32X writes
- * y encoded (for a y that only feeds a convolution), mu_bn_act_bwd / mu_bn_act_bwd_scaled with MU_F32X write dx encoded (dx of a BatchNorm
- * is the dy of the convolution in front of it); their inputs, dres and all statistics stay plain fp32. */
+ * Outputs, biases, residual / addend tensors, x / oattn / grad_out / dY of the attention block are plain fp32.  Producers that write an encoded form directly and save the encoding pass: mu_bn_act_fwd with MU_F32X writes
+ * y in the 3x3 operand encoding (for a y that only feeds a 3x3 convolution), mu_bn_act_bwd_h / mu_bn_pair_bwd_h write dx as the scaled fp16
+ * dy of the 3x3 convolution in front of the BatchNorm; their inputs, dres and all statistics stay plain fp32. */
 #define MU_F32X 2
 
 #define MU_ACT_NONE 0
@@ -68,6 +75,15 @@ int mu_transpose_pad(const void* src, int src_dtype, long src_ld, void* dst, int
 /* fp32x operand encoding (see MU_F32X): n_elems fp32 values (a multiple of 4, 16-byte aligned, contiguous rows) -> the chunk-encoded
  * operand; dst may be src (in place). */
 int mu_split_encode(const void* src, void* dst, long n_elems, void* stream);
+/* fp32x 3x3-CONVOLUTION operand encoding (see MU_F32X): n_elems fp32 values (a multiple of 4, 16-byte aligned, contiguous rows) ->
+ * [4 fp16 hi | 4 fp16 lo] per chunk of four, hi = fp16(x), lo = fp16(x - hi); dst may be src (in place).  The input of a 3x3 layer
+ * (nn.Conv2d k = 3 in ConvBlock, ade_semantic.py:199,202) that no producer wrote encoded. */
+int mu_split_encode_h4(const void* src, void* dst, long n_elems, void* stream);
+/* A plain fp32 gradient (n_elems values, a multiple of 4) -> ONE power-of-two-scaled fp16 operand dy_h (n_elems halves; must not alias
+ * dy) + dy_scale = {S, 1 / S} on the device (S max|dy| in [2^13, 2^14); no host sync): the dy form of mu_conv_dgrad_h / mu_conv_wgrad_h
+ * for a 3x3 layer whose dy does not come out of mu_bn_act_bwd_h (a conv without a BatchNorm behind it, city_instance.py:243). */
+long mu_dy_encode_h_workspace_bytes(void);
+int mu_dy_encode_h(const void* dy, void* dy_h, float* dy_scale, long n_elems, void* workspace, long ws_bytes, void* stream);
 /* fp32x ATTENTION operand encoding (see MU_F32X): n_elems fp32 values (a multiple of 8, 32-byte aligned) -> [8 fp16 hi | 8 fp16 lo] per
  * group of eight, hi = fp16(x), lo = fp16(x - hi); dst may be src (in place).  qkv of mu_attn_fwd / mu_attn_bwd* with MU_F32X. */
 int mu_split_encode_h(const void* src, void* dst, long n_elems, void* stream);
@@ -80,7 +96,10 @@ int mu_conv1x1_fwd_enc_h(const void* x, const void* w, const float* bias, void* 
 int mu_cast(const void* src, int src_dtype, void* dst, int dst_dtype, long n, void* stream);
 /* OIHW fp32 parameter -> tap-major compute layout [taps][rows_pad][cols_pad].
  * mode 0: forward weights (rows=O, cols=I); mode 1: data-gradient weights (taps flipped, rows=I, cols=O);
- * mode 2: both in one launch, dst = the mode-0 block followed by the mode-1 block [taps][cols_pad][rows_pad]. */
+ * mode 2: both in one launch, dst = the mode-0 block followed by the mode-1 block [taps][cols_pad][rows_pad].
+ * dtype MU_F32X: fp32-sized blocks in their operand encodings (see MU_F32X) -- taps = 1: both blocks bf16 chunk-encoded; taps = 9: the
+ * forward block fp16 chunk-encoded (x 2^6), the data-gradient block as "HL" rows for mu_conv_dgrad_h: each row (tap, in) of the padded
+ * output-channel count n becomes [n fp16 lo | n fp16 hi] of 2^6 w (the same bytes). */
 int mu_prep_weight(const float* w_oihw, void* dst, int dtype, int O, int I, int taps, int rows_pad, int cols_pad, int mode,
                    void* stream);
 
@@ -124,6 +143,18 @@ int mu_conv_fwd_fused(const void* x, const void* w, const float* scale, const fl
 int mu_conv_stats_rows(int B, int H, int W, int Cin, int Cout, int taps, int dtype);
 int mu_conv_fwd_stats(const void* x, const void* w, const float* bias, void* y, int B, int H, int W, int Cin, int Cout, int taps,
                       long x_ld, long y_ld, int dtype, float* stat_part, void* stream);
+/* fp32x 3x3 layers, two-term data gradient (round 6; autograd of nn.Conv2d k = 3, ade_semantic.py:199,202,400): dx[p][ci] =
+ * (1 / S) sum_{tap,co} dy_h[p - shift(tap)][co] * w[co][ci][tap] with dy_h = fp16(S dy) ONE scaled fp16 operand (rows of Cin halves,
+ * stride dy_ld halves; Cin = the layer's OUTPUT channels) and w_hl the HL data-gradient block of mu_prep_weight(MU_F32X, taps 9);
+ * dx plain fp32 rows of Cout floats (the layer's INPUT channels, stride dx_ld floats); dy_scale = {S, 1 / S} on the device. */
+int mu_conv_dgrad_h(const void* dy_h, const void* w_hl, const float* dy_scale, void* dx, int B, int H, int W, int Cin, int Cout, long dy_ld,
+                    long dx_ld, void* stream);
+/* fp32x 3x3 layers, two-term weight gradient: dw_oihw as mu_conv_wgrad from x = the layer's input in the 3x3 operand encoding
+ * (mu_split_encode_h4 form, Cin channels, stride x_ld floats) and dy_h / dy_scale as above (Cout halves per row, stride dy_ld halves).
+ * cin_valid > 3 (the first layer keeps mu_conv_wgrad on plain operands). */
+long mu_conv_wgrad_h_workspace_bytes(int B, int H, int W, int Cin, int Cout);
+int mu_conv_wgrad_h(const void* x, const void* dy_h, const float* dy_scale, float* dw_oihw, int B, int H, int W, int Cin, int Cout,
+                    int cin_valid, int cout_valid, long x_ld, long dy_ld, void* workspace, long ws_bytes, void* stream);
 /* dw_oihw[o][i][tap] = sum_p dy[p][o] * x[p+shift(tap)][i] for o < cout_valid, i < cin_valid (fp32, OIHW). */
 long mu_conv_wgrad_workspace_bytes(int B, int H, int W, int Cin, int Cout, int taps);
 int mu_conv_wgrad(const void* x, const void* dy, float* dw_oihw, int B, int H, int W, int Cin, int Cout, int taps, int cin_valid,
@@ -192,6 +223,19 @@ int mu_bn_act_bwd_scaled(const void* x, const void* res, const void* grad_out, v
 int mu_bn_pair_bwd(const void* x, const void* grad_out, void* dx, long M, int C, long ld, const float* mean, const float* rstd,
                    const float* gamma_eff, const float* beta2, const float* xhat_scale, const float* dgamma2_coef,
                    const float* dgamma1_coef, float* pair_grads, float* dbeta2, void* workspace, long ws_bytes, int dtype, void* stream);
+
+/* fp32x (round 6): mu_bn_act_bwd / mu_bn_pair_bwd on fp32 storage (contiguous rows, ld = C) with dx written as ONE power-of-two-scaled
+ * fp16 operand -- dx of a BatchNorm is the dy of the 3x3 convolution in front of it and of nothing else (ConvBlock wiring,
+ * ade_semantic.py:199-204).  dx_h: M rows of C halves (row stride C); dy_scale = {S, 1 / S}, two floats written on the device from
+ * maxima the statistics sweep collects (|S dx| < 2^14; no host sync), handed to mu_conv_dgrad_h / mu_conv_wgrad_h.  dres (residual
+ * form) stays plain fp32.  The BatchNorm's own parameter gradients are computed from the fp32 operands as always. */
+int mu_bn_act_bwd_h(const void* x, const void* res, const void* grad_out, void* dx_h, void* dres, long M, int C, const float* mean,
+                    const float* rstd, const float* gamma, const float* beta, int act, int training, float* dgamma, float* dbeta,
+                    float* dy_scale, void* workspace, long ws_bytes, void* stream);
+int mu_bn_pair_bwd_h(const void* x, const void* grad_out, void* dx_h, long M, int C, const float* mean, const float* rstd,
+                     const float* gamma_eff, const float* beta2, const float* xhat_scale, const float* dgamma2_coef,
+                     const float* dgamma1_coef, float* pair_grads, float* dbeta2, float* dy_scale, void* workspace, long ws_bytes,
+                     void* stream);
 
 /* ---- per-sample LayerNorm with full-shape affine: nn.LayerNorm([64,128,128]) (:281,311) ------ */
 long mu_ln_sample_workspace_bytes(int B);

@@ -28,6 +28,14 @@ SIGNATURES = {
     "mu_cast": (I, [P, I, P, I, L, P]),
     "mu_split_encode": (I, [P, P, L, P]),
     "mu_split_encode_h": (I, [P, P, L, P]),
+    "mu_split_encode_h4": (I, [P, P, L, P]),
+    "mu_dy_encode_h_workspace_bytes": (L, []),
+    "mu_dy_encode_h": (I, [P, P, P, L, P, L, P]),
+    "mu_conv_dgrad_h": (I, [P, P, P, P, I, I, I, I, I, L, L, P]),
+    "mu_conv_wgrad_h_workspace_bytes": (L, [I, I, I, I, I]),
+    "mu_conv_wgrad_h": (I, [P, P, P, P, I, I, I, I, I, I, I, L, L, P, L, P]),
+    "mu_bn_act_bwd_h": (I, [P, P, P, P, P, L, I, P, P, P, P, I, I, P, P, P, P, L, P]),
+    "mu_bn_pair_bwd_h": (I, [P, P, P, L, I, P, P, P, P, P, P, P, P, P, P, P, L, P]),
     "mu_conv1x1_fwd_enc_h": (I, [P, P, P, P, L, I, I, L, L, P]),
     "mu_prep_weight": (I, [P, P, I, I, I, I, I, I, I, P]),
     "mu_conv_fwd": (I, [P, P, P, P, I, I, I, I, I, I, L, L, I, P]),

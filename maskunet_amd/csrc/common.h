@@ -142,6 +142,43 @@ __device__ __forceinline__ void mu_hdec8(const SplitH8& e, float (&x)[8]) {
     for (int i = 0; i < 8; ++i) x[i] = (float)e.hi[i] + (float)e.lo[i];
 }
 
+// ------------------------------------------------------------------------------------------
+// fp16-pair CHUNK encoding of the 3x3-convolution operands in the fp32x mode (round 6; `xh32` = float storage like xf32): every aligned
+// 16-byte chunk of four fp32 values is
+//     [hi0 hi1 hi2 hi3 | lo0 lo1 lo2 lo3]      (fp16 each)
+// -- the layout of the bf16 chunk encoding above (same strides, LDS-DMA pieces, swizzles, tile shapes) with fp16 halves: 22 mantissa
+// bits instead of 16 down to an absolute floor of 2^-25 (v_mfma_f32_16x16x32_f16 keeps subnormal inputs: tools/probe_mfma_denorm.py).
+// Forward: three fp16 MFMAs per product (lo hi + hi lo + hi hi).  Backward: dy travels as ONE fp16 operand under a per-tensor
+// power-of-two scale (written so by the BatchNorm backward that produces it, norm.hip) against the two-term pair of its partner -- the
+// weights for the data gradient, the saved input for the weight gradient: two MFMAs per product.  Weights are encoded under a static
+// shift of 2^MU_XH_WSHIFT so that their lo halves stay fp16-normal (|w| < 2^(16 - MU_XH_WSHIFT)); the conv epilogues undo it.
+// Sizing on the CPU oracle before building: tests/aids/numerics_conv_bwd_two_term.py (outputs 4.8e-6, worst gradient 1.5e-3 on the
+// reference golden; the bf16 scheme it replaces: 5.1e-5 / 2.1e-2).  1x1 convolutions / Linear layers keep the bf16 encoding (their
+// backward operands are unscaled gradients, far below fp16's range).
+// ------------------------------------------------------------------------------------------
+#define MU_XH_WSHIFT 6
+struct xh32 {
+    float v;
+    __host__ __device__ xh32() = default;
+    __host__ __device__ xh32(float f) : v(f) {}
+    __host__ __device__ operator float() const { return v; }
+};
+static_assert(sizeof(xh32) == 4, "xh32 is float storage");
+struct SplitH4 { h16x4 hi, lo; };
+__device__ __forceinline__ uint4 mu_ench4(const f32x4& x) {
+    uint4 e;
+    mu_hsplit2(x[0], x[1], e.x, e.z);
+    mu_hsplit2(x[2], x[3], e.y, e.w);
+    return e;
+}
+__device__ __forceinline__ f32x4 mu_dech4(const uint4& e) {
+    const h16x4 h = __builtin_bit_cast(h16x4, make_uint2(e.x, e.y)), l = __builtin_bit_cast(h16x4, make_uint2(e.z, e.w));
+    return (f32x4){(float)h[0] + (float)l[0], (float)h[1] + (float)l[1], (float)h[2] + (float)l[2], (float)h[3] + (float)l[3]};
+}
+template <typename T> struct mu_is_split { static constexpr bool value = false; };
+template <> struct mu_is_split<xf32> { static constexpr bool value = true; };
+template <> struct mu_is_split<xh32> { static constexpr bool value = true; };
+
 // 16-byte vector of T: 8 halves or 4 floats.
 template <typename T> struct Vec16;
 template <> struct Vec16<float> {

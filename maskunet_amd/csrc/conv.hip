@@ -44,6 +44,47 @@ template <> struct Mma<xf32> {
     }
     static __device__ __forceinline__ void mma2(const Frag2& a, const Frag2& b, f32x4& c) { mu_mma_split(a, b, c); }
 };
+// fp32x 3x3 layers (round 6, common.h xh32): the same chunk layout with fp16 halves -- three v_mfma_f32_16x16x16/32_f16 per fragment pair
+template <> struct Mma<xh32> {
+    static constexpr int VN = 4;
+    using Frag = SplitH4;
+    static __device__ __forceinline__ Frag ld(const void* p) {
+        const uint4 e = *reinterpret_cast<const uint4*>(p);
+        Frag r;
+        r.hi = __builtin_bit_cast(h16x4, make_uint2(e.x, e.y));
+        r.lo = __builtin_bit_cast(h16x4, make_uint2(e.z, e.w));
+        return r;
+    }
+    static __device__ __forceinline__ void mma(const Frag& a, const Frag& b, f32x4& c) {
+        c = __builtin_amdgcn_mfma_f32_16x16x16f16(a.lo, b.hi, c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x16f16(a.hi, b.lo, c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x16f16(a.hi, b.hi, c, 0, 0, 0);
+    }
+    static constexpr bool PAIR = true;
+    using Frag2 = SplitH8;
+    static __device__ __forceinline__ Frag2 ld2(const void* p0, const void* p1) {
+        const uint4 e0 = *reinterpret_cast<const uint4*>(p0), e1 = *reinterpret_cast<const uint4*>(p1);
+        Frag2 r;
+        r.hi = __builtin_bit_cast(h16x8, make_uint4(e0.x, e0.y, e1.x, e1.y));
+        r.lo = __builtin_bit_cast(h16x8, make_uint4(e0.z, e0.w, e1.z, e1.w));
+        return r;
+    }
+    static __device__ __forceinline__ void mma2(const Frag2& a, const Frag2& b, f32x4& c) {
+        c = __builtin_amdgcn_mfma_f32_16x16x32_f16(a.lo, b.hi, c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x32_f16(a.hi, b.lo, c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x32_f16(a.hi, b.hi, c, 0, 0, 0);
+    }
+};
+// the xh32 weights carry a static shift of 2^MU_XH_WSHIFT (common.h): every kernel un-shifts its accumulators in front of its epilogue
+template <typename T, int TM, int TN>
+__device__ __forceinline__ void mma_unshift(f32x4 (&acc)[TM][TN]) {
+    if constexpr (std::is_same<T, xh32>::value) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) acc[i][j] *= 1.0f / (float)(1 << MU_XH_WSHIFT);
+    }
+}
 template <> struct Mma<float> {
     static constexpr int VN = 4;
     using Frag = f32x4;
@@ -78,10 +119,14 @@ __device__ __forceinline__ int swz64(int row, int chunk) { return chunk ^ ((0x78
 template <typename T>
 __device__ __forceinline__ float epi_act(float v, int act) { return mu_act_t<sizeof(T) == 2>(v, act); }
 
-template <typename T, int TM, int TN, int WR, int TAPS, bool FEPI = false>
+// HL (round 6, T = h16 only: the two-term data gradient of the fp32x 3x3 layers, mu_conv_dgrad_h): x is the ONE-term fp16 dy, w the "HL"
+// weight rows [Cin lo | Cin hi] of 2 * Cin halves (elementwise.hip mu_prep_weight), the K loop walks every input chunk twice -- against
+// the lo halves, then against the hi halves -- and the result leaves as fp32 rows yf, multiplied by oscale[1] / 2^MU_XH_WSHIFT.
+template <typename T, int TM, int TN, int WR, int TAPS, bool FEPI = false, bool HL = false>
 __global__ __launch_bounds__(256) void conv_nt_kernel(const T* __restrict__ x, const T* __restrict__ w, const float* __restrict__ bias,
                                                       T* __restrict__ y, int B, int H, int W, int Cin, int Cout, long x_ld, long y_ld,
-                                                      const float* __restrict__ scale = nullptr, const T* __restrict__ res = nullptr, int act = 0) {
+                                                      const float* __restrict__ scale = nullptr, const T* __restrict__ res = nullptr, int act = 0,
+                                                      float* __restrict__ yf = nullptr, const float* __restrict__ oscale = nullptr) {
     using M_ = Mma<T>;
     using Frag = typename M_::Frag;
     constexpr int VN = M_::VN, KC = 4 * VN;
@@ -122,18 +167,21 @@ __global__ __launch_bounds__(256) void conv_nt_kernel(const T* __restrict__ x, c
         prow[i] = pp;
     }
 
-    const int kchunks = Cin / KC;
+    const int kreal = Cin / KC;
+    const int kchunks = HL ? 2 * kreal : kreal;
+    const int Cw = HL ? 2 * Cin : Cin;                       // weight row length
     const int nsteps = TAPS * kchunks;
     uint4 ra[NA], rb[NB];
 
     auto gload = [&](int s) {
-        const int tap = s / kchunks, ci0 = (s % kchunks) * KC;
+        const int tap = s / kchunks, ciw = (s % kchunks) * KC;
+        const int ci0 = HL ? (ciw >= Cin ? ciw - Cin : ciw) : ciw;
         const int dh = TAPS == 9 ? tap / 3 - 1 : 0, dw = TAPS == 9 ? tap % 3 - 1 : 0;
 #pragma unroll
         for (int i = 0; i < NA; ++i) {
             const int row = ldrow + i * 64, co = co0 + row;
             if (row < BCO && co < Cout)
-                ra[i] = *reinterpret_cast<const uint4*>(w + ((long)tap * Cout + co) * Cin + ci0 + ch * VN);
+                ra[i] = *reinterpret_cast<const uint4*>(w + ((long)tap * Cout + co) * Cw + ciw + ch * VN);
             else
                 ra[i] = make_uint4(0, 0, 0, 0);
         }
@@ -189,7 +237,23 @@ __global__ __launch_bounds__(256) void conv_nt_kernel(const T* __restrict__ x, c
         if (s + 1 < nsteps) lstore(buf ^ 1);
         __syncthreads();
     }
+    mma_unshift<T>(acc);
 
+    if constexpr (HL) {
+        const float os = oscale[1] * (1.0f / (float)(1 << MU_XH_WSHIFT));
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const long p = px0 + (wc * TN + j) * 16 + r16;
+            if (p >= Mtot) continue;
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                const int co = co0 + (wr * TM + i) * 16 + 4 * g;
+                if (co >= Cout) continue;
+                *reinterpret_cast<f32x4*>(yf + p * y_ld + co) = acc[i][j] * os;
+            }
+        }
+        return;
+    }
     if constexpr (sizeof(T) == 2) {
         // fp16: the block's tile goes through LDS (all fragment reads are behind the loop's last barrier) and leaves as 16-byte
         // chunks of contiguous output rows (as conv_nt2_kernel) instead of 8-byte pieces of sixteen rows per store
@@ -429,6 +493,7 @@ __global__ __launch_bounds__(256, SB ? MU_NT2_SB_OCC : MU_NT2_OCC) void conv_nt2
         }
         __syncthreads();          // drains the LDS-DMA of stage s+1 (vmcnt(0)) and fences the reads of stage s
     }
+    mma_unshift<T>(acc);
 
     if constexpr (EPI) {
         // the block's BPX x BCO tile goes through LDS (the loop's last barrier fenced the fragment reads) and leaves as whole
@@ -561,11 +626,14 @@ __device__ __forceinline__ void tile_stats_store(float (&ssum)[8], float (&ssq)[
     }
 }
 
-template <typename T, int TM, int TN, int WR, int NWV, bool RINGP, bool FEPI>
+// HL: see conv_nt_kernel -- here the lo / hi passes of one input chunk follow each other (chunk instance c = 2 * chunk + {lo, hi}), so the
+// halo of a chunk is staged ONCE for both (the odd instance stages the next chunk's halo, the even one stages nothing).
+template <typename T, int TM, int TN, int WR, int NWV, bool RINGP, bool FEPI, bool HL = false>
 __device__ __forceinline__ void conv_nt3_body(const T* __restrict__ x, const T* __restrict__ w, const float* __restrict__ bias,
                                               T* __restrict__ y, int B, int H, int W, int Cin, int Cout, long x_ld, long y_ld,
                                               const float* __restrict__ scale, const T* __restrict__ res, int act,
-                                              float* __restrict__ stat_part = nullptr) {
+                                              float* __restrict__ stat_part = nullptr, float* __restrict__ yf = nullptr,
+                                              const float* __restrict__ oscale = nullptr) {
     // stat_part (training kernels, may be NULL): per-channel (sum, sum of squares) of the values this kernel stores, one row per
     // (tile, wave row wc) -- [ntile * WC][Cout][2] floats, the layout mu_bn_train_stats_rows folds (round 5: the statistics epilogue the
     // ping-pong kernels have had since round 1, for the layers the halo-tile kernel serves: Cout = 64 and small grids)
@@ -587,7 +655,7 @@ __device__ __forceinline__ void conv_nt3_body(const T* __restrict__ x, const T* 
     // In-process A/B: 128 -> 64 @128^2 0.226 -> 0.203 ms; with a single 64-channel chunk (9 taps per tile) the longer prologue
     // costs more than the waits it removes (64 -> 64 @128^2 0.110 -> 0.116 ms), so the launcher picks RINGP for Cin >= 128 only.
     // (fp32x, MU_XF_NT3_RING8: the same ring on 8-wave blocks with 128 output channels x 16 x 16 pixels -- one block per CU, two waves per SIMD)
-    constexpr bool RING = RINGP && MU_NT3_RING && ((sizeof(T) == 2 && BCO == 64 && NWV == 4) || (std::is_same<T, xf32>::value && BCO == 128 && NWV == 8));
+    constexpr bool RING = RINGP && MU_NT3_RING && ((sizeof(T) == 2 && BCO == 64 && NWV == 4) || (mu_is_split<T>::value && BCO == 128 && NWV == 8));
     constexpr int NWS = RING ? 3 : 2;
 
     __shared__ __attribute__((aligned(16))) char lds[2 * HBYTES + NWS * WBYTES + (RING ? 1024 : 0)];
@@ -608,7 +676,8 @@ __device__ __forceinline__ void conv_nt3_body(const T* __restrict__ x, const T* 
     const int r16 = lane & 15, g = lane >> 4;
     const int srow = lane >> 3, sch = lane & 7;
 
-    const int kchunks = Cin / KC;
+    const int kchunks = HL ? 2 * (Cin / KC) : Cin / KC;     // chunk INSTANCES (HL: lo and hi pass of every chunk)
+    const int Cw = HL ? 2 * Cin : Cin;                       // weight row length
     const int nsteps = 9 * kchunks;
 
     // DMA source offsets are loop-invariant per lane too: precompute them once (element offsets, int), so a stage costs one
@@ -617,7 +686,7 @@ __device__ __forceinline__ void conv_nt3_body(const T* __restrict__ x, const T* 
 #pragma unroll
     for (int i = 0; i < PA; ++i) {
         const int row = (i * NWV + wave) * 8 + srow;
-        wl[i] = (co0 + row) * Cin + (sch ^ (row & 7)) * VN;
+        wl[i] = (co0 + row) * Cw + (sch ^ (row & 7)) * VN;
     }
     constexpr int HPW = (HINST + NWV - 1) / NWV;            // halo instructions owned by this wave: inst = k * NWV + wave
     int hl[HPW];                                            // (hh * W + ww) * x_ld + swizzled chunk, or -1 for the zero ring
@@ -632,8 +701,9 @@ __device__ __forceinline__ void conv_nt3_body(const T* __restrict__ x, const T* 
     const T* xb = x + (long)bimg * H * W * x_ld;
 
     auto stage_w = [&](int s, int buf) {
-        const int tap = s % 9, ci0 = (s / 9) * KC;
-        const T* wb = w + (long)tap * Cout * Cin + ci0;      // wave-uniform
+        const int tap = s % 9, c_ = s / 9;
+        const int ci0 = HL ? ((c_ & 1) ? Cin : 0) + (c_ >> 1) * KC : c_ * KC;
+        const T* wb = w + (long)tap * Cout * Cw + ci0;       // wave-uniform
         char* Wb = Ws + buf * WBYTES;
 #pragma unroll
         for (int i = 0; i < PA; ++i) glds16(wb + wl[i], Wb + (i * NWV + wave) * 1024);
@@ -642,6 +712,9 @@ __device__ __forceinline__ void conv_nt3_body(const T* __restrict__ x, const T* 
         const void* src = hl[k] >= 0 ? (const void*)(xb + hl[k] + ci0) : (const void*)mu_zero_page;
         glds16(src, Hs + buf * HBYTES + (k * NWV + wave) * 1024);
     };
+    // halo of chunk instance c: data chunk and buffer (HL: two instances share one halo); next_h: does instance c + 1 need a new halo?
+    auto hchunk = [&](int c) { return HL ? (c >> 1) : c; };
+    auto next_h = [&](int c) { return c + 1 < kchunks && (!HL || ((c + 1) & 1) == 0); };
 
     f32x4 acc[TM][TN];
 #pragma unroll
@@ -670,7 +743,7 @@ __device__ __forceinline__ void conv_nt3_body(const T* __restrict__ x, const T* 
 
     int s = 0, wslot = 0;                                    // RING: slot of W(s) = s % 3, carried
     for (int c = 0; c < kchunks; ++c) {
-        const int hbuf = (c & 1) * HBYTES;
+        const int hbuf = (hchunk(c) & 1) * HBYTES;
 #pragma unroll
         for (int dh = 0; dh < 3; ++dh) {
 #pragma unroll
@@ -683,7 +756,7 @@ __device__ __forceinline__ void conv_nt3_body(const T* __restrict__ x, const T* 
 #pragma unroll
                         for (int i = 0; i < PA; ++i) glds16(mu_zero_page, dump);
                     }
-                    if (t < HPW && c + 1 < kchunks && t * NWV + wave < HINST) stage_h(t, (c + 1) * KC, (c + 1) & 1);
+                    if (t < HPW && next_h(c) && t * NWV + wave < HINST) stage_h(t, hchunk(c + 1) * KC, hchunk(c + 1) & 1);
                     else glds16(mu_zero_page, dump);
                 } else {
 #if MU_NT3_ABL_WONCE            // timing-only ablation (wrong results): weights staged once, no per-tap wait -- upper bound of a weights-resident kernel
@@ -691,8 +764,8 @@ __device__ __forceinline__ void conv_nt3_body(const T* __restrict__ x, const T* 
 #else
                 if (s + 1 < nsteps) stage_w(s + 1, (s + 1) & 1);
 #endif
-                if (t < HPW && c + 1 < kchunks && t * NWV + wave < HINST)        // one halo piece of the next chunk per tap step
-                    stage_h(t, (c + 1) * KC, (c + 1) & 1);
+                if (t < HPW && next_h(c) && t * NWV + wave < HINST)        // one halo piece of the next chunk per tap step
+                    stage_h(t, hchunk(c + 1) * KC, hchunk(c + 1) & 1);
                 }
                 const char* Wb = Ws + (RING ? wslot : (MU_NT3_ABL_WONCE ? 0 : (s & 1))) * WBYTES;
                 const char* Hb = Hs + hbuf + dh * (HW_ * 128);
@@ -746,6 +819,22 @@ __device__ __forceinline__ void conv_nt3_body(const T* __restrict__ x, const T* 
 #ifndef MU_NT3_EPI
 #define MU_NT3_EPI 1
 #endif
+    mma_unshift<T>(acc);
+    if constexpr (HL) {
+        // two-term data gradient: fp32 rows, un-scaled (the dy scale and the weight shift are powers of two); a lane's four channels of
+        // one pixel are 16 contiguous bytes, the 16 lanes of a quad group cover 16 consecutive pixels of an image row
+        const float os = oscale[1] * (1.0f / (float)(1 << MU_XH_WSHIFT));
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const long p = ((long)bimg * H + h0 + wc * TN + j) * W + w0 + r16;
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                const int co = co0 + (wr * TM + i) * 16 + 4 * g;
+                *reinterpret_cast<f32x4*>(yf + p * y_ld + co) = acc[i][j] * os;
+            }
+        }
+        return;
+    }
     if constexpr (sizeof(T) == 2 && TM == 4 && MU_NT3_EPI) {
         // wave-private staged epilogue (as conv_nt4_kernel): the wave's (TN x 16) px x 64 co tile goes through its own LDS slice
         // (every fragment read and DMA of the loop is behind its last barrier) and leaves as whole 128-byte rows
@@ -858,6 +947,11 @@ __global__ __launch_bounds__(NWV * 64, NWV == 4 ? 2 : 1) void conv_nt3_kernel(co
                                                        T* __restrict__ y, int B, int H, int W, int Cin, int Cout, long x_ld, long y_ld,
                                                        float* __restrict__ stat_part = nullptr) {
     conv_nt3_body<T, TM, TN, WR, NWV, RINGP, false>(x, w, bias, y, B, H, W, Cin, Cout, x_ld, y_ld, nullptr, nullptr, 0, stat_part);
+}
+template <int TM, int TN, int WR, bool RINGP = false>
+__global__ __launch_bounds__(256, 2) void conv_nt3hl_kernel(const h16* __restrict__ dy, const h16* __restrict__ w, float* __restrict__ dx, int B, int H,
+                                                            int W, int Cin, int Cout, long x_ld, long y_ld, const float* __restrict__ oscale) {
+    conv_nt3_body<h16, TM, TN, WR, 4, RINGP, false, true>(dy, w, nullptr, nullptr, B, H, W, Cin, Cout, x_ld, y_ld, nullptr, nullptr, 0, nullptr, dx, oscale);
 }
 template <typename T, int TM, int TN, int WR>
 __global__ __launch_bounds__(256, 2) void conv_nt3f_kernel(const T* __restrict__ x, const T* __restrict__ w, const float* __restrict__ bias,
@@ -1024,7 +1118,11 @@ __global__ __launch_bounds__(256, 2) void conv_nt3p_kernel(const T* __restrict__
                     const int co = co0 + (wr * TM + i) * 16 + 4 * g;
                     float v[4];
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) v[r] = acc[i][j][r] + (bias ? bias[co + r] : 0.f);
+                    for (int r = 0; r < 4; ++r) {
+                        v[r] = acc[i][j][r];
+                        if constexpr (std::is_same<T, xh32>::value) v[r] *= 1.0f / (float)(1 << MU_XH_WSHIFT);
+                        v[r] += (bias ? bias[co + r] : 0.f);
+                    }
                     if constexpr (sizeof(T) == 2) {
                         h16x4 o = {(h16)v[0], (h16)v[1], (h16)v[2], (h16)v[3]};
                         *reinterpret_cast<h16x4*>(y + p * y_ld + co) = o;
@@ -1080,10 +1178,14 @@ __global__ __launch_bounds__(256, 2) void conv_nt3p_kernel(const T* __restrict__
 #endif
 // (body shared by the training kernel, whose signature and code are exactly what they were without the inference epilogue, and the
 //  FEPI kernel below: three more kernel arguments on the hot kernel shifted its code enough to cost 0.1 ms per training step)
-template <bool FEPI>
+// HL (round 6): the two-term data gradient of the fp32x 3x3 layers on this pipeline (see conv_nt_kernel / conv_nt3_body): x = the one-term
+// fp16 dy, w = HL rows of 2 * Cin halves, chunk instance c = 2 * chunk + {lo, hi} -- the DMA slot that would fetch the next chunk's halo
+// carries a dummy in the even instances (the counted waits stay as they are) --, fp32 output rows through conv_nt4x_kernel's epilogue.
+template <bool FEPI, bool HL = false>
 __device__ __forceinline__ void conv_nt4_body(const h16* __restrict__ x, const h16* __restrict__ w, const float* __restrict__ bias,
                                               h16* __restrict__ y, int B, int H, int W, int Cin, int Cout, long x_ld, long y_ld,
-                                              float* __restrict__ stat_part, const float* __restrict__ scale, const h16* __restrict__ res, int act) {
+                                              float* __restrict__ stat_part, const float* __restrict__ scale, const h16* __restrict__ res, int act,
+                                              float* __restrict__ yf = nullptr, const float* __restrict__ oscale = nullptr) {
     using M_ = Mma<h16>;
     using Frag = M_::Frag;
     constexpr int VN = 8, KC = 64, TM = 4, TN = 4, WC = 4, NWV = 8, BCO = 128;
@@ -1111,14 +1213,15 @@ __device__ __forceinline__ void conv_nt4_body(const h16* __restrict__ x, const h
     const int r16 = lane & 15, g = lane >> 4;
     const int srow = lane >> 3, sch = lane & 7;
 
-    const int kchunks = Cin / KC;
+    const int kchunks = HL ? 2 * (Cin / KC) : Cin / KC;      // chunk instances
+    const int Cw = HL ? 2 * Cin : Cin;                       // weight row length
     const int nsteps = 9 * kchunks;
 
     int wl[2];                                               // this wave's two weight-DMA instructions: rows (i*8+wave)*8 + srow
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
         const int row = (i * NWV + wave) * 8 + srow;
-        wl[i] = (co0 + row) * Cin + (sch ^ (row & 7)) * VN;
+        wl[i] = (co0 + row) * Cw + (sch ^ (row & 7)) * VN;
     }
     int hl[HPW];                                             // halo pieces k*8+wave: element offset, -1 = zero ring
 #pragma unroll
@@ -1133,8 +1236,9 @@ __device__ __forceinline__ void conv_nt4_body(const h16* __restrict__ x, const h
 
     auto stage_w = [&](int s) {                              // W(s) -> ring slot s & 3 (dummy beyond the last step)
         if (s < nsteps) {
-            const int tap = s % 9, ci0 = (s / 9) * KC;
-            const h16* wb = w + (long)tap * Cout * Cin + ci0;
+            const int tap = s % 9, c_ = s / 9;
+            const int ci0 = HL ? ((c_ & 1) ? Cin : 0) + (c_ >> 1) * KC : c_ * KC;
+            const h16* wb = w + (long)tap * Cout * Cw + ci0;
             char* Wb = Ws + (s & 3) * WBYTES;
 #pragma unroll
             for (int i = 0; i < 2; ++i) glds16(wb + wl[i], Wb + (i * NWV + wave) * 1024);
@@ -1145,13 +1249,14 @@ __device__ __forceinline__ void conv_nt4_body(const h16* __restrict__ x, const h
     };
     auto stage_h = [&](int k, int c) {                       // piece k of chunk c's halo -> buffer c & 1 (dummy if none)
         const int off = hl[k];
-        if (c < kchunks && k * NWV + wave < HINST) {        // wave-uniform
+        const int hc = HL ? (c >> 1) : c;                    // HL: instances 2 hc and 2 hc + 1 share a halo, staged for the even one
+        if (c < kchunks && (!HL || (c & 1) == 0) && k * NWV + wave < HINST) {        // wave-uniform
 #ifdef MU_NT4_ABL_NOHALO
             const void* src = (const void*)mu_zero_page;
 #else
-            const void* src = off >= 0 ? (const void*)(xb + off + c * KC) : (const void*)mu_zero_page;
+            const void* src = off >= 0 ? (const void*)(xb + off + hc * KC) : (const void*)mu_zero_page;
 #endif
-            glds16(src, Hs + (c & 1) * HBYTES + (k * NWV + wave) * 1024);
+            glds16(src, Hs + (hc & 1) * HBYTES + (k * NWV + wave) * 1024);
         } else {
             glds16(mu_zero_page, dump);
         }
@@ -1190,7 +1295,7 @@ __device__ __forceinline__ void conv_nt4_body(const h16* __restrict__ x, const h
 
     int s = 0;
     for (int c = 0; c < kchunks; ++c) {
-        const int hbuf = (c & 1) * HBYTES;
+        const int hbuf = ((HL ? (c >> 1) : c) & 1) * HBYTES;
 #pragma unroll
         for (int t = 0; t < 9; ++t, ++s) {
             const int dh = t / 3, dw = t % 3;
@@ -1243,6 +1348,30 @@ __device__ __forceinline__ void conv_nt4_body(const h16* __restrict__ x, const h
     }
     if (wr == 0) __builtin_amdgcn_s_barrier();
 
+    if constexpr (HL) {
+        // fp32 rows, un-scaled: conv_nt4x_kernel's epilogue (the wave's 64 px x 64 co tile as [pixel][16 slots of 16 B], slot ^ (p & 15),
+        // read back as whole 256-byte pixel rows)
+        const float os = oscale[1] * (1.0f / (float)(1 << MU_XH_WSHIFT));
+        char* Of = lds + wave * 16384;
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int p = j * 16 + r16;
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                const int co = i * 16 + 4 * g;
+                *reinterpret_cast<f32x4*>(Of + p * 256 + ((((co >> 2)) ^ (p & 15)) << 4)) = acc[i][j] * os;
+            }
+        }
+        const int q4 = lane & 15, pl = lane >> 4;
+#pragma unroll
+        for (int it = 0; it < 16; ++it) {
+            const int p = it * 4 + pl;
+            const f32x4 o = *reinterpret_cast<const f32x4*>(Of + p * 256 + ((q4 ^ (p & 15)) << 4));
+            const long gp = ((long)bimg * H + h0 + wc * TN + (p >> 4)) * W + w0 + (p & 15);
+            *reinterpret_cast<f32x4*>(yf + gp * y_ld + co0 + wr * 64 + q4 * 4) = o;
+        }
+        return;
+    }
     // Epilogue, wave-private and barrier-free (all LDS is free now): every wave stages its own 64 co x 64 px tile (8 KB as
     // [pixel][64 co], 128-byte rows) and reads it back as 16-byte pieces, so each wave store writes eight whole 128-byte rows
     // instead of 32-byte fragments.  8-byte slot XORed with ((p >> 1) & 7) << 1 on the write == 16-byte slot ^ ((p >> 1) & 7)
@@ -1292,6 +1421,10 @@ __global__ __launch_bounds__(512, 1) void conv_nt4_kernel(const h16* __restrict_
                                                           float* __restrict__ stat_part) {
     conv_nt4_body<false>(x, w, bias, y, B, H, W, Cin, Cout, x_ld, y_ld, stat_part, nullptr, nullptr, 0);
 }
+__global__ __launch_bounds__(512, 1) void conv_nt4hl_kernel(const h16* __restrict__ dy, const h16* __restrict__ w, float* __restrict__ dx, int B, int H,
+                                                            int W, int Cin, int Cout, long x_ld, long y_ld, const float* __restrict__ oscale) {
+    conv_nt4_body<false, true>(dy, w, nullptr, nullptr, B, H, W, Cin, Cout, x_ld, y_ld, nullptr, nullptr, nullptr, 0, dx, oscale);
+}
 __global__ __launch_bounds__(512, 1) void conv_nt4f_kernel(const h16* __restrict__ x, const h16* __restrict__ w, const float* __restrict__ bias,
                                                            h16* __restrict__ y, int B, int H, int W, int Cin, int Cout, long x_ld, long y_ld,
                                                            const float* __restrict__ scale, const h16* __restrict__ res, int act) {
@@ -1313,11 +1446,12 @@ __global__ __launch_bounds__(512, 1) void conv_nt4f_kernel(const h16* __restrict
 #ifndef MU_CONV_NT4X
 #define MU_CONV_NT4X 1
 #endif
-__global__ __launch_bounds__(512, 1) void conv_nt4x_kernel(const xf32* __restrict__ x, const xf32* __restrict__ w, const float* __restrict__ bias,
-                                                           xf32* __restrict__ y, int B, int H, int W, int Cin, int Cout, long x_ld, long y_ld,
+template <typename XT>           // xf32 (bf16 pairs) or xh32 (fp16 pairs, round 6: what the 3x3 layers of the fp32x mode run on)
+__global__ __launch_bounds__(512, 1) void conv_nt4x_kernel(const XT* __restrict__ x, const XT* __restrict__ w, const float* __restrict__ bias,
+                                                           XT* __restrict__ y, int B, int H, int W, int Cin, int Cout, long x_ld, long y_ld,
                                                            float* __restrict__ stat_part) {
-    using M_ = Mma<xf32>;
-    using Frag2 = M_::Frag2;
+    using M_ = Mma<XT>;
+    using Frag2 = typename M_::Frag2;
     constexpr int VN = 4, KC = 32, TM = 4, TN = 4, NWV = 8, BCO = 128;
     constexpr int TH = 16, TW = 16, HW_ = TW + 2, HROWS = (TH + 2) * HW_;       // 324 halo rows of 128 B
     constexpr int HINST = (HROWS + 7) / 8;                                       // 41 wave-DMA instructions (8 rows each)
@@ -1360,12 +1494,12 @@ __global__ __launch_bounds__(512, 1) void conv_nt4x_kernel(const xf32* __restric
         const bool ok = hr < HROWS && hh >= 0 && hh < H && ww >= 0 && ww < W;
         hl[k] = ok ? (int)(((long)hh * W + ww) * x_ld) + (sch ^ (hx & 7)) * VN : -1;
     }
-    const xf32* xb = x + (long)bimg * H * W * x_ld;
+    const XT* xb = x + (long)bimg * H * W * x_ld;
 
     auto stage_w = [&](int s) {
         if (s < nsteps) {
             const int tap = s % 9, ci0 = (s / 9) * KC;
-            const xf32* wb = w + (long)tap * Cout * Cin + ci0;
+            const XT* wb = w + (long)tap * Cout * Cin + ci0;
             char* Wb = Ws + (s & 3) * WBYTES;
 #pragma unroll
             for (int i = 0; i < 2; ++i) glds16(wb + wl[i], Wb + (i * NWV + wave) * 1024);
@@ -1463,6 +1597,7 @@ __global__ __launch_bounds__(512, 1) void conv_nt4x_kernel(const xf32* __restric
 
     // Epilogue, wave-private and barrier-free: the wave's 64 px x 64 co fp32 tile as [pixel][16 slots of 16 B], slot XORed with (p & 15)
     // (the 16 lanes that write one (i, g) slot hold 16 different pixels), read back as whole 256-byte pixel rows: 4 rows per wave store.
+    mma_unshift<XT>(acc);
     char* Os = lds + wave * 16384;
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
@@ -1976,7 +2111,7 @@ static int conv_fwd_launch(const T* x, const T* w, const float* bias, T* y, int 
             conv_nt3_kernel<T, 4, 4, 2, 8><<<B * (H / 16) * (W / 16) * (Cout / 128), 512, 0, st>>>(x, w, bias, y, B, H, W, Cin, Cout, x_ld, y_ld);
             return MU_OK;
         }
-        if constexpr (std::is_same<T, xf32>::value && MU_XF_NT3_RING8) {
+        if constexpr (mu_is_split<T>::value && MU_XF_NT3_RING8) {
             if (Cout % 128 == 0 && H % 16 == 0) {
                 conv_nt3_kernel<T, 4, 4, 2, 8, true><<<B * (H / 16) * (W / 16) * (Cout / 128), 512, 0, st>>>(x, w, bias, y, B, H, W, Cin, Cout, x_ld, y_ld);
                 return MU_OK;
@@ -2010,9 +2145,9 @@ static int conv_fwd_launch(const T* x, const T* w, const float* bias, T* y, int 
                 return MU_OK;
             }
         }
-        if constexpr (std::is_same<T, xf32>::value && MU_CONV_NT4X) {
+        if constexpr (mu_is_split<T>::value && MU_CONV_NT4X) {
             if (nt4x_serves(B, H, W, Cin, Cout)) {
-                conv_nt4x_kernel<<<B * (H / 16) * (W / 16) * (Cout / 128), 512, 0, st>>>(x, w, bias, y, B, H, W, Cin, Cout, x_ld, y_ld, stat_part);
+                conv_nt4x_kernel<T><<<B * (H / 16) * (W / 16) * (Cout / 128), 512, 0, st>>>(x, w, bias, y, B, H, W, Cin, Cout, x_ld, y_ld, stat_part);
                 return MU_OK;
             }
         }
@@ -2092,7 +2227,7 @@ extern "C" int mu_conv_fwd_stats(const void* x, const void* w, const float* bias
     if (Cin <= 0 || Cout <= 0 || Cin % 32 || Cout % 32 || x_ld < Cin || y_ld < Cout || x_ld % 8 || y_ld % 8) return MU_ERR_SHAPE;
     if (stat_part && mu_conv_stats_rows(B, H, W, Cin, Cout, taps, dtype) == 0) return MU_ERR_SHAPE;
     if (!stat_part) return mu_conv_fwd(x, w, bias, y, B, H, W, Cin, Cout, taps, x_ld, y_ld, dtype, stream);
-    if (dtype == MU_F32X) conv_fwd_launch<xf32, 9>((const xf32*)x, (const xf32*)w, bias, (xf32*)y, B, H, W, Cin, Cout, x_ld, y_ld, (hipStream_t)stream, stat_part);
+    if (dtype == MU_F32X) conv_fwd_launch<xh32, 9>((const xh32*)x, (const xh32*)w, bias, (xh32*)y, B, H, W, Cin, Cout, x_ld, y_ld, (hipStream_t)stream, stat_part);
     else conv_fwd_launch<h16, 9>((const h16*)x, (const h16*)w, bias, (h16*)y, B, H, W, Cin, Cout, x_ld, y_ld, (hipStream_t)stream, stat_part);
     MU_CHECK_LAUNCH();
     return MU_OK;
@@ -2111,7 +2246,7 @@ extern "C" int mu_conv_fwd_fused(const void* x, const void* w, const float* scal
         if (taps == 9) conv_fwd_fused_launch<float, 9>((const float*)x, (const float*)w, scale, bias, (const float*)res, act, (float*)y, B, H, W, Cin, Cout, x_ld, y_ld, st);
         else conv_fwd_fused_launch<float, 1>((const float*)x, (const float*)w, scale, bias, (const float*)res, act, (float*)y, B, H, W, Cin, Cout, x_ld, y_ld, st);
     } else if (dtype == MU_F32X) {
-        if (taps == 9) conv_fwd_fused_launch<xf32, 9>((const xf32*)x, (const xf32*)w, scale, bias, (const xf32*)res, act, (xf32*)y, B, H, W, Cin, Cout, x_ld, y_ld, st);
+        if (taps == 9) conv_fwd_fused_launch<xh32, 9>((const xh32*)x, (const xh32*)w, scale, bias, (const xh32*)res, act, (xh32*)y, B, H, W, Cin, Cout, x_ld, y_ld, st);
         else conv_fwd_fused_launch<xf32, 1>((const xf32*)x, (const xf32*)w, scale, bias, (const xf32*)res, act, (xf32*)y, B, H, W, Cin, Cout, x_ld, y_ld, st);
     } else return MU_ERR_ARG;
     MU_CHECK_LAUNCH();
@@ -2131,9 +2266,42 @@ extern "C" int mu_conv_fwd(const void* x, const void* w, const float* bias, void
         if (taps == 9) conv_fwd_launch<float, 9>((const float*)x, (const float*)w, bias, (float*)y, B, H, W, Cin, Cout, x_ld, y_ld, st);
         else conv_fwd_launch<float, 1>((const float*)x, (const float*)w, bias, (float*)y, B, H, W, Cin, Cout, x_ld, y_ld, st);
     } else if (dtype == MU_F32X) {
-        if (taps == 9) conv_fwd_launch<xf32, 9>((const xf32*)x, (const xf32*)w, bias, (xf32*)y, B, H, W, Cin, Cout, x_ld, y_ld, st);
+        if (taps == 9) conv_fwd_launch<xh32, 9>((const xh32*)x, (const xh32*)w, bias, (xh32*)y, B, H, W, Cin, Cout, x_ld, y_ld, st);
         else conv_fwd_launch<xf32, 1>((const xf32*)x, (const xf32*)w, bias, (xf32*)y, B, H, W, Cin, Cout, x_ld, y_ld, st);
     } else return MU_ERR_ARG;
+    MU_CHECK_LAUNCH();
+    return MU_OK;
+}
+
+// fp32x, 3x3 layers: the TWO-TERM data gradient (round 6).  dx = conv3x3(dy, flipped / transposed weights) with dy as ONE fp16 operand
+// S * dy (mu_bn_act_bwd_h / mu_bn_pair_bwd_h / mu_dy_encode_h: rows of Cin halves, row stride dy_ld halves) against the fp16 (hi, lo) pair
+// of the weights (the HL data-gradient block of mu_prep_weight / mu_prep_weights_multi with MU_F32X: [9][Cout][2 * Cin] halves): two fp16
+// MFMAs per product instead of the forward's three.  dx: plain fp32 rows (row stride dx_ld floats), multiplied by dy_scale[1] = 1 / S and by
+// 2^-MU_XH_WSHIFT in the epilogue (exact: powers of two).  Cin = channels of dy (the layer's output), Cout = channels of dx (its input).
+extern "C" int mu_conv_dgrad_h(const void* dy_h, const void* w_hl, const float* dy_scale, void* dx, int B, int H, int W, int Cin, int Cout,
+                               long dy_ld, long dx_ld, void* stream) {
+    if (!dy_h || !w_hl || !dy_scale || !dx || B <= 0 || H <= 0 || W <= 0) return MU_ERR_ARG;
+    if (Cin <= 0 || Cout <= 0 || Cin % 32 || Cout % 32 || dy_ld < Cin || dx_ld < Cout || dy_ld % 8 || dx_ld % 4) return MU_ERR_SHAPE;
+    hipStream_t st = (hipStream_t)stream;
+    const h16* x = (const h16*)dy_h;
+    const h16* w = (const h16*)w_hl;
+    float* y = (float*)dx;
+    const long M = (long)B * H * W;
+    const int npb = (int)((M + 127) / 128);
+    if (Cin % 64 == 0 && W % 16 == 0 && H % 8 == 0 && Cout % 64 == 0 && !getenv("MU_DGRAD_H_GENERIC")) {
+        if (Cout % 128 == 0 && H % 16 == 0 && MU_CONV_NT4 && !getenv("MU_CONV_NO_NT4"))
+            conv_nt4hl_kernel<<<B * (H / 16) * (W / 16) * (Cout / 128), 512, 0, st>>>(x, w, y, B, H, W, Cin, Cout, dy_ld, dx_ld, dy_scale);
+        else if (Cout % 128 == 0)
+            conv_nt3hl_kernel<4, 4, 2><<<B * (H / 8) * (W / 16) * (Cout / 128), 256, 0, st>>>(x, w, y, B, H, W, Cin, Cout, dy_ld, dx_ld, dy_scale);
+        else
+            conv_nt3hl_kernel<4, 2, 1, true><<<B * (H / 8) * (W / 16) * (Cout / 64), 256, 0, st>>>(x, w, y, B, H, W, Cin, Cout, dy_ld, dx_ld, dy_scale);
+    } else if (Cout % 128 == 0) {
+        conv_nt_kernel<h16, 4, 4, 2, 9, false, true><<<npb * (Cout / 128), 256, 0, st>>>(x, w, nullptr, nullptr, B, H, W, Cin, Cout, dy_ld, dx_ld, nullptr, nullptr, 0, y, dy_scale);
+    } else if (Cout % 64 == 0) {
+        conv_nt_kernel<h16, 4, 2, 1, 9, false, true><<<npb * (Cout / 64), 256, 0, st>>>(x, w, nullptr, nullptr, B, H, W, Cin, Cout, dy_ld, dx_ld, nullptr, nullptr, 0, y, dy_scale);
+    } else {
+        conv_nt_kernel<h16, 2, 2, 1, 9, false, true><<<npb * (Cout / 32), 256, 0, st>>>(x, w, nullptr, nullptr, B, H, W, Cin, Cout, dy_ld, dx_ld, nullptr, nullptr, 0, y, dy_scale);
+    }
     MU_CHECK_LAUNCH();
     return MU_OK;
 }
@@ -2947,6 +3115,49 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
     }
 }
 
+// The same reduce for the two-term weight gradient of the fp32x 3x3 layers (mu_conv_wgrad_h): the slabs hold dW against the 16-bit VIEW of
+// the chunk-encoded input -- column 8 (i / 4) + i % 4 is the hi half of input channel i, 4 columns further its lo half (common.h
+// mu_ench4) -- so an output element is the sum of two slab columns, times the 1 / S of the scaled fp16 dy (oscale[1]).
+template <int KL>
+__global__ __launch_bounds__(256) void wgrad_reduce_pair_kernel(const float* __restrict__ part, float* __restrict__ dst, int nsplit, int taps,
+                                                                int Cout, int Cin2, int O, int I, const float* __restrict__ oscale) {
+    constexpr int EPB = 256 / KL;
+    __shared__ float red[KL][EPB];
+    const long n = (long)O * I * taps;
+    const int e = threadIdx.x % EPB, kl = threadIdx.x / EPB;
+    const long slab = (long)taps * Cout * Cin2;
+    const float os = oscale[1];
+    for (long base = (long)blockIdx.x * EPB; base < n; base += (long)gridDim.x * EPB) {
+        const long idx = base + e;
+        const int i = idx % I;
+        const int o = (idx / I) % O;
+        const int t = idx / ((long)I * O);
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+        if (idx < n) {
+            const float* p = part + ((long)t * Cout + o) * Cin2 + 8 * (i >> 2) + (i & 3);
+            int k = kl;
+            for (; k + KL < nsplit; k += 2 * KL) {
+                s0 += p[(long)k * slab];
+                s1 += p[(long)k * slab + 4];
+                s2 += p[(long)(k + KL) * slab];
+                s3 += p[(long)(k + KL) * slab + 4];
+            }
+            for (; k < nsplit; k += KL) { s0 += p[(long)k * slab]; s1 += p[(long)k * slab + 4]; }
+        }
+        float s = (s1 + s3) + (s0 + s2);                  // lo columns, then hi columns
+        if (KL > 1) {
+            red[kl][e] = s;
+            __syncthreads();
+            if (kl == 0) {
+#pragma unroll
+                for (int j = 1; j < KL; ++j) s += red[j][e];
+            }
+        }
+        if (kl == 0 && idx < n) dst[((long)o * I + i) * taps + t] = s * os;
+        if (KL > 1) __syncthreads();
+    }
+}
+
 #ifndef MU_WG1_WIDE
 #define MU_WG1_WIDE 1           // fp16 1x1 layers: tiles that span all (or 192) output channels, both operands read once
 #endif
@@ -3631,9 +3842,11 @@ extern "C" int mu_conv_wgrad_bias_supported(int Cin, int Cout, int taps, int dty
     return dtype == MU_F16 && taps == 1 && Cin % 32 == 0 && Cout % 32 == 0 && wgrad_is_wide(bco) ? 1 : 0;
 }
 
+// pair_I > 0 (mu_conv_wgrad_h): x is the 16-bit view of a chunk-encoded fp32x input (Cin = 2 x its channels), dy the scaled fp16 gradient;
+// the slabs are reduced pairwise into dw_oihw[cout_valid][pair_I][taps] and multiplied by oscale[1]
 static int conv_wgrad_impl(const void* x, const void* dy, float* dw_oihw, float* db, int B, int H, int W, int Cin, int Cout, int taps,
                            int cin_valid, int cout_valid, long x_ld, long dy_ld, void* workspace, long ws_bytes, int dtype,
-                           void* stream) {
+                           void* stream, int pair_I = 0, const float* oscale = nullptr) {
     if (!x || !dy || !dw_oihw || !workspace || B <= 0 || H <= 0 || W <= 0) return MU_ERR_ARG;
     if (db && !mu_conv_wgrad_bias_supported(Cin, Cout, taps, dtype)) return MU_ERR_SHAPE;
     if (Cin % 32 || Cout % 32 || x_ld < Cin || dy_ld < Cout || x_ld % 8 || dy_ld % 8) return MU_ERR_SHAPE;
@@ -3737,6 +3950,18 @@ static int conv_wgrad_impl(const void* x, const void* dy, float* dw_oihw, float*
         if (taps == 9) wgrad_launch<xf32, 9>((const xf32*)x, (const xf32*)dy, part, B, H, W, Cin, Cout, x_ld, dy_ld, bco, nsplit, pps, st);
         else wgrad_launch<xf32, 1>((const xf32*)x, (const xf32*)dy, part, B, H, W, Cin, Cout, x_ld, dy_ld, bco, nsplit, pps, st);
     } else return MU_ERR_ARG;
+    if (pair_I > 0) {
+        const long n2 = (long)cout_valid * pair_I * taps;
+        if (nsplit >= 16) {
+            const long nb = (n2 + 63) / 64;
+            wgrad_reduce_pair_kernel<4><<<(int)(nb > 4096 ? 4096 : nb), 256, 0, st>>>(part, dw_oihw, nsplit, taps, Cout, Cin, cout_valid, pair_I, oscale);
+        } else {
+            const long nb = (n2 + 255) / 256;
+            wgrad_reduce_pair_kernel<1><<<(int)(nb > 2048 ? 2048 : nb), 256, 0, st>>>(part, dw_oihw, nsplit, taps, Cout, Cin, cout_valid, pair_I, oscale);
+        }
+        MU_CHECK_LAUNCH();
+        return MU_OK;
+    }
     const long n = (long)cout_valid * cin_valid * taps;
     if (nsplit >= 16) {
         const long nb = (n + 63) / 64;
@@ -3754,6 +3979,21 @@ extern "C" int mu_conv_wgrad(const void* x, const void* dy, float* dw_oihw, int 
                              void* stream) {
     return conv_wgrad_impl(x, dy, dw_oihw, nullptr, B, H, W, Cin, Cout, taps, cin_valid, cout_valid, x_ld, dy_ld, workspace, ws_bytes, dtype,
                            stream);
+}
+
+// fp32x, 3x3 layers: the TWO-TERM weight gradient (round 6).  x: the layer's saved input, chunk-encoded fp16 pairs (mu_split_encode_h4 /
+// mu_bn_act_fwd with MU_F32X; Cin fp32 channels per pixel, row stride x_ld floats); dy_h: ONE scaled fp16 operand (rows of Cout halves,
+// stride dy_ld halves) with its scale pair dy_scale = {S, 1 / S}.  The fp16 kernels of mu_conv_wgrad run on the 16-bit view of x
+// ([M, 2 Cin] halves: dy x hi and dy x lo columns -- two MFMAs per product), the slab reduce adds the column pairs and applies 1 / S.
+extern "C" long mu_conv_wgrad_h_workspace_bytes(int B, int H, int W, int Cin, int Cout) {
+    return mu_conv_wgrad_workspace_bytes(B, H, W, 2 * Cin, Cout, 9);
+}
+extern "C" int mu_conv_wgrad_h(const void* x, const void* dy_h, const float* dy_scale, float* dw_oihw, int B, int H, int W, int Cin, int Cout,
+                               int cin_valid, int cout_valid, long x_ld, long dy_ld, void* workspace, long ws_bytes, void* stream) {
+    if (!dy_scale || cin_valid <= 3) return MU_ERR_ARG;      // (the <= 3-channel first layer is a plain-FMA kernel on plain operands: mu_conv_wgrad)
+    if (Cin % 32 || cin_valid > Cin) return MU_ERR_SHAPE;
+    return conv_wgrad_impl(x, dy_h, dw_oihw, nullptr, B, H, W, 2 * Cin, Cout, 9, 2 * Cin, cout_valid, 2 * x_ld, dy_ld, workspace, ws_bytes, MU_F16,
+                           stream, cin_valid, dy_scale);
 }
 
 extern "C" int mu_conv_wgrad_bias(const void* x, const void* dy, float* dw_oihw, float* db, int B, int H, int W, int Cin, int Cout,

@@ -154,6 +154,37 @@ __global__ void prep_weight_kernel(const float* __restrict__ w, T* __restrict__ 
     }
 }
 
+// fp32x operand encodings of the prepared layouts (common.h; round 6):
+//   1x1 layers / Linear: both blocks chunk-encoded bf16 pairs (mu_split_encode form);
+//   3x3 layers: forward block chunk-encoded fp16 pairs of 2^MU_XH_WSHIFT * w (mu_split_encode_h4 form); data-gradient block as the
+//   "HL" rows the two-term data gradient reads: row (tap, in) of rows_pad fp32 values -> [rows_pad fp16 lo | rows_pad fp16 hi] of
+//   2^MU_XH_WSHIFT * w (the same bytes; the kernel walks the lo halves first, then the hi halves: smallest terms first).
+__global__ __launch_bounds__(256) void split_encode_kernel(const f32x4* src, uint4* dst, long n16);
+__global__ __launch_bounds__(256) void split_encode_h4_kernel(const f32x4* src, uint4* dst, long n16, float scale);
+__global__ __launch_bounds__(256) void encode_hl_rows_kernel(float* rows, long nrows, int len, float scale) {
+    // in place: a block owns a row, every 16-byte piece is in registers before the first store
+    constexpr int MAXV = 8;                                  // up to 8 x 256 x 4 = 8192 values per row
+    const int nv = len / 4;
+    for (long r = blockIdx.x; r < nrows; r += gridDim.x) {
+        float* row = rows + r * len;
+        f32x4 v[MAXV];
+#pragma unroll
+        for (int u = 0; u < MAXV; ++u)
+            if (threadIdx.x + u * 256 < nv) v[u] = *reinterpret_cast<const f32x4*>(row + (threadIdx.x + u * 256) * 4) * scale;
+        __syncthreads();
+        h16* hrow = reinterpret_cast<h16*>(row);
+#pragma unroll
+        for (int u = 0; u < MAXV; ++u)
+            if (threadIdx.x + u * 256 < nv) {
+                const uint4 e = mu_ench4(v[u]);              // (x, y) = four hi halves, (z, w) = four lo halves
+                *reinterpret_cast<uint2*>(hrow + (threadIdx.x + u * 256) * 4) = make_uint2(e.z, e.w);
+                *reinterpret_cast<uint2*>(hrow + len + (threadIdx.x + u * 256) * 4) = make_uint2(e.x, e.y);
+            }
+        __syncthreads();
+    }
+}
+static inline int enc_grid(long n16) { long g = (n16 + 1023) / 1024; return (int)(g < 1 ? 1 : (g > 8192 ? 8192 : g)); }
+
 extern "C" int mu_prep_weight(const float* w_oihw, void* dst, int dtype, int O, int I, int taps, int rows_pad,
                               int cols_pad, int mode, void* stream) {
     if (!w_oihw || !dst || O <= 0 || I <= 0 || (taps != 1 && taps != 9)) return MU_ERR_ARG;
@@ -162,12 +193,32 @@ extern "C" int mu_prep_weight(const float* w_oihw, void* dst, int dtype, int O, 
     long n = (long)taps * rows_pad * cols_pad * (mode == 2 ? 2 : 1);
     int grid = (int)((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048);
     hipStream_t st = (hipStream_t)stream;
-    if (dtype == MU_F32)
+    if (dtype == MU_F32 || dtype == MU_F32X)
         prep_weight_kernel<float><<<grid, 256, 0, st>>>(w_oihw, (float*)dst, O, I, taps, rows_pad, cols_pad, mode);
     else if (dtype == MU_F16)
         prep_weight_kernel<h16><<<grid, 256, 0, st>>>(w_oihw, (h16*)dst, O, I, taps, rows_pad, cols_pad, mode);
     else
         return MU_ERR_ARG;
+    if (dtype == MU_F32X) {
+        if (rows_pad % 4 || cols_pad % 4) return MU_ERR_SHAPE;
+        const long n1 = (long)taps * rows_pad * cols_pad;    // one block
+        const float sh = (float)(1 << MU_XH_WSHIFT);
+        float* d = (float*)dst;
+        if (taps == 1) {
+            split_encode_kernel<<<enc_grid(n / 4), 256, 0, st>>>((const f32x4*)d, (uint4*)d, n / 4);
+        } else {
+            if (mode != 1) split_encode_h4_kernel<<<enc_grid(n1 / 4), 256, 0, st>>>((const f32x4*)d, (uint4*)d, n1 / 4, sh);
+            if (mode != 0) {
+                // the data-gradient block's rows run over the layer's OUTPUT channels: rows_pad long in mode 2, cols_pad (as the caller
+                // named the padded output count) in mode 1
+                float* d1 = mode == 2 ? d + n1 : d;
+                const int len = mode == 2 ? rows_pad : cols_pad;
+                const long nrows = n1 / len;
+                if (len > 8192) return MU_ERR_SHAPE;
+                encode_hl_rows_kernel<<<(int)(nrows < 4096 ? nrows : 4096), 256, 0, st>>>(d1, nrows, len, sh);
+            }
+        }
+    }
     MU_CHECK_LAUNCH();
     return MU_OK;
 }
@@ -181,7 +232,8 @@ extern "C" int mu_prep_weight(const float* w_oihw, void* dst, int dtype, int O, 
 // stores).  Tiles [first_tile, first_tile + rows_pad/32 * cols_pad/32) belong to the layer.
 #define MU_PREP_JOB_FIELDS 10
 #define MU_PREP_MAX_JOBS 128
-template <typename T>
+// ENC (T = float, MU_F32X): the blocks are written in their operand encodings directly (see mu_prep_weight): no separate encoding pass.
+template <typename T, bool ENC = false>
 __global__ __launch_bounds__(256) void prep_weights_multi_kernel(const long* __restrict__ jobs, int njobs, long ntiles, T* __restrict__ base) {
     constexpr int TS = 32, MAXT = 9, LD = TS * MAXT + 1;      // LDS row of one output channel: [in][tap], padded to an odd length
     __shared__ long sj[MU_PREP_MAX_JOBS * MU_PREP_JOB_FIELDS];
@@ -217,7 +269,11 @@ __global__ __launch_bounds__(256) void prep_weights_multi_kernel(const long* __r
                 Vec16<T> v;
 #pragma unroll
                 for (int e = 0; e < VN; ++e) v.set(e, tile[ol * LD + (iv * VN + e) * taps + t]);
-                v.store(dst + ((long)t * rows_pad + o0 + ol) * cols_pad + i0 + iv * VN);
+                T* q = dst + ((long)t * rows_pad + o0 + ol) * cols_pad + i0 + iv * VN;
+                if constexpr (ENC) {
+                    const f32x4 f = {v.get(0), v.get(1), v.get(2), v.get(3)};
+                    *reinterpret_cast<uint4*>(q) = taps == 1 ? mu_enc4(f) : mu_ench4(f * (float)(1 << MU_XH_WSHIFT));
+                } else v.store(q);
             }
         if (mode != 0) {                                       // data-gradient block [taps-1-tap][in][out]
             T* d1 = mode == 2 ? dst + n : dst;
@@ -226,7 +282,17 @@ __global__ __launch_bounds__(256) void prep_weights_multi_kernel(const long* __r
                 Vec16<T> v;
 #pragma unroll
                 for (int e = 0; e < VN; ++e) v.set(e, tile[(ov * VN + e) * LD + il * taps + t]);
-                v.store(d1 + ((long)(taps - 1 - t) * cols_pad + i0 + il) * rows_pad + o0 + ov * VN);
+                T* q = d1 + ((long)(taps - 1 - t) * cols_pad + i0 + il) * rows_pad + o0 + ov * VN;
+                if constexpr (ENC) {
+                    const f32x4 f = {v.get(0), v.get(1), v.get(2), v.get(3)};
+                    if (taps == 1) *reinterpret_cast<uint4*>(q) = mu_enc4(f);
+                    else {                                     // HL row: [rows_pad fp16 lo | rows_pad fp16 hi]
+                        const uint4 e4 = mu_ench4(f * (float)(1 << MU_XH_WSHIFT));
+                        h16* hrow = reinterpret_cast<h16*>(d1 + ((long)(taps - 1 - t) * cols_pad + i0 + il) * rows_pad);
+                        *reinterpret_cast<uint2*>(hrow + o0 + ov * VN) = make_uint2(e4.z, e4.w);
+                        *reinterpret_cast<uint2*>(hrow + rows_pad + o0 + ov * VN) = make_uint2(e4.x, e4.y);
+                    }
+                } else v.store(q);
             }
         }
         __syncthreads();
@@ -238,6 +304,7 @@ extern "C" int mu_prep_weights_multi(const void* jobs, int njobs, long ntiles, v
     const int grid = (int)(ntiles < 4096 ? ntiles : 4096);
     hipStream_t st = (hipStream_t)stream;
     if (dtype == MU_F32) prep_weights_multi_kernel<float><<<grid, 256, 0, st>>>((const long*)jobs, njobs, ntiles, (float*)dst_base);
+    else if (dtype == MU_F32X) prep_weights_multi_kernel<float, true><<<grid, 256, 0, st>>>((const long*)jobs, njobs, ntiles, (float*)dst_base);
     else if (dtype == MU_F16) prep_weights_multi_kernel<h16><<<grid, 256, 0, st>>>((const long*)jobs, njobs, ntiles, (h16*)dst_base);
     else return MU_ERR_ARG;
     MU_CHECK_LAUNCH();
@@ -278,6 +345,79 @@ __global__ __launch_bounds__(256) void split_encode_kernel(const f32x4* src, uin
             if (i + u * stride < n16) dst[i + u * stride] = mu_enc4(v[u]);
     }
 }
+// the fp16-pair chunk encoding of the 3x3-convolution operands (common.h mu_ench4); scale: a power of two (1 for activations)
+__global__ __launch_bounds__(256) void split_encode_h4_kernel(const f32x4* src, uint4* dst, long n16, float scale) {
+    const long stride = (long)gridDim.x * 256;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n16; i += 4 * stride) {
+        f32x4 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (i + u * stride < n16) v[u] = __builtin_nontemporal_load(src + i + u * stride);
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (i + u * stride < n16) dst[i + u * stride] = mu_ench4(v[u] * scale);
+    }
+}
+extern "C" int mu_split_encode_h4(const void* src, void* dst, long n_elems, void* stream) {
+    if (!src || !dst || n_elems <= 0 || n_elems % 4) return MU_ERR_ARG;
+    const long n16 = n_elems / 4;
+    split_encode_h4_kernel<<<enc_grid(n16), 256, 0, (hipStream_t)stream>>>((const f32x4*)src, (uint4*)dst, n16, 1.0f);
+    MU_CHECK_LAUNCH();
+    return MU_OK;
+}
+
+// A plain fp32 gradient -> ONE power-of-two-scaled fp16 operand + its scale {S, 1 / S} (the form mu_bn_act_bwd_h writes; for a 3x3
+// convolution whose dy does not come from a BatchNorm backward).  Two launches, no atomics, no host sync: per-block maxima, then every
+// block reduces all of them (<= 1024 values) and converts its share.  S max|dy| in [2^13, 2^14).
+#define MU_DYH_MAXBLK 1024
+__global__ __launch_bounds__(256) void dyh_max_kernel(const f32x4* __restrict__ src, long n16, float* __restrict__ pmax) {
+    float m = 0.f;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n16; i += (long)gridDim.x * 256) {
+        const f32x4 v = src[i];
+        m = fmaxf(m, fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))));
+    }
+    m = wave_max(m);
+    __shared__ float sm[4];
+    if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) pmax[blockIdx.x] = fmaxf(fmaxf(sm[0], sm[1]), fmaxf(sm[2], sm[3]));
+}
+__global__ __launch_bounds__(256) void dyh_convert_kernel(const f32x4* __restrict__ src, long n16, const float* __restrict__ pmax, int nmax,
+                                                          h16x4* __restrict__ dst, float* __restrict__ dy_scale) {
+    float m = 0.f;
+    for (int k = threadIdx.x; k < nmax; k += 256) m = fmaxf(m, pmax[k]);
+    m = wave_max(m);
+    __shared__ float sm[4];
+    if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = m;
+    __syncthreads();
+    m = fmaxf(fmaxf(sm[0], sm[1]), fmaxf(sm[2], sm[3]));
+    const int e = (int)((__float_as_uint(m) >> 23) & 0xff) - 127;
+    float S = 1.f;
+    if (m > 0.f && e > -127 && e < 128) {
+        int k = 13 - e;
+        k = k < -100 ? -100 : (k > 100 ? 100 : k);
+        S = __uint_as_float((uint32_t)(127 + k) << 23);
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) { dy_scale[0] = S; dy_scale[1] = 1.0f / S; }
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n16; i += (long)gridDim.x * 256) {
+        const f32x4 v = src[i] * S;
+        dst[i] = (h16x4){(h16)v[0], (h16)v[1], (h16)v[2], (h16)v[3]};
+    }
+}
+extern "C" long mu_dy_encode_h_workspace_bytes(void) { return (long)MU_DYH_MAXBLK * sizeof(float); }
+extern "C" int mu_dy_encode_h(const void* dy, void* dy_h, float* dy_scale, long n_elems, void* workspace, long ws_bytes, void* stream) {
+    if (!dy || !dy_h || !dy_scale || !workspace || n_elems <= 0 || n_elems % 4 || dy == dy_h) return MU_ERR_ARG;
+    if (ws_bytes < mu_dy_encode_h_workspace_bytes()) return MU_ERR_WORKSPACE;
+    const long n16 = n_elems / 4;
+    long g = (n16 + 1023) / 1024;
+    const int nb = (int)(g < 1 ? 1 : (g > MU_DYH_MAXBLK ? MU_DYH_MAXBLK : g));
+    hipStream_t st = (hipStream_t)stream;
+    dyh_max_kernel<<<nb, 256, 0, st>>>((const f32x4*)dy, n16, (float*)workspace);
+    dyh_convert_kernel<<<enc_grid(n16), 256, 0, st>>>((const f32x4*)dy, n16, (const float*)workspace, nb, (h16x4*)dy_h, dy_scale);
+    MU_CHECK_LAUNCH();
+    return MU_OK;
+}
+
 extern "C" int mu_split_encode(const void* src, void* dst, long n_elems, void* stream) {
     if (!src || !dst || n_elems <= 0 || n_elems % 4) return MU_ERR_ARG;
     const long n16 = n_elems / 4;

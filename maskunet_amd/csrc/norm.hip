@@ -50,12 +50,15 @@
 // With `act` a kernel argument every element pair sat in its own basic block behind two scalar branches (GELU / ReLU / none), the
 // residual select cost a v_cndmask + a conversion per element even without a residual, and -- the expensive part in these VALU-bound
 // sweeps -- the dependent Horner chains of different pairs could not be interleaved (s_nop between every two packed FMAs).
-template <typename T, int MODE, int ACT = -1, int RES = -1>
+// MAXT (round 6, MODE 1 with fp32 storage): the block also leaves PER CHANNEL max|dz| and max|xhat| over its rows in
+// pmax[(block * C + c) * 2 + {0, 1}] -- the finalize kernel turns them into a per-channel bound of |dx|, the apply pass into the power-of-two
+// scale under which it writes dx as ONE fp16 operand (see bn_bwd_final_kernel / bn_bwd_apply_kernel).
+template <typename T, int MODE, int ACT = -1, int RES = -1, bool MAXT = false>
 __global__ __launch_bounds__(256, MODE == 1 ? MU_BN_OCC1 : 1) void bn_partial_kernel(const T* __restrict__ x, const T* __restrict__ g, const T* __restrict__ res,
                                                          T* __restrict__ dzbuf, long M, int C, long ld,
                                                          const float* __restrict__ mean, const float* __restrict__ rstd,
                                                          const float* __restrict__ gamma, const float* __restrict__ beta, int act_arg,
-                                                         double* __restrict__ part) {
+                                                         double* __restrict__ part, float* __restrict__ pmax = nullptr) {
     constexpr int N = Vec16<T>::N;
     constexpr int U = MODE == 0 ? 8 : MU_BN_U1;
     constexpr bool FAST = sizeof(T) == 2;
@@ -76,6 +79,9 @@ __global__ __launch_bounds__(256, MODE == 1 ? MU_BN_OCC1 : 1) void bn_partial_ke
     const long rstride = (long)U * rpi;
 #endif
     double s0[N], s1[N];
+    float mxg[N], mxx[N];                                       // MAXT: running max|dz|, max|xhat| of this thread's channels
+#pragma unroll
+    for (int i = 0; i < N; ++i) { mxg[i] = 0.f; mxx[i] = 0.f; }
 #pragma unroll
     for (int i = 0; i < N; ++i) { s0[i] = 0.0; s1[i] = 0.0; }
     if (tr < rpi) {
@@ -129,6 +135,12 @@ __global__ __launch_bounds__(256, MODE == 1 ? MU_BN_OCC1 : 1) void bn_partial_ke
                         dz.set(i, dzf[0]);
                         dz.set(i + 1, dzf[1]);
                         const mu_f32x2 d = {dz.get(i), dz.get(i + 1)};       // the values the apply pass will re-read (rounded to T)
+                        if constexpr (MAXT) {
+                            if (rr < r1) {                                   // (rows beyond the tensor: xhat of a zero is not data)
+                                mxg[i] = fmaxf(mxg[i], fabsf(d[0])); mxg[i + 1] = fmaxf(mxg[i + 1], fabsf(d[1]));
+                                mxx[i] = fmaxf(mxx[i], fabsf(xh[0])); mxx[i + 1] = fmaxf(mxx[i + 1], fabsf(xh[1]));
+                            }
+                        }
                         mu_f32x2 a0 = {f0[i], f0[i + 1]}, a1 = {f1[i], f1[i + 1]};
                         a0 += d;
                         a1 = __builtin_elementwise_fma(d, xh, a1);
@@ -153,6 +165,23 @@ __global__ __launch_bounds__(256, MODE == 1 ? MU_BN_OCC1 : 1) void bn_partial_ke
         for (int k = 0; k < rpi; ++k) { a += sh[((long)k * C + c) * 2]; b += sh[((long)k * C + c) * 2 + 1]; }
         part[((long)blockIdx.x * C + c) * 2] = a;
         part[((long)blockIdx.x * C + c) * 2 + 1] = b;
+    }
+    if constexpr (MAXT) {                                       // max is exact and order-free: any reduction order gives the same bits
+        __syncthreads();                                        // the sums above have been read out of `sh`
+        float* shm = reinterpret_cast<float*>(sh);              // [rpi][C][2] floats
+        if (tr < rpi) {
+#pragma unroll
+            for (int i = 0; i < N; ++i) {
+                shm[((long)tr * C + tc * N + i) * 2 + 0] = mxg[i];
+                shm[((long)tr * C + tc * N + i) * 2 + 1] = mxx[i];
+            }
+        }
+        __syncthreads();
+        for (int c = threadIdx.x; c < C; c += 256) {
+            float a = 0.f, b = 0.f;
+            for (int k = 0; k < rpi; ++k) { a = fmaxf(a, shm[((long)k * C + c) * 2]); b = fmaxf(b, shm[((long)k * C + c) * 2 + 1]); }
+            *reinterpret_cast<float2*>(pmax + ((long)blockIdx.x * C + c) * 2) = make_float2(a, b);
+        }
     }
 }
 
@@ -213,7 +242,9 @@ __global__ void bn_eval_stats_kernel(const float* __restrict__ running_mean, con
 __global__ void bn_bwd_final_kernel(const double* __restrict__ part, int nblk, int C, long M, int training,
                                     float* __restrict__ dgamma, float* __restrict__ dbeta, float* __restrict__ s1, float* __restrict__ s2,
                                     const float* __restrict__ xscale = nullptr, const float* __restrict__ pc2 = nullptr,
-                                    const float* __restrict__ pc1 = nullptr, float* __restrict__ pair_grads = nullptr) {
+                                    const float* __restrict__ pc1 = nullptr, float* __restrict__ pair_grads = nullptr,
+                                    const float* __restrict__ pmax = nullptr, const float* __restrict__ gamma = nullptr,
+                                    const float* __restrict__ rstd = nullptr, float* __restrict__ bound = nullptr) {
     const int c = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (c >= C) return;
     double av[MU_STAT_MAXBLK / 64], bv[MU_STAT_MAXBLK / 64];       // every load in flight before the first add (see bn_fwd_final_kernel)
@@ -227,6 +258,14 @@ __global__ void bn_bwd_final_kernel(const double* __restrict__ part, int nblk, i
 #pragma unroll
     for (int u = 0; u < MU_STAT_MAXBLK / 64; ++u) { a += av[u]; b += bv[u]; }
     a = wave_sum_d(a); b = wave_sum_d(b);
+    float mg = 0.f, mx = 0.f;
+    if (bound) {                                                   // mu_bn_act_bwd_h: this channel's max|dz|, max|xhat| over the blocks
+        for (int k = lane; k < nblk; k += 64) {
+            const float2 v = *reinterpret_cast<const float2*>(pmax + ((long)k * C + c) * 2);
+            mg = fmaxf(mg, v.x); mx = fmaxf(mx, v.y);
+        }
+        mg = wave_max(mg); mx = wave_max(mx);
+    }
     if (lane) return;
     dbeta[c] = (float)a;
     dgamma[c] = (float)b;
@@ -235,14 +274,20 @@ __global__ void bn_bwd_final_kernel(const double* __restrict__ part, int nblk, i
         pair_grads[C + c] = pc1[c] * (float)b;
         pair_grads[2 * C + c] = 0.f;
     }
-    s1[c] = training ? (float)(a / (double)M) : 0.f;
-    s2[c] = training ? (float)((xscale ? (double)xscale[c] : 1.0) * b / (double)M) : 0.f;      // xscale: BatchNorm pair (below)
+    const float s1c = training ? (float)(a / (double)M) : 0.f;
+    const float s2c = training ? (float)((xscale ? (double)xscale[c] : 1.0) * b / (double)M) : 0.f;      // xscale: BatchNorm pair (below)
+    s1[c] = s1c;
+    s2[c] = s2c;
+    // dx = gamma rstd (dz - s1 - xhat s2)  =>  |dx| <= |gamma rstd| (max|dz| + |s1| + max|xhat| |s2|) in this channel: the apply pass takes
+    // the maximum over the channels and writes dx as fp16(S dx) with the power of two S that puts that maximum into [2^13, 2^14)
+    if (bound) bound[c] = fabsf(gamma[c] * rstd[c]) * (mg + fabsf(s1c) + mx * fabsf(s2c));
 }
 
 // Elementwise passes: grid-stride over 16-byte vectors with a stride that is a multiple of the vectors per row (ew_grid),
 // so a thread's channel chunk -- and its per-channel constants -- never change; U vectors per operand in flight.
-// ENC (fp32 storage only, MU_F32X at the entry point): y feeds nothing but a convolution, so it is written as that convolution's chunk-encoded
-// matrix operand (common.h mu_enc4: a thread's 16-byte vector IS one chunk) -- the separate mu_split_encode pass (read + write) disappears.
+// ENC (fp32 storage only, MU_F32X at the entry point): y feeds nothing but a 3x3 convolution, so it is written as that convolution's chunk-encoded
+// matrix operand (common.h mu_ench4, the fp16-pair form: a thread's 16-byte vector IS one chunk) -- the separate mu_split_encode_h4 pass
+// (read + write) disappears.
 template <typename T, bool ENC = false, int ACT = -1, int RES = -1>
 __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const T* __restrict__ x, const T* __restrict__ res, T* __restrict__ y, long M,
                                                          int C, long ld, const float* __restrict__ mean, const float* __restrict__ rstd,
@@ -288,7 +333,7 @@ __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const T* __restrict__ x
                     o.set(i + 1, o1);
                 }
                 if constexpr (ENC) {
-                    *reinterpret_cast<uint4*>(y + (r + u * rstep) * ld + c) = mu_enc4((f32x4){o.get(0), o.get(1), o.get(2), o.get(3)});
+                    *reinterpret_cast<uint4*>(y + (r + u * rstep) * ld + c) = mu_ench4((f32x4){o.get(0), o.get(1), o.get(2), o.get(3)});
                 } else {
 #if MU_BN_NT & 2
                 o.store_nt(y + (r + u * rstep) * ld + c);
@@ -304,11 +349,15 @@ __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const T* __restrict__ x
 // dx = gamma*rstd*(dz - s1 - xhat*s2).  RECOMP = false: dz is read from dzbuf (may alias dx) -- the residual form, whose
 // d(residual) IS dz and has to be written anyway.  RECOMP = true (no residual): dz = g * act'(pre) is recomputed from x and
 // the incoming gradient, so the statistics sweep writes nothing: 5 tensor passes per BatchNorm backward instead of 6.
+// ENC (fp32 storage, mu_bn_act_bwd_h): dx -- the dy of the 3x3 convolution in front of this BatchNorm and of nothing else -- is written
+// as ONE fp16 operand S * dx (plain fp16 rows of C halves at the start of the dx buffer, row stride C) with S = dy_scale[0] the
+// power-of-two the finalize kernel derived: half the bytes, and the convolution's data- and weight-gradient take two MFMAs per product.
 template <typename T, bool RECOMP, bool ENC = false, int ACT = -1>
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__ x, const T* dzbuf, T* dx, long M, int C, long ld,
                                                            const float* __restrict__ mean, const float* __restrict__ rstd,
                                                            const float* __restrict__ gamma, const float* __restrict__ beta, int act_arg,
-                                                           const float* __restrict__ s1, const float* __restrict__ s2) {
+                                                           const float* __restrict__ s1, const float* __restrict__ s2,
+                                                           const float* __restrict__ bound = nullptr, float* __restrict__ dy_scale = nullptr) {
     constexpr int N = Vec16<T>::N;
     constexpr int U = MU_BN_UA;
     constexpr bool FAST = sizeof(T) == 2;
@@ -329,6 +378,21 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
         k1[i] = -gr[i] * rs * s2[c + i];
         k0[i] = -gr[i] * s1[c + i] - k1[i] * mean[c + i];
         mu[i] = mean[c + i]; rsv[i] = rs; ga[i] = gamma[c + i]; be[i] = RECOMP ? beta[c + i] : 0.f;
+    }
+    float S = 1.f;
+    if constexpr (ENC) {
+        // every wave derives the same S from the per-channel bounds (<= 512 floats out of L2; maxima only: deterministic); a zero or
+        // non-finite bound gives S = 1 (a NaN / inf gradient then surfaces as NaN / inf, never silently)
+        float bm = 0.f;
+        for (int k = threadIdx.x & 63; k < C; k += 64) bm = fmaxf(bm, bound[k]);
+        bm = wave_max(bm);
+        const int e = (int)((__float_as_uint(bm) >> 23) & 0xff) - 127;           // floor(log2 bm) of a normal value
+        if (bm > 0.f && e > -127 && e < 128) {
+            int k = 13 - e;
+            k = k < -100 ? -100 : (k > 100 ? 100 : k);
+            S = __uint_as_float((uint32_t)(127 + k) << 23);
+        }
+        if (blockIdx.x == 0 && threadIdx.x == 0) { dy_scale[0] = S; dy_scale[1] = 1.0f / S; }
     }
     for (long idx = first; idx < total; idx += U * stride) {
         const long r = idx / cv;
@@ -364,8 +428,11 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
                     o.set(i, ov[0]);
                     o.set(i + 1, ov[1]);
                 }
-                if constexpr (ENC) *reinterpret_cast<uint4*>(dx + (r + u * rstep) * ld + c) = mu_enc4((f32x4){o.get(0), o.get(1), o.get(2), o.get(3)});
-                else o.store(dx + (r + u * rstep) * ld + c);
+                if constexpr (ENC) {
+                    static_assert(N == 4, "fp16 dx rows come from fp32 storage");
+                    const h16x4 oh = {(h16)(o.get(0) * S), (h16)(o.get(1) * S), (h16)(o.get(2) * S), (h16)(o.get(3) * S)};
+                    *reinterpret_cast<h16x4*>(reinterpret_cast<h16*>(dx) + (r + u * rstep) * (long)C + c) = oh;
+                } else o.store(dx + (r + u * rstep) * ld + c);
             }
         }
     }
@@ -465,7 +532,10 @@ extern "C" int mu_colsum(const void* x, long M, int C, long ld, float* out, void
 }
 
 // fp64 partial slab | s1, s2 (the apply pass's per-channel means) | A (mu_bn_pair_bwd: the single-layer dgamma nobody outside reads)
-extern "C" long mu_bn_workspace_bytes(int C) { return (long)MU_STAT_MAXBLK * C * 2 * sizeof(double) + 3L * C * sizeof(float); }
+// ... | bound[C] | per-block, per-channel (max|dz|, max|xhat|) of the backward statistics sweep (mu_bn_act_bwd_h)
+extern "C" long mu_bn_workspace_bytes(int C) {
+    return (long)MU_STAT_MAXBLK * C * 2 * sizeof(double) + 4L * C * sizeof(float) + (long)MU_STAT_MAXBLK * C * 2 * sizeof(float);
+}
 
 template <typename T>
 static int bn_train_stats_t(const T* x, long M, int C, long ld, float* mean, float* rstd, float* rmean, float* rvar, long* nbt,
@@ -613,7 +683,7 @@ template <typename T>
 static int bn_act_bwd_t(const T* x, const T* res, const T* g, T* dx, T* dres, long M, int C, long ld, const float* mean,
                         const float* rstd, const float* gamma, const float* beta, int act, int training, float* dgamma,
                         float* dbeta, void* ws, hipStream_t st, const float* xscale = nullptr, bool enc = false, const float* pc2 = nullptr,
-                        const float* pc1 = nullptr, float* pair_grads = nullptr) {
+                        const float* pc1 = nullptr, float* pair_grads = nullptr, float* dy_scale = nullptr) {
     constexpr int N = Vec16<T>::N;
     int cv = C / N;
     if (cv > 256) return MU_ERR_SHAPE;
@@ -626,20 +696,33 @@ static int bn_act_bwd_t(const T* x, const T* res, const T* g, T* dx, T* dres, lo
     double* part = (double*)ws;
     float* s1 = (float*)((char*)ws + (size_t)MU_STAT_MAXBLK * C * 2 * sizeof(double));
     float* s2 = s1 + C;
+    float* bound = s1 + 3 * (size_t)C;
+    float* pmax = bound + C;
     if (act != MU_ACT_NONE && act != MU_ACT_GELU && act != MU_ACT_RELU) return MU_ERR_ARG;
+    if (enc && (sizeof(T) != 4 || !dy_scale || ld != C)) return MU_ERR_ARG;      // fp16 dx rows: fp32 storage, contiguous rows
     if (res) {                      // d(residual) == dz exactly, so it doubles as the dz buffer
+        if constexpr (sizeof(T) == 4) {
+            if (enc) {
+                MU_BN_ACT_SWITCH(act, (bn_partial_kernel<T, 1, A_, 1, true><<<nblk, 256, lds, st>>>(x, g, res, dres, M, C, ld, mean, rstd, gamma, beta, act, part, pmax)))
+                bn_bwd_final_kernel<<<mu_cdiv(C, 4), 256, 0, st>>>(part, nblk, C, M, training, dgamma, dbeta, s1, s2, xscale, nullptr, nullptr, nullptr, pmax, gamma, rstd, bound);
+                bn_bwd_apply_kernel<T, false, true><<<ew_grid(M * cv, cv), 256, 0, st>>>(x, dres, dx, M, C, ld, mean, rstd, gamma, beta, act, s1, s2, bound, dy_scale);
+                return MU_OK;
+            }
+        }
         MU_BN_ACT_SWITCH(act, (bn_partial_kernel<T, 1, A_, 1><<<nblk, 256, lds, st>>>(x, g, res, dres, M, C, ld, mean, rstd, gamma, beta, act, part)))
         bn_bwd_final_kernel<<<mu_cdiv(C, 4), 256, 0, st>>>(part, nblk, C, M, training, dgamma, dbeta, s1, s2, xscale);
-        if constexpr (sizeof(T) == 4) {
-            if (enc) { bn_bwd_apply_kernel<T, false, true><<<ew_grid(M * cv, cv), 256, 0, st>>>(x, dres, dx, M, C, ld, mean, rstd, gamma, beta, act, s1, s2); return MU_OK; }
-        }
         bn_bwd_apply_kernel<T, false><<<ew_grid(M * cv, cv), 256, 0, st>>>(x, dres, dx, M, C, ld, mean, rstd, gamma, beta, act, s1, s2);
     } else {                        // no residual: nothing is written by the statistics sweep, dz is recomputed in the apply pass
+        if constexpr (sizeof(T) == 4) {
+            if (enc) {
+                MU_BN_ACT_SWITCH(act, (bn_partial_kernel<T, 1, A_, 0, true><<<nblk, 256, lds, st>>>(x, g, nullptr, nullptr, M, C, ld, mean, rstd, gamma, beta, act, part, pmax)))
+                bn_bwd_final_kernel<<<mu_cdiv(C, 4), 256, 0, st>>>(part, nblk, C, M, training, dgamma, dbeta, s1, s2, xscale, pc2, pc1, pair_grads, pmax, gamma, rstd, bound);
+                MU_BN_ACT_SWITCH(act, (bn_bwd_apply_kernel<T, true, true, A_><<<ew_grid(M * cv, cv), 256, 0, st>>>(x, g, dx, M, C, ld, mean, rstd, gamma, beta, act, s1, s2, bound, dy_scale)))
+                return MU_OK;
+            }
+        }
         MU_BN_ACT_SWITCH(act, (bn_partial_kernel<T, 1, A_, 0><<<nblk, 256, lds, st>>>(x, g, nullptr, nullptr, M, C, ld, mean, rstd, gamma, beta, act, part)))
         bn_bwd_final_kernel<<<mu_cdiv(C, 4), 256, 0, st>>>(part, nblk, C, M, training, dgamma, dbeta, s1, s2, xscale, pc2, pc1, pair_grads);
-        if constexpr (sizeof(T) == 4) {
-            if (enc) { MU_BN_ACT_SWITCH(act, (bn_bwd_apply_kernel<T, true, true, A_><<<ew_grid(M * cv, cv), 256, 0, st>>>(x, g, dx, M, C, ld, mean, rstd, gamma, beta, act, s1, s2))) return MU_OK; }
-        }
         MU_BN_ACT_SWITCH(act, (bn_bwd_apply_kernel<T, true, false, A_><<<ew_grid(M * cv, cv), 256, 0, st>>>(x, g, dx, M, C, ld, mean, rstd, gamma, beta, act, s1, s2)))
     }
     return MU_OK;
@@ -717,8 +800,6 @@ extern "C" int mu_bn_act_bwd_scaled(const void* x, const void* res, const void* 
     int rc;
     if (dtype == MU_F32)
         rc = bn_act_bwd_t<float>((const float*)x, (const float*)res, (const float*)grad_out, (float*)dx, (float*)dres, M, C, ld, mean, rstd, gamma, beta, act, training, dgamma, dbeta, workspace, st, xhat_scale);
-    else if (dtype == MU_F32X)      // fp32 storage; dx -- the dy of the convolution in front of this BatchNorm -- written chunk-encoded (dres stays plain)
-        rc = bn_act_bwd_t<float>((const float*)x, (const float*)res, (const float*)grad_out, (float*)dx, (float*)dres, M, C, ld, mean, rstd, gamma, beta, act, training, dgamma, dbeta, workspace, st, xhat_scale, true);
     else if (dtype == MU_F16)
         rc = bn_act_bwd_t<h16>((const h16*)x, (const h16*)res, (const h16*)grad_out, (h16*)dx, (h16*)dres, M, C, ld, mean, rstd, gamma, beta, act, training, dgamma, dbeta, workspace, st, xhat_scale);
     else return MU_ERR_ARG;
@@ -741,11 +822,48 @@ extern "C" int mu_bn_pair_bwd(const void* x, const void* grad_out, void* dx, lon
     int rc;
     if (dtype == MU_F32)
         rc = bn_act_bwd_t<float>((const float*)x, nullptr, (const float*)grad_out, (float*)dx, nullptr, M, C, ld, mean, rstd, gamma_eff, beta2, MU_ACT_NONE, 1, A, dbeta2, workspace, st, xhat_scale, false, dgamma2_coef, dgamma1_coef, pair_grads);
-    else if (dtype == MU_F32X)
-        rc = bn_act_bwd_t<float>((const float*)x, nullptr, (const float*)grad_out, (float*)dx, nullptr, M, C, ld, mean, rstd, gamma_eff, beta2, MU_ACT_NONE, 1, A, dbeta2, workspace, st, xhat_scale, true, dgamma2_coef, dgamma1_coef, pair_grads);
     else if (dtype == MU_F16)
         rc = bn_act_bwd_t<h16>((const h16*)x, nullptr, (const h16*)grad_out, (h16*)dx, nullptr, M, C, ld, mean, rstd, gamma_eff, beta2, MU_ACT_NONE, 1, A, dbeta2, workspace, st, xhat_scale, false, dgamma2_coef, dgamma1_coef, pair_grads);
     else return MU_ERR_ARG;
+    if (rc) return rc;
+    MU_CHECK_LAUNCH();
+    return MU_OK;
+}
+
+// fp32x (round 6): the same backward passes with dx written as ONE power-of-two-scaled fp16 operand -- dx is the dy of the 3x3
+// convolution in front of the BatchNorm (ConvBlock wiring, ade_semantic.py:199-204) and of nothing else.  dx_h: M rows of C halves
+// (row stride C) = the first half of a buffer sized like x; dy_scale: two floats {S, 1 / S} written on the device (no host sync) and
+// handed to mu_conv_dgrad_h / mu_conv_wgrad_h.  fp32 storage, contiguous rows (ld == C).  dres (residual form) stays plain fp32.
+// The scale: the statistics sweep also collects max|dz| and max|xhat| per channel, the finalize kernel bounds |dx| per channel
+// (|gamma rstd| (max|dz| + |s1| + max|xhat| |s2|): tight to ~2 bits, and a padded or degenerate channel -- rstd = 1 / sqrt(eps), dz = 0 --
+// bounds itself with 0 instead of inflating a global product), the apply pass takes the maximum.  Maxima only: bit-reproducible.
+extern "C" int mu_bn_act_bwd_h(const void* x, const void* res, const void* grad_out, void* dx_h, void* dres, long M, int C,
+                               const float* mean, const float* rstd, const float* gamma, const float* beta, int act, int training,
+                               float* dgamma, float* dbeta, float* dy_scale, void* workspace, long ws_bytes, void* stream) {
+    if (!x || !grad_out || !dx_h || !mean || !rstd || !gamma || !beta || !dgamma || !dbeta || !dy_scale || !workspace) return MU_ERR_ARG;
+    if ((res != nullptr) != (dres != nullptr)) return MU_ERR_ARG;
+    if (M <= 0 || C <= 0 || C % 8) return MU_ERR_ARG;
+    if (ws_bytes < mu_bn_workspace_bytes(C)) return MU_ERR_WORKSPACE;
+    int rc = bn_act_bwd_t<float>((const float*)x, (const float*)res, (const float*)grad_out, (float*)dx_h, (float*)dres, M, C, C, mean, rstd, gamma,
+                                 beta, act, training, dgamma, dbeta, workspace, (hipStream_t)stream, nullptr, true, nullptr, nullptr, nullptr, dy_scale);
+    if (rc) return rc;
+    MU_CHECK_LAUNCH();
+    return MU_OK;
+}
+
+extern "C" int mu_bn_pair_bwd_h(const void* x, const void* grad_out, void* dx_h, long M, int C, const float* mean, const float* rstd,
+                                const float* gamma_eff, const float* beta2, const float* xhat_scale, const float* dgamma2_coef,
+                                const float* dgamma1_coef, float* pair_grads, float* dbeta2, float* dy_scale, void* workspace, long ws_bytes,
+                                void* stream) {
+    if (!x || !grad_out || !dx_h || !mean || !rstd || !gamma_eff || !beta2 || !xhat_scale || !dgamma2_coef || !dgamma1_coef || !pair_grads ||
+        !dbeta2 || !dy_scale || !workspace)
+        return MU_ERR_ARG;
+    if (M <= 0 || C <= 0 || C % 8) return MU_ERR_ARG;
+    if (ws_bytes < mu_bn_workspace_bytes(C)) return MU_ERR_WORKSPACE;
+    float* A = (float*)((char*)workspace + (size_t)MU_STAT_MAXBLK * C * 2 * sizeof(double)) + 2 * (size_t)C;
+    int rc = bn_act_bwd_t<float>((const float*)x, nullptr, (const float*)grad_out, (float*)dx_h, nullptr, M, C, C, mean, rstd, gamma_eff, beta2,
+                                 MU_ACT_NONE, 1, A, dbeta2, workspace, (hipStream_t)stream, xhat_scale, true, dgamma2_coef, dgamma1_coef, pair_grads,
+                                 dy_scale);
     if (rc) return rc;
     MU_CHECK_LAUNCH();
     return MU_OK;

@@ -45,6 +45,32 @@ def _enc(t):
     return e
 
 
+def _enc3(t):
+    """fp32x: the 3x3-convolution operand encoding ([4 fp16 hi | 4 fp16 lo] per chunk, round 6) of an activation; the tensor itself otherwise."""
+    if not _is_x(t):
+        return t
+    t = t.contiguous()
+    e = torch.empty_like(t)
+    call("mu_split_encode_h4", ptr(t), ptr(e), t.numel(), stream())
+    return e
+
+
+def _enc_for(t, taps):
+    """The operand encoding a layer with `taps` taps reads: fp16 pairs for the 3x3 layers, bf16 pairs for 1x1 / Linear."""
+    return _enc3(t) if taps == 9 else _enc(t)
+
+
+def dy_encode_h(gy):
+    """fp32x, 3x3 backward: a plain fp32 gradient as ONE power-of-two-scaled fp16 operand -> (tensor holding the halves, scale pair).  The
+    halves live at the start of an fp32-typed buffer of gy's shape (the form the BatchNorm backward hands over through EncLink)."""
+    gy = gy.contiguous()
+    out = torch.empty_like(gy)
+    scale = torch.empty(2, dtype=torch.float32, device=gy.device)
+    ws = torch.empty(_lib.load().mu_dy_encode_h_workspace_bytes(), dtype=torch.uint8, device=gy.device)      # (own buffer: also called on the side stream)
+    call("mu_dy_encode_h", ptr(gy), ptr(out), ptr(scale), gy.numel(), ptr(ws), ws.numel(), stream())
+    return out, scale
+
+
 def _enc_(t):
     """The same in place (buffers nobody reads as plain fp32 afterwards: prepared weights, qkv)."""
     if _is_x(t):
@@ -99,20 +125,25 @@ _graph_task_id = getattr(torch._C, "_current_graph_task_id", lambda: -1)     # i
 
 
 class EncLink:
-    """fp32x: tells a conv's backward that the dy it is handed was WRITTEN chunk-encoded by the backward of the BatchNorm behind that conv
-    (mu_bn_act_bwd with MU_F32X) -- the BatchNorm's dx is the conv's dy and has no other consumer (ConvBlock wiring), so the separate
-    encoding pass disappears.  One link per (conv, BatchNorm) pair and forward call; valid only within the backward pass that marked it."""
-    __slots__ = ("task",)
+    """fp32x: tells a 3x3 conv's backward that the dy it is handed was WRITTEN as one scaled fp16 operand by the backward of the BatchNorm
+    behind that conv (mu_bn_act_bwd_h) -- the BatchNorm's dx is the conv's dy and has no other consumer (ConvBlock wiring), so the separate
+    encoding pass disappears.  Carries the device-side scale pair {S, 1 / S} of that tensor.  One link per (conv, BatchNorm) pair and
+    forward call; valid only within the backward pass that marked it."""
+    __slots__ = ("task", "scale")
 
     def __init__(self):
         self.task = None
+        self.scale = None
 
-    def mark(self):
+    def mark(self, scale):
         self.task = _graph_task_id()
+        self.scale = scale
 
     def take(self):
-        t, self.task = self.task, None
-        return t is not None and t == _graph_task_id()
+        """-> the scale pair if this backward pass marked the link, else None"""
+        t, sc = self.task, self.scale
+        self.task = self.scale = None
+        return sc if (t is not None and t == _graph_task_id()) else None
 
 
 def enc_link(x):
@@ -292,8 +323,9 @@ def _prep_weight_raw(w, dtype, rows_pad, cols_pad, mode):
     n = taps * rows_pad * cols_pad
     dst = torch.empty((2 * n if mode == 2 else n,), dtype=dtype, device=w.device)
     wf = w.detach().float().contiguous()
-    call("mu_prep_weight", ptr(wf), ptr(dst), dt(dtype), O, I, taps, rows_pad, cols_pad, mode, stream())
-    _enc_(dst)                          # fp32x: the compute layouts are matrix operands (rows of cols_pad % 32 == 0 elements: whole chunks)
+    # fp32x (MU_F32X): the library writes the layouts in their operand encodings -- bf16 chunks for 1x1 layers, fp16 chunks (forward) and
+    # HL rows (data gradient) for 3x3 layers (include/maskunet_hip.h)
+    call("mu_prep_weight", ptr(wf), ptr(dst), mdt(dtype), O, I, taps, rows_pad, cols_pad, mode, stream())
     if mode == 2:
         return dst[:n].view(taps, rows_pad, cols_pad), dst[n:].view(taps, cols_pad, rows_pad)
     return dst.view(taps, rows_pad, cols_pad)
@@ -346,8 +378,7 @@ def prep_conv_weights(holder, weights, dtype, fwd_only=()):
             del plans[old]
     _, table, metas, total, nchunks = plan
     dst = torch.empty(total, dtype=dtype, device=dev)
-    call("mu_prep_weights_multi", ptr(table), len(weights), nchunks, ptr(dst), dt(dtype), stream())
-    _enc_(dst)
+    call("mu_prep_weights_multi", ptr(table), len(weights), nchunks, ptr(dst), mdt(dtype), stream())      # (fp32x: encoded by the kernel)
     tag = (dtype, mdt(dtype))
     for w, (off, n, taps, rp, cp, mode) in zip(weights, metas):
         fwd = dst[off:off + n].view(taps, rp, cp)
@@ -374,7 +405,7 @@ def _conv_raw(x, wprep, bias_p, Cout_p, taps, want_stats=False, x_encoded=False)
     B, H, W, Cin_p = x.shape
     y = torch.empty((B, H, W, Cout_p), dtype=x.dtype, device=x.device)
     if not x_encoded:
-        x = _enc(x)
+        x = _enc_for(x, taps)
     if want_stats:
         rows = _lib.load().mu_conv_stats_rows(B, H, W, Cin_p, Cout_p, taps, mdt(x))
         if rows > 0:
@@ -427,12 +458,28 @@ def grad_out(param, shape, device):
     return torch.empty(shape, dtype=torch.float32, device=device)
 
 
-def _wgrad_raw(x, gy, w_shape, taps, st=None, ws=None, gy_encoded=False, x_encoded=False, param=None):
+def _wgrad_raw(x, gy, w_shape, taps, st=None, ws=None, gy_encoded=False, x_encoded=False, param=None, gy_scale=None):
+    """gy_scale (fp32x 3x3 layers): gy holds ONE scaled fp16 operand (dy_encode_h form) and this is its scale pair."""
     B, H, W, Cin_p = x.shape
     O, I = w_shape[0], w_shape[1]
     code = mdt(x)
     if code == _lib.MU_F32X and taps == 9 and I <= 3 and not gy_encoded and not x_encoded:
         code = _lib.MU_F32               # the first layer's weight gradient is a plain-FMA kernel (no matrix cores): plain fp32 operands
+    if code == _lib.MU_F32X and taps == 9:
+        # two-term weight gradient (round 6): the saved input as fp16 pairs x dy as one scaled fp16 operand
+        if not x_encoded:
+            x = _enc3(x)
+        if gy_scale is None:
+            if gy_encoded:
+                raise RuntimeError("conv weight gradient: a 3x3 layer takes dy as a scaled fp16 operand, not chunk-encoded")
+            gy, gy_scale = dy_encode_h(gy)
+        Cout_p = gy.shape[-1]
+        gw = grad_out(param, tuple(w_shape), x.device)
+        if ws is None:
+            ws = workspace(_lib.load().mu_conv_wgrad_h_workspace_bytes(B, H, W, Cin_p, Cout_p), x.device)
+        call("mu_conv_wgrad_h", ptr(x), ptr(gy), ptr(gy_scale), ptr(gw), B, H, W, Cin_p, Cout_p, I, O, Cin_p, Cout_p, ptr(ws), ws.numel(),
+             stream() if st is None else st)
+        return gw
     if code == _lib.MU_F32X:
         if not x_encoded:
             x = _enc(x)
@@ -508,6 +555,8 @@ def _wgrad_side(x, gy, w_shape, taps, x_encoded=False, param=None):
     with torch.cuda.stream(side):
         B, H, W, Cin_p = x.shape
         nbytes = _lib.load().mu_conv_wgrad_workspace_bytes(B, H, W, Cin_p, gy.shape[-1], taps)
+        if taps == 9 and _is_x(x):
+            nbytes = max(nbytes, _lib.load().mu_conv_wgrad_h_workspace_bytes(B, H, W, Cin_p, gy.shape[-1]))
         ws = _SIDE_WS.get(dev.index)
         if ws is None or ws.numel() < nbytes:
             ws = _SIDE_WS[dev.index] = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=dev)
@@ -561,7 +610,7 @@ class _Conv(torch.autograd.Function):
         if x_encoded and not ctx.x_enc:
             raise RuntimeError("conv: a pre-encoded input needs the fp32x mode and a matrix-core layer")
         if ctx.x_enc and not x_encoded:
-            x = _enc(x)
+            x = _enc_for(x, taps)
         if want_stats:
             y, part = _conv_raw(x, wprep, bias_p, Cout_p, taps, True, x_encoded=ctx.x_enc)
         else:
@@ -585,18 +634,38 @@ class _Conv(torch.autograd.Function):
         x, weight = ctx.saved_tensors
         gy = gy.contiguous()
         _same_mode(ctx.is_x, gy)
-        gy_pre = ctx.dy_link is not None and ctx.dy_link.take()      # fp32x: dy arrived chunk-encoded from the BatchNorm's backward
+        gy_sc = ctx.dy_link.take() if ctx.dy_link is not None else None      # fp32x: dy arrived as ONE scaled fp16 operand from the BatchNorm's backward
+        gy_pre = gy_sc is not None
         O, I = weight.shape[0], weight.shape[1]
         gx = gw = gb = None
         side = ctx.needs_input_grad[1] and WGRAD_SIDE_STREAM and ctx.wparam.grad is None and x.shape[1] <= WGRAD_SIDE_MAXHW
         if side and os.environ.get("MU_WGRAD_SIDE_FIRST"):
             gw = _wgrad_side(x, gy, tuple(weight.shape), ctx.taps, ctx.x_enc, ctx.wparam)
-        if gy_pre:
-            ge = gy
-            if side or not ctx.x_enc or (ctx.has_bias and ctx.needs_input_grad[2]):
-                raise RuntimeError("conv backward: an encoded dy reached a path that needs it plain")
-        else:
-            ge = _enc(gy) if (ctx.needs_input_grad[0] or (ctx.needs_input_grad[1] and not side)) else gy     # fp32x: one encoding of dy for both
+        if gy_pre and (side or not ctx.x_enc or ctx.taps != 9 or (ctx.has_bias and ctx.needs_input_grad[2])):
+            raise RuntimeError("conv backward: an encoded dy reached a path that needs it plain")
+        if ctx.is_x and ctx.taps == 9:
+            # fp32x 3x3 layer: the two-term backward (round 6) -- dy as ONE power-of-two-scaled fp16 operand, shared by the data gradient
+            # (against the fp16 pair of the weights) and the weight gradient (against the fp16 pair of the saved input)
+            wg_h = ctx.needs_input_grad[1] and not side and ctx.x_enc      # (a <= 3-channel layer's weight gradient: plain-FMA kernel, plain dy)
+            gh = gy if gy_pre else None
+            if gh is None and (ctx.needs_input_grad[0] or wg_h):
+                gh, gy_sc = dy_encode_h(gy)
+            if ctx.needs_input_grad[0]:
+                wd = ctx.wd if ctx.wd is not None else _prep_weight(weight, gy.dtype, x.shape[-1], gy.shape[-1], 1)
+                ctx.wd = None
+                B, H, W, Cin_p = x.shape
+                gx = torch.empty((B, H, W, Cin_p), dtype=torch.float32, device=x.device)
+                call("mu_conv_dgrad_h", ptr(gh), ptr(wd), ptr(gy_sc), ptr(gx), B, H, W, gy.shape[-1], Cin_p, gy.shape[-1], Cin_p, stream())
+            if side and gw is None:
+                gw = _wgrad_side(x, gy, tuple(weight.shape), ctx.taps, ctx.x_enc, ctx.wparam)
+            if wg_h:
+                gw = _wgrad_raw(x, gh, tuple(weight.shape), 9, x_encoded=True, param=ctx.wparam, gy_scale=gy_sc)
+            elif ctx.needs_input_grad[1] and not side:
+                gw = _wgrad_raw(x, gy, tuple(weight.shape), 9, param=ctx.wparam)
+            if ctx.has_bias and ctx.needs_input_grad[2]:
+                gb = _colsum(gy, O)
+            return gx, gw, gb, None, None, None, None
+        ge = _enc(gy) if (ctx.needs_input_grad[0] or (ctx.needs_input_grad[1] and not side)) else gy     # fp32x: one encoding of dy for both
         if ctx.needs_input_grad[0]:
             wd = ctx.wd if ctx.wd is not None else _prep_weight(weight, gy.dtype, x.shape[-1], gy.shape[-1], 1)
             ctx.wd = None
@@ -685,11 +754,15 @@ class _BNAct(torch.autograd.Function):
         dgamma = torch.empty(C, dtype=torch.float32, device=x.device)
         dbeta = torch.empty_like(dgamma)
         ws = workspace(_lib.load().mu_bn_workspace_bytes(C), x.device)
-        enc = ctx.dx_link is not None            # fp32x: dx is the dy of the conv in front -- written chunk-encoded, the conv is told (EncLink)
-        call("mu_bn_act_bwd", ptr(x), ptr(res), ptr(gy), ptr(dx), ptr(dres), M, C, C, ptr(mean), ptr(rstd), ptr(g_p), ptr(b_p),
-             ctx.act, int(ctx.training), ptr(dgamma), ptr(dbeta), ptr(ws), ws.numel(), _lib.MU_F32X if enc else dt(x), stream())
+        enc = ctx.dx_link is not None            # fp32x: dx is the dy of the 3x3 conv in front -- written as ONE scaled fp16 operand, the conv is told (EncLink)
         if enc:
-            ctx.dx_link.mark()
+            sc = torch.empty(2, dtype=torch.float32, device=x.device)      # {S, 1 / S}, written on the device
+            call("mu_bn_act_bwd_h", ptr(x), ptr(res), ptr(gy), ptr(dx), ptr(dres), M, C, ptr(mean), ptr(rstd), ptr(g_p), ptr(b_p),
+                 ctx.act, int(ctx.training), ptr(dgamma), ptr(dbeta), ptr(sc), ptr(ws), ws.numel(), stream())
+            ctx.dx_link.mark(sc)
+        else:
+            call("mu_bn_act_bwd", ptr(x), ptr(res), ptr(gy), ptr(dx), ptr(dres), M, C, C, ptr(mean), ptr(rstd), ptr(g_p), ptr(b_p),
+                 ctx.act, int(ctx.training), ptr(dgamma), ptr(dbeta), ptr(ws), ws.numel(), dt(x), stream())
         if ctx.res_link is not None:             # the residual-branch gradient travels to the backward of x's producer (GradLink)
             ctx.res_link.put(dres)
             dres = None
@@ -739,10 +812,14 @@ class _BNPair(torch.autograd.Function):
         dbeta2 = torch.empty(C, dtype=torch.float32, device=x.device)
         ws = workspace(_lib.load().mu_bn_workspace_bytes(C), x.device)
         enc = ctx.dx_link is not None
-        call("mu_bn_pair_bwd", ptr(x), ptr(gy), ptr(dx), M, C, C, ptr(mean), ptr(rstd), ptr(coef[0]), ptr(b2p), ptr(coef[1]), ptr(coef[2]),
-             ptr(coef[3]), ptr(dg), ptr(dbeta2), ptr(ws), ws.numel(), _lib.MU_F32X if enc else dt(x), stream())
         if enc:
-            ctx.dx_link.mark()
+            sc = torch.empty(2, dtype=torch.float32, device=x.device)
+            call("mu_bn_pair_bwd_h", ptr(x), ptr(gy), ptr(dx), M, C, ptr(mean), ptr(rstd), ptr(coef[0]), ptr(b2p), ptr(coef[1]), ptr(coef[2]),
+                 ptr(coef[3]), ptr(dg), ptr(dbeta2), ptr(sc), ptr(ws), ws.numel(), stream())
+            ctx.dx_link.mark(sc)
+        else:
+            call("mu_bn_pair_bwd", ptr(x), ptr(gy), ptr(dx), M, C, C, ptr(mean), ptr(rstd), ptr(coef[0]), ptr(b2p), ptr(coef[1]), ptr(coef[2]),
+                 ptr(coef[3]), ptr(dg), ptr(dbeta2), ptr(ws), ws.numel(), dt(x), stream())
         cv = ctx.cv
         return (dx, dg[1, :cv], dg[2, :cv], dg[0, :cv], dbeta2[:cv]) + (None,) * 12
 
@@ -816,7 +893,7 @@ def conv_bn_act_eval(x, weight, conv_bias, bn, act=ACT_NONE, res=None, bn2=None)
     y = torch.empty((B, H, W, Cout_p), dtype=x.dtype, device=x.device)
     if res is not None:
         res = res.contiguous()
-    call("mu_conv_fwd_fused", ptr(_enc(x)), ptr(wprep), ptr(fold[0]), ptr(fold[1]), ptr(res), act, ptr(y), B, H, W, Cin_p, Cout_p, taps, Cin_p,
+    call("mu_conv_fwd_fused", ptr(_enc_for(x, taps)), ptr(wprep), ptr(fold[0]), ptr(fold[1]), ptr(res), act, ptr(y), B, H, W, Cin_p, Cout_p, taps, Cin_p,
          Cout_p, mdt(x), stream())
     return y
 

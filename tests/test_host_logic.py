@@ -176,18 +176,19 @@ def test_bench_spawns_a_child_launcher_for_bare_gpus(monkeypatch):
 
 
 def test_enc_link_is_valid_only_within_the_marking_backward_pass(monkeypatch):
-    """ops.EncLink (fp32x): "the dy you are handed is chunk-encoded" holds only for the backward pass in which the BatchNorm behind the
-    conv wrote it so; a leftover mark of another pass (partial backward) must read as plain."""
+    """ops.EncLink (fp32x): "the dy you are handed is one scaled fp16 operand, and this is its scale" holds only for the backward pass in
+    which the BatchNorm behind the conv wrote it so; a leftover mark of another pass (partial backward) must read as plain."""
     from maskunet_amd import ops
     task = {"id": 3}
     monkeypatch.setattr(ops, "_graph_task_id", lambda: task["id"])
     link = ops.EncLink()
-    assert link.take() is False
-    link.mark()
-    assert link.take() is True and link.take() is False          # consumed once
-    link.mark()
+    assert link.take() is None
+    sc = torch.tensor([8.0, 0.125])
+    link.mark(sc)
+    assert link.take() is sc and link.take() is None              # consumed once, hands the scale pair over
+    link.mark(sc)
     task["id"] = 4
-    assert link.take() is False                                   # another pass
+    assert link.take() is None                                    # another pass
     assert ops.enc_link(torch.zeros(4)) is None                   # exact-fp32 mode: no links at all
 
 
