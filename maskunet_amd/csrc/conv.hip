@@ -2185,6 +2185,14 @@ static int conv_fwd_launch(const T* x, const T* w, const float* bias, T* y, int 
             return MU_OK;
         }
     }
+    if constexpr (TAPS == 1 && mu_is_split<T>::value && MU_CONV_WIDE1X1) {
+        // fp32x: the 150-class head (64 -> 160) on one tile that spans all output channels instead of five 32-wide tiles of the generic
+        // register-staged kernel (320 -> ~130 us at B = 64)
+        if ((Cin * 4) % 128 == 0 && Cout == 160) {
+            conv_nt2_kernel<T, 5, 4, 2, 1><<<npb, 256, 0, st>>>(x, w, bias, y, B, H, W, Cin, Cout, x_ld, y_ld);
+            return MU_OK;
+        }
+    }
     if ((Cin * (int)sizeof(T)) % 128 == 0 && Cout % 64 == 0) {         // LDS-DMA version
         if (Cout % 128 == 0)
             conv_nt2_kernel<T, 4, 4, 2, TAPS><<<npb * (Cout / 128), 256, 0, st>>>(x, w, bias, y, B, H, W, Cin, Cout, x_ld, y_ld);
@@ -3811,7 +3819,7 @@ extern "C" long mu_conv_wgrad_workspace_bytes(int B, int H, int W, int Cin, int 
 template <typename T, int TAPS>
 static int wgrad_launch(const T* x, const T* dy, float* part, int B, int H, int W, int Cin, int Cout, long x_ld, long dy_ld, int bt,
                         int nsplit, long pps, hipStream_t st, int bci = 0, float* bias_part = nullptr) {
-    if constexpr (TAPS == 1 && sizeof(T) == 2) {
+    if constexpr (TAPS == 1 && (sizeof(T) == 2 || std::is_same<T, xf32>::value)) {
         if (wgrad_is_wide(bt)) {                            // bt x bci tiles (bci = 64 or 128)
             const int grid = ((Cout + bt - 1) / bt) * ((Cin + bci - 1) / bci) * nsplit;
 #define WG1(TM_, TN_)                                                                                                                  \
@@ -3853,7 +3861,9 @@ static int conv_wgrad_impl(const void* x, const void* dy, float* dw_oihw, float*
     if (cin_valid <= 0 || cin_valid > Cin || cout_valid <= 0 || cout_valid > Cout) return MU_ERR_ARG;
     if (taps != 1 && taps != 9) return MU_ERR_ARG;
     int bco, bci, nsplit; long pps;
-    wgrad_tile(Cin, Cout, &bco, &bci, taps, dtype == MU_F16);
+    // (fp32x: the wide 160-channel tile of the class head as well -- 32 x 32 tiles otherwise; the 192-wide q/k/v tiles stay fp16-only:
+    //  64 x 64 tiles serve those layers)
+    wgrad_tile(Cin, Cout, &bco, &bci, taps, dtype == MU_F16 || (dtype == MU_F32X && Cout == 160));
     wgrad_plan((long)B * H * W, Cin, Cout, taps, bco, bci, &nsplit, &pps);
     hipStream_t st = (hipStream_t)stream;
     float* part = (float*)workspace;
@@ -3948,7 +3958,7 @@ static int conv_wgrad_impl(const void* x, const void* dy, float* dw_oihw, float*
         else wgrad_launch<float, 1>((const float*)x, (const float*)dy, part, B, H, W, Cin, Cout, x_ld, dy_ld, bco, nsplit, pps, st);
     } else if (dtype == MU_F32X) {
         if (taps == 9) wgrad_launch<xf32, 9>((const xf32*)x, (const xf32*)dy, part, B, H, W, Cin, Cout, x_ld, dy_ld, bco, nsplit, pps, st);
-        else wgrad_launch<xf32, 1>((const xf32*)x, (const xf32*)dy, part, B, H, W, Cin, Cout, x_ld, dy_ld, bco, nsplit, pps, st);
+        else wgrad_launch<xf32, 1>((const xf32*)x, (const xf32*)dy, part, B, H, W, Cin, Cout, x_ld, dy_ld, bco, nsplit, pps, st, bci);
     } else return MU_ERR_ARG;
     if (pair_I > 0) {
         const long n2 = (long)cout_valid * pair_I * taps;

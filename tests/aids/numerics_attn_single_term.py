@@ -18,6 +18,10 @@ from oracle import maskunet_oracle as O  # noqa: E402
 
 MODE = sys.argv[1] if len(sys.argv) > 1 else "p16ds16"
 JSHIFT = 12
+# round 6 probes (env): KSINGLE=1 -- the key operand of S = Q K^T as ONE fp16 term (two MFMAs instead of three), forward and recompute alike;
+# VSINGLE=1 -- the value operand of dP = dO V^T as one fp16 term
+KSINGLE = os.environ.get("KSINGLE", "0") == "1"
+VSINGLE = os.environ.get("VSINGLE", "0") == "1"
 
 
 def h(x):
@@ -42,7 +46,7 @@ class Attn(torch.autograd.Function):
         for b in range(B):
             idx = keep[b].nonzero()[:, 0]
             qs = pair16(Qe[b] * sl2) if pair else Qe[b] * sl2
-            s2 = qs @ Ke[b, idx].T
+            s2 = qs @ (h(Ke[b, idx]) if KSINGLE else Ke[b, idx]).T
             m = s2.max(-1, keepdim=True).values
             p = torch.exp2(s2 - m)
             if MODE.startswith("p16"):
@@ -71,9 +75,11 @@ class Attn(torch.autograd.Function):
         for b in range(B):
             idx = keep[b].nonzero()[:, 0]
             qs = pair16(Qe[b] * sl2) if pair else Qe[b] * sl2
-            s2 = qs @ Ke[b, idx].T
+            s2 = qs @ (h(Ke[b, idx]) if KSINGLE else Ke[b, idx]).T
             P = torch.exp2(s2 - lse2[b][:, None] + j)
             vs = pair16(Ve[b, idx] * scale) if pair else Ve[b, idx] * scale
+            if VSINGLE:
+                vs = h(vs)
             dP = dYe[b] @ vs.T - (delta[b] * scale * gs)[:, None]
             if MODE.startswith("p16"):
                 P = h(P)
@@ -136,7 +142,7 @@ def main():
     gsl = p["norm.weight"].grad[:, ::16, ::16]
     rs = torch.from_numpy(rec["g_slice/norm.weight"])
     e3 = float((gsl - rs).abs().max()) / float(rs.abs().max())
-    print(f"mode {MODE}: out err {eo:.3e} (gate 1e-3)  loss err {abs(loss.item() - float(rec['loss'])):.3e}  "
+    print(f"mode {MODE} ksingle {int(KSINGLE)} vsingle {int(VSINGLE)}: out err {eo:.3e} (gate 1e-3)  loss err {abs(loss.item() - float(rec['loss'])):.3e}  "
           f"worst grad {worst[0]:.3e} [{worst[1]}] (gate 5e-2)  d norm.weight slice {e3:.3e} (gate 1e-1)")
 
 
