@@ -225,6 +225,11 @@ template <> struct AT<h16> {
     static __device__ __forceinline__ f32x4 mma_row_from(const Frag& a, const Frag& b, const f32x4& c0) {
         return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c0, 0, 0, 0);
     }
+    // (fp32x only: the row products with the key / value operand as ONE term -- see AT<xf32>; here they are the plain products)
+    static __device__ __forceinline__ void mma_row_sa(const Frag& a, const Frag& b, f32x4& c) { mma_row(a, b, c); }
+    static __device__ __forceinline__ void mma_row_sb(const Frag& a, const Frag& b, f32x4& c) { mma_row(a, b, c); }
+    static __device__ __forceinline__ f32x4 mma_row_from_sa(const Frag& a, const Frag& b, const f32x4& c0) { return mma_row_from(a, b, c0); }
+    static __device__ __forceinline__ f32x4 mma_row_from_sb(const Frag& a, const Frag& b, const f32x4& c0) { return mma_row_from(a, b, c0); }
     // A operand [m = tile column col0+r16][k-slot j <-> tile row 4g+j, 16+4g+j]
     static __device__ __forceinline__ AccA ld_acc_a(const h16* tile, int stride, int col0, int g, int r16) {
         const int q = r16 >> 2, pc = r16 & 3;
@@ -262,6 +267,10 @@ template <> struct AT<float> {
 #pragma unroll
         for (int s = 0; s < 4; ++s) c = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s], b[s], c, 0, 0, 0);
     }
+    static __device__ __forceinline__ void mma_row_sa(const Frag& a, const Frag& b, f32x4& c) { mma_row(a, b, c); }
+    static __device__ __forceinline__ void mma_row_sb(const Frag& a, const Frag& b, f32x4& c) { mma_row(a, b, c); }
+    static __device__ __forceinline__ f32x4 mma_row_from_sa(const Frag& a, const Frag& b, const f32x4& c0) { return mma_row_from(a, b, c0); }
+    static __device__ __forceinline__ f32x4 mma_row_from_sb(const Frag& a, const Frag& b, const f32x4& c0) { return mma_row_from(a, b, c0); }
     static __device__ __forceinline__ f32x4 mma_row_from(const Frag& a, const Frag& b, const f32x4& c0) {
         f32x4 c = __builtin_amdgcn_mfma_f32_16x16x4f32(a[0], b[0], c0, 0, 0, 0);
 #pragma unroll
@@ -330,6 +339,34 @@ template <> struct AT<xf32> {
     static __device__ __forceinline__ f32x4 mma_row_from(const Frag& a, const Frag& b, const f32x4& c0) {
         f32x4 c = __builtin_amdgcn_mfma_f32_16x16x32_f16(a.lo, b.hi, c0, 0, 0, 0);
         c = __builtin_amdgcn_mfma_f32_16x16x32_f16(a.hi, b.lo, c, 0, 0, 0);
+        return __builtin_amdgcn_mfma_f32_16x16x32_f16(a.hi, b.hi, c, 0, 0, 0);
+    }
+    // Round 6: the KEY operand of the score product S = Q K^T and the VALUE operand of dP = dO V^T as ONE fp16 term (their hi halves)
+    // against the two-term query / dO: two MFMAs instead of three -- in the forward, the dQ sweep (`_sa`: the single operand is A) and the
+    // dK/dV sweep (`_sb`: it is B) alike, so every sweep recomputes exactly the S the forward normalised with.  Sized on the CPU oracle
+    // first (tests/aids/numerics_attn_single_term.py, KSINGLE / VSINGLE): outputs 2.0e-5 -> 2.3e-5, worst gradient 5.9e-3 -> 8.7e-3
+    // (gates 1e-3 / 5e-2), the value operand without any measurable effect.  The lo halves of K / V stay in memory: P V, dS K keep them.
+#ifndef MU_XF_KSINGLE
+#define MU_XF_KSINGLE 1
+#endif
+    static __device__ __forceinline__ void mma_row_sa(const Frag& a, const Frag& b, f32x4& c) {
+        if (!MU_XF_KSINGLE) { mma_row(a, b, c); return; }
+        c = __builtin_amdgcn_mfma_f32_16x16x32_f16(a.hi, b.lo, c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x32_f16(a.hi, b.hi, c, 0, 0, 0);
+    }
+    static __device__ __forceinline__ void mma_row_sb(const Frag& a, const Frag& b, f32x4& c) {
+        if (!MU_XF_KSINGLE) { mma_row(a, b, c); return; }
+        c = __builtin_amdgcn_mfma_f32_16x16x32_f16(a.lo, b.hi, c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x32_f16(a.hi, b.hi, c, 0, 0, 0);
+    }
+    static __device__ __forceinline__ f32x4 mma_row_from_sa(const Frag& a, const Frag& b, const f32x4& c0) {
+        if (!MU_XF_KSINGLE) return mma_row_from(a, b, c0);
+        f32x4 c = __builtin_amdgcn_mfma_f32_16x16x32_f16(a.hi, b.lo, c0, 0, 0, 0);
+        return __builtin_amdgcn_mfma_f32_16x16x32_f16(a.hi, b.hi, c, 0, 0, 0);
+    }
+    static __device__ __forceinline__ f32x4 mma_row_from_sb(const Frag& a, const Frag& b, const f32x4& c0) {
+        if (!MU_XF_KSINGLE) return mma_row_from(a, b, c0);
+        f32x4 c = __builtin_amdgcn_mfma_f32_16x16x32_f16(a.lo, b.hi, c0, 0, 0, 0);
         return __builtin_amdgcn_mfma_f32_16x16x32_f16(a.hi, b.hi, c, 0, 0, 0);
     }
     static __device__ __forceinline__ Packed pack(const f32x4& p0, const f32x4& p1) {
@@ -656,8 +693,8 @@ __global__ __launch_bounds__(NW * 64, OCC ? OCC : ((NW == 4 && D <= 128 && std::
                 Frag a = A::template ldt<Z>(Kt, kt * 16 + r16, ks * KR + g * A::GS);
 #pragma unroll
                 for (int t = 0; t < NQ; ++t) {
-                    if (ks == 0) s[kt][t] = A::mma_row_from(a, qf[t][0], negm[t]);     // -m rides in as the C operand
-                    else A::mma_row(a, qf[t][ks], s[kt][t]);
+                    if (ks == 0) s[kt][t] = A::mma_row_from_sa(a, qf[t][0], negm[t]);     // -m rides in as the C operand
+                    else A::mma_row_sa(a, qf[t][ks], s[kt][t]);
                 }
 #endif
             }
@@ -1144,11 +1181,11 @@ __global__ __launch_bounds__(NW * 64, OCCQ ? OCCQ : (NW == 4 && D <= 64 && std::
 #pragma unroll
                 for (int t = 0; t < NQT; ++t) {
                     if (ks == 0) {                            // row constants as the C operand of the first k-step (no copies)
-                        s[kt][t] = A::mma_row_from(ka, qf[t][0], nlse[t]);
-                        dp[kt][t] = A::mma_row_from(va, dof[t][0], ndel[t]);
+                        s[kt][t] = A::mma_row_from_sa(ka, qf[t][0], nlse[t]);
+                        dp[kt][t] = A::mma_row_from_sa(va, dof[t][0], ndel[t]);
                     } else {
-                        A::mma_row(ka, qf[t][ks], s[kt][t]);
-                        A::mma_row(va, dof[t][ks], dp[kt][t]);
+                        A::mma_row_sa(ka, qf[t][ks], s[kt][t]);
+                        A::mma_row_sa(va, dof[t][ks], dp[kt][t]);
                     }
                 }
             }
@@ -1416,11 +1453,11 @@ __global__ __launch_bounds__(NW * 64, NW >= 8 ? 1 : ((D <= 64 && std::is_same<T,
 #pragma unroll
                 for (int kt = 0; kt < NKT; ++kt) {
                     if (ks == 0) {                           // the row constants enter as the C operand of the first k-step
-                        s[qt][kt] = A::mma_row_from(qa, kf[kt][0], nl[qt]);
-                        dp[qt][kt] = A::mma_row_from(oa, vf[kt][0], nd[qt]);
+                        s[qt][kt] = A::mma_row_from_sb(qa, kf[kt][0], nl[qt]);
+                        dp[qt][kt] = A::mma_row_from_sb(oa, vf[kt][0], nd[qt]);
                     } else {
-                        A::mma_row(qa, kf[kt][ks], s[qt][kt]);
-                        A::mma_row(oa, vf[kt][ks], dp[qt][kt]);
+                        A::mma_row_sb(qa, kf[kt][ks], s[qt][kt]);
+                        A::mma_row_sb(oa, vf[kt][ks], dp[qt][kt]);
                     }
                 }
                 if constexpr (std::is_same<T, xf32>::value && D >= 128 && MU_XF_DKV_SCHED2) { if (qt == 1) __builtin_amdgcn_sched_barrier(0); }

@@ -88,8 +88,17 @@ class Attn(torch.autograd.Function):
             else:
                 dS = P * dP
             un = 1.0 / (gs * 2.0 ** j)
-            dV[b, idx] = (P.T @ dYe[b]) * un
-            dK[b, idx] = (dS.T @ Qe[b]) * un
+            Pk, dSk = P, dS
+            if KSINGLE and os.environ.get("KVSWEEP_SCALED_K", "0") == "1":
+                # the dK/dV sweep keeps the SCALED keys resident (one fp16 term of c K) against the streamed unscaled query pair: its scores
+                # differ from the forward's (c Q pair x one term of K) by the two different roundings -- emulate that sweep's own P / dS
+                s2k = Qe[b] @ h(Ke[b, idx] * sl2).T
+                Pk = torch.exp2(s2k - lse2[b][:, None] + j)
+                dPk = dYe[b] @ (h(pair16(Ve[b, idx] * scale)) if VSINGLE else pair16(Ve[b, idx] * scale)).T - (delta[b] * scale * gs)[:, None]
+                Pk = h(Pk)
+                dSk = h(Pk * h(dPk))
+            dV[b, idx] = (Pk.T @ dYe[b]) * un
+            dK[b, idx] = (dSk.T @ Qe[b]) * un
             dQ[b] = (dS @ Ke[b, idx]) * un
         return dQ, dK, dV, None
 
