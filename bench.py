@@ -490,7 +490,7 @@ def main():
     model.set_keep_masks(keeps)
     # N > 1 times the step the reference runs under nn.DataParallel: every replica forward draws a fresh mask (SURVEY 0 trap #2,
     # 8-e1), i.e. per step six randint draws + six key compactions (mu_compact_keys) on the device stream, no host sync
-    mask_mode = args.mask_mode if args.mask_mode != "auto" else ("resample" if (multi and not args.graph) else "fixed")
+    mask_mode = args.mask_mode if args.mask_mode != "auto" else ("resample" if multi else "fixed")
     model.set_mask_mode(mask_mode)
     net = maskunet_amd.DataParallel(model, force_sync=True) if multi else model
     scale = args.loss_scale if dtype == torch.float16 else 1.0
@@ -509,8 +509,8 @@ def main():
     if args.graph:
         if args.fused_loss or args.three_head or args.torch_loss:
             raise SystemExit("--graph: maskunet_amd.CrossEntropyLoss, 1-head model only")
-        if mask_mode == "resample":
-            raise SystemExit("--graph: a captured step replays the masks it was captured with; use --mask-mode fixed")
+        # mask_mode "resample" (the reference's N > 1 semantics): the six randint draws + key compactions are captured too -- torch's CUDA
+        # generator hands a captured graph a fresh Philox offset on every replay, mu_compact_keys is stream-ordered (round 6)
         # N > 1: each replica replays its own graph and the bucketed all-reduce follows the replay (a replay runs no autograd hooks,
         # so the exchange does not overlap the backward) -- opt-in, for small per-GPU batches where the host enqueue is the bound
         graphed = maskunet_amd.GraphedStep(net, criterion, x, labels, loss_scale=scale)

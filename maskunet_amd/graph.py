@@ -12,7 +12,11 @@ stream with no host synchronisation, so the step can be captured (torch.cuda.CUD
 
 What changes under capture: the dropout seed drawn on the host is baked into the graph, so a device step counter -- incremented inside the
 graph -- is mixed into it (mu_dropout_step); BatchNorm running statistics / step counters are updated on the device as always; the
-attention keep-masks are whatever the modules hold at capture time (set_keep_masks / the lazily drawn, cached masks of the reference).
+attention keep-masks are whatever the modules hold at capture time (set_keep_masks / the lazily drawn, cached masks of the reference)
+-- or, with mask_mode = "resample" (what the reference does under multi-GPU nn.DataParallel: a fresh draw per replica forward,
+ade_semantic.py:177-181 + :373), REDRAWN BY EVERY REPLAY: the torch.randint draws and the key compactions (mu_compact_keys) are captured
+with the step, and torch's CUDA generator gives a captured graph a fresh Philox offset per replay (round 6).  After a replay the
+modules' `_keep` tensors hold the masks that replay used.
 
 With a maskunet_amd.DataParallel model the replica's step is captured (the graph holds no collective) and the gradient exchange runs
 eagerly after every replay: the same bucketed all-reduce on the comm stream, without overlap with the backward -- the hooks of

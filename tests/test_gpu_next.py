@@ -477,3 +477,41 @@ def test_fused_adamw_skip_counters_survive_rollback_reallocation_and_an_unchecke
     assert our.effective_steps(w) == 4 and our.state_dict()["state"][0]["step"] == 4
     assert torch.allclose(w, w_ref, rtol=2e-5, atol=2e-6)
 
+
+
+@pytest.mark.gpu
+def test_graphed_step_redraws_the_key_masks_per_replay():
+    """GraphedStep with mask_mode = "resample" -- the reference's multi-GPU semantics (a fresh randint(0, 2, (B, H, W)) per replica
+    forward, ade_semantic.py:177-181 under nn.DataParallel :373; VERDICT r5 #5a): the draws and the key compactions are captured with
+    the step, every replay sees new masks, and the gradients of a replay equal an EAGER step run with the masks that replay drew."""
+    import maskunet_amd
+    from tests import _gpu_checks as G
+    model, params, keeps, x, labels = G.build_unet(19, False, 611, torch.float16, True, 2)
+    x, labels = x.cuda(), labels.cuda()
+    crit = maskunet_amd.CrossEntropyLoss()
+    model.dropout.p = 0.0
+    model.set_mask_mode("resample")
+    state = {k: v.clone() for k, v in model.state_dict().items()}
+    torch.manual_seed(1234)
+    step = maskunet_amd.GraphedStep(model, crit, x, labels, loss_scale=128.0, warmup=1)
+    drawn, grads, losses_ = [], [], []
+    for it in range(3):
+        model.load_state_dict(state)                          # (the BatchNorm buffers advance with every step)
+        losses_.append(step(x, labels).item())
+        drawn.append([blk._keep.clone() for blk in model.attention_blocks()])
+        grads.append({k: v.grad.clone() for k, v in model.named_parameters() if v.grad is not None})
+    for a, b in ((0, 1), (1, 2), (0, 2)):                     # six masks of 256 ... 16384 fair coin flips each: no two replays agree
+        assert all(not torch.equal(ka, kb) for ka, kb in zip(drawn[a], drawn[b])), (a, b)
+    assert all(0.4 < float(k.float().mean()) < 0.6 for ks in drawn for k in ks)
+    assert len(set(losses_)) == 3
+    # an eager step with replay 1's masks, fixed
+    model.zero_grad(set_to_none=True)
+    model.load_state_dict(state)
+    model.set_mask_mode("fixed")
+    model.set_keep_masks([k.clone() for k in drawn[1]])
+    loss_e = crit(model(x), labels)
+    (loss_e * 128.0).backward()
+    assert loss_e.item() == losses_[1]
+    for k, v in model.named_parameters():
+        if v.grad is not None:
+            assert torch.equal(v.grad, grads[1][k]), k
