@@ -1,6 +1,8 @@
 """GPU parity tests, kernel level: every HIP op (called through maskunet_amd.ops -> ctypes -> the C ABI of
 libmaskunet_hip.so) against stock torch / the CPU oracle on the same seeded inputs.  fp32 compute must meet the
 north_star's 1e-3; fp16 compute (fp16 storage, fp32 accumulate) is held to 3e-2."""
+import math
+
 import pytest
 import torch
 
@@ -242,3 +244,142 @@ def test_colsum_of_a_chunk_encoded_tensor():
         ref = dec.double().sum(0)
         assert float((out.double() - ref).abs().max()) <= 1e-6 * float(ref.abs().max() + dec.abs().double().sum(0).max())
 
+
+
+# ------------------------------------------------------------------------------------------------
+# round 6: the fp32x 3x3 convolutions -- fp16-pair operands, dy as ONE scaled fp16 operand, two-term backward -- through the C ABI
+# ------------------------------------------------------------------------------------------------
+def test_split_encode_h4_is_a_per_chunk_fp16_hi_lo_rewrite():
+    """mu_split_encode_h4 (the fp32x 3x3-CONVOLUTION operand encoding): every aligned 16-byte chunk of four fp32 values becomes
+    [4 fp16 hi | 4 fp16 lo] with hi = fp16_rne(x), lo = fp16_rne(x - hi); hi + lo reproduces x to 2^-21 relative or 2^-25 absolute, in place too."""
+    from maskunet_amd import _lib
+    g = torch.Generator(device="cuda").manual_seed(9)
+    x = torch.randn(8192, device="cuda", generator=g) * torch.logspace(-5, 3, 8192, device="cuda")
+    x[:8] = torch.tensor([0.0, -0.0, 1.0, -1.0, 65504.0, -65504.0, 1e-9, 2.0 ** -24], device="cuda")
+    e = torch.empty_like(x)
+    _lib.call("mu_split_encode_h4", x.data_ptr(), e.data_ptr(), x.numel(), _lib.stream())
+    h = e.view(torch.float16).view(-1, 8)
+    hi, lo = h[:, :4].reshape(-1).float(), h[:, 4:].reshape(-1).float()
+    assert torch.equal(hi, x.half().float())
+    assert torch.equal(lo, (x - hi).half().float())
+    err = (hi.double() + lo.double() - x.double()).abs()
+    assert bool((err <= torch.maximum(x.double().abs() * 2.0 ** -21, torch.tensor(2.0 ** -25, device="cuda", dtype=torch.float64))).all())
+    y = x.clone()
+    _lib.call("mu_split_encode_h4", y.data_ptr(), y.data_ptr(), y.numel(), _lib.stream())
+    assert torch.equal(y.view(torch.int32), e.view(torch.int32))
+    with pytest.raises(RuntimeError, match="MU_ERR_ARG"):
+        _lib.call("mu_split_encode_h4", x.data_ptr(), e.data_ptr(), 6, _lib.stream())
+
+
+@pytest.mark.parametrize("mag", [1e-9, 3e-5, 1.0, 7e3])
+def test_dy_encode_h_scale_is_an_exact_power_of_two(mag):
+    """mu_dy_encode_h: dy_h = fp16(S dy) with S a power of two chosen on the device so that S max|dy| lands in [2^13, 2^14); the scale
+    pair is {S, 1 / S}; zeros give S = 1; a NaN stays a NaN."""
+    from maskunet_amd import _lib
+    g = torch.Generator(device="cuda").manual_seed(11)
+    dy = torch.randn(3 * 1024 * 40, device="cuda", generator=g) * mag
+    out = torch.empty(dy.numel(), dtype=torch.float16, device="cuda")
+    sc = torch.empty(2, device="cuda")
+    ws = torch.empty(_lib.load().mu_dy_encode_h_workspace_bytes(), dtype=torch.uint8, device="cuda")
+    _lib.call("mu_dy_encode_h", dy.data_ptr(), out.data_ptr(), sc.data_ptr(), dy.numel(), ws.data_ptr(), ws.numel(), _lib.stream())
+    S, inv = float(sc[0]), float(sc[1])
+    assert S > 0 and S * inv == 1.0 and math.log2(S) == int(math.log2(S))
+    top = S * float(dy.abs().max())
+    assert 2.0 ** 13 <= top < 2.0 ** 14, top
+    assert torch.equal(out, (dy * S).half())
+    z = torch.zeros(64, device="cuda")
+    _lib.call("mu_dy_encode_h", z.data_ptr(), out.data_ptr(), sc.data_ptr(), 64, ws.data_ptr(), ws.numel(), _lib.stream())
+    assert float(sc[0]) == 1.0 and float(out[:64].abs().max()) == 0.0
+    dy[5] = float("nan")
+    _lib.call("mu_dy_encode_h", dy.data_ptr(), out.data_ptr(), sc.data_ptr(), dy.numel(), ws.data_ptr(), ws.numel(), _lib.stream())
+    assert bool(torch.isnan(out[5])) and float(sc[0]) == S          # (fmax ignores the NaN: the scale follows the finite values)
+    with pytest.raises(RuntimeError, match="MU_ERR_ARG"):
+        _lib.call("mu_dy_encode_h", dy.data_ptr(), dy.data_ptr(), sc.data_ptr(), dy.numel(), ws.data_ptr(), ws.numel(), _lib.stream())
+
+
+# (B, H, W, Cin, Cout): the ping-pong kernel (Cin of the layer % 128, H % 16), the halo-tile kernel at 128 / 64 output channels, the
+# generic register-staged kernel (odd sizes, 32-channel operands)
+H2_SHAPES = [(2, 32, 32, 128, 128), (1, 16, 16, 256, 64), (2, 8, 16, 64, 128), (1, 24, 16, 64, 64), (2, 13, 9, 32, 64), (1, 7, 20, 96, 32),
+             (1, 16, 16, 512, 512)]
+
+
+@pytest.mark.parametrize("shape", H2_SHAPES)
+@pytest.mark.parametrize("gmag", [1e-7, 1.0])
+def test_conv3x3_two_term_backward_through_the_abi(shape, gmag):
+    """mu_conv_dgrad_h / mu_conv_wgrad_h against fp64 torch: dy as ONE scaled fp16 operand (mu_dy_encode_h), weights as HL rows
+    (mu_prep_weight, MU_F32X, mode 1), the input chunk-encoded fp16 pairs (mu_split_encode_h4).  Gate 1e-3 of the gradient's maximum,
+    independent of the gradient's magnitude (the scale is an exact power of two)."""
+    from maskunet_amd import _lib
+    B, H, W, Cin, Cout = shape
+    g = torch.Generator().manual_seed(B * 1000 + Cin + Cout + H)
+    x = torch.randn(B, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) * (1.0 / math.sqrt(9 * Cin))
+    dy = torch.randn(B, Cout, H, W, generator=g) * gmag
+    xr, wr = x.double().requires_grad_(True), w.double().requires_grad_(True)
+    torch.nn.functional.conv2d(xr, wr, padding=1).backward(dy.double())
+    xd = x.permute(0, 2, 3, 1).contiguous().cuda()
+    dyd = dy.permute(0, 2, 3, 1).contiguous().cuda()
+    wd = w.cuda().contiguous()
+    st = _lib.stream()
+    whl = torch.empty(9 * Cin * Cout, device="cuda")
+    _lib.call("mu_prep_weight", wd.data_ptr(), whl.data_ptr(), _lib.MU_F32X, Cout, Cin, 9, Cin, Cout, 1, st)
+    dyh = torch.empty(dyd.numel(), dtype=torch.float16, device="cuda")
+    sc = torch.empty(2, device="cuda")
+    ws0 = torch.empty(_lib.load().mu_dy_encode_h_workspace_bytes(), dtype=torch.uint8, device="cuda")
+    _lib.call("mu_dy_encode_h", dyd.data_ptr(), dyh.data_ptr(), sc.data_ptr(), dyd.numel(), ws0.data_ptr(), ws0.numel(), st)
+    dx = torch.full((B, H, W, Cin), float("nan"), device="cuda")
+    _lib.call("mu_conv_dgrad_h", dyh.data_ptr(), whl.data_ptr(), sc.data_ptr(), dx.data_ptr(), B, H, W, Cout, Cin, Cout, Cin, st)
+    xe = torch.empty_like(xd)
+    _lib.call("mu_split_encode_h4", xd.data_ptr(), xe.data_ptr(), xd.numel(), st)
+    nws = _lib.load().mu_conv_wgrad_h_workspace_bytes(B, H, W, Cin, Cout)
+    ws = torch.empty(nws, dtype=torch.uint8, device="cuda")
+    gw = torch.full((Cout, Cin, 3, 3), float("nan"), device="cuda")
+    _lib.call("mu_conv_wgrad_h", xe.data_ptr(), dyh.data_ptr(), sc.data_ptr(), gw.data_ptr(), B, H, W, Cin, Cout, Cin, Cout, Cin, Cout,
+              ws.data_ptr(), ws.numel(), st)
+    ex = float((dx.permute(0, 3, 1, 2).double().cpu() - xr.grad).abs().max() / xr.grad.abs().max())
+    ew = float((gw.double().cpu() - wr.grad).abs().max() / wr.grad.abs().max())
+    assert ex <= 1e-3 and ew <= 1e-3, (shape, gmag, ex, ew)
+
+
+@pytest.mark.parametrize("gmag", [1e-8, 1.0, 3e4])
+def test_bn_backward_writes_dx_as_one_scaled_fp16_operand(gmag):
+    """mu_bn_act_bwd_h against mu_bn_act_bwd on the same fp32 operands: dgamma / dbeta / dres bit-identical, dx_h / S = dx to fp16
+    rounding (2^-11 of |S dx| per element), S a power of two with S max|dx| in [2^11, 2^14) (the device-side per-channel bound is tight
+    to ~2 bits), whatever the gradient's magnitude; zero-padded channels (gamma = 1, rstd = 1 / sqrt(eps), dy = 0) do not move the scale."""
+    from maskunet_amd import _lib
+    lib = _lib.load()
+    g = torch.Generator(device="cuda").manual_seed(21)
+    for (M, C, cv, act, use_res) in [(2048, 64, 64, _lib.ACT_GELU, False), (1536, 160, 150, _lib.ACT_NONE, False), (4096, 32, 19, _lib.ACT_GELU, True)]:
+        x = torch.randn(M, C, device="cuda", generator=g) * 2.0 + 0.5
+        x[:, cv:] = 0.0
+        dy = torch.randn(M, C, device="cuda", generator=g) * gmag
+        dy[:, cv:] = 0.0
+        res = (torch.randn(M, C, device="cuda", generator=g) if use_res else None)
+        gamma = torch.rand(C, device="cuda", generator=g) + 0.5
+        beta = torch.randn(C, device="cuda", generator=g) * 0.1
+        gamma[cv:], beta[cv:] = 1.0, 0.0
+        mean = x.mean(0)
+        rstd = torch.rsqrt(x.var(0, unbiased=False) + 1e-5)
+        ws = torch.empty(lib.mu_bn_workspace_bytes(C), dtype=torch.uint8, device="cuda")
+        outs = []
+        for h_ in (False, True):
+            dx = torch.full((M, C), float("nan"), device="cuda")
+            dres = torch.empty_like(x) if use_res else None
+            dg, db = torch.empty(C, device="cuda"), torch.empty(C, device="cuda")
+            sc = torch.zeros(2, device="cuda")
+            rp, drp = (res.data_ptr() if use_res else None), (dres.data_ptr() if use_res else None)
+            if h_:
+                _lib.call("mu_bn_act_bwd_h", x.data_ptr(), rp, dy.data_ptr(), dx.data_ptr(), drp, M, C, mean.data_ptr(), rstd.data_ptr(),
+                          gamma.data_ptr(), beta.data_ptr(), act, 1, dg.data_ptr(), db.data_ptr(), sc.data_ptr(), ws.data_ptr(), ws.numel(), _lib.stream())
+            else:
+                _lib.call("mu_bn_act_bwd", x.data_ptr(), rp, dy.data_ptr(), dx.data_ptr(), drp, M, C, C, mean.data_ptr(), rstd.data_ptr(),
+                          gamma.data_ptr(), beta.data_ptr(), act, 1, dg.data_ptr(), db.data_ptr(), ws.data_ptr(), ws.numel(), _lib.MU_F32, _lib.stream())
+            outs.append((dx, dres, dg, db, sc))
+        (dx0, dr0, dg0, db0, _), (dxh, dr1, dg1, db1, sc) = outs
+        assert torch.equal(dg0, dg1) and torch.equal(db0, db1) and (not use_res or torch.equal(dr0, dr1))
+        S = float(sc[0])
+        assert S > 0 and S * float(sc[1]) == 1.0 and math.log2(S) == int(math.log2(S))
+        top = S * float(dx0.abs().max())
+        assert 2.0 ** 11 <= top < 2.0 ** 14, (M, C, gmag, top)
+        got = dxh.view(torch.float16).view(-1)[: M * C].view(M, C).float() / S      # the halves sit at the start of the buffer
+        assert float((got - dx0).abs().max()) <= 2.0 ** -11 * float(dx0.abs().max()) * 1.01
