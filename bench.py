@@ -36,16 +36,18 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 # dense, MI355X_MICROARCH.md.  fp32x = fp32 storage, every matrix product evaluated as several 16-bit MFMAs on (hi, lo) operand splits:
-# three per product in the convolutions and in Q K^T / dO V^T, two where the softmax P / dS enters as a single fp16 operand.  The fp32x
+# three per product in the forward convolutions, two wherever one operand is a single fp16 term (attention: P, dS, the key in Q K^T, the value
+# in dO V^T; 3x3 backward: the scaled dy -- round 6).  The fp32x
 # `peak` is the dense 16-bit peak; `achieved` counts the MFMA FLOPs the kernel ISSUES (useful FLOPs x terms, TERMS below), so `frac` is
 # a matrix-pipe utilisation like the fp16 line's; the useful rate is carried next to it.
 PEAK_MFMA_TFLOPS = {"fp16": 2500.0, "fp32": 157.3, "fp32x": 2500.0}
 PEAK_HBM_GBS = 8000.0
 DOMINANT_KERNEL = "attn_bwd_dkv3_kernel"
 # the three sweeps of one attention block: products per (query, key) pair [each 2*C FLOP] and, for fp32x, 16-bit MFMA terms per product
-SWEEPS = {"fwd": {"kernel": "attn_fwd2_kernel", "products": 2, "terms_fp32x": (3, 2)},                  # S = Q K^T, O = P V
-          "dq": {"kernel": "attn_bwd_dq2_kernel", "products": 3, "terms_fp32x": (3, 3, 2)},             # S, dP = dO V^T, dQ = dS K
-          "dkv": {"kernel": "attn_bwd_dkv3_kernel", "products": 4, "terms_fp32x": (3, 3, 2, 2)}}        # S, dP, dV = P^T dO, dK = dS^T Q
+# (round 6: the key operand of S and the value operand of dP are ONE fp16 term against the two-term query / dO -- two terms per product everywhere)
+SWEEPS = {"fwd": {"kernel": "attn_fwd2_kernel", "products": 2, "terms_fp32x": (2, 2)},                  # S = Q K^T, O = P V
+          "dq": {"kernel": "attn_bwd_dq2_kernel", "products": 3, "terms_fp32x": (2, 2, 2)},             # S, dP = dO V^T, dQ = dS K
+          "dkv": {"kernel": "attn_bwd_dkv3_kernel", "products": 4, "terms_fp32x": (2, 2, 2, 2)}}        # S, dP, dV = P^T dO, dK = dS^T Q
 REF_CLOCK_MHZ = 1900.0       # convention for `clock.ms_per_step_at_ref_clock` (about what the pool's boxes hold in the MFMA probe)
 # share of the step spent in MFMA-bound kernels (attention, conv, weight-grad: 23.5 of 29.5 ms, profiles/r04_kernel_time_split.txt) --
 # measured on the configs[1] fp16 line ONLY, so `ms_per_step_at_ref_clock` is emitted for that configuration only
@@ -298,7 +300,7 @@ def sweep_rooflines(dtype_name, events, hw, batch, kept, clk, traffic=None, traf
             "HIP-event time; algorithmic_* FLOPs = SURVEY 8-d4's full-key-set count 8*N*N*C; algorithmic_bytes = Q, dO, K, V read + dK, dV "
             "written once (6*N*C elements per image)")
     if dtype_name == "fp32x":
-        note += ("; fp32x: achieved/frac count the 16-bit MFMA FLOPs ISSUED (useful x terms: S and dP three terms, dV and dK two) against the "
+        note += ("; fp32x: achieved/frac count the 16-bit MFMA FLOPs ISSUED (useful x terms: two 16-bit MFMAs per product since round 6 -- one operand of every product is a single fp16 term) against the "
                  "dense 16-bit peak, `useful_tflops` the fp32-grade products delivered")
     return {"bound": "mfma", "achieved": d["achieved"], "peak": peak, "unit": "TFLOP/s", "frac": d["frac"],
             # the same FLOPs against the matrix peak at the clock this chip holds under a dense MFMA load
@@ -319,7 +321,7 @@ def load_traffic(args, dtype_name):
     read inside this process, so the figure comes from the committed rocprofv3 --pmc run of the same command -- one file per workload
     shape, named in `traffic_source`; null where no counter pass was taken for the shape."""
     tkey = f"b{args.batch}_c{args.c_out}_hw{args.hw}_{dtype_name}" + ("_3head" if args.three_head else "")
-    for rnd in ("r05", "r04"):
+    for rnd in ("r06", "r05", "r04"):
         tfile = f"{rnd}_dkv_traffic_{tkey}.json"
         tpath = os.path.join(ROOT, "profiles", tfile)
         if os.path.exists(tpath):
