@@ -15,6 +15,10 @@ run --optimizer --warmup 8                       # configs[1] + fused AdamW insi
 run --dtype fp32 --steps 4 --warmup 2             # fp32 parity path (exact-fp32 MFMA)
 run --dtype fp32x --steps 6 --warmup 2            # fp32 storage, split-bf16 matrix products (set_float32_matmul_precision("high"))
 run --batch 16
+# context only: the reference's own batch range (1-14, ade_semantic.py:18) is launch-bound on this path
+run --batch 8
+run --batch 8 --graph
+run --batch 16 --graph
 # the other configuration shapes in the fp32x mode
 run --dtype fp32x --c-out 133 --batch 128 --steps 4 --warmup 2
 run --dtype fp32x --three-head --c-out 19 --batch 64 --steps 6 --warmup 2

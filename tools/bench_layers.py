@@ -28,7 +28,7 @@ def timeit(f, n=20):
 def main():
     args = [a for a in sys.argv[1:] if not a.startswith("--")]
     B = int(args[0]) if args else 64
-    X = "--fp32x" in sys.argv                                # fp32 storage, chunk-encoded operands, split-bf16 products (MU_F32X)
+    X = "--fp32x" in sys.argv                                # fp32 storage, fp16-pair operands: 3-term forward, 2-term backward (MU_F32X, round 6)
     dev, dt = "cuda", (torch.float32 if X else torch.float16)
     code = 2 if X else 1
     st = _lib.stream()
@@ -42,18 +42,34 @@ def main():
         w = (torch.randn(9, Cout, Cin, device=dev) * 0.05).to(dt)
         wt = (torch.randn(9, Cin, Cout, device=dev) * 0.05).to(dt)
         y = torch.empty(B, H, H, Cout, device=dev, dtype=dt)
-        if X:
-            for t in (x, dy, w, wt):
-                _lib.call("mu_split_encode", t.data_ptr(), t.data_ptr(), t.numel(), st)
         dx = torch.empty(B, H, H, Cin, device=dev, dtype=dt)
+        if X:
+            # round 6: fp16-pair operands for the forward, dy as ONE scaled fp16 operand + HL weight rows for the two-term backward
+            woihw = torch.randn(Cout, Cin, 3, 3, device=dev) * 0.05
+            both = torch.empty(2 * 9 * Cout * Cin, device=dev)
+            _lib.call("mu_prep_weight", woihw.data_ptr(), both.data_ptr(), 2, Cout, Cin, 9, Cout, Cin, 2, st)
+            w, wt = both[:9 * Cout * Cin], both[9 * Cout * Cin:]
+            _lib.call("mu_split_encode_h4", x.data_ptr(), x.data_ptr(), x.numel(), st)
+            dyh = torch.empty(dy.numel(), dtype=torch.float16, device=dev)
+            sc = torch.empty(2, device=dev)
+            ws0 = torch.empty(lib.mu_dy_encode_h_workspace_bytes(), dtype=torch.uint8, device=dev)
+            _lib.call("mu_dy_encode_h", dy.data_ptr(), dyh.data_ptr(), sc.data_ptr(), dy.numel(), ws0.data_ptr(), ws0.numel(), st)
+            wsx = _lib.workspace(lib.mu_conv_wgrad_h_workspace_bytes(B, H, H, Cin, Cout), torch.device(dev)) if Cin > 32 else None
         cin_v = 3 if Cin == 32 else Cin
         gw = torch.empty(Cout, cin_v, 3, 3, device=dev)
         ws = _lib.workspace(lib.mu_conv_wgrad_workspace_bytes(B, H, H, Cin, Cout, 9), torch.device(dev))
         fl = 2.0 * B * H * H * Cin * Cout * 9
         def fwd(): _lib.call("mu_conv_fwd", x.data_ptr(), w.data_ptr(), None, y.data_ptr(), B, H, H, Cin, Cout, 9, Cin, Cout, code, st)
-        def dg(): _lib.call("mu_conv_fwd", dy.data_ptr(), wt.data_ptr(), None, dx.data_ptr(), B, H, H, Cout, Cin, 9, Cout, Cin, code, st)
-        def wg(): _lib.call("mu_conv_wgrad", x.data_ptr(), dy.data_ptr(), gw.data_ptr(), B, H, H, Cin, Cout, 9, cin_v, Cout, Cin, Cout,
-                            ws.data_ptr(), ws.numel(), code, st)
+        def dg():
+            if X: _lib.call("mu_conv_dgrad_h", dyh.data_ptr(), wt.data_ptr(), sc.data_ptr(), dx.data_ptr(), B, H, H, Cout, Cin, Cout, Cin, st)
+            else: _lib.call("mu_conv_fwd", dy.data_ptr(), wt.data_ptr(), None, dx.data_ptr(), B, H, H, Cout, Cin, 9, Cout, Cin, code, st)
+        def wg():
+            if X and Cin > 32:
+                _lib.call("mu_conv_wgrad_h", x.data_ptr(), dyh.data_ptr(), sc.data_ptr(), gw.data_ptr(), B, H, H, Cin, Cout, cin_v, Cout, Cin, Cout,
+                          wsx.data_ptr(), wsx.numel(), st)
+            else:       # (fp32x: the <= 3-channel first layer is the plain-FMA kernel on plain operands)
+                _lib.call("mu_conv_wgrad", x.data_ptr(), dy.data_ptr(), gw.data_ptr(), B, H, H, Cin, Cout, 9, cin_v, Cout, Cin, Cout,
+                          ws.data_ptr(), ws.numel(), code, st)
         row = []
         for name, f in (("fwd", fwd), ("dgrad", dg), ("wgrad", wg)):
             if name == "dgrad" and Cin == 32:
