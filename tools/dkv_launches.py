@@ -8,10 +8,19 @@ for f in glob.glob(os.path.join(sys.argv[1], "**", "*kernel_trace.csv"), recursi
     rows += [r for r in csv.DictReader(open(f)) if "attn_bwd_dkv3" in r["Kernel_Name"]]
 if not rows:
     print("no dK/dV launches in the trace"); sys.exit(1)
-grid = max(int(r["Grid_Size"]) for r in rows)
-big = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6 for r in rows if int(r["Grid_Size"]) == grid]
-small = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6 for r in rows if int(r["Grid_Size"]) != grid]
-name = next(r["Kernel_Name"] for r in rows if int(r["Grid_Size"]) == grid)
+def gsz(r):                                     # kernel-trace CSVs carry Grid_Size or Grid_Size_X/Y/Z depending on the rocprofv3 build
+    if r.get("Grid_Size"):
+        return int(r["Grid_Size"])
+    n = 1
+    for k in ("Grid_Size_X", "Grid_Size_Y", "Grid_Size_Z"):
+        n *= int(r.get(k) or 1)
+    return n
+
+
+grid = max(gsz(r) for r in rows)
+big = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6 for r in rows if gsz(r) == grid]
+small = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6 for r in rows if gsz(r) != grid]
+name = next(r["Kernel_Name"] for r in rows if gsz(r) == grid)
 print(f"{name[:80]}: largest-grid launches (self_attention6, N = 16384) in the kernel trace")
 print(f"launches {len(big)}, mean {statistics.mean(big):.3f} ms, median {statistics.median(big):.3f} ms, min {min(big):.3f}, max {max(big):.3f}")
 print("all: " + " ".join(f"{t:.3f}" for t in big))

@@ -10,7 +10,7 @@ export TMPDIR=/tmp
 ( cd /tmp; timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $ROOT/gpurun_out/${TAG}_prof -o a -- python3 $ROOT/bench.py --no-cpu-baseline --no-parity-gate --no-clock-probe --no-fp32x-line --no-host-inclusive --steps 8 --warmup 2 > $ROOT/gpurun_out/${TAG}_prof.log 2>&1 )
 f=$(find gpurun_out/${TAG}_prof -name '*kernel_stats.csv' | head -1)
 python tools/prof_summary.py $f 10 40 > gpurun_out/${TAG}_prof_summary.txt; cp $f gpurun_out/${TAG}_kernel_stats.csv
-python tools/dkv_launches.py gpurun_out/${TAG}_prof gpurun_out/${TAG}_bench.json > gpurun_out/${TAG}_dkv_launches.txt
+python tools/dkv_launches.py gpurun_out/${TAG}_prof gpurun_out/${TAG}_bench.json > gpurun_out/${TAG}_dkv_launches.txt 2>&1
 bash tools/gpu_session.sh $TAG pmc
 ( cd /tmp; timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $ROOT/gpurun_out/${TAG}x_prof -o a -- python3 $ROOT/bench.py --no-cpu-baseline --no-parity-gate --no-clock-probe --no-fp32x-line --no-host-inclusive --dtype fp32x --steps 8 --warmup 2 > $ROOT/gpurun_out/${TAG}x_prof.log 2>&1 )
 f=$(find gpurun_out/${TAG}x_prof -name '*kernel_stats.csv' | head -1)
