@@ -2372,7 +2372,7 @@ template <typename T> struct WgTile;
 template <> struct WgTile<h16> { static constexpr int PAD = 0; static constexpr int KP = 32; };
 // fp32: row pad (elements) puts the g=0/1 pixel rows of a ds_read_b32 on different banks
 template <> struct WgTile<float> { static constexpr int PAD = 16; static constexpr int KP = 16; };
-template <> struct WgTile<xf32> { static constexpr int PAD = 16; static constexpr int KP = 32; };     // K = 32 per stage: v_mfma_f32_16x16x32_bf16 triples
+template <> struct WgTile<xf32> { static constexpr int PAD = 16; static constexpr int KP = 32; };     // K = 32 per stage: v_mfma_f32_16x16x32_bf16 triples (1x1 layers)
 #ifndef MU_WG_XSWAP
 #define MU_WG_XSWAP 1
 #endif
@@ -2629,20 +2629,6 @@ __global__ __launch_bounds__(256) void wgrad_bias_reduce_kernel(const float* __r
 template <int BCH> __device__ __forceinline__ int wg_hash(int row) {
     return (BCH >= 128) ? ((row & 3) | (((row >> 3) & 1) << 2)) : (((row >> 1) & 1) | (((row >> 3) & 1) << 1));
 }
-// fp32x tiles (chunk-encoded, 4-byte elements): the swizzle granule is still 16 channels (64 bytes = the four 16-byte chunks one 16-lane
-// group of a transposed read touches in a row); rows are 256 or 512 bytes = whole bank lines, so the four consecutive rows of a lane group
-// (a .. a+3) must land on four different granules modulo 4: row bits 0-1.  A transposed read that fetches only the hi (or only the lo)
-// half of every chunk touches half of the banks: 2-way for a 32-lane group whatever the layout (round 4: SQ_LDS_BANK_CONFLICT 33-50 % of
-// the LDS cycles).  Round 5 (MU_WGX_PAIRED): the two lane groups of a 32-lane half fetch the hi halves AND the lo halves of the SAME four
-// rows -- together 16 whole chunks on 16 distinct slots, conflict-free -- and v_permlane16_swap puts the lo halves a group fetched for its
-// neighbour's rows where they belong (rd_tr_x below).
-template <typename T, int BCH> __device__ __forceinline__ int wg_hash_t(int row) {
-    if constexpr (sizeof(T) == 2) return wg_hash<BCH>(row);
-    else return row & 3;
-}
-template <typename T> struct WgFrag { typedef h16x8 type; };
-template <> struct WgFrag<xf32> { typedef SplitF8 type; };
-
 template <int N> __device__ __forceinline__ void wait_vmcnt_c() {
     static_assert(N >= 0 && N < 64, "vmcnt is a 6-bit counter");
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
@@ -2677,16 +2663,6 @@ template <int N> __device__ __forceinline__ void wait_vmcnt_c() {
 #ifndef MU_WG_SPLIT_DMA
 #define MU_WG_SPLIT_DMA 1
 #endif
-#ifndef MU_WGX_STAGGER
-#define MU_WGX_STAGGER 1
-#endif
-#ifndef MU_WGX_PAIRED
-#define MU_WGX_PAIRED 0         // (round 5 probe: hi / lo halves of the same rows fetched by neighbouring lane groups + v_permlane16_swap -- conflict-free but
-#endif                          //  8-10 % SLOWER on every layer, gpurun_out/r05d_ab_wgrad.txt: the swaps cost more than the conflicts; superseded by MU_WGX_SHIFT)
-#ifndef MU_WGX_SHIFT
-#define MU_WGX_SHIFT 1
-#endif
-static_assert(!(MU_WGX_PAIRED && MU_WGX_SHIFT), "the paired-fetch probe reads the unshifted image");
 // SPS = 32-pixel k-steps per DMA stage.  SPS = 2 (W % 64 == 0): one barrier / DMA batch / ring step per 64 pixels -- the two
 // waves of a SIMD run in lockstep behind the per-stage barrier, so the ~500 cycles of scalar + address work per ring step sit
 // in front of both waves' MFMA bursts (PMC: SQ_ACTIVE_INST_SCA 18 % of wave cycles, MFMA pipe 44 % busy at SPS = 1).
@@ -2694,11 +2670,8 @@ static_assert(!(MU_WGX_PAIRED && MU_WGX_SHIFT), "the paired-fetch probe reads th
 // PP = ping-pong schedule (8 waves, SPS = 2): the two wave groups (wr = 0 / 1, one wave of each per SIMD) run one section apart,
 // a section being either a k-step's 24 MFMAs or its DMA issue + 20 transposed reads, so one group's matrix burst covers the
 // other group's scalar / address / LDS work instead of both doing each in lockstep.
-// T = xf32 (fp32x, chunk-encoded operands; SPS = 1 only): the same ring and window logic on 4-byte elements, four stages of 33.8 KB (128 x 128
-// tiles) or 17.4 KB (64 x 64), fragments = transposed reads of the hi and of the lo halves, three v_mfma_f32_16x16x32_bf16 per tile pair.  The
-// fragments of a stage take 80 registers next to the 96 accumulators, so they are NOT double-buffered; instead the two wave groups of an
-// 8-wave block run half a stage apart (group 0: reads then MFMAs of stage s; group 1: MFMAs of stage s-1, then the reads of stage s), one
-// barrier per stage for both.
+// (fp32x, round 6: the 3x3 weight gradient of that mode runs THIS fp16 kernel on the 16-bit view of its chunk-encoded input -- mu_conv_wgrad_h;
+//  the bf16-pair instantiation of rounds 4-5 is gone.)
 template <typename T, int TM, int TN, int WR, int NWV = 4, bool W16 = false, int SPS = 1, bool PP = false>
 __global__ __launch_bounds__(NWV * 64, 1) void conv_wgrad3_kernel(const T* __restrict__ x, const T* __restrict__ dy, float* __restrict__ part,
                                                              int B, int H, int W, int Cin, int Cout, long x_ld, long dy_ld, int nsplit,
@@ -2707,28 +2680,19 @@ __global__ __launch_bounds__(NWV * 64, 1) void conv_wgrad3_kernel(const T* __res
     constexpr int BCO = WR * TM * 16, BCI = WC * TN * 16;
     // the dy tile (BCO wide) and the x window (BCI wide) may differ in width (128 x 64 tiles for the 64-channel layers): each has
     // its own row size, DMA lane mapping and swizzle hash
-    constexpr bool XF = std::is_same<T, xf32>::value;
-    static_assert(!XF || (SPS == 1 && !PP), "fp32x: one 32-pixel k-step per stage");
+    static_assert(sizeof(T) == 2, "fp16 operands (the fp32x mode hands over 16-bit views)");
     constexpr int VN = 16 / (int)sizeof(T);                 // elements per 16-byte chunk
-    constexpr int GS = XF ? 2 : 1;                          // log2(chunks per 16-channel swizzle granule)
+    constexpr int GS = 1;                                   // log2(chunks per 16-channel swizzle granule)
     constexpr int CPRA = BCO / VN, RPWA = 64 / CPRA, CPRB = BCI / VN, RPWB = 64 / CPRB;
     constexpr int KP = 32, SP = SPS * KP;                   // pixels per k-step (one MFMA K) and per DMA stage
     constexpr int RW = SP / 2;                              // two-row mode: image width
     constexpr int XR = ((W16 ? SP + 4 : SP + 2) + RPWB - 1) / RPWB * RPWB;   // x-window rows allocated (SP + 2, or 2 x (RW + 2))
     constexpr int NIA = SP / RPWA, NIB = XR / RPWB;        // DMA wave-instructions per tile
-    // fp32x (MU_WGX_SHIFT, round 5): every 8-row group of a tile sits 8 more bytes into LDS than the previous one (row r at
-    // r * ROWB + 8 (r >> 3); the LDS-DMA takes any 4-byte-aligned base: tools/micro_dma_align.hip).  A transposed read fetches only the hi
-    // (or only the lo) 8 bytes of every 16-byte chunk, i.e. half of the banks -- 2-way for a 32-lane half whatever the chunk placement
-    // (50 % of this kernel's LDS cycles were conflicts).  With the shift the two lane groups of a half (rows a.., a+8..) hit complementary
-    // bank pairs: conflict-free on the dy tile, and on the x window up to one slot where a tap offset makes a read straddle three groups.
-    // In-process A/B (gpurun_out/r05l_ab_wgrad_shift.txt): conflict share 50 % -> 17 % of the LDS cycles, time unchanged on the 128 x 128 tiles
-    // (the reads hide behind the partner wave's MFMAs either way) and 3-4 % WORSE on the 64 x 64 tiles, which therefore keep the plain image.
-    constexpr int XSH = (XF && MU_WGX_SHIFT && BCO == 128 && BCI == 128) ? 1 : 0;
-    constexpr int PADA = XSH ? 16 : 0, PADB = XSH ? 16 : 0; // elements (the last group's shift, rounded up to 64 bytes)
+    constexpr int PADA = 0, PADB = 0;
     constexpr int STAGE = SP * BCO + PADA + XR * BCI + PADB;   // elements per stage
 
     static_assert(!PP || (SPS == 2 && NWV == 8 && WR == 2), "ping-pong needs two 4-wave groups and two k-steps per stage");
-    constexpr int NS = XF ? 4 : (SPS == 1 ? MU_WG_NS : 4);
+    constexpr int NS = SPS == 1 ? MU_WG_NS : 4;
     __shared__ __attribute__((aligned(16))) T lds[NS * STAGE];
 
     const long Mtot = (long)B * H * W;
@@ -2763,7 +2727,7 @@ __global__ __launch_bounds__(NWV * 64, 1) void conv_wgrad3_kernel(const T* __res
 #pragma unroll
     for (int k = 0; k < NAW; ++k) {
         const int row = (wave + k * NWV) * RPWA + lrowA;
-        const int sc = (((c16A >> GS) ^ wg_hash_t<T, BCO>(row)) << GS) | (c16A & ((1 << GS) - 1));
+        const int sc = (((c16A >> GS) ^ wg_hash<BCO>(row)) << GS) | (c16A & ((1 << GS) - 1));
         aoff[k] = row * (int)dy_ld + co0 + sc * VN;
     }
     // W == 16: a 32-pixel stage is two whole image rows; the window is two 18-row halves (columns -1 .. 16 of each image
@@ -2772,7 +2736,7 @@ __global__ __launch_bounds__(NWV * 64, 1) void conv_wgrad3_kernel(const T* __res
 #pragma unroll
     for (int k = 0; k < NBW; ++k) {
         const int row = (wave + k * NWV) * RPWB + lrowB;    // window row: flat pixel pbase + dh*W - 1 + row
-        const int sc = (((c16B >> GS) ^ wg_hash_t<T, BCI>(row)) << GS) | (c16B & ((1 << GS) - 1));
+        const int sc = (((c16B >> GS) ^ wg_hash<BCI>(row)) << GS) | (c16B & ((1 << GS) - 1));
         if (w16) {
             const int half = row >= RW + 2, kk = row - half * (RW + 2);
             boff[k] = (half * RW + kk - 1) * (int)x_ld + ci0 + sc * VN;
@@ -2797,7 +2761,7 @@ __global__ __launch_bounds__(NWV * 64, 1) void conv_wgrad3_kernel(const T* __res
             const int i = wave + k * NWV;
             if (i < NIA) {
                 const void* src = live ? (const void*)(dyp + aoff[k]) : (const void*)mu_zero_page;
-                glds16a(src, At + i * RPWA * BCO + XSH * 2 * ((i * RPWA) >> 3));
+                glds16a(src, At + i * RPWA * BCO);
             }
         }
     };
@@ -2815,7 +2779,7 @@ __global__ __launch_bounds__(NWV * 64, 1) void conv_wgrad3_kernel(const T* __res
                 const bool ok = W16 ? ((rowok && bkind[k] == 4) || (rowok1 && bkind[k] == 5))
                                     : (rowok && (bkind[k] == 0 || (bkind[k] == 1 && lok) || (bkind[k] == 2 && rok)));
                 const void* src = ok ? (const void*)(xp + boff[k]) : (const void*)mu_zero_page;
-                glds16a(src, Bt + i * RPWB * BCI + XSH * 2 * ((i * RPWB) >> 3));
+                glds16a(src, Bt + i * RPWB * BCI);
             }
         }
         pis += SP;
@@ -2844,45 +2808,15 @@ __global__ __launch_bounds__(NWV * 64, 1) void conv_wgrad3_kernel(const T* __res
 
     // Register double-buffered fragments: the transposed LDS reads of stage s+1 are issued before the MFMAs of stage s, so
     // the LDS latency (8 + 12 dependent-free ds_read_tr per 24 MFMAs) no longer sits between the MFMA groups.
-    typedef typename WgFrag<T>::type Frag;
+    typedef h16x8 Frag;
     struct Frags { Frag a[TM]; Frag b[3][TN]; };
     const int wsh = (W16 && SPS == 1 && g >= 2) ? 2 : 0;     // W = 16: the second image row's window starts 18 rows in
     auto rd_tr = [&](const T* tile, int stride, int r0, int col, int hash0, int hash1) -> Frag {
-        const T* p0 = tile + r0 * stride + ((((col >> 4) ^ hash0) << 4) | (col & 15)) + XSH * 2 * (r0 >> 3);
-        const T* p1 = tile + (r0 + 4) * stride + ((((col >> 4) ^ hash1) << 4) | (col & 15)) + XSH * 2 * ((r0 + 4) >> 3);
-        if constexpr (XF) {
-            const char* c0 = reinterpret_cast<const char*>(p0);
-            const char* c1 = reinterpret_cast<const char*>(p1);
-            const uint2 h0 = __builtin_bit_cast(uint2, __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) fp16x4v*)(c0)));
-            const uint2 h1 = __builtin_bit_cast(uint2, __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) fp16x4v*)(c1)));
-            const uint2 l0 = __builtin_bit_cast(uint2, __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) fp16x4v*)(c0 + 8)));
-            const uint2 l1 = __builtin_bit_cast(uint2, __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) fp16x4v*)(c1 + 8)));
-            SplitF8 f;
-            f.hi = __builtin_bit_cast(bf16x8, make_uint4(h0.x, h0.y, h1.x, h1.y));
-            f.lo = __builtin_bit_cast(bf16x8, make_uint4(l0.x, l0.y, l1.x, l1.y));
-            return f;
-        } else {
-            auto lo = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) fp16x4v*)(p0));
-            auto hi = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) fp16x4v*)(p1));
-            return (h16x8){(h16)lo[0], (h16)lo[1], (h16)lo[2], (h16)lo[3], (h16)hi[0], (h16)hi[1], (h16)hi[2], (h16)hi[3]};
-        }
-    };
-    // fp32x, paired fetch: read 1 = lane groups (0, 1) -> (hi, lo) halves of the rows of group 0, groups (2, 3) -> of group 2; read 2 = the same
-    // for the rows of groups 1 and 3; permlane16_swap(read 1, read 2) = {(hi g0, hi g1, hi g2, hi g3), (lo g0, lo g1, lo g2, lo g3)}.
-    // rbase = the fragment's first row for lane group 0 (+ q); col as in rd_tr.  Same four reads per fragment, +4 VALU, no bank conflicts.
-    auto rd_tr_x = [&](const T* tile, int stride, int rbase, int col) -> SplitF8 {
-        const int re = rbase + 8 * (g & 2), ro = re + 8, pb = (g & 1) * 8;
-        auto rd = [&](int row) -> uint2 {
-            const char* c = reinterpret_cast<const char*>(tile + row * stride + ((((col >> 4) ^ (row & 3)) << 4) | (col & 15))) + pb;
-            return __builtin_bit_cast(uint2, __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) fp16x4v*)(c)));
-        };
-        const uint2 d0 = rd(re), s0 = rd(ro), d1 = rd(re + 4), s1 = rd(ro + 4);
-        const auto a0 = __builtin_amdgcn_permlane16_swap(d0.x, s0.x, false, false), a1 = __builtin_amdgcn_permlane16_swap(d0.y, s0.y, false, false);
-        const auto b0 = __builtin_amdgcn_permlane16_swap(d1.x, s1.x, false, false), b1 = __builtin_amdgcn_permlane16_swap(d1.y, s1.y, false, false);
-        SplitF8 f;
-        f.hi = __builtin_bit_cast(bf16x8, make_uint4(a0[0], a1[0], b0[0], b1[0]));
-        f.lo = __builtin_bit_cast(bf16x8, make_uint4(a0[1], a1[1], b0[1], b1[1]));
-        return f;
+        const T* p0 = tile + r0 * stride + ((((col >> 4) ^ hash0) << 4) | (col & 15));
+        const T* p1 = tile + (r0 + 4) * stride + ((((col >> 4) ^ hash1) << 4) | (col & 15));
+        auto lo = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) fp16x4v*)(p0));
+        auto hi = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) fp16x4v*)(p1));
+        return (h16x8){(h16)lo[0], (h16)lo[1], (h16)lo[2], (h16)lo[3], (h16)hi[0], (h16)hi[1], (h16)hi[2], (h16)hi[3]};
     };
     auto load_frags = [&](int buf, int half, Frags& f) {     // k-step `half` of the stage in slot `buf`
         const T* At = lds + buf * STAGE;
@@ -2894,8 +2828,7 @@ __global__ __launch_bounds__(NWV * 64, 1) void conv_wgrad3_kernel(const T* __res
         for (int i = 0; i < TM; ++i) {
             const int col = (wr * TM + i) * 16 + 4 * pc;    // 4 channels inside the 16-channel granule (col >> 4)
             const int r0 = ra + 8 * g + q;
-            if constexpr (XF && MU_WGX_PAIRED) f.a[i] = rd_tr_x(At, BCO, ra + q, col);
-            else f.a[i] = rd_tr(At, BCO, r0, col, wg_hash_t<T, BCO>(r0), wg_hash_t<T, BCO>(r0 + 4));
+            f.a[i] = rd_tr(At, BCO, r0, col, wg_hash<BCO>(r0), wg_hash<BCO>(r0 + 4));
         }
 #pragma unroll
         for (int t = 0; t < 3; ++t) {
@@ -2903,8 +2836,7 @@ __global__ __launch_bounds__(NWV * 64, 1) void conv_wgrad3_kernel(const T* __res
             for (int j = 0; j < TN; ++j) {
                 const int col = (wc * TN + j) * 16 + 4 * pc;
                 const int r0 = rb + 8 * g + q + t + wsh;
-                if constexpr (XF && MU_WGX_PAIRED) f.b[t][j] = rd_tr_x(Bt, BCI, rb + q + t + wsh, col);
-                else f.b[t][j] = rd_tr(Bt, BCI, r0, col, wg_hash_t<T, BCI>(r0), wg_hash_t<T, BCI>(r0 + 4));
+                f.b[t][j] = rd_tr(Bt, BCI, r0, col, wg_hash<BCI>(r0), wg_hash<BCI>(r0 + 4));
             }
         }
     };
@@ -2915,8 +2847,7 @@ __global__ __launch_bounds__(NWV * 64, 1) void conv_wgrad3_kernel(const T* __res
             for (int j = 0; j < TN; ++j)
 #pragma unroll
                 for (int i = 0; i < TM; ++i) {
-                    if constexpr (XF) mu_mma_split(f.a[i], f.b[t][j], acc[t][i][j]);
-                    else acc[t][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(f.a[i], f.b[t][j], acc[t][i][j], 0, 0, 0);
+                    acc[t][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(f.a[i], f.b[t][j], acc[t][i][j], 0, 0, 0);
                 }
     };
 
@@ -2924,50 +2855,7 @@ __global__ __launch_bounds__(NWV * 64, 1) void conv_wgrad3_kernel(const T* __res
     //   top of step s : this wave's DMAs of stage s+1 have landed (vmcnt <= (NS-3) n_w); barrier -> everybody's have, and
     //                   everybody's reads of stage s-1 (issued in step s-2, consumed by the MFMAs of step s-1) are complete
     //   then          : DMA of stage s+NS-1 into the slot of stage s-1; fragment reads of stage s+1; MFMAs of stage s
-    if constexpr (XF) {
-        constexpr int FULL = NAW + NBW;
-        auto wait_landed = [&]() {                           // the oldest outstanding stage of this wave has landed: NS-2 younger ones may fly
-            if (n_w == FULL) wait_vmcnt_c<(NS - 2) * FULL>();
-            else if (n_w == FULL - 1) wait_vmcnt_c<(NS - 2) * (FULL - 1)>();
-            else wait_vmcnt_c<(NS - 2) * (FULL > 2 ? FULL - 2 : 0)>();
-        };
-#pragma unroll 1
-        for (int k = 0; k < NS - 1; ++k) stage(k);
-        Frags f;
-        int buf = 0;
-        const bool late = NWV == 8 && MU_WGX_STAGGER && wr == 1;      // group 1 of an 8-wave block: MFMAs one stage behind its reads
-        // step s: stage s landed for everybody (counted wait + barrier), and everybody's reads of stage s-1 are complete (group 0 consumed
-        // them in its MFMAs, group 1 drained lgkmcnt before the barrier) -> stage s+NS-1 goes into the slot of stage s-1
-        if (!late) {
-#pragma unroll 1
-            for (int s = 0; s < nsteps; ++s) {
-                wait_landed();
-                __builtin_amdgcn_s_barrier();
-                stage(buf == 0 ? NS - 1 : buf - 1);
-                load_frags(buf, 0, f);
-                compute(f);
-                buf = buf + 1 == NS ? 0 : buf + 1;
-            }
-        } else if (nsteps > 0) {
-            wait_landed();
-            __builtin_amdgcn_s_barrier();
-            stage(NS - 1);
-            load_frags(0, 0, f);
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            buf = 1;
-#pragma unroll 1
-            for (int s = 1; s < nsteps; ++s) {
-                wait_landed();
-                __builtin_amdgcn_s_barrier();
-                stage(buf == 0 ? NS - 1 : buf - 1);
-                compute(f);
-                load_frags(buf, 0, f);
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                buf = buf + 1 == NS ? 0 : buf + 1;
-            }
-            compute(f);
-        }
-    } else if constexpr (PP) {
+    if constexpr (PP) {
         // Epochs: group A runs X(k) [DMA issue of stage S+2 when k opens stage S, then the k-step's fragment reads] at epoch 2k and
         // M(k) [its MFMAs, and when k opens a stage the wait for stage S+1] at 2k+1; group B one epoch later; one raw barrier per
         // epoch.  RAW: stage S+1 is first read in X(2S+2) (A: epoch 4S+4); both groups' waits sit in M(2S) (B: epoch 4S+2) and a
@@ -3219,14 +3107,11 @@ static inline void wgrad_tile(int Cin, int Cout, int* bco, int* bci, int taps = 
 #ifndef MU_WG_BLOCKS64
 #define MU_WG_BLOCKS64 512
 #endif
-#ifndef MU_WGX
-#define MU_WGX 1               // fp32x: the 3-taps-per-block ring kernel (0 = the generic register-staged kernel)
-#endif
 static inline bool wgrad3_choose(int H, int W, int Cin, int Cout, int taps, int dtype, int* tco, int* tci) {
-    if ((dtype != MU_F16 && !(dtype == MU_F32X && MU_WGX)) || taps != 9 || !(W % 32 == 0 || (W == 16 && H % 2 == 0))) return false;
+    if (dtype != MU_F16 || taps != 9 || !(W % 32 == 0 || (W == 16 && H % 2 == 0))) return false;
     const int a = Cout % 128 == 0 ? 128 : (Cout % 64 == 0 ? 64 : 0), b = Cin % 128 == 0 ? 128 : (Cin % 64 == 0 ? 64 : 0);
     if (!a || !b) return false;
-    if (a == b || (MU_WG_MIXED && dtype == MU_F16)) { *tco = a; *tci = b; }
+    if (a == b || MU_WG_MIXED) { *tco = a; *tci = b; }
     else { *tco = 64; *tci = 64; }
     return true;
 }
@@ -3916,12 +3801,8 @@ static int conv_wgrad_impl(const void* x, const void* dy, float* dw_oihw, float*
         const int grid = 3 * (Cout / tco) * (Cin / tci) * nsplit;
         const h16 *xh = (const h16*)x, *dyh = (const h16*)dy;
 #define WG3(...) conv_wgrad3_kernel<h16, __VA_ARGS__><<<grid, (tco == 128 && tci == 128) ? 512 : 256, 0, st>>>(xh, dyh, part, B, H, W, Cin, Cout, x_ld, dy_ld, nsplit, pps)
-#define WG3X(...) conv_wgrad3_kernel<xf32, __VA_ARGS__><<<grid, (tco == 128 && tci == 128) ? 512 : 256, 0, st>>>((const xf32*)x, (const xf32*)dy, part, B, H, W, Cin, Cout, x_ld, dy_ld, nsplit, pps)
         const bool two_row32 = W == 32 && H % 2 == 0, flat64 = W % 64 == 0;
-        if (dtype == MU_F32X) {           // square tiles only, one 32-pixel k-step per stage
-            if (tco == 128) { if (W == 16) WG3X(4, 2, 2, 8, true); else WG3X(4, 2, 2, 8); }
-            else { if (W == 16) WG3X(2, 2, 2, 4, true); else WG3X(2, 2, 2, 4); }
-        } else if (tco == 128 && tci == 128) {   // 8 waves, 64x32 tile x 3 taps per wave (96 accumulators): 2 waves/SIMD
+        if (tco == 128 && tci == 128) {   // 8 waves, 64x32 tile x 3 taps per wave (96 accumulators): 2 waves/SIMD
             if (W == 16) WG3(4, 2, 2, 8, true);
             else if (two_row32 && MU_WG_SPS2 && MU_WG_PP == 2) WG3(4, 2, 2, 8, true, 2, true);      // (W = 32: +2.6 % slower, opt-in)
             else if (two_row32 && MU_WG_SPS2) WG3(4, 2, 2, 8, true, 2);
@@ -3941,7 +3822,6 @@ static int conv_wgrad_impl(const void* x, const void* dy, float* dw_oihw, float*
             else WG3(2, 2, 2);
         }
 #undef WG3
-#undef WG3X
     } else if (ws_bytes < (long)nsplit * taps * Cout * Cin * (long)sizeof(float)) {
         return MU_ERR_WORKSPACE;
     } else if (dtype == MU_F16) {
@@ -3957,7 +3837,9 @@ static int conv_wgrad_impl(const void* x, const void* dy, float* dw_oihw, float*
         if (taps == 9) wgrad_launch<float, 9>((const float*)x, (const float*)dy, part, B, H, W, Cin, Cout, x_ld, dy_ld, bco, nsplit, pps, st);
         else wgrad_launch<float, 1>((const float*)x, (const float*)dy, part, B, H, W, Cin, Cout, x_ld, dy_ld, bco, nsplit, pps, st);
     } else if (dtype == MU_F32X) {
-        if (taps == 9) wgrad_launch<xf32, 9>((const xf32*)x, (const xf32*)dy, part, B, H, W, Cin, Cout, x_ld, dy_ld, bco, nsplit, pps, st);
+        // (3x3 layers of this mode: mu_conv_wgrad_h -- fp16-pair input, one scaled fp16 dy; only the <= 3-channel first layer, served above on
+        //  plain operands, comes through here with taps = 9)
+        if (taps == 9) return MU_ERR_ARG;
         else wgrad_launch<xf32, 1>((const xf32*)x, (const xf32*)dy, part, B, H, W, Cin, Cout, x_ld, dy_ld, bco, nsplit, pps, st, bci);
     } else return MU_ERR_ARG;
     if (pair_I > 0) {
