@@ -3646,8 +3646,11 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad9_w16_kernel(const h16* __re
 #ifndef MU_WG9_MAXC16
 #define MU_WG9_MAXC16 512
 #endif
-static inline bool wgrad9_w16_choose(int B, int H, int W, int Cin, int Cout, int taps, int dtype, int* nb, int* rpb) {
-    if (!MU_WG9_W16 || dtype != MU_F16 || taps != 9 || W != 16 || H % 2 || Cin % 64 || Cout % 64 || Cin > MU_WG9_MAXC16 || Cout > MU_WG9_MAXC16) return false;
+// `pair` (mu_conv_wgrad_h, round 6): Cin counts the 16-bit COLUMNS of a chunk-encoded fp32x input -- two per channel -- and the layer-size
+// limits below, which were measured on real channel counts, apply to Cin / 2 (MU_WG9_PAIR_WIDE=0 in the environment: the limits as they are)
+static inline int wg9_pair_div(bool pair) { return (pair && !(getenv("MU_WG9_PAIR_WIDE") && atoi(getenv("MU_WG9_PAIR_WIDE")) == 0)) ? 2 : 1; }
+static inline bool wgrad9_w16_choose(int B, int H, int W, int Cin, int Cout, int taps, int dtype, int* nb, int* rpb, bool pair = false) {
+    if (!MU_WG9_W16 || dtype != MU_F16 || taps != 9 || W != 16 || H % 2 || Cin % 64 || Cout % 64 || Cin / wg9_pair_div(pair) > MU_WG9_MAXC16 || Cout > MU_WG9_MAXC16) return false;
     const long rows = (long)B * H;
     long want = MU_WG9_BLOCKS / ((Cin / 64) * (Cout / 64));
     if (want < 1) want = 1;
@@ -3658,13 +3661,14 @@ static inline bool wgrad9_w16_choose(int B, int H, int W, int Cin, int Cout, int
     return true;
 }
 
-static inline bool wgrad9_choose(int B, int H, int W, int Cin, int Cout, int taps, int dtype, int* nb, int* rpb) {
+static inline bool wgrad9_choose(int B, int H, int W, int Cin, int Cout, int taps, int dtype, int* nb, int* rpb, bool pair = false) {
     // which layers: one of the two channel counts 64 (the ring kernel's 64-wide tiles), or both <= MU_WG9_MAXC32 at W = 32 -- in-process A/B, B = 64:
     // 32^2 128->128 40.9 -> 36.1 us; the 128-wide layers at 64^2 / 128^2 are 5-7 % SLOWER here than on the ring kernel's 128 x 128 tiles
     const int maxc = W <= 32 ? MU_WG9_MAXC32 : MU_WG9_MAXC;
     const bool need64 = MU_WG9_NEED64 && W > 32;
-    if (!MU_WG9 || dtype != MU_F16 || taps != 9 || W % 32 || W > 128 || Cin % 64 || Cout % 64 || (need64 && !(Cin == 64 || Cout == 64)) ||
-        Cin > maxc || Cout > maxc) return false;
+    const int creal = Cin / wg9_pair_div(pair);
+    if (!MU_WG9 || dtype != MU_F16 || taps != 9 || W % 32 || W > 128 || Cin % 64 || Cout % 64 || (need64 && !(creal == 64 || Cout == 64)) ||
+        creal > maxc || Cout > maxc) return false;
     const long rows = (long)B * H;
     long want = (W <= 64 ? MU_WG9_BLOCKS_W64 : MU_WG9_BLOCKS) / ((Cin / 64) * (Cout / 64));
     if (want > rows) want = rows;
@@ -3674,7 +3678,7 @@ static inline bool wgrad9_choose(int B, int H, int W, int Cin, int Cout, int tap
     return true;
 }
 
-extern "C" long mu_conv_wgrad_workspace_bytes(int B, int H, int W, int Cin, int Cout, int taps) {
+static long wgrad_workspace_bytes(int B, int H, int W, int Cin, int Cout, int taps, bool pair) {
     int bco, bci, nsplit; long pps;
     wgrad_tile(Cin, Cout, &bco, &bci);
     wgrad_plan((long)B * H * W, Cin, Cout, taps, bco, bci, &nsplit, &pps);
@@ -3690,7 +3694,7 @@ extern "C" long mu_conv_wgrad_workspace_bytes(int B, int H, int W, int Cin, int 
         if (b > a) a = b;
     }
     int nb9, rpb9;
-    if (wgrad9_choose(B, H, W, Cin, Cout, taps, MU_F16, &nb9, &rpb9) || wgrad9_w16_choose(B, H, W, Cin, Cout, taps, MU_F16, &nb9, &rpb9)) {
+    if (wgrad9_choose(B, H, W, Cin, Cout, taps, MU_F16, &nb9, &rpb9, pair) || wgrad9_w16_choose(B, H, W, Cin, Cout, taps, MU_F16, &nb9, &rpb9, pair)) {
         long b = (long)nb9 * taps * Cout * Cin * sizeof(float);
         if (b > a) a = b;
     }
@@ -3699,6 +3703,10 @@ extern "C" long mu_conv_wgrad_workspace_bytes(int B, int H, int W, int Cin, int 
         if (c > a) a = c;
     }
     return a;
+}
+
+extern "C" long mu_conv_wgrad_workspace_bytes(int B, int H, int W, int Cin, int Cout, int taps) {
+    return wgrad_workspace_bytes(B, H, W, Cin, Cout, taps, false);
 }
 
 template <typename T, int TAPS>
@@ -3783,14 +3791,14 @@ static int conv_wgrad_impl(const void* x, const void* dy, float* dw_oihw, float*
         return MU_OK;
     }
     int tco, tci, nb9, rpb9;
-    if (wgrad9_choose(B, H, W, Cin, Cout, taps, dtype, &nb9, &rpb9) && x_ld % 8 == 0 && dy_ld % 8 == 0) {
+    if (wgrad9_choose(B, H, W, Cin, Cout, taps, dtype, &nb9, &rpb9, pair_I > 0) && x_ld % 8 == 0 && dy_ld % 8 == 0) {
         if (ws_bytes < (long)nb9 * taps * Cout * Cin * (long)sizeof(float)) return MU_ERR_WORKSPACE;
         const dim3 grid9(nb9, Cout / 64, Cin / 64);
 #define WG9(NPT) conv_wgrad9_kernel<NPT><<<grid9, 256, 0, st>>>((const h16*)x, (const h16*)dy, part, B, H, W, Cin, Cout, x_ld, dy_ld, rpb9)
         switch (W / 32) { case 1: WG9(1); break; case 2: WG9(2); break; case 3: WG9(3); break; default: WG9(4); break; }
 #undef WG9
         nsplit = nb9;
-    } else if (wgrad9_w16_choose(B, H, W, Cin, Cout, taps, dtype, &nb9, &rpb9) && x_ld % 8 == 0 && dy_ld % 8 == 0) {
+    } else if (wgrad9_w16_choose(B, H, W, Cin, Cout, taps, dtype, &nb9, &rpb9, pair_I > 0) && x_ld % 8 == 0 && dy_ld % 8 == 0) {
         if (ws_bytes < (long)nb9 * taps * Cout * Cin * (long)sizeof(float)) return MU_ERR_WORKSPACE;
         conv_wgrad9_w16_kernel<<<dim3(nb9, Cout / 64, Cin / 64), 256, 0, st>>>((const h16*)x, (const h16*)dy, part, B, H, Cin, Cout, x_ld, dy_ld, rpb9);
         nsplit = nb9;
@@ -3878,7 +3886,7 @@ extern "C" int mu_conv_wgrad(const void* x, const void* dy, float* dw_oihw, int 
 // stride dy_ld halves) with its scale pair dy_scale = {S, 1 / S}.  The fp16 kernels of mu_conv_wgrad run on the 16-bit view of x
 // ([M, 2 Cin] halves: dy x hi and dy x lo columns -- two MFMAs per product), the slab reduce adds the column pairs and applies 1 / S.
 extern "C" long mu_conv_wgrad_h_workspace_bytes(int B, int H, int W, int Cin, int Cout) {
-    return mu_conv_wgrad_workspace_bytes(B, H, W, 2 * Cin, Cout, 9);
+    return wgrad_workspace_bytes(B, H, W, 2 * Cin, Cout, 9, true);
 }
 extern "C" int mu_conv_wgrad_h(const void* x, const void* dy_h, const float* dy_scale, float* dw_oihw, int B, int H, int W, int Cin, int Cout,
                                int cin_valid, int cout_valid, long x_ld, long dy_ld, void* workspace, long ws_bytes, void* stream) {

@@ -254,16 +254,22 @@ __global__ void bn_bwd_final_kernel(const double* __restrict__ part, int nblk, i
         const double2 v = k < nblk ? *reinterpret_cast<const double2*>(part + ((long)k * C + c) * 2) : make_double2(0.0, 0.0);
         av[u] = v.x; bv[u] = v.y;
     }
+    float2 pv[MU_STAT_MAXBLK / 64];                                // mu_bn_act_bwd_h: this channel's (max|dz|, max|xhat|) per block, requested with the sums
+    if (bound) {
+#pragma unroll
+        for (int u = 0; u < MU_STAT_MAXBLK / 64; ++u) {
+            const int k = lane + 64 * u;
+            pv[u] = k < nblk ? *reinterpret_cast<const float2*>(pmax + ((long)k * C + c) * 2) : make_float2(0.f, 0.f);
+        }
+    }
     double a = 0.0, b = 0.0;
 #pragma unroll
     for (int u = 0; u < MU_STAT_MAXBLK / 64; ++u) { a += av[u]; b += bv[u]; }
     a = wave_sum_d(a); b = wave_sum_d(b);
     float mg = 0.f, mx = 0.f;
-    if (bound) {                                                   // mu_bn_act_bwd_h: this channel's max|dz|, max|xhat| over the blocks
-        for (int k = lane; k < nblk; k += 64) {
-            const float2 v = *reinterpret_cast<const float2*>(pmax + ((long)k * C + c) * 2);
-            mg = fmaxf(mg, v.x); mx = fmaxf(mx, v.y);
-        }
+    if (bound) {
+#pragma unroll
+        for (int u = 0; u < MU_STAT_MAXBLK / 64; ++u) { mg = fmaxf(mg, pv[u].x); mx = fmaxf(mx, pv[u].y); }
         mg = wave_max(mg); mx = wave_max(mx);
     }
     if (lane) return;
