@@ -383,3 +383,59 @@ def test_bench_gpus2_over_rccl_on_a_one_gpu_box_refuses_with_a_message():
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode != 0 and "needs 2 visible GPUs" in (r.stdout + r.stderr)
 
+
+
+_RCCL_FP32X_WORKER = r"""
+import os, sys
+sys.path.insert(0, {root!r})
+import torch, torch.distributed as dist, torch.nn.functional as F
+torch.cuda.set_device(0)
+dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+import maskunet_amd
+from maskunet_amd.dp import DataParallel
+from oracle import maskunet_oracle as O          # deterministic parameter / input recipe only
+maskunet_amd.set_float32_matmul_precision("high")          # fp32x: the 3x3 weight gradients come out of mu_conv_wgrad_h (round 6)
+c_out, B = 19, 2
+params = O.make_params(O.unet_state_shapes(3, c_out, False), 91)
+keeps = O.make_keeps(92, B)
+x, labels = O.make_inputs(93, B, c_out)
+model = maskunet_amd.UNet(3, c_out)
+model.load_state_dict(params)
+model.cuda().train()
+model.dropout.p = 0.0
+model.set_keep_masks(keeps)
+xd, ld = x.cuda(), labels.cuda()
+F.cross_entropy(model(xd), ld).backward()
+ref = {{n: p.grad.clone() for n, p in model.named_parameters() if p.grad is not None}}
+ddp = DataParallel(model, bucket_mb=4.0, force_sync=True)
+for step in range(3):
+    model.zero_grad(set_to_none=True)
+    F.cross_entropy(ddp(xd), ld).backward()
+    ddp.finish_gradient_sync()
+    for n, p in model.named_parameters():
+        if n in ref:
+            assert torch.equal(p.grad, ref[n]), (step, n)          # one rank: the mean is the gradient itself, bit for bit
+            if step:
+                assert p.grad.data_ptr() == ddp.gradient_slice(p).data_ptr(), n
+# the two-term weight-gradient kernels wrote straight into their bucket slices (no copy in between)
+model.zero_grad(set_to_none=True)
+with ddp.no_sync():
+    F.cross_entropy(ddp(xd), ld).backward()
+n3 = 0
+for n, p in model.named_parameters():
+    if n in ref and p.dim() == 4 and p.shape[-1] == 3 and p.shape[1] > 3:
+        assert p.grad.data_ptr() == ddp.gradient_slice(p).data_ptr(), n
+        n3 += 1
+assert n3 >= 30, n3
+ddp.finish_gradient_sync()
+dist.destroy_process_group()
+print("fp32x exchange ok", flush=True)
+"""
+
+
+def test_rccl_single_rank_exchange_in_the_fp32x_mode():
+    """The zero-copy exchange with the round-6 fp32x backward: mu_conv_wgrad_h (two-term weight gradient, pair-reduced slabs) writes the 3x3
+    weight gradients into DataParallel's bucket slices like the kernels of the other modes; gradients bit-equal to the plain model's."""
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, "-c", _RCCL_FP32X_WORKER.format(root=ROOT)], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and "fp32x exchange ok" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
