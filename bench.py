@@ -44,10 +44,11 @@ PEAK_MFMA_TFLOPS = {"fp16": 2500.0, "fp32": 157.3, "fp32x": 2500.0}
 PEAK_HBM_GBS = 8000.0
 DOMINANT_KERNEL = "attn_bwd_dkv3_kernel"
 # the three sweeps of one attention block: products per (query, key) pair [each 2*C FLOP] and, for fp32x, 16-bit MFMA terms per product
-# (round 6: the key operand of S and the value operand of dP are ONE fp16 term against the two-term query / dO -- two terms per product everywhere)
+# (round 6: S = Q K^T with the key as ONE fp16 term against the two-term query in all three sweeps, P V two terms in the forward; in the
+#  backward sweeps dP and the gradient products run as single fp16 MFMAs on exactly scaled operands)
 SWEEPS = {"fwd": {"kernel": "attn_fwd2_kernel", "products": 2, "terms_fp32x": (2, 2)},                  # S = Q K^T, O = P V
-          "dq": {"kernel": "attn_bwd_dq2_kernel", "products": 3, "terms_fp32x": (2, 2, 2)},             # S, dP = dO V^T, dQ = dS K
-          "dkv": {"kernel": "attn_bwd_dkv3_kernel", "products": 4, "terms_fp32x": (2, 2, 2, 2)}}        # S, dP, dV = P^T dO, dK = dS^T Q
+          "dq": {"kernel": "attn_bwd_dq2_kernel", "products": 3, "terms_fp32x": (2, 1, 1)},             # S, dP = dO V^T, dQ = dS K
+          "dkv": {"kernel": "attn_bwd_dkv3_kernel", "products": 4, "terms_fp32x": (2, 1, 1, 1)}}        # S, dP, dV = P^T dO, dK = dS^T Q
 REF_CLOCK_MHZ = 1900.0       # convention for `clock.ms_per_step_at_ref_clock` (about what the pool's boxes hold in the MFMA probe)
 # share of the step spent in MFMA-bound kernels (attention, conv, weight-grad: 23.5 of 29.5 ms, profiles/r04_kernel_time_split.txt) --
 # measured on the configs[1] fp16 line ONLY, so `ms_per_step_at_ref_clock` is emitted for that configuration only
@@ -300,7 +301,7 @@ def sweep_rooflines(dtype_name, events, hw, batch, kept, clk, traffic=None, traf
             "HIP-event time; algorithmic_* FLOPs = SURVEY 8-d4's full-key-set count 8*N*N*C; algorithmic_bytes = Q, dO, K, V read + dK, dV "
             "written once (6*N*C elements per image)")
     if dtype_name == "fp32x":
-        note += ("; fp32x: achieved/frac count the 16-bit MFMA FLOPs ISSUED (useful x terms: two 16-bit MFMAs per product since round 6 -- one operand of every product is a single fp16 term) against the "
+        note += ("; fp32x: achieved/frac count the 16-bit MFMA FLOPs ISSUED (useful x terms: round 6 -- two for S and P V, one for dP and the gradient products of the backward sweeps) against the "
                  "dense 16-bit peak, `useful_tflops` the fp32-grade products delivered")
     return {"bound": "mfma", "achieved": d["achieved"], "peak": peak, "unit": "TFLOP/s", "frac": d["frac"],
             # the same FLOPs against the matrix peak at the clock this chip holds under a dense MFMA load

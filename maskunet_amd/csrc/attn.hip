@@ -230,6 +230,15 @@ template <> struct AT<h16> {
     static __device__ __forceinline__ void mma_row_sb(const Frag& a, const Frag& b, f32x4& c) { mma_row(a, b, c); }
     static __device__ __forceinline__ f32x4 mma_row_from_sa(const Frag& a, const Frag& b, const f32x4& c0) { return mma_row_from(a, b, c0); }
     static __device__ __forceinline__ f32x4 mma_row_from_sb(const Frag& a, const Frag& b, const f32x4& c0) { return mma_row_from(a, b, c0); }
+    // backward-only names (fp32x trades precision differently in the backward sweeps -- see AT<xf32>; here they are the plain products)
+    static __device__ __forceinline__ void mma_row_bs_sa(const Frag& a, const Frag& b, f32x4& c) { mma_row(a, b, c); }
+    static __device__ __forceinline__ void mma_row_bs_sb(const Frag& a, const Frag& b, f32x4& c) { mma_row(a, b, c); }
+    static __device__ __forceinline__ f32x4 mma_row_from_bs_sa(const Frag& a, const Frag& b, const f32x4& c0) { return mma_row_from(a, b, c0); }
+    static __device__ __forceinline__ f32x4 mma_row_from_bs_sb(const Frag& a, const Frag& b, const f32x4& c0) { return mma_row_from(a, b, c0); }
+    static __device__ __forceinline__ void mma_row_bp_sa(const Frag& a, const Frag& b, f32x4& c) { mma_row(a, b, c); }
+    static __device__ __forceinline__ void mma_row_bp_sb(const Frag& a, const Frag& b, f32x4& c) { mma_row(a, b, c); }
+    static __device__ __forceinline__ f32x4 mma_row_from_bp_sa(const Frag& a, const Frag& b, const f32x4& c0) { return mma_row_from(a, b, c0); }
+    static __device__ __forceinline__ f32x4 mma_row_from_bp_sb(const Frag& a, const Frag& b, const f32x4& c0) { return mma_row_from(a, b, c0); }
     // A operand [m = tile column col0+r16][k-slot j <-> tile row 4g+j, 16+4g+j]
     static __device__ __forceinline__ AccA ld_acc_a(const h16* tile, int stride, int col0, int g, int r16) {
         const int q = r16 >> 2, pc = r16 & 3;
@@ -253,6 +262,8 @@ template <> struct AT<h16> {
     static __device__ __forceinline__ void mma_acc_pk(const AccA& a, const Packed& b, f32x4& c) {
         c = __builtin_amdgcn_mfma_f32_16x16x32_f16(a.v, b, c, 0, 0, 0);
     }
+    static __device__ __forceinline__ void mma_accb(const AccA& a, const f32x4& p0, const f32x4& p1, f32x4& c) { mma_acc(a, p0, p1, c); }
+    static __device__ __forceinline__ void mma_accb_pk(const AccA& a, const Packed& b, f32x4& c) { mma_acc_pk(a, b, c); }
 };
 template <> struct AT<float> {
     static constexpr int VN = 4, KR = 16, GS = 4;
@@ -271,6 +282,15 @@ template <> struct AT<float> {
     static __device__ __forceinline__ void mma_row_sb(const Frag& a, const Frag& b, f32x4& c) { mma_row(a, b, c); }
     static __device__ __forceinline__ f32x4 mma_row_from_sa(const Frag& a, const Frag& b, const f32x4& c0) { return mma_row_from(a, b, c0); }
     static __device__ __forceinline__ f32x4 mma_row_from_sb(const Frag& a, const Frag& b, const f32x4& c0) { return mma_row_from(a, b, c0); }
+    // backward-only names (fp32x trades precision differently in the backward sweeps -- see AT<xf32>; here they are the plain products)
+    static __device__ __forceinline__ void mma_row_bs_sa(const Frag& a, const Frag& b, f32x4& c) { mma_row(a, b, c); }
+    static __device__ __forceinline__ void mma_row_bs_sb(const Frag& a, const Frag& b, f32x4& c) { mma_row(a, b, c); }
+    static __device__ __forceinline__ f32x4 mma_row_from_bs_sa(const Frag& a, const Frag& b, const f32x4& c0) { return mma_row_from(a, b, c0); }
+    static __device__ __forceinline__ f32x4 mma_row_from_bs_sb(const Frag& a, const Frag& b, const f32x4& c0) { return mma_row_from(a, b, c0); }
+    static __device__ __forceinline__ void mma_row_bp_sa(const Frag& a, const Frag& b, f32x4& c) { mma_row(a, b, c); }
+    static __device__ __forceinline__ void mma_row_bp_sb(const Frag& a, const Frag& b, f32x4& c) { mma_row(a, b, c); }
+    static __device__ __forceinline__ f32x4 mma_row_from_bp_sa(const Frag& a, const Frag& b, const f32x4& c0) { return mma_row_from(a, b, c0); }
+    static __device__ __forceinline__ f32x4 mma_row_from_bp_sb(const Frag& a, const Frag& b, const f32x4& c0) { return mma_row_from(a, b, c0); }
     static __device__ __forceinline__ f32x4 mma_row_from(const Frag& a, const Frag& b, const f32x4& c0) {
         f32x4 c = __builtin_amdgcn_mfma_f32_16x16x4f32(a[0], b[0], c0, 0, 0, 0);
 #pragma unroll
@@ -293,6 +313,7 @@ template <> struct AT<float> {
         for (int r = 0; r < 4; ++r) c = __builtin_amdgcn_mfma_f32_16x16x4f32(a.v[4 + r], p1[r], c, 0, 0, 0);
     }
     static __device__ __forceinline__ void mma_ones(const AccA& a, const f32x4& p0, const f32x4& p1, f32x4& c) { mma_acc(a, p0, p1, c); }
+    static __device__ __forceinline__ void mma_accb(const AccA& a, const f32x4& p0, const f32x4& p1, f32x4& c) { mma_acc(a, p0, p1, c); }
 };
 
 // fp32x (common.h): fp32 storage and the fp32 kernels' tiling on FP16-PAIR-ENCODED qkv / dY (32 bytes = [8 fp16 hi | 8 fp16 lo] of
@@ -380,6 +401,60 @@ template <> struct AT<xf32> {
     static __device__ __forceinline__ void mma_ones(const AccA& a, const f32x4& p0, const f32x4& p1, f32x4& c) {
         c = __builtin_amdgcn_mfma_f32_16x16x32_f16(a.hi, pack(p0, p1), c, 0, 0, 0);          // (the ones operand has no lo part)
     }
+    // Round 6, BACKWARD sweeps only (the forward keeps the two-term products above: north_star's 1e-3 is a gate on OUTPUTS): dP = dO V^T
+    // (MU_XF_BWD_DP1) and the gradient products dV = P^T dO, dK = dS^T Q, dQ = dS K (MU_XF_BWD_G1) as ONE fp16 MFMA on the hi halves, i.e.
+    // the fp16 kernels' arithmetic on exactly scaled operands (dY carries its power-of-two scale, P its 2^pshift).  Each of these sums runs
+    // over hundreds to thousands of keys / queries, so the 2^-12 operand roundings average out: the CPU sizing
+    // (tests/aids/numerics_attn_single_term.py DP1 / DV1 / DK1 / DQ1 on the reference's golden) shows NO measurable change of any gradient
+    // metric (worst parameter gradient 8.7e-3 with and without, gate 5e-2), and on the GPU the goldens' worst gradients did not move.
+    // The recomputed SCORES keep the forward's two terms (MU_XF_BWD_S1 = 0): with one term the backward's P is no longer the forward's
+    // (dQ / dK of the kernel-level check 6.4e-4 -> 1.1e-3 against its 1e-3 gate) for another 4.5 % of the step -- measured, not adopted.
+#ifndef MU_XF_BWD_S1
+#define MU_XF_BWD_S1 0
+#endif
+#ifndef MU_XF_BWD_DP1
+#define MU_XF_BWD_DP1 1
+#endif
+#ifndef MU_XF_BWD_G1
+#define MU_XF_BWD_G1 1
+#endif
+    static __device__ __forceinline__ void mma_row_bs_sa(const Frag& a, const Frag& b, f32x4& c) {
+        if (!MU_XF_BWD_S1) { mma_row_sa(a, b, c); return; }
+        c = __builtin_amdgcn_mfma_f32_16x16x32_f16(a.hi, b.hi, c, 0, 0, 0);
+    }
+    static __device__ __forceinline__ void mma_row_bs_sb(const Frag& a, const Frag& b, f32x4& c) {
+        if (!MU_XF_BWD_S1) { mma_row_sb(a, b, c); return; }
+        c = __builtin_amdgcn_mfma_f32_16x16x32_f16(a.hi, b.hi, c, 0, 0, 0);
+    }
+    static __device__ __forceinline__ f32x4 mma_row_from_bs_sa(const Frag& a, const Frag& b, const f32x4& c0) {
+        if (!MU_XF_BWD_S1) return mma_row_from_sa(a, b, c0);
+        return __builtin_amdgcn_mfma_f32_16x16x32_f16(a.hi, b.hi, c0, 0, 0, 0);
+    }
+    static __device__ __forceinline__ f32x4 mma_row_from_bs_sb(const Frag& a, const Frag& b, const f32x4& c0) {
+        if (!MU_XF_BWD_S1) return mma_row_from_sb(a, b, c0);
+        return __builtin_amdgcn_mfma_f32_16x16x32_f16(a.hi, b.hi, c0, 0, 0, 0);
+    }
+    static __device__ __forceinline__ void mma_row_bp_sa(const Frag& a, const Frag& b, f32x4& c) {
+        if (!MU_XF_BWD_DP1) { mma_row_sa(a, b, c); return; }
+        c = __builtin_amdgcn_mfma_f32_16x16x32_f16(a.hi, b.hi, c, 0, 0, 0);
+    }
+    static __device__ __forceinline__ void mma_row_bp_sb(const Frag& a, const Frag& b, f32x4& c) {
+        if (!MU_XF_BWD_DP1) { mma_row_sb(a, b, c); return; }
+        c = __builtin_amdgcn_mfma_f32_16x16x32_f16(a.hi, b.hi, c, 0, 0, 0);
+    }
+    static __device__ __forceinline__ f32x4 mma_row_from_bp_sa(const Frag& a, const Frag& b, const f32x4& c0) {
+        if (!MU_XF_BWD_DP1) return mma_row_from_sa(a, b, c0);
+        return __builtin_amdgcn_mfma_f32_16x16x32_f16(a.hi, b.hi, c0, 0, 0, 0);
+    }
+    static __device__ __forceinline__ f32x4 mma_row_from_bp_sb(const Frag& a, const Frag& b, const f32x4& c0) {
+        if (!MU_XF_BWD_DP1) return mma_row_from_sb(a, b, c0);
+        return __builtin_amdgcn_mfma_f32_16x16x32_f16(a.hi, b.hi, c0, 0, 0, 0);
+    }
+    static __device__ __forceinline__ void mma_accb_pk(const AccA& a, const Packed& b, f32x4& c) {
+        if (!MU_XF_BWD_G1) { mma_acc_pk(a, b, c); return; }
+        c = __builtin_amdgcn_mfma_f32_16x16x32_f16(a.hi, b, c, 0, 0, 0);
+    }
+    static __device__ __forceinline__ void mma_accb(const AccA& a, const f32x4& p0, const f32x4& p1, f32x4& c) { mma_accb_pk(a, pack(p0, p1), c); }
 };
 // reductions over the 4 lanes {r16 + 16g}: v_permlane16_swap / v_permlane32_swap exchange 16-/32-lane rows in
 // registers (no LDS round trip, unlike the ds_bpermute behind __shfl_xor).  swap(v, v) returns {own, partner} in
@@ -1181,11 +1256,11 @@ __global__ __launch_bounds__(NW * 64, OCCQ ? OCCQ : (NW == 4 && D <= 64 && std::
 #pragma unroll
                 for (int t = 0; t < NQT; ++t) {
                     if (ks == 0) {                            // row constants as the C operand of the first k-step (no copies)
-                        s[kt][t] = A::mma_row_from_sa(ka, qf[t][0], nlse[t]);
-                        dp[kt][t] = A::mma_row_from_sa(va, dof[t][0], ndel[t]);
+                        s[kt][t] = A::mma_row_from_bs_sa(ka, qf[t][0], nlse[t]);
+                        dp[kt][t] = A::mma_row_from_bp_sa(va, dof[t][0], ndel[t]);
                     } else {
-                        A::mma_row_sa(ka, qf[t][ks], s[kt][t]);
-                        A::mma_row_sa(va, dof[t][ks], dp[kt][t]);
+                        A::mma_row_bs_sa(ka, qf[t][ks], s[kt][t]);
+                        A::mma_row_bp_sa(va, dof[t][ks], dp[kt][t]);
                     }
                 }
             }
@@ -1222,7 +1297,7 @@ __global__ __launch_bounds__(NW * 64, OCCQ ? OCCQ : (NW == 4 && D <= 64 && std::
                 if (h == 0 && dt < PREQ) ka = kap[dt];
                 else ka = AccLd<T, D>::ld(Kt, 32 * h, dt * 16, g, r16);
 #pragma unroll
-                for (int t = 0; t < NQT; ++t) A::mma_acc(ka, s[2 * h][t], s[2 * h + 1][t], dq[dt][t]);
+                for (int t = 0; t < NQT; ++t) A::mma_accb(ka, s[2 * h][t], s[2 * h + 1][t], dq[dt][t]);
             }
         MU_PRIO(0);
 #ifdef MU_DQ_ABL_NOBAR
@@ -1453,11 +1528,11 @@ __global__ __launch_bounds__(NW * 64, NW >= 8 ? 1 : ((D <= 64 && std::is_same<T,
 #pragma unroll
                 for (int kt = 0; kt < NKT; ++kt) {
                     if (ks == 0) {                           // the row constants enter as the C operand of the first k-step
-                        s[qt][kt] = A::mma_row_from_sb(qa, kf[kt][0], nl[qt]);
-                        dp[qt][kt] = A::mma_row_from_sb(oa, vf[kt][0], nd[qt]);
+                        s[qt][kt] = A::mma_row_from_bs_sb(qa, kf[kt][0], nl[qt]);
+                        dp[qt][kt] = A::mma_row_from_bp_sb(oa, vf[kt][0], nd[qt]);
                     } else {
-                        A::mma_row_sb(qa, kf[kt][ks], s[qt][kt]);
-                        A::mma_row_sb(oa, vf[kt][ks], dp[qt][kt]);
+                        A::mma_row_bs_sb(qa, kf[kt][ks], s[qt][kt]);
+                        A::mma_row_bp_sb(oa, vf[kt][ks], dp[qt][kt]);
                     }
                 }
                 if constexpr (std::is_same<T, xf32>::value && D >= 128 && MU_XF_DKV_SCHED2) { if (qt == 1) __builtin_amdgcn_sched_barrier(0); }
@@ -1514,8 +1589,8 @@ __global__ __launch_bounds__(NW * 64, NW >= 8 ? 1 : ((D <= 64 && std::is_same<T,
                 else { oa = AccLd<T, D>::ld(Ot, 0, dt * 16, g, r16); qa = AccLd<T, D>::ld(Qt, 0, dt * 16, g, r16); }
 #pragma unroll
                 for (int kt = 0; kt < NKT; ++kt) {
-                    A::mma_acc_pk(oa, pb[kt], dv[dt][kt]);
-                    A::mma_acc_pk(qa, db[kt], dk[dt][kt]);
+                    A::mma_accb_pk(oa, pb[kt], dv[dt][kt]);
+                    A::mma_accb_pk(qa, db[kt], dk[dt][kt]);
                 }
                 // fp32x at C >= 128: the resident K / V pairs and the accumulators alone are 128 registers; left alone the scheduler
                 // hoists the transposed reads of ALL column blocks (16 registers each) above the first MFMA and spills ~130 registers
@@ -1542,8 +1617,8 @@ __global__ __launch_bounds__(NW * 64, NW >= 8 ? 1 : ((D <= 64 && std::is_same<T,
             else { oa = AccLd<T, D>::ld(Ot, 0, dt * 16, g, r16); qa = AccLd<T, D>::ld(Qt, 0, dt * 16, g, r16); }
 #pragma unroll
             for (int kt = 0; kt < NKT; ++kt) {
-                A::mma_acc(oa, s[0][kt], s[1][kt], dv[dt][kt]);
-                A::mma_acc(qa, dp[0][kt], dp[1][kt], dk[dt][kt]);
+                A::mma_accb(oa, s[0][kt], s[1][kt], dv[dt][kt]);
+                A::mma_accb(qa, dp[0][kt], dp[1][kt], dk[dt][kt]);
             }
         }
         MU_PRIO(0);

@@ -22,6 +22,10 @@ JSHIFT = 12
 # VSINGLE=1 -- the value operand of dP = dO V^T as one fp16 term
 KSINGLE = os.environ.get("KSINGLE", "0") == "1"
 VSINGLE = os.environ.get("VSINGLE", "0") == "1"
+# further probes (not built): the SECOND operand of the gradient products as one fp16 term too -- dV = P^T dO with dO single (DV1), dK = dS^T Q
+# with Q single (DK1), dQ = dS K with K single (DQ1), dP = dO V^T with dO single as well (DP1): one MFMA per product
+DV1, DK1, DQ1, DP1 = (os.environ.get(k, "0") == "1" for k in ("DV1", "DK1", "DQ1", "DP1"))
+SB1 = os.environ.get("SB1", "0") == "1"      # the BACKWARD's recomputed scores with the query as one fp16 term too (the forward keeps two terms)
 
 
 def h(x):
@@ -75,12 +79,14 @@ class Attn(torch.autograd.Function):
         for b in range(B):
             idx = keep[b].nonzero()[:, 0]
             qs = pair16(Qe[b] * sl2) if pair else Qe[b] * sl2
+            if SB1:
+                qs = h(qs)
             s2 = qs @ (h(Ke[b, idx]) if KSINGLE else Ke[b, idx]).T
             P = torch.exp2(s2 - lse2[b][:, None] + j)
             vs = pair16(Ve[b, idx] * scale) if pair else Ve[b, idx] * scale
             if VSINGLE:
                 vs = h(vs)
-            dP = dYe[b] @ vs.T - (delta[b] * scale * gs)[:, None]
+            dP = (h(dYe[b]) if DP1 else dYe[b]) @ vs.T - (delta[b] * scale * gs)[:, None]
             if MODE.startswith("p16"):
                 P = h(P)
             if MODE.startswith("p16ds16"):
@@ -92,14 +98,14 @@ class Attn(torch.autograd.Function):
             if KSINGLE and os.environ.get("KVSWEEP_SCALED_K", "0") == "1":
                 # the dK/dV sweep keeps the SCALED keys resident (one fp16 term of c K) against the streamed unscaled query pair: its scores
                 # differ from the forward's (c Q pair x one term of K) by the two different roundings -- emulate that sweep's own P / dS
-                s2k = Qe[b] @ h(Ke[b, idx] * sl2).T
+                s2k = (h(Qe[b]) if SB1 else Qe[b]) @ h(Ke[b, idx] * sl2).T
                 Pk = torch.exp2(s2k - lse2[b][:, None] + j)
-                dPk = dYe[b] @ (h(pair16(Ve[b, idx] * scale)) if VSINGLE else pair16(Ve[b, idx] * scale)).T - (delta[b] * scale * gs)[:, None]
+                dPk = (h(dYe[b]) if DP1 else dYe[b]) @ (h(pair16(Ve[b, idx] * scale)) if VSINGLE else pair16(Ve[b, idx] * scale)).T - (delta[b] * scale * gs)[:, None]
                 Pk = h(Pk)
                 dSk = h(Pk * h(dPk))
-            dV[b, idx] = (Pk.T @ dYe[b]) * un
-            dK[b, idx] = (dSk.T @ Qe[b]) * un
-            dQ[b] = (dS @ Ke[b, idx]) * un
+            dV[b, idx] = (Pk.T @ (h(dYe[b]) if DV1 else dYe[b])) * un
+            dK[b, idx] = (dSk.T @ (h(Qe[b]) if DK1 else Qe[b])) * un
+            dQ[b] = (dS @ (h(Ke[b, idx]) if DQ1 else Ke[b, idx])) * un
         return dQ, dK, dV, None
 
 
@@ -151,7 +157,7 @@ def main():
     gsl = p["norm.weight"].grad[:, ::16, ::16]
     rs = torch.from_numpy(rec["g_slice/norm.weight"])
     e3 = float((gsl - rs).abs().max()) / float(rs.abs().max())
-    print(f"mode {MODE} ksingle {int(KSINGLE)} vsingle {int(VSINGLE)}: out err {eo:.3e} (gate 1e-3)  loss err {abs(loss.item() - float(rec['loss'])):.3e}  "
+    print(f"mode {MODE} ksingle {int(KSINGLE)} vsingle {int(VSINGLE)} dv1 {int(DV1)} dk1 {int(DK1)} dq1 {int(DQ1)} dp1 {int(DP1)} sb1 {int(SB1)}: out err {eo:.3e} (gate 1e-3)  loss err {abs(loss.item() - float(rec['loss'])):.3e}  "
           f"worst grad {worst[0]:.3e} [{worst[1]}] (gate 5e-2)  d norm.weight slice {e3:.3e} (gate 1e-1)")
 
 

@@ -194,7 +194,7 @@ def test_enc_link_is_valid_only_within_the_marking_backward_pass(monkeypatch):
 
 def test_bench_sweep_roofline_arithmetic():
     """bench.sweep_rooflines: executed FLOPs = 2 * products * N * Nk * C per image (Nk = kept keys), fp32x counts the 16-bit MFMA FLOPs
-    ISSUED (two terms per product: one operand of each -- P, dS, the key in S, the value in dP -- is a single fp16 term) against the dense 16-bit peak and
+    ISSUED (two terms for S and P V, one for dP and the gradient products of the backward sweeps: round 6) against the dense 16-bit peak and
     carries the fp32-grade rate next to it; `kernels` holds all three sweeps."""
     import bench
 
@@ -218,8 +218,8 @@ def test_bench_sweep_roofline_arithmetic():
     assert set(r["kernels"]) == {"fwd", "dq", "dkv"} and abs(r["kernels"]["fwd"]["flops_per_launch"] - exec_dkv / 2) < 1
     assert abs(r["algorithmic_achieved"] - 2 * r["achieved"]) < 0.02           # full key set = twice the kept half
     x = bench.sweep_rooflines("fp32x", events({"fwd": 4.0, "dq": 6.0, "dkv": 8.0}), hw, B, kept, None)
-    assert abs(x["flops_per_launch"] - exec_dkv * 8 / 4) < 1                    # (2 + 2 + 2 + 2) terms over 4 products
-    assert abs(x["kernels"]["fwd"]["flops_per_launch"] - (exec_dkv / 2) * 4 / 2) < 1 and abs(x["kernels"]["dq"]["flops_per_launch"] - (exec_dkv * 3 / 4) * 6 / 3) < 1
+    assert abs(x["flops_per_launch"] - exec_dkv * 5 / 4) < 1                    # (2 + 1 + 1 + 1) terms over 4 products
+    assert abs(x["kernels"]["fwd"]["flops_per_launch"] - (exec_dkv / 2) * 4 / 2) < 1 and abs(x["kernels"]["dq"]["flops_per_launch"] - (exec_dkv * 3 / 4) * 4 / 3) < 1
     assert abs(x["useful_tflops"] - exec_dkv / 8e-3 / 1e12) < 0.01 and x["peak"] == 2500.0 and x["frac_at_measured_clock"] is None
     assert bench.sweep_rooflines("fp16", events({"fwd": 2.0}), hw, B, kept, None) is None     # no dominant-kernel launch timed
 

@@ -8,9 +8,10 @@ ROOT=$(cd "$(dirname "$0")/.." && pwd)
 SRC=$ROOT/maskunet_amd/csrc
 OUT=$ROOT/gpurun_variants
 mkdir -p $OUT
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -fPIC -std=c++17 -Wno-unused-value -Wno-pass-failed $EXTRA -c $SRC/$F.hip -o $OUT/${F}_$NAME.o
+FL=""; { [ $F = attn ] || [ $F = conv ]; } && FL="-fno-slp-vectorize"      # as the Makefile builds these two (FLAGS_attn / FLAGS_conv)
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -fPIC -std=c++17 -Wno-unused-value -Wno-pass-failed $FL $EXTRA -c $SRC/$F.hip -o $OUT/${F}_$NAME.o
 OBJS=""
-for f in elementwise norm conv attn loss probe version; do
+for f in elementwise norm conv attn attn_wide loss probe version; do
   if [ $f = $F ]; then OBJS="$OBJS $OUT/${F}_$NAME.o"; else OBJS="$OBJS $SRC/$f.o"; fi
 done
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC $OBJS -o $OUT/libmu_$NAME.so
