@@ -79,6 +79,9 @@ int mu_split_encode(const void* src, void* dst, long n_elems, void* stream);
  * [4 fp16 hi | 4 fp16 lo] per chunk of four, hi = fp16(x), lo = fp16(x - hi); dst may be src (in place).  The input of a 3x3 layer
  * (nn.Conv2d k = 3 in ConvBlock, ade_semantic.py:199,202) that no producer wrote encoded. */
 int mu_split_encode_h4(const void* src, void* dst, long n_elems, void* stream);
+/* mu_split_encode_h4 with a second output: dst16 = the fp16 rounding of the values (n_elems halves: the hi halves as plain rows) -- the
+ * saved-input form of the one-term weight gradient mu_conv_wgrad_h1.  Out of place. */
+int mu_split_encode_h4x(const void* src, void* dst, void* dst16, long n_elems, void* stream);
 /* A plain fp32 gradient (n_elems values, a multiple of 4) -> ONE power-of-two-scaled fp16 operand dy_h (n_elems halves; must not alias
  * dy) + dy_scale = {S, 1 / S} on the device (S max|dy| in [2^13, 2^14); no host sync): the dy form of mu_conv_dgrad_h / mu_conv_wgrad_h
  * for a 3x3 layer whose dy does not come out of mu_bn_act_bwd_h (a conv without a BatchNorm behind it, city_instance.py:243). */
@@ -155,6 +158,11 @@ int mu_conv_dgrad_h(const void* dy_h, const void* w_hl, const float* dy_scale, v
 long mu_conv_wgrad_h_workspace_bytes(int B, int H, int W, int Cin, int Cout);
 int mu_conv_wgrad_h(const void* x, const void* dy_h, const float* dy_scale, float* dw_oihw, int B, int H, int W, int Cin, int Cout,
                     int cin_valid, int cout_valid, long x_ld, long dy_ld, void* workspace, long ws_bytes, void* stream);
+/* ... and its ONE-term form: x_h = the fp16 rounding of the input (rows of Cin halves, stride x_ld halves: the second output of
+ * mu_bn_act_fwd_enc / mu_split_encode_h4x).  One MFMA per product on the fp16 kernels; dW sums over every pixel of the batch, so the roundings
+ * average out (no change of any gradient metric in the oracle sizing).  Workspace: mu_conv_wgrad_workspace_bytes(B, H, W, Cin, Cout, 9). */
+int mu_conv_wgrad_h1(const void* x_h, const void* dy_h, const float* dy_scale, float* dw_oihw, int B, int H, int W, int Cin, int Cout,
+                     int cin_valid, int cout_valid, long x_ld, long dy_ld, void* workspace, long ws_bytes, void* stream);
 /* dw_oihw[o][i][tap] = sum_p dy[p][o] * x[p+shift(tap)][i] for o < cout_valid, i < cin_valid (fp32, OIHW). */
 long mu_conv_wgrad_workspace_bytes(int B, int H, int W, int Cin, int Cout, int taps);
 int mu_conv_wgrad(const void* x, const void* dy, float* dw_oihw, int B, int H, int W, int Cin, int Cout, int taps, int cin_valid,
@@ -195,6 +203,10 @@ int mu_bn_eval_fold(const float* running_mean1, const float* running_var1, const
  * (:204,208) and final_layer's BN+ReLU (:285-286). */
 int mu_bn_act_fwd(const void* x, const void* res, void* y, long M, int C, long ld, const float* mean, const float* rstd,
                   const float* gamma, const float* beta, int act, int dtype, void* stream);
+/* fp32x: mu_bn_act_fwd(MU_F32X) -- y written in the 3x3 operand encoding -- with a second output y16 = the fp16 rounding of y as plain rows
+ * of C halves (row stride C; contiguous input rows): the form of y the backward of the convolution behind keeps (mu_conv_wgrad_h1). */
+int mu_bn_act_fwd_enc(const void* x, const void* res, void* y_enc, void* y16, long M, int C, const float* mean, const float* rstd,
+                      const float* gamma, const float* beta, int act, void* stream);
 /* backward of mu_bn_act_fwd: dx (wrt x), dres (wrt res, iff res given), dgamma, dbeta.  training=1 uses the
  * batch-statistics formula, 0 treats mean/rstd as constants. */
 int mu_bn_act_bwd(const void* x, const void* res, const void* grad_out, void* dx, void* dres, long M, int C, long ld,

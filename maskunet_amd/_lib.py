@@ -29,6 +29,9 @@ SIGNATURES = {
     "mu_split_encode": (I, [P, P, L, P]),
     "mu_split_encode_h": (I, [P, P, L, P]),
     "mu_split_encode_h4": (I, [P, P, L, P]),
+    "mu_split_encode_h4x": (I, [P, P, P, L, P]),
+    "mu_conv_wgrad_h1": (I, [P, P, P, P, I, I, I, I, I, I, I, L, L, P, L, P]),
+    "mu_bn_act_fwd_enc": (I, [P, P, P, P, L, I, P, P, P, P, I, P]),
     "mu_dy_encode_h_workspace_bytes": (L, []),
     "mu_dy_encode_h": (I, [P, P, P, L, P, L, P]),
     "mu_conv_dgrad_h": (I, [P, P, P, P, I, I, I, I, I, L, L, P]),

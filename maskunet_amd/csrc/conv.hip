@@ -122,7 +122,9 @@ __device__ __forceinline__ float epi_act(float v, int act) { return mu_act_t<siz
 // HL (round 6, T = h16 only: the two-term data gradient of the fp32x 3x3 layers, mu_conv_dgrad_h): x is the ONE-term fp16 dy, w the "HL"
 // weight rows [Cin lo | Cin hi] of 2 * Cin halves (elementwise.hip mu_prep_weight), the K loop walks every input chunk twice -- against
 // the lo halves, then against the hi halves -- and the result leaves as fp32 rows yf, multiplied by oscale[1] / 2^MU_XH_WSHIFT.
-template <typename T, int TM, int TN, int WR, int TAPS, bool FEPI = false, bool HL = false>
+// HL = 2: both halves (two MFMAs per product); HL = 1: the hi halves only -- the weights of the data gradient as ONE fp16 term (one MFMA
+// per product: sized on the oracle like everything else, NOTES_r06 §2b); HL = 0: the ordinary kernel.
+template <typename T, int TM, int TN, int WR, int TAPS, bool FEPI = false, int HL = 0>
 __global__ __launch_bounds__(256) void conv_nt_kernel(const T* __restrict__ x, const T* __restrict__ w, const float* __restrict__ bias,
                                                       T* __restrict__ y, int B, int H, int W, int Cin, int Cout, long x_ld, long y_ld,
                                                       const float* __restrict__ scale = nullptr, const T* __restrict__ res = nullptr, int act = 0,
@@ -168,13 +170,13 @@ __global__ __launch_bounds__(256) void conv_nt_kernel(const T* __restrict__ x, c
     }
 
     const int kreal = Cin / KC;
-    const int kchunks = HL ? 2 * kreal : kreal;
+    const int kchunks = HL == 2 ? 2 * kreal : kreal;
     const int Cw = HL ? 2 * Cin : Cin;                       // weight row length
     const int nsteps = TAPS * kchunks;
     uint4 ra[NA], rb[NB];
 
     auto gload = [&](int s) {
-        const int tap = s / kchunks, ciw = (s % kchunks) * KC;
+        const int tap = s / kchunks, ciw = (s % kchunks) * KC + (HL == 1 ? Cin : 0);
         const int ci0 = HL ? (ciw >= Cin ? ciw - Cin : ciw) : ciw;
         const int dh = TAPS == 9 ? tap / 3 - 1 : 0, dw = TAPS == 9 ? tap % 3 - 1 : 0;
 #pragma unroll
@@ -628,7 +630,7 @@ __device__ __forceinline__ void tile_stats_store(float (&ssum)[8], float (&ssq)[
 
 // HL: see conv_nt_kernel -- here the lo / hi passes of one input chunk follow each other (chunk instance c = 2 * chunk + {lo, hi}), so the
 // halo of a chunk is staged ONCE for both (the odd instance stages the next chunk's halo, the even one stages nothing).
-template <typename T, int TM, int TN, int WR, int NWV, bool RINGP, bool FEPI, bool HL = false>
+template <typename T, int TM, int TN, int WR, int NWV, bool RINGP, bool FEPI, int HL = 0>
 __device__ __forceinline__ void conv_nt3_body(const T* __restrict__ x, const T* __restrict__ w, const float* __restrict__ bias,
                                               T* __restrict__ y, int B, int H, int W, int Cin, int Cout, long x_ld, long y_ld,
                                               const float* __restrict__ scale, const T* __restrict__ res, int act,
@@ -676,7 +678,8 @@ __device__ __forceinline__ void conv_nt3_body(const T* __restrict__ x, const T* 
     const int r16 = lane & 15, g = lane >> 4;
     const int srow = lane >> 3, sch = lane & 7;
 
-    const int kchunks = HL ? 2 * (Cin / KC) : Cin / KC;     // chunk INSTANCES (HL: lo and hi pass of every chunk)
+    constexpr bool HL2 = HL == 2;
+    const int kchunks = HL2 ? 2 * (Cin / KC) : Cin / KC;    // chunk INSTANCES (HL = 2: lo and hi pass of every chunk)
     const int Cw = HL ? 2 * Cin : Cin;                       // weight row length
     const int nsteps = 9 * kchunks;
 
@@ -702,7 +705,7 @@ __device__ __forceinline__ void conv_nt3_body(const T* __restrict__ x, const T* 
 
     auto stage_w = [&](int s, int buf) {
         const int tap = s % 9, c_ = s / 9;
-        const int ci0 = HL ? ((c_ & 1) ? Cin : 0) + (c_ >> 1) * KC : c_ * KC;
+        const int ci0 = HL2 ? ((c_ & 1) ? Cin : 0) + (c_ >> 1) * KC : (HL == 1 ? Cin : 0) + c_ * KC;
         const T* wb = w + (long)tap * Cout * Cw + ci0;       // wave-uniform
         char* Wb = Ws + buf * WBYTES;
 #pragma unroll
@@ -713,8 +716,8 @@ __device__ __forceinline__ void conv_nt3_body(const T* __restrict__ x, const T* 
         glds16(src, Hs + buf * HBYTES + (k * NWV + wave) * 1024);
     };
     // halo of chunk instance c: data chunk and buffer (HL: two instances share one halo); next_h: does instance c + 1 need a new halo?
-    auto hchunk = [&](int c) { return HL ? (c >> 1) : c; };
-    auto next_h = [&](int c) { return c + 1 < kchunks && (!HL || ((c + 1) & 1) == 0); };
+    auto hchunk = [&](int c) { return HL2 ? (c >> 1) : c; };
+    auto next_h = [&](int c) { return c + 1 < kchunks && (!HL2 || ((c + 1) & 1) == 0); };
 
     f32x4 acc[TM][TN];
 #pragma unroll
@@ -948,10 +951,10 @@ __global__ __launch_bounds__(NWV * 64, NWV == 4 ? 2 : 1) void conv_nt3_kernel(co
                                                        float* __restrict__ stat_part = nullptr) {
     conv_nt3_body<T, TM, TN, WR, NWV, RINGP, false>(x, w, bias, y, B, H, W, Cin, Cout, x_ld, y_ld, nullptr, nullptr, 0, stat_part);
 }
-template <int TM, int TN, int WR, bool RINGP = false>
+template <int TM, int TN, int WR, bool RINGP = false, int HL = 2>
 __global__ __launch_bounds__(256, 2) void conv_nt3hl_kernel(const h16* __restrict__ dy, const h16* __restrict__ w, float* __restrict__ dx, int B, int H,
                                                             int W, int Cin, int Cout, long x_ld, long y_ld, const float* __restrict__ oscale) {
-    conv_nt3_body<h16, TM, TN, WR, 4, RINGP, false, true>(dy, w, nullptr, nullptr, B, H, W, Cin, Cout, x_ld, y_ld, nullptr, nullptr, 0, nullptr, dx, oscale);
+    conv_nt3_body<h16, TM, TN, WR, 4, RINGP, false, HL>(dy, w, nullptr, nullptr, B, H, W, Cin, Cout, x_ld, y_ld, nullptr, nullptr, 0, nullptr, dx, oscale);
 }
 template <typename T, int TM, int TN, int WR>
 __global__ __launch_bounds__(256, 2) void conv_nt3f_kernel(const T* __restrict__ x, const T* __restrict__ w, const float* __restrict__ bias,
@@ -1181,7 +1184,7 @@ __global__ __launch_bounds__(256, 2) void conv_nt3p_kernel(const T* __restrict__
 // HL (round 6): the two-term data gradient of the fp32x 3x3 layers on this pipeline (see conv_nt_kernel / conv_nt3_body): x = the one-term
 // fp16 dy, w = HL rows of 2 * Cin halves, chunk instance c = 2 * chunk + {lo, hi} -- the DMA slot that would fetch the next chunk's halo
 // carries a dummy in the even instances (the counted waits stay as they are) --, fp32 output rows through conv_nt4x_kernel's epilogue.
-template <bool FEPI, bool HL = false>
+template <bool FEPI, int HL = 0>
 __device__ __forceinline__ void conv_nt4_body(const h16* __restrict__ x, const h16* __restrict__ w, const float* __restrict__ bias,
                                               h16* __restrict__ y, int B, int H, int W, int Cin, int Cout, long x_ld, long y_ld,
                                               float* __restrict__ stat_part, const float* __restrict__ scale, const h16* __restrict__ res, int act,
@@ -1213,7 +1216,8 @@ __device__ __forceinline__ void conv_nt4_body(const h16* __restrict__ x, const h
     const int r16 = lane & 15, g = lane >> 4;
     const int srow = lane >> 3, sch = lane & 7;
 
-    const int kchunks = HL ? 2 * (Cin / KC) : Cin / KC;      // chunk instances
+    constexpr bool HL2 = HL == 2;
+    const int kchunks = HL2 ? 2 * (Cin / KC) : Cin / KC;     // chunk instances
     const int Cw = HL ? 2 * Cin : Cin;                       // weight row length
     const int nsteps = 9 * kchunks;
 
@@ -1237,7 +1241,7 @@ __device__ __forceinline__ void conv_nt4_body(const h16* __restrict__ x, const h
     auto stage_w = [&](int s) {                              // W(s) -> ring slot s & 3 (dummy beyond the last step)
         if (s < nsteps) {
             const int tap = s % 9, c_ = s / 9;
-            const int ci0 = HL ? ((c_ & 1) ? Cin : 0) + (c_ >> 1) * KC : c_ * KC;
+            const int ci0 = HL2 ? ((c_ & 1) ? Cin : 0) + (c_ >> 1) * KC : (HL == 1 ? Cin : 0) + c_ * KC;
             const h16* wb = w + (long)tap * Cout * Cw + ci0;
             char* Wb = Ws + (s & 3) * WBYTES;
 #pragma unroll
@@ -1249,8 +1253,8 @@ __device__ __forceinline__ void conv_nt4_body(const h16* __restrict__ x, const h
     };
     auto stage_h = [&](int k, int c) {                       // piece k of chunk c's halo -> buffer c & 1 (dummy if none)
         const int off = hl[k];
-        const int hc = HL ? (c >> 1) : c;                    // HL: instances 2 hc and 2 hc + 1 share a halo, staged for the even one
-        if (c < kchunks && (!HL || (c & 1) == 0) && k * NWV + wave < HINST) {        // wave-uniform
+        const int hc = HL2 ? (c >> 1) : c;                   // HL = 2: instances 2 hc and 2 hc + 1 share a halo, staged for the even one
+        if (c < kchunks && (!HL2 || (c & 1) == 0) && k * NWV + wave < HINST) {       // wave-uniform
 #ifdef MU_NT4_ABL_NOHALO
             const void* src = (const void*)mu_zero_page;
 #else
@@ -1295,7 +1299,7 @@ __device__ __forceinline__ void conv_nt4_body(const h16* __restrict__ x, const h
 
     int s = 0;
     for (int c = 0; c < kchunks; ++c) {
-        const int hbuf = ((HL ? (c >> 1) : c) & 1) * HBYTES;
+        const int hbuf = ((HL2 ? (c >> 1) : c) & 1) * HBYTES;
 #pragma unroll
         for (int t = 0; t < 9; ++t, ++s) {
             const int dh = t / 3, dw = t % 3;
@@ -1421,9 +1425,10 @@ __global__ __launch_bounds__(512, 1) void conv_nt4_kernel(const h16* __restrict_
                                                           float* __restrict__ stat_part) {
     conv_nt4_body<false>(x, w, bias, y, B, H, W, Cin, Cout, x_ld, y_ld, stat_part, nullptr, nullptr, 0);
 }
+template <int HL>
 __global__ __launch_bounds__(512, 1) void conv_nt4hl_kernel(const h16* __restrict__ dy, const h16* __restrict__ w, float* __restrict__ dx, int B, int H,
                                                             int W, int Cin, int Cout, long x_ld, long y_ld, const float* __restrict__ oscale) {
-    conv_nt4_body<false, true>(dy, w, nullptr, nullptr, B, H, W, Cin, Cout, x_ld, y_ld, nullptr, nullptr, nullptr, 0, dx, oscale);
+    conv_nt4_body<false, HL>(dy, w, nullptr, nullptr, B, H, W, Cin, Cout, x_ld, y_ld, nullptr, nullptr, nullptr, 0, dx, oscale);
 }
 __global__ __launch_bounds__(512, 1) void conv_nt4f_kernel(const h16* __restrict__ x, const h16* __restrict__ w, const float* __restrict__ bias,
                                                            h16* __restrict__ y, int B, int H, int W, int Cin, int Cout, long x_ld, long y_ld,
@@ -2286,6 +2291,11 @@ extern "C" int mu_conv_fwd(const void* x, const void* w, const float* bias, void
 // of the weights (the HL data-gradient block of mu_prep_weight / mu_prep_weights_multi with MU_F32X: [9][Cout][2 * Cin] halves): two fp16
 // MFMAs per product instead of the forward's three.  dx: plain fp32 rows (row stride dx_ld floats), multiplied by dy_scale[1] = 1 / S and by
 // 2^-MU_XH_WSHIFT in the epilogue (exact: powers of two).  Cin = channels of dy (the layer's output), Cout = channels of dx (its input).
+// (1 = the weights as one fp16 term, one MFMA per product: step -1.5 ms same-box, but the small-module goldens' parameter gradients land
+//  at 1.06e-3 .. 1.17e-3 against their 1e-3 gate -- 9 * Cout = 72 .. 288 terms average too little --, so the default keeps both halves)
+#ifndef MU_DGRAD_H_TERMS
+#define MU_DGRAD_H_TERMS 2
+#endif
 extern "C" int mu_conv_dgrad_h(const void* dy_h, const void* w_hl, const float* dy_scale, void* dx, int B, int H, int W, int Cin, int Cout,
                                long dy_ld, long dx_ld, void* stream) {
     if (!dy_h || !w_hl || !dy_scale || !dx || B <= 0 || H <= 0 || W <= 0) return MU_ERR_ARG;
@@ -2296,20 +2306,28 @@ extern "C" int mu_conv_dgrad_h(const void* dy_h, const void* w_hl, const float* 
     float* y = (float*)dx;
     const long M = (long)B * H * W;
     const int npb = (int)((M + 127) / 128);
+    // weight terms: 2 = lo + hi halves (default, MU_DGRAD_H_TERMS), 1 = the hi halves only; MU_DGRAD_H_TERMS in the environment overrides (A/B aid)
+    const int terms = getenv("MU_DGRAD_H_TERMS") ? atoi(getenv("MU_DGRAD_H_TERMS")) : MU_DGRAD_H_TERMS;
+#define MU_DGH(KERNEL2, KERNEL1, GRID, BLK) do { if (terms == 2) KERNEL2<<<GRID, BLK, 0, st>>>(x, w, y, B, H, W, Cin, Cout, dy_ld, dx_ld, dy_scale); \
+                                                 else KERNEL1<<<GRID, BLK, 0, st>>>(x, w, y, B, H, W, Cin, Cout, dy_ld, dx_ld, dy_scale); } while (0)
+#define MU_DGG(TM_, TN_, WR_, GRID) do { if (terms == 2) conv_nt_kernel<h16, TM_, TN_, WR_, 9, false, 2><<<GRID, 256, 0, st>>>(x, w, nullptr, nullptr, B, H, W, Cin, Cout, dy_ld, dx_ld, nullptr, nullptr, 0, y, dy_scale); \
+                                         else conv_nt_kernel<h16, TM_, TN_, WR_, 9, false, 1><<<GRID, 256, 0, st>>>(x, w, nullptr, nullptr, B, H, W, Cin, Cout, dy_ld, dx_ld, nullptr, nullptr, 0, y, dy_scale); } while (0)
     if (Cin % 64 == 0 && W % 16 == 0 && H % 8 == 0 && Cout % 64 == 0 && !getenv("MU_DGRAD_H_GENERIC")) {
         if (Cout % 128 == 0 && H % 16 == 0 && MU_CONV_NT4 && !getenv("MU_CONV_NO_NT4"))
-            conv_nt4hl_kernel<<<B * (H / 16) * (W / 16) * (Cout / 128), 512, 0, st>>>(x, w, y, B, H, W, Cin, Cout, dy_ld, dx_ld, dy_scale);
+            MU_DGH(conv_nt4hl_kernel<2>, conv_nt4hl_kernel<1>, B * (H / 16) * (W / 16) * (Cout / 128), 512);
         else if (Cout % 128 == 0)
-            conv_nt3hl_kernel<4, 4, 2><<<B * (H / 8) * (W / 16) * (Cout / 128), 256, 0, st>>>(x, w, y, B, H, W, Cin, Cout, dy_ld, dx_ld, dy_scale);
+            MU_DGH((conv_nt3hl_kernel<4, 4, 2, false, 2>), (conv_nt3hl_kernel<4, 4, 2, false, 1>), B * (H / 8) * (W / 16) * (Cout / 128), 256);
         else
-            conv_nt3hl_kernel<4, 2, 1, true><<<B * (H / 8) * (W / 16) * (Cout / 64), 256, 0, st>>>(x, w, y, B, H, W, Cin, Cout, dy_ld, dx_ld, dy_scale);
+            MU_DGH((conv_nt3hl_kernel<4, 2, 1, true, 2>), (conv_nt3hl_kernel<4, 2, 1, true, 1>), B * (H / 8) * (W / 16) * (Cout / 64), 256);
     } else if (Cout % 128 == 0) {
-        conv_nt_kernel<h16, 4, 4, 2, 9, false, true><<<npb * (Cout / 128), 256, 0, st>>>(x, w, nullptr, nullptr, B, H, W, Cin, Cout, dy_ld, dx_ld, nullptr, nullptr, 0, y, dy_scale);
+        MU_DGG(4, 4, 2, npb * (Cout / 128));
     } else if (Cout % 64 == 0) {
-        conv_nt_kernel<h16, 4, 2, 1, 9, false, true><<<npb * (Cout / 64), 256, 0, st>>>(x, w, nullptr, nullptr, B, H, W, Cin, Cout, dy_ld, dx_ld, nullptr, nullptr, 0, y, dy_scale);
+        MU_DGG(4, 2, 1, npb * (Cout / 64));
     } else {
-        conv_nt_kernel<h16, 2, 2, 1, 9, false, true><<<npb * (Cout / 32), 256, 0, st>>>(x, w, nullptr, nullptr, B, H, W, Cin, Cout, dy_ld, dx_ld, nullptr, nullptr, 0, y, dy_scale);
+        MU_DGG(2, 2, 1, npb * (Cout / 32));
     }
+#undef MU_DGH
+#undef MU_DGG
     MU_CHECK_LAUNCH();
     return MU_OK;
 }
@@ -2971,9 +2989,10 @@ __global__ __launch_bounds__(NWV * 64, 1) void conv_wgrad3_kernel(const T* __res
 // dst_oihw[o][i][t] = sum_split part[split][t][o][i]   (valid region only)
 // KL k-lanes per output element: each lane sums every KL-th slab with 4 independent accumulators (16 loads in flight per
 // element instead of one dependent chain); lanes are combined through LDS in a fixed order, so the result is deterministic.
+// oscale (may be NULL): the result is multiplied by oscale[1] (mu_conv_wgrad_h1: the 1 / S of a scaled fp16 dy)
 template <int KL>
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ dst, int nsplit, int taps,
-                                                           int Cout, int Cin, int O, int I) {
+                                                           int Cout, int Cin, int O, int I, const float* __restrict__ oscale = nullptr) {
     constexpr int EPB = 256 / KL;                     // elements per block
     __shared__ float red[KL][EPB];
     const long n = (long)O * I * taps;
@@ -3006,7 +3025,7 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
                 for (int j = 1; j < KL; ++j) s += red[j][e];
             }
         }
-        if (kl == 0 && idx < n) dst[((long)o * I + i) * taps + t] = s;
+        if (kl == 0 && idx < n) dst[((long)o * I + i) * taps + t] = oscale ? s * oscale[1] : s;
         if (KL > 1) __syncthreads();
     }
 }
@@ -3865,10 +3884,10 @@ static int conv_wgrad_impl(const void* x, const void* dy, float* dw_oihw, float*
     const long n = (long)cout_valid * cin_valid * taps;
     if (nsplit >= 16) {
         const long nb = (n + 63) / 64;
-        wgrad_reduce_kernel<4><<<(int)(nb > 4096 ? 4096 : nb), 256, 0, st>>>(part, dw_oihw, nsplit, taps, Cout, Cin, cout_valid, cin_valid);
+        wgrad_reduce_kernel<4><<<(int)(nb > 4096 ? 4096 : nb), 256, 0, st>>>(part, dw_oihw, nsplit, taps, Cout, Cin, cout_valid, cin_valid, oscale);
     } else {
         const long nb = (n + 255) / 256;
-        wgrad_reduce_kernel<1><<<(int)(nb > 2048 ? 2048 : nb), 256, 0, st>>>(part, dw_oihw, nsplit, taps, Cout, Cin, cout_valid, cin_valid);
+        wgrad_reduce_kernel<1><<<(int)(nb > 2048 ? 2048 : nb), 256, 0, st>>>(part, dw_oihw, nsplit, taps, Cout, Cin, cout_valid, cin_valid, oscale);
     }
     MU_CHECK_LAUNCH();
     return MU_OK;
@@ -3894,6 +3913,17 @@ extern "C" int mu_conv_wgrad_h(const void* x, const void* dy_h, const float* dy_
     if (Cin % 32 || cin_valid > Cin) return MU_ERR_SHAPE;
     return conv_wgrad_impl(x, dy_h, dw_oihw, nullptr, B, H, W, 2 * Cin, Cout, 9, 2 * Cin, cout_valid, 2 * x_ld, dy_ld, workspace, ws_bytes, MU_F16,
                            stream, cin_valid, dy_scale);
+}
+
+// The ONE-term form: x_h = the fp16 ROUNDING of the layer's input (rows of Cin halves, stride x_ld halves: the second output of
+// mu_bn_act_fwd_enc / mu_split_encode_h4x), dy_h / dy_scale as above -- the fp16 weight-gradient kernels as they are, one MFMA per product,
+// 1 / S applied in the slab reduce.  dW sums over every pixel of the batch, so the 2^-12 roundings of x average out: the CPU sizing shows no
+// change of any gradient metric against the two-term form (tests/aids/numerics_conv_bwd_two_term.py h1x).  Workspace: mu_conv_wgrad_workspace_bytes.
+extern "C" int mu_conv_wgrad_h1(const void* x_h, const void* dy_h, const float* dy_scale, float* dw_oihw, int B, int H, int W, int Cin, int Cout,
+                                int cin_valid, int cout_valid, long x_ld, long dy_ld, void* workspace, long ws_bytes, void* stream) {
+    if (!dy_scale || cin_valid <= 3) return MU_ERR_ARG;
+    return conv_wgrad_impl(x_h, dy_h, dw_oihw, nullptr, B, H, W, Cin, Cout, 9, cin_valid, cout_valid, x_ld, dy_ld, workspace, ws_bytes, MU_F16,
+                           stream, 0, dy_scale);
 }
 
 extern "C" int mu_conv_wgrad_bias(const void* x, const void* dy, float* dw_oihw, float* db, int B, int H, int W, int Cin, int Cout,

@@ -358,6 +358,30 @@ __global__ __launch_bounds__(256) void split_encode_h4_kernel(const f32x4* src, 
             if (i + u * stride < n16) dst[i + u * stride] = mu_ench4(v[u] * scale);
     }
 }
+// the same with the fp16 rounding of the values (the hi halves) as a second, plain output: dst16 = n_elems halves
+__global__ __launch_bounds__(256) void split_encode_h4x_kernel(const f32x4* __restrict__ src, uint4* __restrict__ dst, uint2* __restrict__ dst16, long n16) {
+    const long stride = (long)gridDim.x * 256;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n16; i += 4 * stride) {
+        f32x4 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (i + u * stride < n16) v[u] = __builtin_nontemporal_load(src + i + u * stride);
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (i + u * stride < n16) {
+                const uint4 e = mu_ench4(v[u]);
+                dst[i + u * stride] = e;
+                dst16[i + u * stride] = make_uint2(e.x, e.y);
+            }
+    }
+}
+extern "C" int mu_split_encode_h4x(const void* src, void* dst, void* dst16, long n_elems, void* stream) {
+    if (!src || !dst || !dst16 || src == dst || n_elems <= 0 || n_elems % 4) return MU_ERR_ARG;
+    const long n16 = n_elems / 4;
+    split_encode_h4x_kernel<<<enc_grid(n16), 256, 0, (hipStream_t)stream>>>((const f32x4*)src, (uint4*)dst, (uint2*)dst16, n16);
+    MU_CHECK_LAUNCH();
+    return MU_OK;
+}
 extern "C" int mu_split_encode_h4(const void* src, void* dst, long n_elems, void* stream) {
     if (!src || !dst || n_elems <= 0 || n_elems % 4) return MU_ERR_ARG;
     const long n16 = n_elems / 4;

@@ -294,10 +294,13 @@ __global__ void bn_bwd_final_kernel(const double* __restrict__ part, int nblk, i
 // ENC (fp32 storage only, MU_F32X at the entry point): y feeds nothing but a 3x3 convolution, so it is written as that convolution's chunk-encoded
 // matrix operand (common.h mu_ench4, the fp16-pair form: a thread's 16-byte vector IS one chunk) -- the separate mu_split_encode_h4 pass
 // (read + write) disappears.
+// y16 (ENC only, may be NULL): the fp16 ROUNDING of y (= the hi halves of the encoding) as plain rows of C halves -- what the one-term
+// weight gradient of the convolution behind reads (mu_conv_wgrad_h1) and the only form of y the backward keeps.
 template <typename T, bool ENC = false, int ACT = -1, int RES = -1>
 __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const T* __restrict__ x, const T* __restrict__ res, T* __restrict__ y, long M,
                                                          int C, long ld, const float* __restrict__ mean, const float* __restrict__ rstd,
-                                                         const float* __restrict__ gamma, const float* __restrict__ beta, int act_arg) {
+                                                         const float* __restrict__ gamma, const float* __restrict__ beta, int act_arg,
+                                                         h16* __restrict__ y16 = nullptr) {
     constexpr int N = Vec16<T>::N;
     constexpr int U = MU_BN_UF;
     constexpr bool FAST = sizeof(T) == 2;
@@ -339,7 +342,9 @@ __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const T* __restrict__ x
                     o.set(i + 1, o1);
                 }
                 if constexpr (ENC) {
-                    *reinterpret_cast<uint4*>(y + (r + u * rstep) * ld + c) = mu_ench4((f32x4){o.get(0), o.get(1), o.get(2), o.get(3)});
+                    const uint4 e4 = mu_ench4((f32x4){o.get(0), o.get(1), o.get(2), o.get(3)});
+                    *reinterpret_cast<uint4*>(y + (r + u * rstep) * ld + c) = e4;
+                    if (y16) *reinterpret_cast<uint2*>(y16 + (r + u * rstep) * (long)C + c) = make_uint2(e4.x, e4.y);
                 } else {
 #if MU_BN_NT & 2
                 o.store_nt(y + (r + u * rstep) * ld + c);
@@ -662,11 +667,21 @@ extern "C" int mu_bn_eval_fold(const float* running_mean1, const float* running_
     }
 template <typename T, bool ENC>
 static void bn_act_fwd_launch(const T* x, const T* res, T* y, long M, int C, long ld, const float* mean, const float* rstd,
-                              const float* gamma, const float* beta, int act, hipStream_t st) {
+                              const float* gamma, const float* beta, int act, hipStream_t st, h16* y16 = nullptr) {
     constexpr int N = Vec16<T>::N;
     const int grid = ew_grid(M * (C / N), C / N);
-    if (res) { MU_BN_ACT_SWITCH(act, (bn_act_fwd_kernel<T, ENC, A_, 1><<<grid, 256, 0, st>>>(x, res, y, M, C, ld, mean, rstd, gamma, beta, act))) }
-    else     { MU_BN_ACT_SWITCH(act, (bn_act_fwd_kernel<T, ENC, A_, 0><<<grid, 256, 0, st>>>(x, res, y, M, C, ld, mean, rstd, gamma, beta, act))) }
+    if (res) { MU_BN_ACT_SWITCH(act, (bn_act_fwd_kernel<T, ENC, A_, 1><<<grid, 256, 0, st>>>(x, res, y, M, C, ld, mean, rstd, gamma, beta, act, y16))) }
+    else     { MU_BN_ACT_SWITCH(act, (bn_act_fwd_kernel<T, ENC, A_, 0><<<grid, 256, 0, st>>>(x, res, y, M, C, ld, mean, rstd, gamma, beta, act, y16))) }
+}
+
+// fp32x: mu_bn_act_fwd(MU_F32X) with the second output y16 (M rows of C halves, row stride C; contiguous input rows: ld == C)
+extern "C" int mu_bn_act_fwd_enc(const void* x, const void* res, void* y_enc, void* y16, long M, int C, const float* mean, const float* rstd,
+                                 const float* gamma, const float* beta, int act, void* stream) {
+    if (!x || !y_enc || !y16 || !mean || !rstd || !gamma || !beta || M <= 0 || C <= 0 || C % 8) return MU_ERR_ARG;
+    if (act != MU_ACT_NONE && act != MU_ACT_GELU && act != MU_ACT_RELU) return MU_ERR_ARG;
+    bn_act_fwd_launch<float, true>((const float*)x, (const float*)res, (float*)y_enc, M, C, C, mean, rstd, gamma, beta, act, (hipStream_t)stream, (h16*)y16);
+    MU_CHECK_LAUNCH();
+    return MU_OK;
 }
 
 extern "C" int mu_bn_act_fwd(const void* x, const void* res, void* y, long M, int C, long ld, const float* mean, const float* rstd,

@@ -55,6 +55,16 @@ def _enc3(t):
     return e
 
 
+def _enc3x(t):
+    """fp32x: (the 3x3 operand encoding of t, the fp16 rounding of t as plain rows) from one pass -- the first feeds the forward conv, the
+    second is what its backward keeps for the one-term weight gradient (mu_conv_wgrad_h1)."""
+    t = t.contiguous()
+    e = torch.empty_like(t)
+    t16 = torch.empty(t.shape, dtype=torch.float16, device=t.device)
+    call("mu_split_encode_h4x", ptr(t), ptr(e), ptr(t16), t.numel(), stream())
+    return e, t16
+
+
 def _enc_for(t, taps):
     """The operand encoding a layer with `taps` taps reads: fp16 pairs for the 3x3 layers, bf16 pairs for 1x1 / Linear."""
     return _enc3(t) if taps == 9 else _enc(t)
@@ -458,10 +468,24 @@ def grad_out(param, shape, device):
     return torch.empty(shape, dtype=torch.float32, device=device)
 
 
+WGRAD_X16 = os.environ.get("MU_WGRAD_X16", "1") != "0"         # debug switch: 0 = the two-term weight gradient on the encoded input (mu_conv_wgrad_h)
+
+
 def _wgrad_raw(x, gy, w_shape, taps, st=None, ws=None, gy_encoded=False, x_encoded=False, param=None, gy_scale=None):
-    """gy_scale (fp32x 3x3 layers): gy holds ONE scaled fp16 operand (dy_encode_h form) and this is its scale pair."""
+    """gy_scale (fp32x 3x3 layers): gy holds ONE scaled fp16 operand (dy_encode_h form) and this is its scale pair.  x may then be the
+    fp16 rounding of the layer's input (a float16 tensor: the one-term weight gradient) or its chunk-encoded fp32x form (two terms)."""
     B, H, W, Cin_p = x.shape
     O, I = w_shape[0], w_shape[1]
+    if x.dtype == torch.float16 and gy.dtype == torch.float32:      # (fp16-mode layers hand over an fp16 dy and take the ordinary path below)
+        if gy_scale is None:
+            gy, gy_scale = dy_encode_h(gy)
+        Cout_p = gy.shape[-1]
+        gw = grad_out(param, tuple(w_shape), x.device)
+        if ws is None:
+            ws = workspace(_lib.load().mu_conv_wgrad_workspace_bytes(B, H, W, Cin_p, Cout_p, 9), x.device)
+        call("mu_conv_wgrad_h1", ptr(x), ptr(gy), ptr(gy_scale), ptr(gw), B, H, W, Cin_p, Cout_p, I, O, Cin_p, Cout_p, ptr(ws), ws.numel(),
+             stream() if st is None else st)
+        return gw
     code = mdt(x)
     if code == _lib.MU_F32X and taps == 9 and I <= 3 and not gy_encoded and not x_encoded:
         code = _lib.MU_F32               # the first layer's weight gradient is a plain-FMA kernel (no matrix cores): plain fp32 operands
@@ -584,7 +608,7 @@ class _Conv(torch.autograd.Function):
     """nn.Conv2d k=3/pad=1 or k=1, NHWC (ade_semantic.py:199,202,284; city_instance.py:243-249)."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, want_stats=False, cache_ok=False, x_encoded=False, dy_link=None):
+    def forward(ctx, x, weight, bias, want_stats=False, cache_ok=False, x_encoded=False, dy_link=None, x16=None):
         x = x.contiguous()
         ctx.dy_link = dy_link
         O, I = weight.shape[0], weight.shape[1]
@@ -609,13 +633,20 @@ class _Conv(torch.autograd.Function):
         ctx.x_enc = ctx.is_x and not (taps == 9 and I <= 3)
         if x_encoded and not ctx.x_enc:
             raise RuntimeError("conv: a pre-encoded input needs the fp32x mode and a matrix-core layer")
+        # fp32x 3x3 layers (round 6): the backward keeps only the fp16 ROUNDING of the input (x16: half the bytes of the encoded form) for the
+        # one-term weight gradient; the encoded form feeds the forward conv and is dropped.  x16 comes from the producer that wrote x
+        # encoded (bn_act: `_mu_x16`), or from the same pass that encodes x here; without it the two-term form on the encoded input remains.
+        keep16 = ctx.x_enc and taps == 9 and WGRAD_X16 and ctx.needs_input_grad[1]
         if ctx.x_enc and not x_encoded:
-            x = _enc_for(x, taps)
+            if keep16:
+                x, x16 = _enc3x(x)
+            else:
+                x = _enc_for(x, taps)
         if want_stats:
             y, part = _conv_raw(x, wprep, bias_p, Cout_p, taps, True, x_encoded=ctx.x_enc)
         else:
             y = _conv_raw(x, wprep, bias_p, Cout_p, taps, x_encoded=ctx.x_enc)
-        ctx.save_for_backward(x, weight)
+        ctx.save_for_backward(x16 if (keep16 and x16 is not None) else x, weight)
         ctx.wparam = weight                      # the Parameter itself: backward looks at its .grad
         ctx.has_bias, ctx.taps = bias is not None, taps
         if not want_stats:
@@ -630,7 +661,7 @@ class _Conv(torch.autograd.Function):
     @once_differentiable
     def backward(ctx, gy, gpart=None):
         if gy is None:
-            return None, None, None, None, None, None, None
+            return None, None, None, None, None, None, None, None
         x, weight = ctx.saved_tensors
         gy = gy.contiguous()
         _same_mode(ctx.is_x, gy)
@@ -658,13 +689,13 @@ class _Conv(torch.autograd.Function):
                 call("mu_conv_dgrad_h", ptr(gh), ptr(wd), ptr(gy_sc), ptr(gx), B, H, W, gy.shape[-1], Cin_p, gy.shape[-1], Cin_p, stream())
             if side and gw is None:
                 gw = _wgrad_side(x, gy, tuple(weight.shape), ctx.taps, ctx.x_enc, ctx.wparam)
-            if wg_h:
+            if wg_h:         # x: the fp16 rounding of the input (one term) or its encoded form (two terms) -- _wgrad_raw tells by dtype
                 gw = _wgrad_raw(x, gh, tuple(weight.shape), 9, x_encoded=True, param=ctx.wparam, gy_scale=gy_sc)
             elif ctx.needs_input_grad[1] and not side:
                 gw = _wgrad_raw(x, gy, tuple(weight.shape), 9, param=ctx.wparam)
             if ctx.has_bias and ctx.needs_input_grad[2]:
                 gb = _colsum(gy, O)
-            return gx, gw, gb, None, None, None, None
+            return gx, gw, gb, None, None, None, None, None
         ge = _enc(gy) if (ctx.needs_input_grad[0] or (ctx.needs_input_grad[1] and not side)) else gy     # fp32x: one encoding of dy for both
         if ctx.needs_input_grad[0]:
             wd = ctx.wd if ctx.wd is not None else _prep_weight(weight, gy.dtype, x.shape[-1], gy.shape[-1], 1)
@@ -682,11 +713,11 @@ class _Conv(torch.autograd.Function):
                                 param=ctx.wparam)
         if ctx.has_bias and ctx.needs_input_grad[2] and gb is None:
             gb = _colsum(gy, O)
-        return gx, gw, gb, None, None, None, None
+        return gx, gw, gb, None, None, None, None, None
 
 
 def conv(x, weight, bias=None):
-    return _Conv.apply(x, weight, bias, False, _cache_ok(), False, None)
+    return _Conv.apply(x, weight, bias, False, _cache_ok(), False, None, None)
 
 
 CONV_STATS = os.environ.get("MU_CONV_STATS", "1") != "0"      # debug switch: 0 = always the separate statistics sweep
@@ -696,9 +727,10 @@ def conv_stats(x, weight, bias=None, want=True, x_encoded=False, dy_link=None):
     """conv() that also returns the BatchNorm statistics rows of its output (an empty tensor when the kernel has none) --
     pass them to bn_act(..., stats=rows) to skip the separate statistics sweep.  fp32x: x_encoded = x was written chunk-encoded by its
     producer (bn_act(..., enc_out=True)); dy_link = EncLink shared with the BatchNorm behind this conv (see EncLink)."""
+    x16 = getattr(x, "_mu_x16", None) if x_encoded else None      # the fp16 rounding its producer wrote beside the encoded form (bn_act)
     if not want or not CONV_STATS:
-        return _Conv.apply(x, weight, bias, False, _cache_ok(), x_encoded, dy_link), None
-    return _Conv.apply(x, weight, bias, True, _cache_ok(), x_encoded, dy_link)
+        return _Conv.apply(x, weight, bias, False, _cache_ok(), x_encoded, dy_link, x16), None
+    return _Conv.apply(x, weight, bias, True, _cache_ok(), x_encoded, dy_link, x16)
 
 
 # ------------------------------------------------------------------------------------------------
@@ -710,7 +742,7 @@ class _BNAct(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, res, gamma, beta, running_mean, running_var, training, momentum, eps, act, nbt=None, stats=None, res_link=None,
-                enc_out=False, dx_link=None):
+                enc_out=False, dx_link=None, x16_box=None):
         x = x.contiguous()
         ctx.res_link = res_link if (res is not None and res_link is not None and res_link.armed) else None
         ctx.dx_link = dx_link if (dx_link is not None and _is_x(x)) else None
@@ -736,8 +768,14 @@ class _BNAct(torch.autograd.Function):
         y = torch.empty_like(x)
         if res is not None:
             res = res.contiguous()
-        call("mu_bn_act_fwd", ptr(x), ptr(res), ptr(y), M, C, C, ptr(mean), ptr(rstd), ptr(g_p), ptr(b_p), act,
-             _lib.MU_F32X if enc_out else dt(x), stream())      # MU_F32X: y written as the next conv's chunk-encoded operand
+        if enc_out and x16_box is not None:
+            # fp32x: y as the next 3x3 conv's encoded operand AND its fp16 rounding (what that conv's backward keeps: ops._Conv)
+            y16 = torch.empty(x.shape, dtype=torch.float16, device=x.device)
+            call("mu_bn_act_fwd_enc", ptr(x), ptr(res), ptr(y), ptr(y16), M, C, ptr(mean), ptr(rstd), ptr(g_p), ptr(b_p), act, stream())
+            x16_box.append(y16)
+        else:
+            call("mu_bn_act_fwd", ptr(x), ptr(res), ptr(y), M, C, C, ptr(mean), ptr(rstd), ptr(g_p), ptr(b_p), act,
+                 _lib.MU_F32X if enc_out else dt(x), stream())      # MU_F32X: y written as the next conv's chunk-encoded operand
         ctx.save_for_backward(x, res, mean, rstd, g_p, b_p)
         ctx.act, ctx.training, ctx.cv = act, bool(training), cv
         return y
@@ -766,7 +804,7 @@ class _BNAct(torch.autograd.Function):
         if ctx.res_link is not None:             # the residual-branch gradient travels to the backward of x's producer (GradLink)
             ctx.res_link.put(dres)
             dres = None
-        return dx, dres, dgamma[:ctx.cv], dbeta[:ctx.cv], None, None, None, None, None, None, None, None, None, None, None
+        return dx, dres, dgamma[:ctx.cv], dbeta[:ctx.cv], None, None, None, None, None, None, None, None, None, None, None, None
 
 
 class _BNPair(torch.autograd.Function):
@@ -851,8 +889,12 @@ def bn_act(x, bn, act=ACT_NONE, res=None, stats=None, res_link=None, enc_out=Fal
         nbt.add_(1)
         nbt = None
     momentum = 0.1 if bn.momentum is None else bn.momentum
-    return _BNAct.apply(x, res, bn.weight, bn.bias, bn.running_mean, bn.running_var, training, momentum, bn.eps, act, nbt,
-                        stats if training else None, res_link, enc_out, dx_link)
+    box = [] if (enc_out and WGRAD_X16 and torch.is_grad_enabled() and _is_x(x)) else None
+    y = _BNAct.apply(x, res, bn.weight, bn.bias, bn.running_mean, bn.running_var, training, momentum, bn.eps, act, nbt,
+                     stats if training else None, res_link, enc_out, dx_link, box)
+    if box:
+        y._mu_x16 = box[0]
+    return y
 
 
 # ------------------------------------------------------------------------------------------------

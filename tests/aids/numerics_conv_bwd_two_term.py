@@ -12,7 +12,9 @@ Emulates the arithmetic inside the oracle's ConvBlock (everything else of the or
 tests/_gpu_checks.check_unet_golden.  Not a test, not product code: sizing evidence quoted in NOTES_r06.md.
 
 usage: python tests/aids/numerics_conv_bwd_two_term.py <fwd> <bwd> [wshift] [ftz] [dyscale_slack]
-   fwd: exact | bf3 (today) | h3          bwd: exact | bf3 (today) | h2 | b1 (dy as ONE bf16: the judge's "too coarse" case)
+   fwd: exact | bf3 (round 5) | h3        bwd: exact | bf3 (round 5) | h2 (built) | b1 (dy as ONE bf16: the judge's "too coarse" case)
+        | h1x (h2 with the saved input of the WEIGHT gradient as one fp16 term too) | h1w (h2 with the weights of the DATA gradient as one
+        term) | h1 (both): probes of a one-MFMA backward, not built
    wshift: log2 of the static weight shift (default 6); ftz: 1 = flush fp16 subnormals to zero (worst case for the matrix core);
    dyscale_slack: log2 of how far BELOW the ideal scale the dy scale sits (the device-side bound is loose by (2 + max|xhat|): ~3 bits)
 """
@@ -93,8 +95,10 @@ class Conv(torch.autograd.Function):
         s = 2.0 ** WSHIFT
         wh, wl = pair(w * s, h)
         xh, xl = pair(x, h)
-        dx = torch.nn.grad.conv2d_input(x.shape, wh + wl, d1, padding=1) / (gs * s)
-        dw = torch.nn.grad.conv2d_weight(xh + xl, w.shape, d1, padding=1) / gs
+        wd = wh if BWD in ("h1w", "h1") else wh + wl
+        xw = xh if BWD in ("h1x", "h1") else xh + xl
+        dx = torch.nn.grad.conv2d_input(x.shape, wd, d1, padding=1) / (gs * s)
+        dw = torch.nn.grad.conv2d_weight(xw, w.shape, d1, padding=1) / gs
         return dx, dw
 
 

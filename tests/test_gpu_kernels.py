@@ -339,6 +339,17 @@ def test_conv3x3_two_term_backward_through_the_abi(shape, gmag):
     ex = float((dx.permute(0, 3, 1, 2).double().cpu() - xr.grad).abs().max() / xr.grad.abs().max())
     ew = float((gw.double().cpu() - wr.grad).abs().max() / wr.grad.abs().max())
     assert ex <= 1e-3 and ew <= 1e-3, (shape, gmag, ex, ew)
+    # the ONE-term weight gradient on the fp16 rounding of the input (mu_split_encode_h4x's second output; mu_conv_wgrad_h1): what the model
+    # path runs -- dW sums over every pixel, so the 2^-12 roundings of x average out
+    xe2, x16 = torch.empty_like(xd), torch.empty(xd.shape, dtype=torch.float16, device="cuda")
+    _lib.call("mu_split_encode_h4x", xd.data_ptr(), xe2.data_ptr(), x16.data_ptr(), xd.numel(), st)
+    assert torch.equal(xe2.view(torch.int32), xe.view(torch.int32)) and torch.equal(x16, xd.half())
+    ws1 = torch.empty(_lib.load().mu_conv_wgrad_workspace_bytes(B, H, W, Cin, Cout, 9), dtype=torch.uint8, device="cuda")
+    gw1 = torch.full((Cout, Cin, 3, 3), float("nan"), device="cuda")
+    _lib.call("mu_conv_wgrad_h1", x16.data_ptr(), dyh.data_ptr(), sc.data_ptr(), gw1.data_ptr(), B, H, W, Cin, Cout, Cin, Cout, Cin, Cout,
+              ws1.data_ptr(), ws1.numel(), st)
+    ew1 = float((gw1.double().cpu() - wr.grad).abs().max() / wr.grad.abs().max())
+    assert ew1 <= 1e-3, (shape, gmag, ew1)
 
 
 @pytest.mark.parametrize("gmag", [1e-8, 1.0, 3e4])
@@ -383,3 +394,25 @@ def test_bn_backward_writes_dx_as_one_scaled_fp16_operand(gmag):
         assert 2.0 ** 11 <= top < 2.0 ** 14, (M, C, gmag, top)
         got = dxh.view(torch.float16).view(-1)[: M * C].view(M, C).float() / S      # the halves sit at the start of the buffer
         assert float((got - dx0).abs().max()) <= 2.0 ** -11 * float(dx0.abs().max()) * 1.01
+
+
+def test_bn_act_fwd_enc_writes_the_encoded_output_and_its_fp16_rounding():
+    """mu_bn_act_fwd_enc: y in the 3x3 operand encoding (bit-identical to mu_bn_act_fwd with MU_F32X) plus y16 = fp16(y) as plain rows."""
+    from maskunet_amd import _lib
+    g = torch.Generator(device="cuda").manual_seed(31)
+    M, C = 1536, 96
+    x = torch.randn(M, C, device="cuda", generator=g)
+    res = torch.randn(M, C, device="cuda", generator=g)
+    mean, rstd = x.mean(0), torch.rsqrt(x.var(0, unbiased=False) + 1e-5)
+    gamma, beta = torch.rand(C, device="cuda", generator=g) + 0.5, torch.randn(C, device="cuda", generator=g) * 0.1
+    for act, r in ((_lib.ACT_GELU, None), (_lib.ACT_NONE, None), (_lib.ACT_GELU, res)):
+        rp = r.data_ptr() if r is not None else None
+        y_plain, y_enc, y_enc2 = torch.empty_like(x), torch.empty_like(x), torch.empty_like(x)
+        y16 = torch.empty(M, C, dtype=torch.float16, device="cuda")
+        _lib.call("mu_bn_act_fwd", x.data_ptr(), rp, y_plain.data_ptr(), M, C, C, mean.data_ptr(), rstd.data_ptr(), gamma.data_ptr(), beta.data_ptr(), act, _lib.MU_F32, _lib.stream())
+        _lib.call("mu_bn_act_fwd", x.data_ptr(), rp, y_enc.data_ptr(), M, C, C, mean.data_ptr(), rstd.data_ptr(), gamma.data_ptr(), beta.data_ptr(), act, _lib.MU_F32X, _lib.stream())
+        _lib.call("mu_bn_act_fwd_enc", x.data_ptr(), rp, y_enc2.data_ptr(), y16.data_ptr(), M, C, mean.data_ptr(), rstd.data_ptr(), gamma.data_ptr(), beta.data_ptr(), act, _lib.stream())
+        assert torch.equal(y_enc.view(torch.int32), y_enc2.view(torch.int32))
+        assert torch.equal(y16, y_plain.half())
+        h = y_enc.view(torch.float16).view(-1, 8)
+        assert torch.equal(h[:, :4].reshape(M, C), y16)                     # the hi halves of the encoding ARE the fp16 rounding
