@@ -404,7 +404,8 @@ template <> struct AT<xf32> {
     // Round 6, BACKWARD sweeps only (the forward keeps the two-term products above: north_star's 1e-3 is a gate on OUTPUTS): dP = dO V^T
     // (MU_XF_BWD_DP1) and the gradient products dV = P^T dO, dK = dS^T Q, dQ = dS K (MU_XF_BWD_G1) as ONE fp16 MFMA on the hi halves, i.e.
     // the fp16 kernels' arithmetic on exactly scaled operands (dY carries its power-of-two scale, P its 2^pshift).  Each of these sums runs
-    // over hundreds to thousands of keys / queries, so the 2^-12 operand roundings average out: the CPU sizing
+    // over hundreds to thousands of keys / queries, and the 2^-12 operand roundings are random-signed: the sum carries ~2^-12 of the root-sum-square of its terms, below the single-term dS
+    // noise these sweeps already have: the CPU sizing
     // (tests/aids/numerics_attn_single_term.py DP1 / DV1 / DK1 / DQ1 on the reference's golden) shows NO measurable change of any gradient
     // metric (worst parameter gradient 8.7e-3 with and without, gate 5e-2), and on the GPU the goldens' worst gradients did not move.
     // The recomputed SCORES keep the forward's two terms (MU_XF_BWD_S1 = 0): with one term the backward's P is no longer the forward's

@@ -3917,7 +3917,8 @@ extern "C" int mu_conv_wgrad_h(const void* x, const void* dy_h, const float* dy_
 
 // The ONE-term form: x_h = the fp16 ROUNDING of the layer's input (rows of Cin halves, stride x_ld halves: the second output of
 // mu_bn_act_fwd_enc / mu_split_encode_h4x), dy_h / dy_scale as above -- the fp16 weight-gradient kernels as they are, one MFMA per product,
-// 1 / S applied in the slab reduce.  dW sums over every pixel of the batch, so the 2^-12 roundings of x average out: the CPU sizing shows no
+// 1 / S applied in the slab reduce.  dW sums over every pixel of the batch and the 2^-12 roundings of x are random-signed (the sum carries ~2^-12 of the root-sum-square
+// of its terms): the CPU sizing shows no
 // change of any gradient metric against the two-term form (tests/aids/numerics_conv_bwd_two_term.py h1x).  Workspace: mu_conv_wgrad_workspace_bytes.
 extern "C" int mu_conv_wgrad_h1(const void* x_h, const void* dy_h, const float* dy_scale, float* dw_oihw, int B, int H, int W, int Cin, int Cout,
                                 int cin_valid, int cout_valid, long x_ld, long dy_ld, void* workspace, long ws_bytes, void* stream) {
