@@ -159,9 +159,9 @@ long mu_conv_wgrad_h_workspace_bytes(int B, int H, int W, int Cin, int Cout);
 int mu_conv_wgrad_h(const void* x, const void* dy_h, const float* dy_scale, float* dw_oihw, int B, int H, int W, int Cin, int Cout,
                     int cin_valid, int cout_valid, long x_ld, long dy_ld, void* workspace, long ws_bytes, void* stream);
 /* ... and its ONE-term form: x_h = the fp16 rounding of the input (rows of Cin halves, stride x_ld halves: the second output of
- * mu_bn_act_fwd_enc / mu_split_encode_h4x).  One MFMA per product on the fp16 kernels; dW sums over every pixel of the batch, so the roundings
-
- * are random-signed: ~2^-12 of the root-sum-square of the terms (no change of any gradient metric in the oracle sizing).  Workspace: mu_conv_wgrad_workspace_bytes(B, H, W, Cin, Cout, 9). */
+ * mu_bn_act_fwd_enc / mu_split_encode_h4x).  One MFMA per product on the fp16 kernels; dW sums over every pixel of the batch and the
+ * roundings of x are random-signed: the sum carries ~2^-12 of the root-sum-square of its terms (no change of any gradient metric in the
+ * oracle sizing).  Workspace: mu_conv_wgrad_workspace_bytes(B, H, W, Cin, Cout, 9). */
 int mu_conv_wgrad_h1(const void* x_h, const void* dy_h, const float* dy_scale, float* dw_oihw, int B, int H, int W, int Cin, int Cout,
                      int cin_valid, int cout_valid, long x_ld, long dy_ld, void* workspace, long ws_bytes, void* stream);
 /* dw_oihw[o][i][tap] = sum_p dy[p][o] * x[p+shift(tap)][i] for o < cout_valid, i < cin_valid (fp32, OIHW). */
