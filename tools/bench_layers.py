@@ -28,7 +28,7 @@ def timeit(f, n=20):
 def main():
     args = [a for a in sys.argv[1:] if not a.startswith("--")]
     B = int(args[0]) if args else 64
-    X = "--fp32x" in sys.argv                                # fp32 storage, fp16-pair operands: 3-term forward, 2-term backward (MU_F32X, round 6)
+    X = "--fp32x" in sys.argv                                # fp32 storage, fp16-pair operands: 3-term forward, 2-term data gradient, 1-term weight gradient (round 6)
     dev, dt = "cuda", (torch.float32 if X else torch.float16)
     code = 2 if X else 1
     st = _lib.stream()
@@ -54,7 +54,8 @@ def main():
             sc = torch.empty(2, device=dev)
             ws0 = torch.empty(lib.mu_dy_encode_h_workspace_bytes(), dtype=torch.uint8, device=dev)
             _lib.call("mu_dy_encode_h", dy.data_ptr(), dyh.data_ptr(), sc.data_ptr(), dy.numel(), ws0.data_ptr(), ws0.numel(), st)
-            wsx = _lib.workspace(lib.mu_conv_wgrad_h_workspace_bytes(B, H, H, Cin, Cout), torch.device(dev)) if Cin > 32 else None
+            # the weight gradient as the model runs it: ONE term on the fp16 rounding of the input (mu_conv_wgrad_h1)
+            x16 = torch.randn(B, H, H, Cin, device=dev, dtype=torch.float16)
         cin_v = 3 if Cin == 32 else Cin
         gw = torch.empty(Cout, cin_v, 3, 3, device=dev)
         ws = _lib.workspace(lib.mu_conv_wgrad_workspace_bytes(B, H, H, Cin, Cout, 9), torch.device(dev))
@@ -65,8 +66,8 @@ def main():
             else: _lib.call("mu_conv_fwd", dy.data_ptr(), wt.data_ptr(), None, dx.data_ptr(), B, H, H, Cout, Cin, 9, Cout, Cin, code, st)
         def wg():
             if X and Cin > 32:
-                _lib.call("mu_conv_wgrad_h", x.data_ptr(), dyh.data_ptr(), sc.data_ptr(), gw.data_ptr(), B, H, H, Cin, Cout, cin_v, Cout, Cin, Cout,
-                          wsx.data_ptr(), wsx.numel(), st)
+                _lib.call("mu_conv_wgrad_h1", x16.data_ptr(), dyh.data_ptr(), sc.data_ptr(), gw.data_ptr(), B, H, H, Cin, Cout, cin_v, Cout, Cin, Cout,
+                          ws.data_ptr(), ws.numel(), st)
             else:       # (fp32x: the <= 3-channel first layer is the plain-FMA kernel on plain operands)
                 _lib.call("mu_conv_wgrad", x.data_ptr(), dy.data_ptr(), gw.data_ptr(), B, H, H, Cin, Cout, 9, cin_v, Cout, Cin, Cout,
                           ws.data_ptr(), ws.numel(), code, st)
