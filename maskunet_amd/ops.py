@@ -675,8 +675,8 @@ class _Conv(torch.autograd.Function):
         if gy_pre and (side or not ctx.x_enc or ctx.taps != 9 or (ctx.has_bias and ctx.needs_input_grad[2])):
             raise RuntimeError("conv backward: an encoded dy reached a path that needs it plain")
         if ctx.is_x and ctx.taps == 9:
-            # fp32x 3x3 layer: the two-term backward (round 6) -- dy as ONE power-of-two-scaled fp16 operand, shared by the data gradient
-            # (against the fp16 pair of the weights) and the weight gradient (against the fp16 pair of the saved input)
+            # fp32x 3x3 layer (round 6): dy as ONE power-of-two-scaled fp16 operand, shared by the data gradient (against the fp16 pair of
+            # the weights: two MFMAs per product) and the weight gradient (against the fp16 rounding of the saved input: one)
             wg_h = ctx.needs_input_grad[1] and not side and ctx.x_enc      # (a <= 3-channel layer's weight gradient: plain-FMA kernel, plain dy)
             gh = gy if gy_pre else None
             if gh is None and (ctx.needs_input_grad[0] or wg_h):
