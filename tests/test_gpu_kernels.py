@@ -300,7 +300,7 @@ def test_dy_encode_h_scale_is_an_exact_power_of_two(mag):
 # (B, H, W, Cin, Cout): the ping-pong kernel (Cin of the layer % 128, H % 16), the halo-tile kernel at 128 / 64 output channels, the
 # generic register-staged kernel (odd sizes, 32-channel operands)
 H2_SHAPES = [(2, 32, 32, 128, 128), (1, 16, 16, 256, 64), (2, 8, 16, 64, 128), (1, 24, 16, 64, 64), (2, 13, 9, 32, 64), (1, 7, 20, 96, 32),
-             (1, 16, 16, 512, 512)]
+             (1, 16, 16, 512, 512), (1, 8, 16, 128, 64), (1, 24, 32, 256, 128)]      # (the last two: the 128-channel halo-tile form, H % 16 != 0)
 
 
 @pytest.mark.parametrize("shape", H2_SHAPES)
