@@ -337,13 +337,16 @@ class UNet(_HipModule):
         # exception leaves behind is dropped so that no later forward can pick up layouts of older weights
         ws = self.__dict__.get("_conv_ws")
         if ws is None:
-            ws = self.__dict__["_conv_ws"] = ([m.weight for m in self.modules() if isinstance(m, nn.Conv2d)], {})
+            ws = self.__dict__["_conv_ws"] = ([m for m in self.modules() if isinstance(m, nn.Conv2d)], {})
+        # the tensors the convs below will see NOW: under torch.func.functional_call (GraphedStep) `m.weight` is the call's fresh leaf,
+        # not the Parameter -- the one-shot entries must sit on those objects or every conv falls back to its own prep launch
+        weights = [m.weight for m in ws[0]]
         first = self.initial_conv.conv_block[0].weight
-        ops.prep_conv_weights(ws[1], ws[0], x.dtype, fwd_only=() if x.requires_grad else (first,))
+        ops.prep_conv_weights(ws[1], weights, x.dtype, fwd_only=() if x.requires_grad else (first,))
         try:
             return self._forward_nhwc(x)
         finally:
-            for w in ws[0]:
+            for w in weights:
                 w._mu_step = None
 
     def _forward_nhwc(self, x):

@@ -480,6 +480,35 @@ def test_fused_adamw_skip_counters_survive_rollback_reallocation_and_an_unchecke
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("precision", ["fp16", "fp32x"])
+def test_training_forward_takes_every_conv_layout_from_the_one_launch(precision, monkeypatch):
+    """A training forward makes the compute layouts of ALL conv weights in one launch (ops.prep_conv_weights); no conv may fall back to
+    its own mu_prep_weight launch -- neither in an eager step nor inside GraphedStep, whose forward runs under
+    torch.func.functional_call on fresh leaves (round 6: the one-shot entries used to be parked on the Parameters there, and all 31
+    convs of a captured step ran their own prep launch beside the unused combined one)."""
+    import maskunet_amd
+    from maskunet_amd import ops
+    from tests import _gpu_checks as G
+    dtype = torch.float16 if precision == "fp16" else torch.float32
+    maskunet_amd.set_float32_matmul_precision("high" if precision == "fp32x" else "highest")
+    try:
+        model, params, keeps, x, labels = G.build_unet(19, False, 733, dtype, True, 2)
+        x, labels = x.cuda(), labels.cuda()
+        crit = maskunet_amd.CrossEntropyLoss()
+        calls = []
+        raw = ops._prep_weight_raw
+        monkeypatch.setattr(ops, "_prep_weight_raw", lambda w, *a: (calls.append(tuple(w.shape)), raw(w, *a))[1])
+        crit(model(x), labels).backward()
+        assert calls == [], f"eager step: {len(calls)} per-layer prep launches {calls[:4]}"
+        model.zero_grad(set_to_none=True)
+        step = maskunet_amd.GraphedStep(model, crit, x, labels, warmup=1)
+        step(x, labels)
+        assert calls == [], f"captured step: {len(calls)} per-layer prep launches {calls[:4]}"
+    finally:
+        maskunet_amd.set_float32_matmul_precision("highest")
+
+
+@pytest.mark.gpu
 def test_graphed_step_redraws_the_key_masks_per_replay():
     """GraphedStep with mask_mode = "resample" -- the reference's multi-GPU semantics (a fresh randint(0, 2, (B, H, W)) per replica
     forward, ade_semantic.py:177-181 under nn.DataParallel :373; VERDICT r5 #5a): the draws and the key compactions are captured with
