@@ -190,7 +190,7 @@ _raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
 
 def stream():
     """hipStream_t of torch's current stream on the current device (every entry point takes it as its last argument).
-    torch.cuda.current_stream() builds a Python Stream object per call (~8 us, ~700 calls per training step); the raw query is the
+    torch.cuda.current_stream() builds a Python Stream object per call (~8 us, several hundred calls per training step); the raw query is the
     same value without the object."""
     if _raw_stream is not None:
         return _raw_stream(torch.cuda.current_device())

@@ -1,7 +1,8 @@
 """Whole training step (forward, criterion, backward) captured in ONE HIP graph.
 
-One step of the path is ~700 kernel launches; enqueueing them from Python costs ~9 ms of host time, which is hidden behind the GPU at
-B >= 32 per GPU and becomes the bound below B ~ 16.  Every launch of the path is stream-ordered on torch's current
+One step of the path is ~430 kernel launches; enqueueing them from Python costs ~8 ms of host time, which is hidden behind the GPU at
+B >= 32 per GPU and becomes the bound below B ~ 16 (profiles/r06_step_gaps_by_batch.txt: 2.7 ms of idle GPU per
+step at B = 8 eager, 0.04 ms replayed).  Every launch of the path is stream-ordered on torch's current
 stream with no host synchronisation, so the step can be captured (torch.cuda.CUDAGraph == hipGraph) and replayed with a single launch:
 
     step = maskunet_amd.GraphedStep(model, criterion, example_inputs, example_labels, loss_scale=1024.0)
